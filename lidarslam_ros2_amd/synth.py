@@ -1,0 +1,274 @@
+"""Deterministic synthetic LiDAR workloads for the registration hot path.
+
+The reference ships no data (its demo bags are external downloads, /root/reference/README.md:
+123-165), so the benchmark/test inputs are ray-cast here: a VLP-32-like or 64-line sensor
+driving along +x through an analytic world (ground plane, axis-aligned boxes, vertical
+cylinders).  The frontend's data flow is mirrored: every scan is voxel-downsampled
+(`vg_size_for_map` for keyframes that go into the target submap,
+scanmatcher_component.cpp:443-464; `vg_size_for_input` for the source scan,
+scanmatcher_component.cpp:324-329), keyframes are `trans_for_mapupdate` = 1.5 m apart
+(scanmatcher_component.cpp:34,423) and the guess is the previous scan's pose
+(scanmatcher_component.cpp:331,353).
+
+This module is workload generation only (numpy, host side); it is not on the product path.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+WORLD_SEED = 20240924
+
+
+@dataclass
+class World:
+    boxes: np.ndarray      # (B, 6) xmin,ymin,zmin,xmax,ymax,zmax
+    cyls: np.ndarray       # (C, 4) cx, cy, r, ztop  (base at ground)
+    ground_z: float = -1.8
+
+
+def make_world(seed: int = WORLD_SEED, n_boxes: int = 70, n_cyls: int = 60, half_extent: float = 80.0,
+               corridor: float = 6.0, x_shift: float = 0.0) -> World:
+    """70 boxes (footprint U(3,25) m, height U(3,15) m) + 60 cylinders placed U(-80,80)^2 around
+    (x_shift, 0), keeping a `corridor`-wide lane along +x free.  (SURVEY.md §8d proposed 40/30;
+    densified, together with azimuth_oversample=3, so a VoxelGrid(0.2) scan keeps >= 30 000 and a
+    64-line VoxelGrid(0.1) scan >= 120 000 points — the survey allows tuning, never padding.)"""
+    rng = np.random.default_rng(seed)
+    gz = -1.8
+    boxes = []
+    while len(boxes) < n_boxes:
+        cx, cy = rng.uniform(-half_extent, half_extent, 2)
+        sx, sy = rng.uniform(3.0, 25.0, 2)
+        h = rng.uniform(3.0, 15.0)
+        y0, y1 = cy - sy / 2, cy + sy / 2
+        if y0 < corridor / 2 and y1 > -corridor / 2:
+            continue
+        boxes.append([cx - sx / 2 + x_shift, y0, gz, cx + sx / 2 + x_shift, y1, gz + h])
+    cyls = []
+    while len(cyls) < n_cyls:
+        cx, cy = rng.uniform(-half_extent, half_extent, 2)
+        r = rng.uniform(0.15, 0.5)
+        h = rng.uniform(3.0, 8.0)
+        if abs(cy) - r < corridor / 2:
+            continue
+        cyls.append([cx + x_shift, cy, r, gz + h])
+    return World(np.asarray(boxes, np.float64), np.asarray(cyls, np.float64), gz)
+
+
+@dataclass
+class Sensor:
+    n_beams: int
+    elev_min_deg: float
+    elev_max_deg: float
+    n_azimuth: int
+    range_noise: float = 0.02
+    max_range: float = 100.0
+    min_range: float = 0.5
+    _dirs: np.ndarray | None = field(default=None, repr=False)
+
+    def directions(self) -> np.ndarray:
+        if self._dirs is None:
+            el = np.deg2rad(np.linspace(self.elev_min_deg, self.elev_max_deg, self.n_beams))
+            az = np.linspace(0.0, 2 * np.pi, self.n_azimuth, endpoint=False)
+            ce, se = np.cos(el), np.sin(el)
+            d = np.stack([np.outer(np.cos(az), ce), np.outer(np.sin(az), ce), np.outer(np.ones_like(az), se)], -1)
+            self._dirs = d.reshape(-1, 3)
+        return self._dirs
+
+
+def vlp32() -> Sensor:
+    return Sensor(32, -25.0, 15.0, 1800)
+
+
+def hdl64() -> Sensor:
+    return Sensor(64, -24.8, 2.0, 2048)
+
+
+def pose_matrix(x: float, y: float, z: float, yaw: float, roll: float = 0.0, pitch: float = 0.0) -> np.ndarray:
+    cr, sr, cp, sp, cy, sy = math.cos(roll), math.sin(roll), math.cos(pitch), math.sin(pitch), math.cos(yaw), math.sin(yaw)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rx @ Ry @ Rz
+    T[:3, 3] = (x, y, z)
+    return T
+
+
+def trajectory_pose(x: float) -> np.ndarray:
+    """Pose of the sensor after travelling x metres: straight +x, yaw = 0.02 sin(0.1 x)."""
+    return pose_matrix(x, 0.0, 0.0, 0.02 * math.sin(0.1 * x))
+
+
+def raycast(world: World, sensor: Sensor, T: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """One revolution from pose T (sensor->map).  Returns hit points in the SENSOR frame, fp32 (n,3)."""
+    d_s = sensor.directions()
+    R, o = T[:3, :3], T[:3, 3]
+    d = d_s @ R.T
+    n = d.shape[0]
+    t_best = np.full(n, np.inf)
+    # ground
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = (world.ground_z - o[2]) / d[:, 2]
+    tg[~(tg > 0)] = np.inf
+    t_best = np.minimum(t_best, tg)
+    # boxes (slab method)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+    for b in world.boxes:
+        t0 = (b[:3] - o) * inv
+        t1 = (b[3:] - o) * inv
+        tn = np.minimum(t0, t1).max(axis=1)
+        tf = np.maximum(t0, t1).min(axis=1)
+        hit = (tf >= tn) & (tf > 0)
+        tt = np.where(tn > 0, tn, tf)
+        tt[~hit] = np.inf
+        t_best = np.minimum(t_best, tt)
+    # cylinders (side surface only)
+    a = d[:, 0] ** 2 + d[:, 1] ** 2
+    for c in world.cyls:
+        ox, oy = o[0] - c[0], o[1] - c[1]
+        bq = ox * d[:, 0] + oy * d[:, 1]
+        cq = ox * ox + oy * oy - c[2] ** 2
+        disc = bq * bq - a * cq
+        ok = disc > 0
+        sq = np.sqrt(np.where(ok, disc, 0.0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tt = (-bq - sq) / a
+        z = o[2] + tt * d[:, 2]
+        ok &= (tt > 0) & (z >= world.ground_z) & (z <= c[3])
+        tt = np.where(ok, tt, np.inf)
+        t_best = np.minimum(t_best, tt)
+    keep = np.isfinite(t_best) & (t_best < sensor.max_range) & (t_best > sensor.min_range)
+    rr = t_best[keep] + rng.normal(0.0, sensor.range_noise, int(keep.sum()))
+    pts = d_s[keep] * rr[:, None]
+    pts[:, 2] += rng.normal(0.0, 0.01, pts.shape[0])  # surface roughness
+    return pts.astype(np.float32)
+
+
+def voxel_downsample(pts: np.ndarray, leaf: float) -> np.ndarray:
+    """Host-side stand-in for pcl::VoxelGrid::filter (centroid per leaf, output ordered by
+    leaf index, x fastest) used only to PREPARE workloads (scanmatcher_component.cpp:324-328)."""
+    pts = np.asarray(pts, np.float32)
+    if pts.shape[0] == 0:
+        return pts.reshape(0, 3)
+    inv = np.float32(1.0) / np.float32(leaf)
+    ijk = np.floor(pts * inv).astype(np.int64)
+    mn = ijk.min(axis=0)
+    ijk -= mn
+    div = ijk.max(axis=0) + 1
+    key = ijk[:, 0] + div[0] * (ijk[:, 1] + div[1] * ijk[:, 2])
+    uniq, inv_idx, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    out = np.zeros((uniq.shape[0], 3), np.float64)
+    for k in range(3):
+        out[:, k] = np.bincount(inv_idx, weights=pts[:, k].astype(np.float64), minlength=uniq.shape[0])
+    out /= cnt[:, None]
+    return out.astype(np.float32)
+
+
+def transform_points(T: np.ndarray, pts: np.ndarray) -> np.ndarray:
+    T = np.asarray(T, np.float32)
+    return (pts @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+
+
+def subsample_exact(pts: np.ndarray, n: int, seed: int) -> np.ndarray:
+    """Keep exactly n points (seeded choice, original order preserved — PCL's VoxelGrid output is
+    ordered by leaf index, i.e. spatially coherent, and a real pipeline would not shuffle it)."""
+    if pts.shape[0] < n:
+        raise ValueError(f"scan has {pts.shape[0]} points after filtering, need >= {n}; tune the generator")
+    rng = np.random.default_rng(seed)
+    keep = np.sort(rng.permutation(pts.shape[0])[:n])
+    return pts[keep]
+
+
+@dataclass
+class RegistrationCase:
+    target: np.ndarray       # (M,3) fp32 map-frame submap
+    source: np.ndarray       # (N,3) fp32 sensor-frame scan
+    guess: np.ndarray        # (4,4) fp32
+    truth: np.ndarray        # (4,4) fp64 ground-truth source->map pose
+    name: str = ""
+
+
+def make_case(*, sensor: Sensor | None = None, world: World | None = None, n_keyframes: int = 10,
+              start_x: float = 0.0, keyframe_spacing: float = 1.5, scan_spacing: float = 0.5,
+              vg_map: float = 0.1, vg_input: float = 0.2, n_source: int | None = 30000,
+              vg_target: float | None = None, guess_perturb: tuple | None = None, seed: int = 0,
+              azimuth_oversample: int = 1, name: str = "") -> RegistrationCase:
+    """Frontend-style case: target = n_keyframes scans (each VoxelGrid(vg_map), moved to the map
+    frame, concatenated without re-filtering: scanmatcher_component.cpp:452-464); source = the
+    next scan, VoxelGrid(vg_input) then cut to exactly n_source points; guess = pose of the
+    previous scan (or truth perturbed by guess_perturb=(dx,dy,dyaw))."""
+    sensor = sensor or vlp32()
+    if azimuth_oversample != 1:
+        sensor = Sensor(sensor.n_beams, sensor.elev_min_deg, sensor.elev_max_deg, sensor.n_azimuth * azimuth_oversample,
+                        sensor.range_noise, sensor.max_range, sensor.min_range)
+    world = world or make_world()
+    rng = np.random.default_rng(WORLD_SEED + 7919 * seed + 1)
+    chunks = []
+    for k in range(n_keyframes):
+        T = trajectory_pose(start_x + keyframe_spacing * k)
+        scan = voxel_downsample(raycast(world, sensor, T, rng), vg_map)
+        chunks.append(transform_points(T, scan))
+    target = np.concatenate(chunks, 0)
+    if vg_target is not None:  # GICP frontend path re-filters the target (scanmatcher_component.cpp:309-315)
+        target = voxel_downsample(target, vg_target)
+    x_last = start_x + keyframe_spacing * (n_keyframes - 1)
+    x_src = x_last + scan_spacing
+    T_src = trajectory_pose(x_src)
+    src = voxel_downsample(raycast(world, sensor, T_src, rng), vg_input)
+    if n_source is not None:
+        src = subsample_exact(src, n_source, seed=WORLD_SEED + seed)
+    if guess_perturb is None:
+        guess = trajectory_pose(x_last)
+    else:
+        dx, dy, dyaw = guess_perturb
+        guess = pose_matrix(x_src + dx, dy, 0.0, 0.02 * math.sin(0.1 * x_src) + dyaw)
+    return RegistrationCase(target, src, guess.astype(np.float32), T_src, name)
+
+
+# ---- BASELINE.json configs ---------------------------------------------------------------
+def cfg_ndt_30k(seed: int = 0, start_x: float = 0.0, guess_perturb=None, world: World | None = None) -> RegistrationCase:
+    """cfg 1/2: 30k-pt VLP-32 scan (vg 0.2) vs 10-frame submap (vg 0.1)."""
+    return make_case(sensor=vlp32(), n_keyframes=10, vg_map=0.1, vg_input=0.2, n_source=30000, seed=seed,
+                     start_x=start_x, guess_perturb=guess_perturb, world=world, azimuth_oversample=3,
+                     name="ndt_30k_vs_10frame")
+
+
+def cfg_gicp_30k(seed: int = 0) -> RegistrationCase:
+    """cfg 3: same source; target additionally VoxelGrid(0.2) (scanmatcher_component.cpp:309-315)."""
+    return make_case(sensor=vlp32(), n_keyframes=10, vg_map=0.1, vg_input=0.2, n_source=30000, vg_target=0.2,
+                     seed=seed, azimuth_oversample=3, name="gicp_30k_vs_10frame")
+
+
+def cfg_loop_candidate(c: int) -> RegistrationCase:
+    """cfg 4: candidate c starts 3*c m along the route; guess perturbed U(-1,1) m xy, U(-3,3) deg yaw."""
+    rng = np.random.default_rng(1000 + c)
+    dx, dy = rng.uniform(-1, 1, 2)
+    dyaw = math.radians(rng.uniform(-3, 3))
+    return cfg_ndt_30k(seed=100 + c, start_x=3.0 * c, guess_perturb=(dx, dy, dyaw),
+                       world=make_world(x_shift=3.0 * c))
+
+
+def cfg_dense_120k(seed: int = 0) -> RegistrationCase:
+    """cfg 5: 64-line scan (vg 0.1) cut to 120k vs 20-frame submap."""
+    return make_case(sensor=hdl64(), n_keyframes=20, vg_map=0.1, vg_input=0.1, n_source=120000, seed=seed,
+                     azimuth_oversample=3, name="ndt_120k_vs_20frame")
+
+
+def small_case(n_source: int = 2000, n_keyframes: int = 3, seed: int = 0, guess_perturb=None,
+               vg_input: float = 0.4, vg_map: float = 0.2) -> RegistrationCase:
+    """Small case for CPU-side oracle tests (seconds, not minutes)."""
+    sensor = Sensor(16, -20.0, 12.0, 600)
+    return make_case(sensor=sensor, n_keyframes=n_keyframes, vg_map=vg_map, vg_input=vg_input, n_source=n_source,
+                     seed=seed, guess_perturb=guess_perturb, name="small")
+
+
+def as_pointxyzi(pts: np.ndarray) -> np.ndarray:
+    """Pack (n,3) fp32 into pcl::PointXYZI's 32-byte layout: x,y,z,1,intensity,pad*3."""
+    out = np.zeros((pts.shape[0], 8), np.float32)
+    out[:, :3] = pts
+    out[:, 3] = 1.0
+    return out
