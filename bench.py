@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the registration hot path (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W            (N=1 default)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one scan registration as the frontend performs it per LiDAR scan
+(scanmatcher_component.cpp:329,353): setInputSource(30k-pt scan, already resident in HBM) + NDT
+align() against the resident 10-frame submap — BASELINE.json configs[1]: ndt_resolution 5.0,
+vg_size_for_input 0.2, DIRECT7, fixed 30 iterations (max_iterations=30, transformation_epsilon=0 so
+the loop never exits early).  value = registrations/s over all ranks (weak scaling:
+every rank registers its own scan stream against its own copy of the submap; the only exchange is
+one all-gather of the K result records per rank at the end — SURVEY.md §8e).
+
+The JSON line also carries
+  roofline      derivative kernel: algorithmic bytes per launch (N*12 + pairs*40 +
+                G*224) / hipEvent-measured launch duration, vs 8 TB/s HBM peak;
+  cpu_baseline  the CPU oracle (C++/OpenMP restatement of ndt_omp — NOT ndt_omp itself) timed on this
+                box's host cores on a bounded sample of the same workload;
+  batched       the same registrations advanced B at a time in shared launches (cfg 4 style).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="registrations per shared launch in the 'batched' leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the registration core has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from lidarslam_ros2_amd import DIRECT7, NormalDistributionsTransform, align_batch, synth
+    from lidarslam_ros2_amd.posemath import pose_delta
+
+    # ---- workload: cfg 1/2; every rank gets its own scan (different seed) against the same route
+    case = synth.cfg_ndt_30k(seed=rank)
+    res, max_iter = 5.0, 30
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def make_ndt():
+        r = NormalDistributionsTransform(device=local_rank, stream=stream)
+        r.setResolution(res)
+        r.setTransformationEpsilon(0.0)
+        r.setMaximumIterations(max_iter)
+        r.setNeighborhoodSearchMethod(DIRECT7)
+        return r
+
+    ndt = make_ndt()
+    tgt_dev = torch.from_numpy(synth.as_pointxyzi(case.target)).cuda()
+    src_dev = torch.from_numpy(synth.as_pointxyzi(case.source)).cuda()   # pcl::PointXYZI records in HBM
+    ndt.setInputTarget(tgt_dev)
+    grid = ndt.gridInfo()
+
+    def step():
+        ndt.setInputSource(src_dev)
+        ndt.align(case.guess)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    records = []
+    for _ in range(args.steps):
+        step()
+        T = ndt.getFinalTransformation()
+        records.append(np.r_[T[:3, :4].reshape(-1), ndt.getTransformationProbability(), ndt.getFinalNumIteration(), 0, 0])
+    rec = torch.tensor(np.asarray(records, np.float32), device="cuda")     # K x 16 floats = 64-byte records
+    if dist is not None:
+        gathered = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(gathered, rec)                                      # C1: pose all-gather over xGMI
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    last = ndt.last_result
+    value = world * args.steps / elapsed
+
+    out = {
+        "metric": "scan registrations/sec (30k-pt scan vs 10-frame submap)",
+        "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 pair maths, f64 accumulation", "data": "synthetic",
+        "config": {"workload": "cfg2: single NDT align(), 30000-pt VLP-32 scan (vg 0.2) vs 10-frame submap (vg 0.1), "
+                               "ndt_resolution 5.0, DIRECT7, max_iterations 30, transformation_epsilon 0",
+                   "target_points": int(case.target.shape[0]), "source_points": int(case.source.shape[0]),
+                   "voxels_valid": grid["n_valid"], "newton_iterations": last["iterations"],
+                   "derivative_passes_per_align": last["n_evaluations"], "parallelism": f"1 registration stream per GPU x{world}"},
+        "ndt_iterations_per_s": world * args.steps * last["iterations"] / elapsed,
+        "derivative_passes_per_s": world * args.steps * last["n_evaluations"] / elapsed,
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (K3+K4 derivative pass), hipEvents around every launch
+        ndt.setProfiling(True)
+        ndt.getProfile(reset=True)
+        for _ in range(3):
+            step()
+        prof = ndt.getProfile(reset=True)
+        ndt.setProfiling(False)
+        n_src = int(case.source.shape[0])
+        nblocks = (n_src + 255) // 256
+        launches = max(1, prof["deriv_launches"])
+        avg_us = 1e3 * prof["deriv_ms_total"] / launches
+        pairs = prof["deriv_pairs"]
+        alg_bytes = n_src * 12 + pairs * 40 + nblocks * 224
+        achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "ndt_eval_kernel<7> (derivative pass + fused Newton/More-Thuente controller)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_us,
+                           "valid_pairs_per_point": pairs / n_src,
+                           "compulsory_bytes_per_launch": n_src * 12 + grid["n_valid"] * 36,
+                           "note": "single 30k-pt scan = 118 workgroups on 256 CUs: latency-bound, voxel table is L2-resident; "
+                                   "see batched.roofline for the bandwidth-relevant figure"}
+
+        # ---- batched leg: B registrations share every launch (loop-closure candidate set / N scans vs submap)
+        B = args.batch
+        regs = [ndt] + [make_ndt() for _ in range(B - 1)]
+        for r in regs[1:]:
+            r.shareTargetOf(ndt)
+        for r in regs:
+            r.setInputSource(src_dev)
+        guesses = [case.guess] * B
+        for _ in range(2):
+            align_batch(regs, guesses)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        nb_steps = max(3, args.steps // 4)
+        for _ in range(nb_steps):
+            for r in regs:
+                r.setInputSource(src_dev)
+            finals, bres = align_batch(regs, guesses)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        ndt.setProfiling(True)
+        ndt.getProfile(reset=True)
+        align_batch(regs, guesses)
+        bprof = ndt.getProfile(reset=True)
+        ndt.setProfiling(False)
+        b_us = 1e3 * bprof["deriv_ms_total"] / max(1, bprof["deriv_launches"])
+        b_bytes = B * (n_src * 12 + nblocks * 224) + bprof["deriv_pairs"] * 40
+        b_ach = b_bytes / (b_us * 1e-6) / 1e9
+        out["batched"] = {"batch": B, "value": B * nb_steps / tb, "unit": "registrations/s", "ms_per_batch": 1e3 * tb / nb_steps,
+                          "roofline": {"bound": "hbm", "achieved": b_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": b_ach / HBM_PEAK_GBS, "avg_launch_us": b_us,
+                                       "algorithmic_bytes_per_launch": b_bytes}}
+
+        # ---- CPU baseline: the oracle (restatement of ndt_omp) on this box's host cores, bounded sample
+        if not args.no_cpu:
+            from oracle import oracle as O
+
+            g = O.VoxelGridCovariance(case.target, res)
+            avail = min(len(os.sched_getaffinity(0)), O.max_threads())
+            p0 = O.matrix_to_pose(case.guess)
+            cores, best = 1, float("inf")
+            cands = [args.cpu_threads] if args.cpu_threads else [c for c in (1, 2, 4, 8, 16, 32, 64, 128) if c <= avail]
+            for c in cands:  # pick the thread count that is fastest on THIS box (oversubscribed hosts get slower with more)
+                O.ndt_derivatives(g, case.source, p0, resolution=res, num_threads=c)
+                tq = time.perf_counter()
+                for _ in range(2):
+                    O.ndt_derivatives(g, case.source, p0, resolution=res, num_threads=c)
+                tq = (time.perf_counter() - tq) / 2
+                if tq < best:
+                    cores, best = c, tq
+            tc = time.perf_counter()
+            ref = O.ndt_align(g, case.source, case.guess, resolution=res, trans_eps=0.0, max_iterations=max_iter,
+                              num_threads=cores)
+            tc = time.perf_counter() - tc
+            dt, ang = pose_delta(ndt.getFinalTransformation() if B == 1 else finals[0], ref["final"])
+            out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "registrations/s", "cores": cores, "kind": "port",
+                                   "sample": "1 registration of the same workload (30 Newton iterations, "
+                                             f"{ref['n_evals'] + ref['n_evals_grad'] + ref['n_hessian_recompute']} derivative passes)",
+                                   "seconds": tc, "newton_iterations": ref["iterations"], "host_threads_available": avail,
+                                   "ms_per_derivative_pass": 1e3 * best,
+                                   "note": "C++/OpenMP restatement of ndt_omp (oracle/), not ndt_omp itself"}
+            out["parity_vs_cpu"] = {"translation_m": dt, "rotation_rad": ang}
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

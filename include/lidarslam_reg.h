@@ -1,0 +1,154 @@
+/*
+ * lidarslam_reg.h — C ABI of the MI355X-native scan-matching registration core.
+ *
+ * This is the drop-in boundary for the ONE hot path of rsasaki0109/lidarslam_ros2: the
+ * pcl::Registration<pcl::PointXYZI,pcl::PointXYZI> object that ScanMatcherComponent
+ * (scanmatcher/include/scanmatcher/scanmatcher_component.h:93) and GraphBasedSlamComponent
+ * (graph_based_slam/include/graph_based_slam/graph_based_slam_component.h:106) hold and call.
+ * Every entry point below names the reference call it replaces (file:line under
+ * /root/reference).  The arithmetic the reference reaches through those calls lives in the
+ * un-vendored submodule Thirdparty/ndt_omp_ros2 (.gitmodules:1-4) + PCL; SURVEY.md §9 is its
+ * restatement.
+ *
+ * Conventions
+ *  - plain C, no exceptions cross this boundary; every function returns an lsr_status
+ *    (0 = ok, < 0 = error) and leaves outputs untouched on error;
+ *  - clouds are "strided xyz": 3 consecutive fp32 at byte offset 0 of every `stride_bytes`
+ *    record (pcl::PointXYZI: stride 32; packed xyz: stride 12; xyzw: stride 16);
+ *  - 4x4 transforms are COLUMN-MAJOR fp32 (Eigen::Matrix4f memory order);
+ *  - a handle is thread-compatible (one caller at a time), distinct handles are re-entrant —
+ *    the reference's threading contract (lidarslam/src/lidarslam.cpp:12-17);
+ *  - there is NO CPU fallback: without a usable gfx950 device lsr_create fails.
+ */
+#ifndef LIDARSLAM_REG_H
+#define LIDARSLAM_REG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lsr_handle_s* lsr_handle;
+
+typedef enum lsr_status {
+  LSR_OK = 0,
+  LSR_ERR_INVALID_ARGUMENT = -1,
+  LSR_ERR_NO_DEVICE = -2,       /* no gfx950 device / HIP runtime unusable */
+  LSR_ERR_HIP = -3,             /* a HIP call failed; see lsr_last_error() */
+  LSR_ERR_NO_TARGET = -4,       /* align/getFitnessScore before setInputTarget */
+  LSR_ERR_NO_SOURCE = -5,       /* align/getFitnessScore before setInputSource */
+  LSR_ERR_NOT_IMPLEMENTED = -6, /* e.g. NDT neighbourhood KDTREE */
+  LSR_ERR_INDEX_OVERFLOW = -7,  /* voxel index space exceeds int32 (PCL: "Leaf size is too small") */
+  LSR_ERR_TOO_FEW_POINTS = -8   /* GICP: cloud smaller than k_correspondences */
+} lsr_status;
+
+/* registration_method: scanmatcher_component.cpp:103-124, graph_based_slam_component.cpp:63-86 */
+typedef enum lsr_method { LSR_METHOD_NDT = 0, LSR_METHOD_GICP = 1 } lsr_method;
+
+/* pclomp::NeighborSearchMethod, selected at scanmatcher_component.cpp:110 */
+typedef enum lsr_neighborhood { LSR_KDTREE = 0, LSR_DIRECT26 = 1, LSR_DIRECT7 = 2, LSR_DIRECT1 = 3 } lsr_neighborhood;
+
+typedef enum lsr_key {
+  /* double-valued (lsr_set_f64 / lsr_get_f64) */
+  LSR_RESOLUTION = 0,                 /* ndt->setResolution                 scanmatcher_component.cpp:107 */
+  LSR_TRANSFORMATION_EPSILON = 1,     /* setTransformationEpsilon           scanmatcher_component.cpp:108,119 */
+  LSR_STEP_SIZE = 2,                  /* NDT step_size_ (ctor default 0.1; never set by the reference) */
+  LSR_OUTLIER_RATIO = 3,              /* NDT outlier_ratio_ (0.55) */
+  LSR_MAX_CORRESPONDENCE_DISTANCE = 4,/* setMaxCorrespondenceDistance      scanmatcher_component.cpp:118 */
+  LSR_ROTATION_EPSILON = 5,           /* GICP rotation_epsilon_ (2e-3) */
+  LSR_EUCLIDEAN_FITNESS_EPSILON = 6,  /* setEuclideanFitnessEpsilon         graph_based_slam_component.cpp:80 (no effect) */
+  LSR_GICP_EPSILON = 7,               /* GICP gicp_epsilon_ (1e-3) */
+  /* int-valued (lsr_set_i32 / lsr_get_i32) */
+  LSR_MAX_ITERATIONS = 32,            /* setMaximumIterations               graph_based_slam_component.cpp:66,77 */
+  LSR_NEIGHBORHOOD = 33,              /* setNeighborhoodSearchMethod        scanmatcher_component.cpp:110 */
+  LSR_NUM_THREADS = 34,               /* setNumThreads (accepted, ignored)  scanmatcher_component.cpp:111 */
+  LSR_K_CORRESPONDENCES = 35,         /* GICP k_correspondences_ (20) */
+  LSR_MAX_INNER_ITERATIONS = 36,      /* GICP max_inner_iterations_ (20) */
+  LSR_RANSAC_ITERATIONS = 37,         /* setRANSACIterations (accepted, ignored) graph_based_slam_component.cpp:81 */
+  LSR_HESSIAN_D1_SIGN = 38,           /* +1 = upstream "+sy" quirk in h_ang d1 (default), -1 = analytic */
+  LSR_PROFILE = 39                    /* 1 = bracket every derivative launch with hipEvents (lsr_get_profile) */
+} lsr_key;
+
+typedef struct lsr_result {
+  int32_t converged;            /* hasConverged()                             scanmatcher_component.cpp:375 */
+  int32_t iterations;           /* nr_iterations_ */
+  double score;                 /* NDT: trans_probability_ (= score / N); GICP: final mean Mahalanobis cost */
+  int32_t n_evaluations;        /* NDT: derivative passes launched; GICP: Gauss-Newton inner steps */
+  int32_t n_correspondences;    /* GICP: pairs in the last outer iteration; NDT: 0 */
+  double gpu_ms;                /* device time of this align (hipEvents on the handle's stream) */
+} lsr_result;
+
+typedef struct lsr_profile {
+  double deriv_ms_total;        /* summed hipEvent time of derivative-kernel launches since last reset */
+  int64_t deriv_launches;
+  int64_t deriv_points;         /* source points processed by those launches */
+  int64_t deriv_pairs;          /* valid (point,voxel) pairs of the LAST launch (K-bar * N) */
+} lsr_profile;
+
+const char* lsr_version(void);
+const char* lsr_status_string(int status);
+const char* lsr_last_error(void);                       /* thread-local, human readable */
+int lsr_device_count(int* count);
+
+/* new pclomp::NormalDistributionsTransform<..>() / new pclomp::GeneralizedIterativeClosestPoint<..>()
+ * scanmatcher_component.cpp:105-106,116-117; graph_based_slam_component.cpp:64-65,74-75.
+ * `stream` is a hipStream_t to run on (NULL = the handle creates its own). */
+int lsr_create(int method, int device_id, void* stream, lsr_handle* out);
+int lsr_destroy(lsr_handle h);
+
+int lsr_set_f64(lsr_handle h, int key, double value);
+int lsr_set_i32(lsr_handle h, int key, int value);
+int lsr_get_f64(lsr_handle h, int key, double* value);
+int lsr_get_i32(lsr_handle h, int key, int* value);
+
+/* registration_->setInputTarget(cloud)   scanmatcher_component.cpp:275,307,315; graph_based_slam_component.cpp:227
+ * NDT: builds the voxel-covariance grid on the device.  GICP: uploads + 20-NN covariances.
+ * Host-memory (`pts` readable by the CPU) and device-memory (`pts` a HIP device pointer) forms. */
+int lsr_set_input_target(lsr_handle h, const void* pts, size_t stride_bytes, size_t n);
+int lsr_set_input_target_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n);
+/* registration_->setInputSource(cloud)   scanmatcher_component.cpp:329; graph_based_slam_component.cpp:181 */
+int lsr_set_input_source(lsr_handle h, const void* pts, size_t stride_bytes, size_t n);
+int lsr_set_input_source_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n);
+/* Let `h` register against the target already resident in `owner` (N keyframes vs ONE submap):
+ * no copy, the voxel grid / target structures are reference counted. */
+int lsr_share_target(lsr_handle h, lsr_handle owner);
+
+/* registration_->align(output, guess)    scanmatcher_component.cpp:353; graph_based_slam_component.cpp:230
+ * guess: col-major 4x4 or NULL (= identity, the backend's align(output)).  final_transformation: out, 16 floats.
+ * output_pts (nullable): host buffer of n_source records of out_stride_bytes; xyz of the source
+ * transformed by the final transformation are written at offset 0 of every record. */
+int lsr_align(lsr_handle h, const float* guess, float* final_transformation, lsr_result* result,
+              void* output_pts, size_t out_stride_bytes);
+/* B independent registrations advanced together in shared launches (loop-closure candidate set /
+ * N keyframes vs submap; BASELINE.json cfg 4).  All handles must live on the same device and use
+ * the same method.  guesses: B*16 floats or NULL; finals: B*16 floats; results: B entries. */
+int lsr_align_batch(lsr_handle* handles, int batch, const float* guesses, float* finals, lsr_result* results);
+
+/* registration_->getFinalTransformation()  scanmatcher_component.cpp:356; graph_based_slam_component.cpp:244,253 */
+int lsr_get_final_transformation(lsr_handle h, float* out16);
+/* registration_->hasConverged()            scanmatcher_component.cpp:375 */
+int lsr_has_converged(lsr_handle h, int* out);
+/* registration_->getFitnessScore(max_range = DBL_MAX)  graph_based_slam_component.cpp:231; scanmatcher_component.cpp:376 */
+int lsr_get_fitness_score(lsr_handle h, double max_range, double* out);
+
+/* ---- inspection (parity tests / profiling; not used by the ROS nodes) ------------------- */
+/* NDT voxel grid: info[0..2]=min_b, [3..5]=max_b, [6]=#leaves (any point count), [7]=#leaves usable (n>=6, valid cov) */
+int lsr_ndt_grid_info(lsr_handle h, int32_t* info8);
+/* Dump all leaves sorted by linear index: idx[L], npts[L] (-1 = invalidated), mean[L*3], icov[L*9] (row-major). */
+int lsr_ndt_grid_dump(lsr_handle h, int32_t* idx, int32_t* npts, double* mean, double* icov);
+/* One derivative pass at pose p = (tx,ty,tz,rx,ry,rz); T16 (nullable, col-major) overrides the point
+ * transform like the first pass of align().  grad: 6, hess: 36 (row-major). */
+int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int compute_hessian, double* score,
+                        double* grad, double* hess);
+/* GICP per-point covariances after setInput*: which = 0 source, 1 target; cov: n*9 doubles. */
+int lsr_gicp_covariances(lsr_handle h, int which, double* cov);
+/* 1-NN of the source transformed by T16 (nullable = identity) in the target: idx[n], d2[n]. */
+int lsr_nearest_neighbors(lsr_handle h, const float* T16, int32_t* idx, float* d2);
+int lsr_get_profile(lsr_handle h, lsr_profile* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARSLAM_REG_H */

@@ -1,0 +1,608 @@
+// C ABI of the registration core (include/lidarslam_reg.h).  Host-side orchestration only:
+// device buffers, launch chains, result read-back.  No CPU fallback exists — every compute
+// entry point runs HIP kernels on a gfx950 device or returns an error status.
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <numeric>
+
+#include "handle.hpp"
+
+namespace lsr {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+}  // namespace lsr
+
+using namespace lsr;
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+#define LSR_CHECK_HANDLE(h)                      \
+  if (!(h)) {                                    \
+    set_last_error("null handle");               \
+    return LSR_ERR_INVALID_ARGUMENT;             \
+  }                                              \
+  DeviceGuard _guard((h)->device);               \
+  if (!_guard.ok) {                              \
+    set_last_error("hipSetDevice failed");       \
+    return LSR_ERR_HIP;                          \
+  }
+
+int upload_cloud(lsr_handle h, const void* pts, size_t stride, size_t n, bool on_device, DeviceCloud& out) {
+  if (stride < 12 || (stride % 4) != 0) {
+    set_last_error("stride_bytes must be a multiple of 4 and >= 12");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  if (n > 0 && !pts) {
+    set_last_error("null point pointer");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  if (n > (size_t)INT32_MAX / 2) {
+    set_last_error("cloud too large");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  const void* d_aos = pts;
+  if (!on_device && n > 0) {
+    int st = h->staging.reserve(n * stride);
+    if (st) return st;
+    LSR_HIP(hipMemcpyAsync(h->staging.p, pts, n * stride, hipMemcpyHostToDevice, h->stream));
+    d_aos = h->staging.p;
+  }
+  return deinterleave(d_aos, stride, n, out, h->stream);
+}
+
+// Workgroups per registration.  A single registration spreads one point per thread over as many CUs as
+// it can (latency); a batch wants ~2 resident workgroups per CU in total and lets every thread stride
+// over several points, which amortises the reduction and the partial-row traffic (throughput).
+int ndt_nblocks(size_t n, int batch = 1) {
+  int nb = (int)((n + NDT_THREADS - 1) / NDT_THREADS);
+  nb = std::max(1, std::min(nb, NDT_MAX_BLOCKS));
+  if (batch > 1) {
+    int per = std::max(4, (2 * 256 + batch - 1) / batch);
+    nb = std::min(nb, per);
+  }
+  return nb;
+}
+
+void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_partials, unsigned int* d_ticket, int batch = 1) {
+  const VoxelGridDev& g = h->target->grid;
+  P.sx = h->source.x(); P.sy = h->source.y(); P.sz = h->source.z();
+  P.n = (int)h->source.n;
+  P.nblocks = ndt_nblocks(h->source.n, batch);
+  P.cell_slot = g.cell_slot.p;
+  P.rec = g.rec.p;
+  for (int k = 0; k < 3; k++) { P.min_b[k] = g.min_b[k]; P.max_b[k] = g.max_b[k]; }
+  P.mul1 = g.div_b[0];
+  P.mul2 = g.div_b[0] * g.div_b[1];
+  P.leaf = g.leaf;
+  P.pad = 0;
+  P.st = d_state;
+  P.partials = d_partials;
+  P.ticket = d_ticket;
+}
+
+int ensure_ndt_grid(lsr_handle h) {
+  TargetData& t = *h->target;
+  float leaf = (float)h->ndt.resolution;
+  if (t.has_grid && t.grid_leaf == leaf) return LSR_OK;
+  int st = ndt_build_grid(t.cloud, leaf, t.grid, h->scratch, h->stream);
+  if (st) return st;
+  t.has_grid = true;
+  t.grid_leaf = leaf;
+  return LSR_OK;
+}
+
+int ensure_target_hash(lsr_handle h) {
+  TargetData& t = *h->target;
+  if (t.has_hash) return LSR_OK;
+  int st = nn_build_hash(t.cloud, nn_pick_cell(t.cloud.n, h), t.hash, h->scratch, h->stream);
+  if (st) return st;
+  t.has_hash = true;
+  return LSR_OK;
+}
+
+// Chain of derivative+controller launches until every problem reports done.
+int run_ndt_chain(lsr_handle lead, NdtProblem* d_probs, const NdtProblem* h_probs, int batch, int max_blocks, NdtState* d_states, NdtState* h_states,
+                  int neighborhood, bool dense, int min_evals, int hard_cap, bool profile, lsr_profile* prof, long points_per_launch) {
+  int launched = 0;
+  int chunk = std::max(1, min_evals);
+  if (profile) chunk = 1;
+  while (launched < hard_cap) {
+    int c = std::min(chunk, hard_cap - launched);
+    if (profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
+    int st = ndt_launch_evals(d_probs, batch == 1 ? h_probs : nullptr, batch, max_blocks, neighborhood, dense, c, lead->stream);
+    if (st) return st;
+    if (profile) LSR_HIP(hipEventRecord(lead->ev1, lead->stream));
+    launched += c;
+    LSR_HIP(hipMemcpyAsync(h_states, d_states, sizeof(NdtState) * batch, hipMemcpyDeviceToHost, lead->stream));
+    LSR_HIP(hipStreamSynchronize(lead->stream));
+    if (profile) {
+      float ms = 0.f;
+      LSR_HIP(hipEventElapsedTime(&ms, lead->ev0, lead->ev1));
+      prof->deriv_ms_total += ms;
+      prof->deriv_launches += 1;
+      prof->deriv_points += points_per_launch;
+      prof->deriv_pairs = 0;
+      for (int b = 0; b < batch; b++) prof->deriv_pairs += (int64_t)h_states[b].last_pairs;
+    }
+    bool all_done = true;
+    for (int b = 0; b < batch; b++) all_done = all_done && (h_states[b].done != 0);
+    if (all_done) return LSR_OK;
+    if (!profile) chunk = 8;
+  }
+  set_last_error("NDT controller did not finish within the launch cap");
+  return LSR_ERR_HIP;
+}
+
+int ndt_hard_cap(const NdtParamsHost& p) {
+  // per Newton iteration: 1 first pass + <=10 trials + 1 Hessian recomputation; max_iter+2 iterations; + initial pass
+  return (p.max_iterations + 2) * 12 + 4;
+}
+
+int ndt_min_evals(const NdtParamsHost& p) {
+  // with a non-positive epsilon the loop can only stop on the iteration count: at least max_iter+2 line searches
+  if (p.trans_eps <= 0) return p.max_iterations + 3;
+  return 8;
+}
+
+int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, lsr_result* results) {
+  lsr_handle lead = hs[0];
+  for (int b = 0; b < B; b++) {
+    lsr_handle h = hs[b];
+    if (!h->target || h->target->n == 0) { set_last_error("align before setInputTarget"); return LSR_ERR_NO_TARGET; }
+    if (!h->has_source) { set_last_error("align before setInputSource"); return LSR_ERR_NO_SOURCE; }
+    if (h->ndt.neighborhood == LSR_KDTREE) { set_last_error("NDT neighbourhood KDTREE is not implemented (reference uses DIRECT7)"); return LSR_ERR_NOT_IMPLEMENTED; }
+    if (h->ndt.neighborhood != lead->ndt.neighborhood) { set_last_error("batched handles must share the neighbourhood method"); return LSR_ERR_INVALID_ARGUMENT; }
+    int st = ensure_ndt_grid(h);
+    if (st) return st;
+  }
+  int st;
+  if ((st = lead->d_state.reserve(B))) return st;
+  if ((st = lead->h_state.reserve(B))) return st;
+  if ((st = lead->d_prob.reserve(B))) return st;
+  if ((st = lead->h_prob.reserve(B))) return st;
+  size_t tot_blocks = 0;
+  int max_blocks = 1;
+  for (int b = 0; b < B; b++) {
+    int nb = ndt_nblocks(hs[b]->source.n, B);
+    tot_blocks += nb;
+    max_blocks = std::max(max_blocks, nb);
+  }
+  if ((st = lead->d_partials.reserve(tot_blocks * NDT_NRED))) return st;
+  size_t old_ticket_cap = lead->d_ticket.cap;
+  if ((st = lead->d_ticket.reserve(B))) return st;
+  if (lead->d_ticket.cap != old_ticket_cap)
+    LSR_HIP(hipMemsetAsync(lead->d_ticket.p, 0, lead->d_ticket.cap * sizeof(unsigned int), lead->stream));
+  size_t blk_off = 0;
+  int min_evals = 1, hard_cap = 1;
+  bool dense = true;
+  for (int b = 0; b < B; b++) dense = dense && hs[b]->target->grid.dense;
+  long pts = 0;
+  for (int b = 0; b < B; b++) {
+    lsr_handle h = hs[b];
+    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + b, lead->d_partials.p + blk_off * NDT_NRED, lead->d_ticket.p + b, B);
+    blk_off += lead->h_prob.p[b].nblocks;
+    ndt_fill_initial_state(lead->h_state.p[b], guesses ? guesses + 16 * b : nullptr, h->ndt, (int)h->source.n);
+    min_evals = std::max(min_evals, ndt_min_evals(h->ndt));
+    hard_cap = std::max(hard_cap, ndt_hard_cap(h->ndt));
+    pts += (long)h->source.n;
+  }
+  LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
+  LSR_HIP(hipMemcpyAsync(lead->d_prob.p, lead->h_prob.p, sizeof(NdtProblem) * B, hipMemcpyHostToDevice, lead->stream));
+  LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * B, hipMemcpyHostToDevice, lead->stream));
+  hipEvent_t e_start = nullptr, e_stop = nullptr;
+  LSR_HIP(hipEventCreate(&e_start));
+  LSR_HIP(hipEventCreate(&e_stop));
+  LSR_HIP(hipEventRecord(e_start, lead->stream));
+  st = run_ndt_chain(lead, lead->d_prob.p, lead->h_prob.p, B, max_blocks, lead->d_state.p, lead->h_state.p, lead->ndt.neighborhood, dense, min_evals,
+                     hard_cap, lead->profile != 0, &lead->prof, pts);
+  if (st) { (void)hipEventDestroy(e_start); (void)hipEventDestroy(e_stop); return st; }
+  LSR_HIP(hipEventRecord(e_stop, lead->stream));
+  LSR_HIP(hipEventSynchronize(e_stop));
+  float ms = 0.f;
+  LSR_HIP(hipEventElapsedTime(&ms, e_start, e_stop));
+  (void)hipEventDestroy(e_start);
+  (void)hipEventDestroy(e_stop);
+  for (int b = 0; b < B; b++) {
+    const NdtState& S = lead->h_state.p[b];
+    lsr_handle h = hs[b];
+    std::memcpy(h->final_T, S.final_T, sizeof(float) * 16);
+    h->converged = S.converged;
+    if (finals) std::memcpy(finals + 16 * b, S.final_T, sizeof(float) * 16);
+    if (results) {
+      results[b].converged = S.converged;
+      results[b].iterations = S.nr_iterations;
+      results[b].score = S.trans_probability;
+      results[b].n_evaluations = S.n_evals;
+      results[b].n_correspondences = 0;
+      results[b].gpu_ms = ms;
+    }
+  }
+  return LSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lsr_version(void) { return "lidarslam_reg 0.1.0 (gfx950)"; }
+
+const char* lsr_status_string(int status) {
+  switch (status) {
+    case LSR_OK: return "ok";
+    case LSR_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case LSR_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case LSR_ERR_HIP: return "HIP runtime error";
+    case LSR_ERR_NO_TARGET: return "input target not set";
+    case LSR_ERR_NO_SOURCE: return "input source not set";
+    case LSR_ERR_NOT_IMPLEMENTED: return "not implemented";
+    case LSR_ERR_INDEX_OVERFLOW: return "voxel index overflow";
+    case LSR_ERR_TOO_FEW_POINTS: return "too few points";
+    default: return "unknown status";
+  }
+}
+
+const char* lsr_last_error(void) { return g_last_error.c_str(); }
+
+int lsr_device_count(int* count) {
+  if (!count) return LSR_ERR_INVALID_ARGUMENT;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    *count = 0;
+    return LSR_ERR_NO_DEVICE;
+  }
+  *count = n;
+  return LSR_OK;
+}
+
+int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
+  if (!out || (method != LSR_METHOD_NDT && method != LSR_METHOD_GICP)) {
+    set_last_error("invalid registration method");  // scanmatcher_component.cpp:121-124
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) {
+    set_last_error("no HIP device available (this library has no CPU path)");
+    return LSR_ERR_NO_DEVICE;
+  }
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return LSR_ERR_NO_DEVICE;
+  lsr_handle h = new (std::nothrow) lsr_handle_s();
+  if (!h) return LSR_ERR_HIP;
+  h->method = method;
+  h->device = device_id;
+  // pclomp ctor defaults
+  h->ndt.resolution = 1.0; h->ndt.step_size = 0.1; h->ndt.outlier_ratio = 0.55; h->ndt.trans_eps = 0.1;
+  h->ndt.max_iterations = 35; h->ndt.neighborhood = LSR_DIRECT7; h->ndt.d1_sign = 1;
+  if (stream) {
+    h->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return LSR_ERR_HIP; }
+    h->own_stream = true;
+  }
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return LSR_ERR_HIP; }
+  if (h->d_T16.reserve(16)) { delete h; return LSR_ERR_HIP; }
+  *out = h;
+  return LSR_OK;
+}
+
+int lsr_destroy(lsr_handle h) {
+  if (!h) return LSR_OK;
+  DeviceGuard guard(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  h->target.reset();
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return LSR_OK;
+}
+
+int lsr_set_f64(lsr_handle h, int key, double v) {
+  LSR_CHECK_HANDLE(h);
+  switch (key) {
+    case LSR_RESOLUTION:
+      if (!(v > 0)) { set_last_error("resolution must be > 0"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->ndt.resolution = v;  // pclomp rebuilds the grid lazily when the resolution changes
+      return LSR_OK;
+    case LSR_TRANSFORMATION_EPSILON: h->ndt.trans_eps = v; h->gicp.trans_eps = v; return LSR_OK;
+    case LSR_STEP_SIZE: h->ndt.step_size = v; return LSR_OK;
+    case LSR_OUTLIER_RATIO: h->ndt.outlier_ratio = v; return LSR_OK;
+    case LSR_MAX_CORRESPONDENCE_DISTANCE: h->gicp.max_corr_dist = v; return LSR_OK;
+    case LSR_ROTATION_EPSILON: h->gicp.rot_eps = v; return LSR_OK;
+    case LSR_EUCLIDEAN_FITNESS_EPSILON: h->euclidean_fitness_eps = v; return LSR_OK;
+    case LSR_GICP_EPSILON: h->gicp.gicp_eps = v; h->source_cov_valid = false; if (h->target) h->target->has_cov = false; return LSR_OK;
+    default: set_last_error("unknown f64 key"); return LSR_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int lsr_get_f64(lsr_handle h, int key, double* v) {
+  LSR_CHECK_HANDLE(h);
+  if (!v) return LSR_ERR_INVALID_ARGUMENT;
+  switch (key) {
+    case LSR_RESOLUTION: *v = h->ndt.resolution; return LSR_OK;
+    case LSR_TRANSFORMATION_EPSILON: *v = (h->method == LSR_METHOD_NDT) ? h->ndt.trans_eps : h->gicp.trans_eps; return LSR_OK;
+    case LSR_STEP_SIZE: *v = h->ndt.step_size; return LSR_OK;
+    case LSR_OUTLIER_RATIO: *v = h->ndt.outlier_ratio; return LSR_OK;
+    case LSR_MAX_CORRESPONDENCE_DISTANCE: *v = h->gicp.max_corr_dist; return LSR_OK;
+    case LSR_ROTATION_EPSILON: *v = h->gicp.rot_eps; return LSR_OK;
+    case LSR_EUCLIDEAN_FITNESS_EPSILON: *v = h->euclidean_fitness_eps; return LSR_OK;
+    case LSR_GICP_EPSILON: *v = h->gicp.gicp_eps; return LSR_OK;
+    default: set_last_error("unknown f64 key"); return LSR_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int lsr_set_i32(lsr_handle h, int key, int v) {
+  LSR_CHECK_HANDLE(h);
+  switch (key) {
+    case LSR_MAX_ITERATIONS:
+      if (v < 0) { set_last_error("max_iterations must be >= 0"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->ndt.max_iterations = v; h->gicp.max_iterations = v; return LSR_OK;
+    case LSR_NEIGHBORHOOD:
+      if (v < LSR_KDTREE || v > LSR_DIRECT1) { set_last_error("unknown neighbourhood"); return LSR_ERR_INVALID_ARGUMENT; }
+      if (v == LSR_KDTREE) { set_last_error("NDT neighbourhood KDTREE is not implemented (reference uses DIRECT7)"); return LSR_ERR_NOT_IMPLEMENTED; }
+      h->ndt.neighborhood = v; return LSR_OK;
+    case LSR_NUM_THREADS: h->num_threads = v; return LSR_OK;          // CPU-only hint: accepted, ignored
+    case LSR_K_CORRESPONDENCES:
+      if (v < 3 || v > GICP_MAX_K) { set_last_error("k_correspondences out of range"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->gicp.k = v; h->source_cov_valid = false; if (h->target) h->target->has_cov = false; return LSR_OK;
+    case LSR_MAX_INNER_ITERATIONS: h->gicp.max_inner = v; return LSR_OK;
+    case LSR_RANSAC_ITERATIONS: h->ransac_iterations = v; return LSR_OK;  // no effect on NDT/GICP maths
+    case LSR_HESSIAN_D1_SIGN: h->ndt.d1_sign = (v >= 0) ? 1 : -1; return LSR_OK;
+    case LSR_PROFILE: h->profile = v ? 1 : 0; return LSR_OK;
+    default: set_last_error("unknown i32 key"); return LSR_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int lsr_get_i32(lsr_handle h, int key, int* v) {
+  LSR_CHECK_HANDLE(h);
+  if (!v) return LSR_ERR_INVALID_ARGUMENT;
+  switch (key) {
+    case LSR_MAX_ITERATIONS: *v = (h->method == LSR_METHOD_NDT) ? h->ndt.max_iterations : h->gicp.max_iterations; return LSR_OK;
+    case LSR_NEIGHBORHOOD: *v = h->ndt.neighborhood; return LSR_OK;
+    case LSR_NUM_THREADS: *v = h->num_threads; return LSR_OK;
+    case LSR_K_CORRESPONDENCES: *v = h->gicp.k; return LSR_OK;
+    case LSR_MAX_INNER_ITERATIONS: *v = h->gicp.max_inner; return LSR_OK;
+    case LSR_RANSAC_ITERATIONS: *v = h->ransac_iterations; return LSR_OK;
+    case LSR_HESSIAN_D1_SIGN: *v = h->ndt.d1_sign; return LSR_OK;
+    case LSR_PROFILE: *v = h->profile; return LSR_OK;
+    default: set_last_error("unknown i32 key"); return LSR_ERR_INVALID_ARGUMENT;
+  }
+}
+
+static int set_target_impl(lsr_handle h, const void* pts, size_t stride, size_t n, bool on_device) {
+  LSR_CHECK_HANDLE(h);
+  auto t = std::make_shared<TargetData>();
+  int st = upload_cloud(h, pts, stride, n, on_device, t->cloud);
+  if (st) return st;
+  t->n = n;
+  h->target = t;
+  if (h->method == LSR_METHOD_NDT) {
+    // pclomp::NDT::setInputTarget -> init(): the voxel-covariance grid is built right here.
+    st = ensure_ndt_grid(h);
+    if (st) { h->target.reset(); return st; }
+  } else {
+    // GICP: target covariances are computed lazily in align() by the reference; the NN structure is
+    // what setInputTarget pays for (kd-tree there, hash grid here).
+    st = ensure_target_hash(h);
+    if (st) { h->target.reset(); return st; }
+  }
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
+int lsr_set_input_target(lsr_handle h, const void* pts, size_t stride_bytes, size_t n) {
+  return set_target_impl(h, pts, stride_bytes, n, false);
+}
+int lsr_set_input_target_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n) {
+  return set_target_impl(h, dev_pts, stride_bytes, n, true);
+}
+
+static int set_source_impl(lsr_handle h, const void* pts, size_t stride, size_t n, bool on_device) {
+  LSR_CHECK_HANDLE(h);
+  int st = upload_cloud(h, pts, stride, n, on_device, h->source);
+  if (st) return st;
+  h->has_source = true;
+  h->source_cov_valid = false;
+  if (!on_device) LSR_HIP(hipStreamSynchronize(h->stream));  // the caller may reuse its host buffer
+  return LSR_OK;
+}
+
+int lsr_set_input_source(lsr_handle h, const void* pts, size_t stride_bytes, size_t n) {
+  return set_source_impl(h, pts, stride_bytes, n, false);
+}
+int lsr_set_input_source_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n) {
+  return set_source_impl(h, dev_pts, stride_bytes, n, true);
+}
+
+int lsr_share_target(lsr_handle h, lsr_handle owner) {
+  LSR_CHECK_HANDLE(h);
+  if (!owner || !owner->target) { set_last_error("owner has no target"); return LSR_ERR_NO_TARGET; }
+  if (owner->device != h->device) { set_last_error("handles live on different devices"); return LSR_ERR_INVALID_ARGUMENT; }
+  h->target = owner->target;
+  return LSR_OK;
+}
+
+int lsr_align_batch(lsr_handle* handles, int batch, const float* guesses, float* finals, lsr_result* results) {
+  if (!handles || batch <= 0) { set_last_error("empty batch"); return LSR_ERR_INVALID_ARGUMENT; }
+  for (int b = 0; b < batch; b++) {
+    if (!handles[b]) { set_last_error("null handle in batch"); return LSR_ERR_INVALID_ARGUMENT; }
+    if (handles[b]->device != handles[0]->device || handles[b]->method != handles[0]->method) {
+      set_last_error("batched handles must share device and method");
+      return LSR_ERR_INVALID_ARGUMENT;
+    }
+  }
+  lsr_handle lead = handles[0];
+  LSR_CHECK_HANDLE(lead);
+  // members may have pending uploads on their own streams
+  for (int b = 1; b < batch; b++)
+    if (handles[b]->stream != lead->stream) LSR_HIP(hipStreamSynchronize(handles[b]->stream));
+  if (lead->method == LSR_METHOD_NDT) return align_ndt_batch(handles, batch, guesses, finals, results);
+  // GICP: registrations are advanced one after another (each is itself a chain of wide launches)
+  for (int b = 0; b < batch; b++) {
+    int st = gicp_align(handles[b], guesses ? guesses + 16 * b : nullptr, finals ? finals + 16 * b : nullptr,
+                        results ? results + b : nullptr);
+    if (st) return st;
+  }
+  return LSR_OK;
+}
+
+int lsr_align(lsr_handle h, const float* guess, float* final_transformation, lsr_result* result, void* output_pts,
+              size_t out_stride_bytes) {
+  LSR_CHECK_HANDLE(h);
+  int st;
+  if (h->method == LSR_METHOD_NDT) {
+    lsr_handle hs[1] = {h};
+    st = align_ndt_batch(hs, 1, guess, final_transformation, result);
+  } else {
+    st = gicp_align(h, guess, final_transformation, result);
+  }
+  if (st) return st;
+  if (output_pts) {
+    if (out_stride_bytes < 12 || (out_stride_bytes % 4) != 0) { set_last_error("bad output stride"); return LSR_ERR_INVALID_ARGUMENT; }
+    size_t bytes = h->source.n * out_stride_bytes;
+    if ((st = h->staging.reserve(bytes))) return st;
+    LSR_HIP(hipMemcpyAsync(h->d_T16.p, h->final_T, 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    LSR_HIP(hipMemsetAsync(h->staging.p, 0, bytes, h->stream));
+    if ((st = transform_to_strided(h->source, h->d_T16.p, h->staging.p, out_stride_bytes, h->stream))) return st;
+    LSR_HIP(hipMemcpyAsync(output_pts, h->staging.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    LSR_HIP(hipStreamSynchronize(h->stream));
+  }
+  return LSR_OK;
+}
+
+int lsr_get_final_transformation(lsr_handle h, float* out16) {
+  LSR_CHECK_HANDLE(h);
+  if (!out16) return LSR_ERR_INVALID_ARGUMENT;
+  std::memcpy(out16, h->final_T, sizeof(float) * 16);
+  return LSR_OK;
+}
+
+int lsr_has_converged(lsr_handle h, int* out) {
+  LSR_CHECK_HANDLE(h);
+  if (!out) return LSR_ERR_INVALID_ARGUMENT;
+  *out = h->converged;
+  return LSR_OK;
+}
+
+int lsr_get_fitness_score(lsr_handle h, double max_range, double* out) {
+  LSR_CHECK_HANDLE(h);
+  if (!out) return LSR_ERR_INVALID_ARGUMENT;
+  if (!h->target || h->target->n == 0) { set_last_error("getFitnessScore before setInputTarget"); return LSR_ERR_NO_TARGET; }
+  if (!h->has_source) { set_last_error("getFitnessScore before setInputSource"); return LSR_ERR_NO_SOURCE; }
+  int st = ensure_target_hash(h);
+  if (st) return st;
+  return nn_fitness_score(h->source, h->final_T, h->target->hash, max_range, out, h->scratch, h->d_T16, h->stream);
+}
+
+int lsr_nearest_neighbors(lsr_handle h, const float* T16, int32_t* idx, float* d2) {
+  LSR_CHECK_HANDLE(h);
+  if (!h->target || h->target->n == 0) return LSR_ERR_NO_TARGET;
+  if (!h->has_source) return LSR_ERR_NO_SOURCE;
+  int st = ensure_target_hash(h);
+  if (st) return st;
+  float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  return nn_search_host(h->source, T16 ? T16 : I16, h->target->hash, idx, d2, h->scratch, h->d_T16, h->stream);
+}
+
+int lsr_ndt_grid_info(lsr_handle h, int32_t* info8) {
+  LSR_CHECK_HANDLE(h);
+  if (!info8) return LSR_ERR_INVALID_ARGUMENT;
+  if (!h->target) return LSR_ERR_NO_TARGET;
+  int st = ensure_ndt_grid(h);
+  if (st) return st;
+  const VoxelGridDev& g = h->target->grid;
+  std::vector<int> keys(g.n_leaves);
+  if (g.n_leaves) LSR_HIP(hipMemcpy(keys.data(), g.leaf_key.p, sizeof(int) * g.n_leaves, hipMemcpyDeviceToHost));
+  int real = 0;
+  for (int k : keys) real += (k >= 0);
+  for (int k = 0; k < 3; k++) { info8[k] = g.min_b[k]; info8[3 + k] = g.max_b[k]; }
+  info8[6] = real;
+  info8[7] = g.n_valid;
+  return LSR_OK;
+}
+
+int lsr_ndt_grid_dump(lsr_handle h, int32_t* idx, int32_t* npts, double* mean, double* icov) {
+  LSR_CHECK_HANDLE(h);
+  if (!h->target) return LSR_ERR_NO_TARGET;
+  int st = ensure_ndt_grid(h);
+  if (st) return st;
+  const VoxelGridDev& g = h->target->grid;
+  const int L = g.n_leaves;
+  if (L == 0) return LSR_OK;
+  std::vector<int> keys(L), cnt(L);
+  std::vector<double> m((size_t)L * 3), ic((size_t)L * 9);
+  LSR_HIP(hipMemcpy(keys.data(), g.leaf_key.p, sizeof(int) * L, hipMemcpyDeviceToHost));
+  LSR_HIP(hipMemcpy(cnt.data(), g.leaf_n.p, sizeof(int) * L, hipMemcpyDeviceToHost));
+  LSR_HIP(hipMemcpy(m.data(), g.mean64.p, sizeof(double) * L * 3, hipMemcpyDeviceToHost));
+  LSR_HIP(hipMemcpy(ic.data(), g.icov64.p, sizeof(double) * L * 9, hipMemcpyDeviceToHost));
+  // leaves are already in ascending key order (radix sort); the non-finite sentinel run has key -1
+  int c = 0;
+  for (int r = 0; r < L; r++) {
+    if (keys[r] < 0) continue;
+    idx[c] = keys[r];
+    npts[c] = cnt[r];
+    for (int k = 0; k < 3; k++) mean[c * 3 + k] = m[(size_t)r * 3 + k];
+    for (int k = 0; k < 9; k++) icov[c * 9 + k] = ic[(size_t)r * 9 + k];
+    c++;
+  }
+  return LSR_OK;
+}
+
+int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int compute_hessian, double* score, double* grad,
+                        double* hess) {
+  LSR_CHECK_HANDLE(h);
+  if (!p6) return LSR_ERR_INVALID_ARGUMENT;
+  if (!h->target || h->target->n == 0) return LSR_ERR_NO_TARGET;
+  if (!h->has_source) return LSR_ERR_NO_SOURCE;
+  int st = ensure_ndt_grid(h);
+  if (st) return st;
+  if ((st = h->d_state.reserve(1))) return st;
+  if ((st = h->h_state.reserve(1))) return st;
+  if ((st = h->d_prob.reserve(1))) return st;
+  if ((st = h->h_prob.reserve(1))) return st;
+  int nb = ndt_nblocks(h->source.n);
+  if ((st = h->d_partials.reserve((size_t)nb * NDT_NRED))) return st;
+  size_t old_cap = h->d_ticket.cap;
+  if ((st = h->d_ticket.reserve(1))) return st;
+  if (h->d_ticket.cap != old_cap) LSR_HIP(hipMemsetAsync(h->d_ticket.p, 0, h->d_ticket.cap * sizeof(unsigned int), h->stream));
+  fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p, h->d_ticket.p);
+  ndt_fill_diag_state(h->h_state.p[0], p6, T16, compute_hessian, h->ndt, (int)h->source.n);
+  LSR_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, sizeof(NdtProblem), hipMemcpyHostToDevice, h->stream));
+  LSR_HIP(hipMemcpyAsync(h->d_state.p, h->h_state.p, sizeof(NdtState), hipMemcpyHostToDevice, h->stream));
+  if ((st = ndt_launch_evals(h->d_prob.p, h->h_prob.p, 1, nb, h->ndt.neighborhood, h->target->grid.dense, 1, h->stream))) return st;
+  LSR_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, sizeof(NdtState), hipMemcpyDeviceToHost, h->stream));
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  const NdtState& S = h->h_state.p[0];
+  if (score) *score = S.score;
+  if (grad) for (int i = 0; i < 6; i++) grad[i] = S.g[i];
+  if (hess) for (int i = 0; i < 36; i++) hess[i] = compute_hessian ? S.H[i] : 0.0;
+  return LSR_OK;
+}
+
+int lsr_gicp_covariances(lsr_handle h, int which, double* cov) {
+  LSR_CHECK_HANDLE(h);
+  if (!cov) return LSR_ERR_INVALID_ARGUMENT;
+  return gicp_get_covariances(h, which, cov);
+}
+
+int lsr_get_profile(lsr_handle h, lsr_profile* out, int reset) {
+  LSR_CHECK_HANDLE(h);
+  if (out) *out = h->prof;
+  if (reset) h->prof = lsr_profile{0, 0, 0, 0};
+  return LSR_OK;
+}
+
+}  // extern "C"

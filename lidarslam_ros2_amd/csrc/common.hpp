@@ -1,0 +1,144 @@
+// Shared host-side plumbing for the gfx950 registration core: error propagation without
+// exceptions across the C ABI, RAII device buffers, and the structs shared by host and device.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/lidarslam_reg.h"
+
+namespace lsr {
+
+void set_last_error(const std::string& s);
+
+struct HipError {
+  hipError_t code;
+};
+
+#define LSR_HIP(expr)                                                                                         \
+  do {                                                                                                        \
+    hipError_t _e = (expr);                                                                                   \
+    if (_e != hipSuccess) {                                                                                   \
+      ::lsr::set_last_error(std::string(#expr) + " -> " + hipGetErrorString(_e) + " (" + __FILE__ + ":" +     \
+                            std::to_string(__LINE__) + ")");                                                  \
+      return LSR_ERR_HIP;                                                                                     \
+    }                                                                                                         \
+  } while (0)
+
+// Growable device allocation (never shrinks; HBM is plentiful: 288 GB per MI355X).
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int reserve(size_t n) {
+    if (n <= cap) return LSR_OK;
+    if (p) LSR_HIP(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    LSR_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return LSR_OK;
+  }
+};
+
+// Pinned host staging buffer.
+template <typename T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  int reserve(size_t n) {
+    if (n <= cap) return LSR_OK;
+    if (p) LSR_HIP(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    LSR_HIP(hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault));
+    cap = n;
+    return LSR_OK;
+  }
+};
+
+// SoA fp32 cloud resident in HBM (x[], y[], z[] planes of one allocation).
+struct DeviceCloud {
+  DevBuf<float> buf;
+  size_t n = 0;
+  float* x() const { return buf.p; }
+  float* y() const { return buf.p + pitch; }
+  float* z() const { return buf.p + 2 * pitch; }
+  size_t pitch = 0;
+  int resize(size_t count) {
+    size_t pt = (count + 63) & ~size_t(63);
+    if (pt == 0) pt = 64;
+    int st = buf.reserve(3 * pt);
+    if (st) return st;
+    pitch = pt;
+    n = count;
+    return LSR_OK;
+  }
+};
+
+// ---- target-side NDT structure (K1/K2 output) ------------------------------------------------
+// One 64-byte record per occupied leaf: {mean.xyz, c00}, {c01, c02, c11, c12}, {c22, n, -, -}, pad.
+struct VoxelGridDev {
+  float leaf = 1.f;
+  int min_b[3] = {0, 0, 0}, max_b[3] = {-1, -1, -1}, div_b[3] = {0, 0, 0};
+  size_t ncells = 0;
+  int n_leaves = 0;        // occupied leaves (any count)
+  int n_valid = 0;         // leaves usable by lookups
+  bool dense = false;      // rec[] indexed by cell (dense) or by leaf slot (compact)
+  DevBuf<int> cell_slot;   // dense [ncells] -> record slot or -1
+  DevBuf<float4> rec;      // [n_leaves * 4]
+  // fp64 copies for inspection/parity (mean 3, icov 9 row-major) + key + count per leaf
+  DevBuf<double> mean64, icov64;
+  DevBuf<int> leaf_key, leaf_n;
+};
+
+// ---- NN hash grid over a cloud (fitness score, GICP) ------------------------------------------
+struct HashGridDev {
+  float cell = 1.f;
+  int mn[3] = {0, 0, 0}, dim[3] = {0, 0, 0};
+  size_t ncells = 0;
+  DevBuf<int> cell_start;  // [ncells + 1]
+  DeviceCloud sorted;      // points in cell order
+  DevBuf<int> order;       // sorted position -> original index
+};
+
+// Per-handle scratch for the target-side builders.
+struct BuildScratch {
+  DevBuf<char> temp;
+  DevBuf<unsigned int> words;
+  DevBuf<double> sums;
+};
+
+struct TargetData {
+  DeviceCloud cloud;
+  size_t n = 0;
+  bool has_grid = false;
+  VoxelGridDev grid;
+  float grid_leaf = 0.f;
+  bool has_hash = false;
+  HashGridDev hash;
+  bool has_cov = false;
+  DevBuf<double> cov;      // GICP: n*9
+  int cov_k = 0;
+  double cov_eps = 0;
+};
+
+}  // namespace lsr

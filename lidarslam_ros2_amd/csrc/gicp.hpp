@@ -1,0 +1,26 @@
+// GICP on gfx950 (replaces pclomp::GeneralizedIterativeClosestPoint).
+#pragma once
+#include "common.hpp"
+
+struct lsr_handle_s;
+
+namespace lsr {
+constexpr int GICP_MAX_K = 32;
+
+struct GicpParamsHost {
+  double max_corr_dist = 5.0;     // corr_dist_threshold_
+  double trans_eps = 5e-4;        // transformation_epsilon_
+  double rot_eps = 2e-3;          // rotation_epsilon_
+  double gicp_eps = 1e-3;         // gicp_epsilon_
+  int max_iterations = 200;
+  int max_inner = 20;
+  int k = 20;
+};
+
+struct GicpWorkspace {
+  DevBuf<double> buf;
+};
+
+int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res);
+int gicp_get_covariances(lsr_handle_s* h, int which, double* cov);
+}  // namespace lsr

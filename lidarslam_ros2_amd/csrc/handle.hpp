@@ -1,0 +1,53 @@
+// The opaque handle behind the C ABI (one registration object = one pcl::Registration instance).
+#pragma once
+#include "common.hpp"
+#include "gicp.hpp"
+#include "ndt.hpp"
+#include "nn.hpp"
+
+struct lsr_handle_s {
+  using NdtParamsHost = lsr::NdtParamsHost; using GicpParamsHost = lsr::GicpParamsHost; using TargetData = lsr::TargetData;
+  using DeviceCloud = lsr::DeviceCloud; using HashGridDev = lsr::HashGridDev; using BuildScratch = lsr::BuildScratch;
+  using NdtState = lsr::NdtState; using NdtProblem = lsr::NdtProblem; using GicpWorkspace = lsr::GicpWorkspace;
+  template <typename T> using DevBuf = lsr::DevBuf<T>;
+  template <typename T> using PinBuf = lsr::PinBuf<T>;
+  int method = LSR_METHOD_NDT;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  NdtParamsHost ndt;
+  GicpParamsHost gicp;
+  bool trans_eps_set = false;
+  bool max_iter_set = false;
+  double euclidean_fitness_eps = -1.7976931348623157e308;
+  int num_threads = 0, ransac_iterations = 0;
+  int profile = 0;
+
+  std::shared_ptr<TargetData> target;
+  DeviceCloud source;
+  bool has_source = false;
+  bool source_cov_valid = false;
+  DevBuf<double> source_cov;  // GICP
+  HashGridDev source_hash;    // GICP (20-NN over the source itself)
+
+  BuildScratch scratch;
+  DevBuf<unsigned char> staging;
+
+  // NDT run-time buffers (batch-capable: the leader of a batch owns arrays for all members)
+  DevBuf<NdtState> d_state;
+  DevBuf<double> d_partials;
+  DevBuf<unsigned int> d_ticket;
+  DevBuf<NdtProblem> d_prob;
+  PinBuf<NdtState> h_state;
+  PinBuf<NdtProblem> h_prob;
+  DevBuf<float> d_T16;
+
+  GicpWorkspace gicp_ws;
+
+  float final_T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  int converged = 0;
+  lsr_profile prof = {0, 0, 0, 0};
+};
+

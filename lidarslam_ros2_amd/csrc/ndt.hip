@@ -1,0 +1,1183 @@
+// NDT kernels for gfx950 (CDNA4).  See ndt.hpp for the decomposition.  Reference behaviour:
+// pclomp::NormalDistributionsTransform / pclomp::VoxelGridCovariance as called from
+// scanmatcher/src/scanmatcher_component.cpp:105-113,275,307,353 and
+// graph_based_slam/src/graph_based_slam_component.cpp:64-72,227,230 — arithmetic restated in
+// SURVEY.md §9 (the ndt_omp sources are not vendored in the reference snapshot).
+//
+// Layout decisions (HBM-side):
+//  * source/target clouds are SoA fp32 planes -> every wave-wide load is one coalesced 256-B burst;
+//  * the voxel table is a dense int32 cell->slot map plus compact 64-B leaf records
+//    {mean.xyz, icov upper triangle} read as three 16-B loads; at the reference resolutions the
+//    whole table (<= a few MB) is L2/Infinity-Cache resident, HBM only streams the source planes;
+//  * the 29 sums of a pass travel: registers -> wave butterfly -> LDS -> one 256-B partial row per
+//    workgroup (write-through) -> last-arriving workgroup sums rows in fixed order (deterministic,
+//    no floating-point atomics).
+#include "ndt.hpp"
+
+#include <cmath>
+
+#include "sort.hpp"
+
+namespace lsr {
+
+// ===========================================================================================
+// Small host/device maths shared by the controller and the host-side state preparation
+// ===========================================================================================
+namespace {
+
+__host__ __device__ inline void angle_tables(const double* p, bool with_hessian, int d1_sign, float* jang, float* hang) {
+  double cx, cy, cz, sx, sy, sz;
+  if (fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(p[3]); sx = sin(p[3]); }
+  if (fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(p[4]); sy = sin(p[4]); }
+  if (fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(p[5]); sz = sin(p[5]); }
+  // rows a..h of eq. 6.19
+  jang[0] = (float)(-sx * sz + cx * sy * cz); jang[1] = (float)(-sx * cz - cx * sy * sz); jang[2] = (float)(-cx * cy);
+  jang[3] = (float)(cx * sz + sx * sy * cz);  jang[4] = (float)(cx * cz - sx * sy * sz);  jang[5] = (float)(-sx * cy);
+  jang[6] = (float)(-sy * cz);                jang[7] = (float)(sy * sz);                 jang[8] = (float)(cy);
+  jang[9] = (float)(sx * cy * cz);            jang[10] = (float)(-sx * cy * sz);          jang[11] = (float)(sx * sy);
+  jang[12] = (float)(-cx * cy * cz);          jang[13] = (float)(cx * cy * sz);           jang[14] = (float)(-cx * sy);
+  jang[15] = (float)(-cy * sz);               jang[16] = (float)(-cy * cz);               jang[17] = 0.f;
+  jang[18] = (float)(cx * cz - sx * sy * sz); jang[19] = (float)(-cx * sz - sx * sy * cz); jang[20] = 0.f;
+  jang[21] = (float)(sx * cz + cx * sy * sz); jang[22] = (float)(cx * sy * cz - sx * sz);  jang[23] = 0.f;
+  if (with_hessian) {
+    // rows a2,a3,b2,b3,c2,c3,d1,d2,d3,e1,e2,e3,f1,f2,f3 of eq. 6.21
+    hang[0] = (float)(-cx * sz - sx * sy * cz); hang[1] = (float)(-cx * cz + sx * sy * sz); hang[2] = (float)(sx * cy);
+    hang[3] = (float)(-sx * sz + cx * sy * cz); hang[4] = (float)(-cx * sy * sz - sx * cz); hang[5] = (float)(-cx * cy);
+    hang[6] = (float)(cx * cy * cz);            hang[7] = (float)(-cx * cy * sz);           hang[8] = (float)(cx * sy);
+    hang[9] = (float)(sx * cy * cz);            hang[10] = (float)(-sx * cy * sz);          hang[11] = (float)(sx * sy);
+    hang[12] = (float)(-sx * cz - cx * sy * sz); hang[13] = (float)(sx * sz - cx * sy * cz); hang[14] = 0.f;
+    hang[15] = (float)(cx * cz - sx * sy * sz); hang[16] = (float)(-sx * sy * cz - cx * sz); hang[17] = 0.f;
+    hang[18] = (float)(-cy * cz);               hang[19] = (float)(cy * sz);                hang[20] = (float)(d1_sign >= 0 ? sy : -sy);
+    hang[21] = (float)(-sx * sy * cz);          hang[22] = (float)(sx * sy * sz);           hang[23] = (float)(sx * cy);
+    hang[24] = (float)(cx * sy * cz);           hang[25] = (float)(-cx * sy * sz);          hang[26] = (float)(-cx * cy);
+    hang[27] = (float)(sy * sz);                hang[28] = (float)(sy * cz);                hang[29] = 0.f;
+    hang[30] = (float)(-sx * cy * sz);          hang[31] = (float)(-sx * cy * cz);          hang[32] = 0.f;
+    hang[33] = (float)(cx * cy * sz);           hang[34] = (float)(cx * cy * cz);           hang[35] = 0.f;
+    hang[36] = (float)(-cy * cz);               hang[37] = (float)(cy * sz);                hang[38] = 0.f;
+    hang[39] = (float)(-cx * sz - sx * sy * cz); hang[40] = (float)(-cx * cz + sx * sy * sz); hang[41] = 0.f;
+    hang[42] = (float)(-sx * sz + cx * sy * cz); hang[43] = (float)(-cx * sy * sz - sx * cz); hang[44] = 0.f;
+    hang[45] = hang[46] = hang[47] = 0.f;
+  }
+}
+
+// fp32 (Translation * Rx * Ry * Rz) exactly as the reference composes Eigen::Affine3f from the
+// float-cast pose vector; T12 row-major 3x4.
+__host__ __device__ inline void pose_to_T12(const double* p, float* T) {
+  float ax = (float)p[3], ay = (float)p[4], az = (float)p[5];
+  float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
+  // A = Rx * Ry
+  float a00 = cy, a01 = 0.f, a02 = sy;
+  float a10 = sx * sy, a11 = cx, a12 = -sx * cy;
+  float a20 = -cx * sy, a21 = sx, a22 = cx * cy;
+  // R = A * Rz
+  T[0] = a00 * cz + a01 * sz; T[1] = -a00 * sz + a01 * cz; T[2] = a02;
+  T[4] = a10 * cz + a11 * sz; T[5] = -a10 * sz + a11 * cz; T[6] = a12;
+  T[8] = a20 * cz + a21 * sz; T[9] = -a20 * sz + a21 * cz; T[10] = a22;
+  T[3] = (float)p[0]; T[7] = (float)p[1]; T[11] = (float)p[2];
+}
+
+__host__ __device__ inline void T12_to_colmajor16(const float* T, float* M) {
+  M[0] = T[0]; M[1] = T[4]; M[2] = T[8];  M[3] = 0.f;
+  M[4] = T[1]; M[5] = T[5]; M[6] = T[9];  M[7] = 0.f;
+  M[8] = T[2]; M[9] = T[6]; M[10] = T[10]; M[11] = 0.f;
+  M[12] = T[3]; M[13] = T[7]; M[14] = T[11]; M[15] = 1.f;
+}
+
+// Eigen 3.4 MatrixBase::eulerAngles(0,1,2) on the fp32 rotation block (host only; used once per align).
+inline void euler012_f(const float* M /*col-major 4x4*/, float* res) {
+  auto c = [&](int r, int cc) { return M[cc * 4 + r]; };
+  const float PI_F = 3.14159265358979323846f;
+  res[0] = atan2f(c(1, 2), c(2, 2));
+  float c2 = sqrtf(c(0, 0) * c(0, 0) + c(0, 1) * c(0, 1));
+  if (res[0] > 0.f) {
+    res[0] -= PI_F;
+    res[1] = atan2f(-c(0, 2), -c2);
+  } else {
+    res[1] = atan2f(-c(0, 2), c2);
+  }
+  float s1 = sinf(res[0]), c1 = cosf(res[0]);
+  res[2] = atan2f(s1 * c(2, 0) - c1 * c(1, 0), c1 * c(1, 1) - s1 * c(2, 1));
+  res[0] = -res[0]; res[1] = -res[1]; res[2] = -res[2];
+}
+
+}  // namespace
+
+void ndt_gauss_constants(double resolution, double outlier_ratio, double* d1, double* d2) {
+  double c1 = 10 * (1 - outlier_ratio);
+  double c2 = outlier_ratio / pow(resolution, 3);
+  double d3 = -log(c2);
+  *d1 = -log(c1 + c2) - d3;
+  *d2 = -2 * log((-log(c1 * exp(-0.5) + c2) - d3) / *d1);
+}
+
+void ndt_fill_align_constants(NdtState& st, const NdtParamsHost& prm, int n_points) {
+  ndt_gauss_constants(prm.resolution, prm.outlier_ratio, &st.d1, &st.d2);
+  st.step_max = prm.step_size;
+  st.step_min = prm.trans_eps / 2;
+  st.eps = prm.trans_eps;
+  st.max_iter = prm.max_iterations;
+  st.n_points = n_points;
+  st.d1_sign = prm.d1_sign;
+}
+
+// Host: state at the entry of computeTransformation: output = guess * input,
+// p from guess (fp32 Euler XYZ), first pass with Hessian.
+void ndt_fill_initial_state(NdtState& st, const float* guess16 /*nullable*/, const NdtParamsHost& prm, int n_points) {
+  std::memset(&st, 0, sizeof(st));
+  ndt_fill_align_constants(st, prm, n_points);
+  float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float* G = guess16 ? guess16 : I16;
+  std::memcpy(st.final_T, G, sizeof(I16));
+  st.T[0] = G[0]; st.T[1] = G[4]; st.T[2] = G[8];  st.T[3] = G[12];
+  st.T[4] = G[1]; st.T[5] = G[5]; st.T[6] = G[9];  st.T[7] = G[13];
+  st.T[8] = G[2]; st.T[9] = G[6]; st.T[10] = G[10]; st.T[11] = G[14];
+  float e[3];
+  euler012_f(G, e);
+  st.p[0] = G[12]; st.p[1] = G[13]; st.p[2] = G[14];
+  st.p[3] = e[0]; st.p[4] = e[1]; st.p[5] = e[2];
+  for (int i = 0; i < 6; i++) st.x_t[i] = st.p[i];
+  angle_tables(st.p, true, st.d1_sign, st.jang, st.hang);
+  st.want_hessian = 1;
+  st.phase = PH_INIT;
+  st.done = 0;
+}
+
+void ndt_fill_diag_state(NdtState& st, const double* p6, const float* T16, int compute_hessian, const NdtParamsHost& prm,
+                         int n_points) {
+  std::memset(&st, 0, sizeof(st));
+  ndt_fill_align_constants(st, prm, n_points);
+  for (int i = 0; i < 6; i++) st.p[i] = st.x_t[i] = p6[i];
+  if (T16) {
+    st.T[0] = T16[0]; st.T[1] = T16[4]; st.T[2] = T16[8];  st.T[3] = T16[12];
+    st.T[4] = T16[1]; st.T[5] = T16[5]; st.T[6] = T16[9];  st.T[7] = T16[13];
+    st.T[8] = T16[2]; st.T[9] = T16[6]; st.T[10] = T16[10]; st.T[11] = T16[14];
+  } else {
+    pose_to_T12(p6, st.T);
+  }
+  angle_tables(p6, true, st.d1_sign, st.jang, st.hang);
+  st.want_hessian = compute_hessian ? 1 : 0;
+  st.phase = PH_DIAG;
+}
+
+// ===========================================================================================
+// K3 + K4: derivative pass with fused controller
+// ===========================================================================================
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// The controller works on an LDS image of NdtState: typed LDS pointers let the compiler emit ds_read /
+// ds_write instead of flat accesses even though the controller is not inlined into the kernel.
+typedef __attribute__((address_space(3))) NdtState LdsState;
+typedef __attribute__((address_space(3))) double LdsDouble;
+
+// ---- More-Thuente helpers ----
+__device__ __forceinline__ double mt_trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t,
+                                 double f_t, double g_t) {
+  if (f_t > f_l) {
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    if (fabs(a_c - a_l) < fabs(a_q - a_l)) return a_c;
+    return 0.5 * (a_q + a_c);
+  } else if (g_t * g_l < 0) {
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    if (fabs(a_c - a_t) >= fabs(a_s - a_t)) return a_c;
+    return a_s;
+  } else if (fabs(g_t) <= fabs(g_l)) {
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    double a_n = (fabs(a_c - a_t) < fabs(a_s - a_t)) ? a_c : a_s;
+    if (a_t > a_l) return fmin(a_t + 0.66 * (a_u - a_t), a_n);
+    return fmax(a_t + 0.66 * (a_u - a_t), a_n);
+  } else {
+    double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
+    double w = sqrt(z * z - g_t * g_u);
+    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+  }
+}
+
+__device__ __forceinline__ bool mt_update_interval(LdsState* S, double a_t, double f_t, double g_t) {
+  if (f_t > S->f_l) {
+    S->a_u = a_t; S->f_u = f_t; S->g_u = g_t;
+    return false;
+  } else if (g_t * (S->a_l - a_t) > 0) {
+    S->a_l = a_t; S->f_l = f_t; S->g_l = g_t;
+    return false;
+  } else if (g_t * (S->a_l - a_t) < 0) {
+    S->a_u = S->a_l; S->f_u = S->f_l; S->g_u = S->g_l;
+    S->a_l = a_t; S->f_l = f_t; S->g_l = g_t;
+    return false;
+  }
+  return true;
+}
+
+// delta = H^{-1} b by Gaussian elimination with partial pivoting, entirely in registers (every loop
+// fully unrolled, row swaps by select).  The reference calls JacobiSVD::solve; for a non-singular 6x6
+// both give H^{-1} b.  A column whose pivot vanishes is dropped = its unknown set to 0, which is the
+// SVD's minimum-norm answer for the degenerate all-zero Hessian of a scan that overlaps no voxel.
+__device__ __forceinline__ void solve6(const LdsDouble* H, const double* __restrict__ b, double* __restrict__ x) {
+  double A[6][7];
+  double scale = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      A[i][j] = H[i * 6 + j];
+      scale = fmax(scale, fabs(A[i][j]));
+    }
+    A[i][6] = b[i];
+  }
+  unsigned int dropped = 0u;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    // pivot search over rows k..5, then bring the pivot row to position k by selects
+    double best = fabs(A[k][k]);
+    int piv = k;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double v = fabs(A[i][k]);
+      if (v > best) { best = v; piv = i; }
+    }
+    if (!(best > scale * 1e-300) || !(best > 0)) { dropped |= (1u << k); continue; }
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const bool sw = (piv == i);
+#pragma unroll
+      for (int j = k; j < 7; j++) {
+        const double a = A[k][j], c = A[i][j];
+        A[k][j] = sw ? c : a;
+        A[i][j] = sw ? a : c;
+      }
+    }
+    const double inv = 1.0 / A[k][k];
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double f = A[i][k] * inv;
+#pragma unroll
+      for (int j = k + 1; j < 7; j++) A[i][j] -= f * A[k][j];
+    }
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; k--) {
+    double sacc = A[k][6];
+#pragma unroll
+    for (int j = k + 1; j < 6; j++) sacc -= A[k][j] * x[j];
+    x[k] = (dropped & (1u << k)) ? 0.0 : sacc / A[k][k];
+  }
+}
+
+// Mark the next evaluation request for pose x_t; the transform / angle tables themselves are built
+// by build_request() right after the controller returns, spread over several lanes.
+__device__ __forceinline__ void request_eval(LdsState* S, int want_hessian, bool refresh_hang, int phase) {
+  S->want_hessian = want_hessian;
+  S->phase = phase;
+  S->pad1 = refresh_hang ? 3 : 1;  // bit0: build T/jang for x_t, bit1: also hang
+}
+
+// Executed by ALL threads of the last workgroup (uniform control flow, two barriers).
+// lanes 0-2: fp64 sin/cos of the three angles (with the reference's 1e-4 snap), lanes 3-5: fp32 sin/cos
+// (the reference composes the point transform from float-cast angles); then four lanes fill
+// jang / hang(lo) / hang(hi) / T + final_T.
+__device__ void build_request(NdtState* S, double* cs_d /*6*/, float* cs_f /*6*/) {
+  const int tid = threadIdx.x;
+  const int mode = S->pad1;
+  if (mode == 0) return;  // uniform: every thread reads the same LDS word
+  if (tid < 3) {
+    const double a = S->x_t[3 + tid];
+    double sn, cn;
+    if (fabs(a) < 10e-5) { cn = 1.0; sn = 0.0; } else { sincos(a, &sn, &cn); }
+    cs_d[tid] = cn;
+    cs_d[3 + tid] = sn;
+  } else if (tid < 6) {
+    const float a = (float)S->x_t[tid];
+    float sn, cn;
+    sincosf(a, &sn, &cn);
+    cs_f[tid - 3] = cn;
+    cs_f[tid] = sn;
+  }
+  __syncthreads();
+  const double cx = cs_d[0], cy = cs_d[1], cz = cs_d[2], sx = cs_d[3], sy = cs_d[4], sz = cs_d[5];
+  if (tid == 0) {
+    float* jang = S->jang;
+    jang[0] = (float)(-sx * sz + cx * sy * cz); jang[1] = (float)(-sx * cz - cx * sy * sz); jang[2] = (float)(-cx * cy);
+    jang[3] = (float)(cx * sz + sx * sy * cz);  jang[4] = (float)(cx * cz - sx * sy * sz);  jang[5] = (float)(-sx * cy);
+    jang[6] = (float)(-sy * cz);                jang[7] = (float)(sy * sz);                 jang[8] = (float)(cy);
+    jang[9] = (float)(sx * cy * cz);            jang[10] = (float)(-sx * cy * sz);          jang[11] = (float)(sx * sy);
+    jang[12] = (float)(-cx * cy * cz);          jang[13] = (float)(cx * cy * sz);           jang[14] = (float)(-cx * sy);
+    jang[15] = (float)(-cy * sz);               jang[16] = (float)(-cy * cz);               jang[17] = 0.f;
+    jang[18] = (float)(cx * cz - sx * sy * sz); jang[19] = (float)(-cx * sz - sx * sy * cz); jang[20] = 0.f;
+    jang[21] = (float)(sx * cz + cx * sy * sz); jang[22] = (float)(cx * sy * cz - sx * sz);  jang[23] = 0.f;
+    S->pad1 = 0;
+  } else if (tid == 64 && (mode & 2)) {
+    float* hang = S->hang;
+    hang[0] = (float)(-cx * sz - sx * sy * cz); hang[1] = (float)(-cx * cz + sx * sy * sz); hang[2] = (float)(sx * cy);
+    hang[3] = (float)(-sx * sz + cx * sy * cz); hang[4] = (float)(-cx * sy * sz - sx * cz); hang[5] = (float)(-cx * cy);
+    hang[6] = (float)(cx * cy * cz);            hang[7] = (float)(-cx * cy * sz);           hang[8] = (float)(cx * sy);
+    hang[9] = (float)(sx * cy * cz);            hang[10] = (float)(-sx * cy * sz);          hang[11] = (float)(sx * sy);
+    hang[12] = (float)(-sx * cz - cx * sy * sz); hang[13] = (float)(sx * sz - cx * sy * cz); hang[14] = 0.f;
+    hang[15] = (float)(cx * cz - sx * sy * sz); hang[16] = (float)(-sx * sy * cz - cx * sz); hang[17] = 0.f;
+    hang[18] = (float)(-cy * cz);               hang[19] = (float)(cy * sz);                hang[20] = (float)(S->d1_sign >= 0 ? sy : -sy);
+    hang[21] = (float)(-sx * sy * cz);          hang[22] = (float)(sx * sy * sz);           hang[23] = (float)(sx * cy);
+  } else if (tid == 128 && (mode & 2)) {
+    float* hang = S->hang;
+    hang[24] = (float)(cx * sy * cz);           hang[25] = (float)(-cx * sy * sz);          hang[26] = (float)(-cx * cy);
+    hang[27] = (float)(sy * sz);                hang[28] = (float)(sy * cz);                hang[29] = 0.f;
+    hang[30] = (float)(-sx * cy * sz);          hang[31] = (float)(-sx * cy * cz);          hang[32] = 0.f;
+    hang[33] = (float)(cx * cy * sz);           hang[34] = (float)(cx * cy * cz);           hang[35] = 0.f;
+    hang[36] = (float)(-cy * cz);               hang[37] = (float)(cy * sz);                hang[38] = 0.f;
+    hang[39] = (float)(-cx * sz - sx * sy * cz); hang[40] = (float)(-cx * cz + sx * sy * sz); hang[41] = 0.f;
+    hang[42] = (float)(-sx * sz + cx * sy * cz); hang[43] = (float)(-cx * sy * sz - sx * cz); hang[44] = 0.f;
+    hang[45] = hang[46] = hang[47] = 0.f;
+  } else if (tid == 192) {
+    // fp32 (Translation * Rx * Ry * Rz), as pose_to_T12
+    const float fcx = cs_f[0], fcy = cs_f[1], fcz = cs_f[2], fsx = cs_f[3], fsy = cs_f[4], fsz = cs_f[5];
+    const float a00 = fcy, a02 = fsy;
+    const float a10 = fsx * fsy, a11 = fcx, a12 = -fsx * fcy;
+    const float a20 = -fcx * fsy, a21 = fsx, a22 = fcx * fcy;
+    float* T = S->T;
+    T[0] = a00 * fcz; T[1] = -a00 * fsz; T[2] = a02;
+    T[4] = a10 * fcz + a11 * fsz; T[5] = -a10 * fsz + a11 * fcz; T[6] = a12;
+    T[8] = a20 * fcz + a21 * fsz; T[9] = -a20 * fsz + a21 * fcz; T[10] = a22;
+    T[3] = (float)S->x_t[0]; T[7] = (float)S->x_t[1]; T[11] = (float)S->x_t[2];
+    T12_to_colmajor16(T, S->final_T);  // final_transformation_ is assigned before every MT pass
+  }
+  __syncthreads();
+}
+
+// K4: consume the sums of the pass that just finished and decide what happens next.
+// Runs on one lane of the last-arriving workgroup.  sums: [0]=score [1..6]=grad [7]=pairs [8..28]=H upper.
+__device__ __attribute__((noinline)) void ndt_controller(LdsState* S, const LdsDouble* sums) {
+  const double mu = 1.e-4, nu = 0.9;
+  const int max_step_iterations = 10;
+  S->n_evals++;
+  S->last_pairs = sums[7];
+  const int phase = S->phase;
+  const bool had_hessian = S->want_hessian != 0;
+  if (phase != PH_MT_HESS) {
+    S->score = sums[0];
+    for (int i = 0; i < 6; i++) S->g[i] = sums[1 + i];
+  }
+  if (had_hessian) {
+    int k = 8;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) {
+        S->H[i * 6 + j] = sums[k];
+        S->H[j * 6 + i] = sums[k];
+        k++;
+      }
+  }
+  if (phase == PH_DIAG) {
+    S->done = 1;
+    return;
+  }
+
+  enum { ST_NEWTON_BEGIN, ST_MT_CHECK, ST_NEWTON_END, ST_FINISH } stage;
+  double phi_t = 0, d_phi_t = 0, psi_t = 0, d_psi_t = 0;
+  if (phase == PH_INIT) {
+    stage = ST_NEWTON_BEGIN;
+  } else if (phase == PH_MT_HESS) {
+    stage = ST_NEWTON_END;
+  } else {
+    phi_t = -S->score;
+    double dot = 0;
+    for (int i = 0; i < 6; i++) dot += S->g[i] * S->dir[i];
+    d_phi_t = -dot;
+    psi_t = phi_t - S->phi_0 - mu * S->d_phi_0 * S->a_t;
+    d_psi_t = d_phi_t - mu * S->d_phi_0;
+    if (phase == PH_MT_TRIAL) {
+      if (S->open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+        S->open_interval = 0;
+        S->f_l = S->f_l + S->phi_0 - mu * S->d_phi_0 * S->a_l;
+        S->g_l = S->g_l + mu * S->d_phi_0;
+        S->f_u = S->f_u + S->phi_0 - mu * S->d_phi_0 * S->a_u;
+        S->g_u = S->g_u + mu * S->d_phi_0;
+      }
+      if (S->open_interval)
+        S->interval_converged = mt_update_interval(S, S->a_t, psi_t, d_psi_t) ? 1 : 0;
+      else
+        S->interval_converged = mt_update_interval(S, S->a_t, phi_t, d_phi_t) ? 1 : 0;
+      S->step_iterations++;
+    }
+    stage = ST_MT_CHECK;
+  }
+
+  for (int guard = 0; guard < 8; guard++) {
+    if (stage == ST_NEWTON_BEGIN) {
+      double neg_g[6], delta[6];
+      for (int i = 0; i < 6; i++) neg_g[i] = -S->g[i];
+      solve6(S->H, neg_g, delta);
+      double nrm = 0;
+      for (int i = 0; i < 6; i++) nrm += delta[i] * delta[i];
+      nrm = sqrt(nrm);
+      if (nrm == 0 || nrm != nrm) {
+        S->converged = (nrm == nrm) ? 1 : 0;
+        stage = ST_FINISH;
+        continue;
+      }
+      for (int i = 0; i < 6; i++) S->dir[i] = delta[i] / nrm;
+      // ---- computeStepLengthMT prologue
+      S->phi_0 = -S->score;
+      double dot = 0;
+      for (int i = 0; i < 6; i++) dot += S->g[i] * S->dir[i];
+      S->d_phi_0 = -dot;
+      if (S->d_phi_0 >= 0) {
+        if (S->d_phi_0 == 0) {
+          S->a_t = 0;
+          stage = ST_NEWTON_END;
+          continue;
+        }
+        S->d_phi_0 = -S->d_phi_0;
+        for (int i = 0; i < 6; i++) S->dir[i] = -S->dir[i];
+      }
+      S->a_l = 0; S->a_u = 0;
+      S->f_l = 0; S->f_u = 0;  // psi(0) = phi_0 - phi_0 - mu*d_phi_0*0
+      S->g_l = S->d_phi_0 - mu * S->d_phi_0;
+      S->g_u = S->g_l;
+      S->interval_converged = (S->step_max - S->step_min) < 0 ? 1 : 0;
+      S->open_interval = 1;
+      S->step_iterations = 0;
+      double a_t = fmin(nrm, S->step_max);
+      a_t = fmax(a_t, S->step_min);
+      S->a_t = a_t;
+      for (int i = 0; i < 6; i++) S->x_t[i] = S->p[i] + S->dir[i] * a_t;
+      request_eval(S, 1, true, PH_MT_FIRST);
+      return;
+    } else if (stage == ST_MT_CHECK) {
+      if (!S->interval_converged && S->step_iterations < max_step_iterations &&
+          !(psi_t <= 0 && d_phi_t <= -nu * S->d_phi_0)) {
+        double a_t;
+        if (S->open_interval)
+          a_t = mt_trial_value(S->a_l, S->f_l, S->g_l, S->a_u, S->f_u, S->g_u, S->a_t, psi_t, d_psi_t);
+        else
+          a_t = mt_trial_value(S->a_l, S->f_l, S->g_l, S->a_u, S->f_u, S->g_u, S->a_t, phi_t, d_phi_t);
+        a_t = fmin(a_t, S->step_max);
+        a_t = fmax(a_t, S->step_min);
+        S->a_t = a_t;
+        for (int i = 0; i < 6; i++) S->x_t[i] = S->p[i] + S->dir[i] * a_t;
+        request_eval(S, 0, false, PH_MT_TRIAL);
+        return;
+      }
+      if (S->step_iterations) {
+        // computeHessian at x_t: current j_ang, h_ang left over from the last with-Hessian pass.
+        S->want_hessian = 1;
+        S->phase = PH_MT_HESS;
+        return;
+      }
+      stage = ST_NEWTON_END;
+    } else if (stage == ST_NEWTON_END) {
+      for (int i = 0; i < 6; i++) S->p[i] += S->dir[i] * S->a_t;
+      if (S->nr_iterations > S->max_iter || (S->nr_iterations && (fabs(S->a_t) < S->eps))) S->converged = 1;
+      S->nr_iterations++;
+      stage = S->converged ? ST_FINISH : ST_NEWTON_BEGIN;
+    } else {  // ST_FINISH
+      S->trans_probability = S->score / (double)S->n_points;
+      S->done = 1;
+      return;
+    }
+  }
+  // unreachable in practice (the a_t == 0 path converges after two rounds)
+  S->trans_probability = S->score / (double)S->n_points;
+  S->done = 1;
+}
+
+#ifdef LSR_TIMING
+__device__ long long* g_lsr_timing = nullptr;  // [blocks][16] {wall, shader} pairs
+#define LSR_STAMP(k)                                                                   \
+  if (threadIdx.x == 0 && g_lsr_timing && blockIdx.y == 0) {                            \
+    g_lsr_timing[blockIdx.x * 32 + 2 * (k)] = (long long)wall_clock64();                \
+    g_lsr_timing[blockIdx.x * 32 + 2 * (k) + 1] = (long long)clock64();                 \
+  }
+#else
+#define LSR_STAMP(k)
+#endif
+
+template <int NOFF>
+struct Offsets;
+template <>
+struct Offsets<1> {
+  static __device__ __forceinline__ void get(int o, int& dx, int& dy, int& dz) { dx = dy = dz = 0; }
+};
+template <>
+struct Offsets<7> {
+  static __device__ __forceinline__ void get(int o, int& dx, int& dy, int& dz) {
+    dx = (o == 1) - (o == 2);
+    dy = (o == 3) - (o == 4);
+    dz = (o == 5) - (o == 6);
+  }
+};
+template <>
+struct Offsets<27> {
+  static __device__ __forceinline__ void get(int o, int& dx, int& dy, int& dz) {
+    dx = o / 9 - 1;
+    dy = (o / 3) % 3 - 1;
+    dz = o % 3 - 1;
+  }
+};
+
+// One derivative pass (K3) with the fused controller epilogue (K4).
+//  BYVAL: a single-registration launch carries its NdtProblem in the kernel arguments, which removes
+//         one dependent memory round trip from the latency chain of every pass.
+//  DENSE: leaf records are stored per grid cell (no cell->slot indirection): one dependent gather
+//         less per point; chosen when the dense table is small enough (ndt_build_grid).
+template <int NOFF, bool BYVAL, bool DENSE>
+__global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs) {
+  const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
+  if ((int)blockIdx.x >= P.nblocks) return;
+  NdtState* __restrict__ S = P.st;
+  const int tid = threadIdx.x;
+  LSR_STAMP(0)
+
+  // LDS: [value][thread] transpose buffer (row pitch 264 doubles: column writes and the strided row
+  // reads below are both bank-conflict free for ds_*_b64).  The epilogue of the last workgroup
+  // re-uses the same bytes for its row sums and for an LDS copy of the controller state.
+  __shared__ double s_raw[29 * NDT_RED_PITCH];
+  __shared__ double s_sum[NDT_NRED];
+  __shared__ double s_lu[8][8];  // rows 0-5: LU scratch, 6: -g, 7: delta
+  __shared__ int s_last;
+  double(*s_part)[NDT_RED_PITCH] = reinterpret_cast<double(*)[NDT_RED_PITCH]>(s_raw);
+
+  // Issue the first point loads and the request loads together, THEN look at `done`.
+  const int stride = P.nblocks * NDT_THREADS;
+  int i = blockIdx.x * NDT_THREADS + tid;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
+  const int done = S->done;
+  const bool hess = S->want_hessian != 0;
+  const double d1d = S->d1;
+  const float d2 = (float)S->d2;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = S->T[k];
+  if (done) return;
+  LSR_STAMP(1)
+  const float leaf = P.leaf;
+
+  double acc[29];
+#pragma unroll
+  for (int k = 0; k < 29; k++) acc[k] = 0.0;
+
+  while (i < P.n) {
+    const float tx = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
+    const float ty = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
+    const float tz = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
+    // DIRECT-N neighbourhood of the TRANSFORMED point: floor(x'/leaf) in fp32.
+    const float fx = floorf(tx / leaf), fy = floorf(ty / leaf), fz = floorf(tz / leaf);
+    // NaN / far-out-of-range points land outside the grid and contribute nothing.
+    const bool finite_ok = (fabsf(fx) < 1.0e9f) && (fabsf(fy) < 1.0e9f) && (fabsf(fz) < 1.0e9f);
+    const int ci = finite_ok ? (int)fx : INT_MIN / 2, cj = finite_ok ? (int)fy : INT_MIN / 2, ck = finite_ok ? (int)fz : INT_MIN / 2;
+
+    int slot[NOFF];
+#pragma unroll
+    for (int o = 0; o < NOFF; o++) {
+      int dx, dy, dz;
+      Offsets<NOFF>::get(o, dx, dy, dz);
+      const int a = ci + dx, b = cj + dy, c = ck + dz;
+      const bool in = (a >= P.min_b[0]) & (a <= P.max_b[0]) & (b >= P.min_b[1]) & (b <= P.max_b[1]) &
+                      (c >= P.min_b[2]) & (c <= P.max_b[2]);
+      int sidx = -1;
+      if (in) {
+        const int cell = (a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2;
+        sidx = DENSE ? cell : P.cell_slot[cell];
+      }
+      slot[o] = sidx;
+    }
+
+    float score = 0.f, npairs = 0.f;
+    float A0 = 0.f, A1 = 0.f, A2 = 0.f;                                      // sum w * C q
+    float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;  // sum w * (C - d2 Cq Cq^T)
+#pragma unroll
+    for (int o = 0; o < NOFF; o++) {
+      if (slot[o] < 0) continue;
+      const float4 r0 = P.rec[(size_t)slot[o] * 4 + 0];
+      const float4 r1 = P.rec[(size_t)slot[o] * 4 + 1];
+      const float4 r2 = P.rec[(size_t)slot[o] * 4 + 2];
+      if (DENSE && !(r2.y >= 6.f)) continue;  // empty / under-populated / invalidated cell
+      const float q0 = tx - r0.x, q1 = ty - r0.y, q2 = tz - r0.z;
+      const float c00 = r0.w, c01 = r1.x, c02 = r1.y, c11 = r1.z, c12 = r1.w, c22 = r2.x;
+      const float Cq0 = fmaf(c00, q0, fmaf(c01, q1, c02 * q2));
+      const float Cq1 = fmaf(c01, q0, fmaf(c11, q1, c12 * q2));
+      const float Cq2 = fmaf(c02, q0, fmaf(c12, q1, c22 * q2));
+      const float qCq = fmaf(q0, Cq0, fmaf(q1, Cq1, q2 * Cq2));
+      const float e = expf(-d2 * qCq * 0.5f);
+      float w = d2 * e;
+      // ndt_omp drops the whole pair (score included) when d2*e is outside [0,1] or NaN
+      if (!(w <= 1.f) || !(w >= 0.f)) continue;
+      score += (float)(-d1d * (double)e);
+      npairs += 1.f;
+      w = (float)((double)w * d1d);
+      A0 = fmaf(w, Cq0, A0); A1 = fmaf(w, Cq1, A1); A2 = fmaf(w, Cq2, A2);
+      if (hess) {
+        const float wd = -w * d2;
+        E00 += fmaf(wd * Cq0, Cq0, w * c00);
+        E01 += fmaf(wd * Cq0, Cq1, w * c01);
+        E02 += fmaf(wd * Cq0, Cq2, w * c02);
+        E11 += fmaf(wd * Cq1, Cq1, w * c11);
+        E12 += fmaf(wd * Cq1, Cq2, w * c12);
+        E22 += fmaf(wd * Cq2, Cq2, w * c22);
+      }
+    }
+    const float px = x, py = y, pz = z;
+    i += stride;
+    if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }   // next point's loads fly under the maths below
+    if (npairs == 0.f) continue;
+
+    // Point Jacobian J = [I | J3 J4 J5] from the UNTRANSFORMED point (eq. 6.18/6.19)
+    const float* ja = S->jang;
+    const float j_a = fmaf(ja[0], px, fmaf(ja[1], py, ja[2] * pz));
+    const float j_b = fmaf(ja[3], px, fmaf(ja[4], py, ja[5] * pz));
+    const float j_c = fmaf(ja[6], px, fmaf(ja[7], py, ja[8] * pz));
+    const float j_d = fmaf(ja[9], px, fmaf(ja[10], py, ja[11] * pz));
+    const float j_e = fmaf(ja[12], px, fmaf(ja[13], py, ja[14] * pz));
+    const float j_f = fmaf(ja[15], px, ja[16] * py);
+    const float j_g = fmaf(ja[18], px, ja[19] * py);
+    const float j_h = fmaf(ja[21], px, ja[22] * py);
+    // J3 = (0, a, b), J4 = (c, d, e), J5 = (f, g, h)
+    acc[0] += (double)score;
+    acc[1] += (double)A0;
+    acc[2] += (double)A1;
+    acc[3] += (double)A2;
+    acc[4] += (double)fmaf(A1, j_a, A2 * j_b);
+    acc[5] += (double)fmaf(A0, j_c, fmaf(A1, j_d, A2 * j_e));
+    acc[6] += (double)fmaf(A0, j_f, fmaf(A1, j_g, A2 * j_h));
+    acc[7] += (double)npairs;
+    if (hess) {
+      // E J_k for k = 3,4,5
+      const float e3x = fmaf(E01, j_a, E02 * j_b), e3y = fmaf(E11, j_a, E12 * j_b), e3z = fmaf(E12, j_a, E22 * j_b);
+      const float e4x = fmaf(E00, j_c, fmaf(E01, j_d, E02 * j_e)), e4y = fmaf(E01, j_c, fmaf(E11, j_d, E12 * j_e)),
+                  e4z = fmaf(E02, j_c, fmaf(E12, j_d, E22 * j_e));
+      const float e5x = fmaf(E00, j_f, fmaf(E01, j_g, E02 * j_h)), e5y = fmaf(E01, j_f, fmaf(E11, j_g, E12 * j_h)),
+                  e5z = fmaf(E02, j_f, fmaf(E12, j_g, E22 * j_h));
+      const float* ha = S->hang;
+      // second-derivative vectors (eq. 6.20/6.21) dotted with A = sum w C q
+      const float ha2 = fmaf(ha[0], px, fmaf(ha[1], py, ha[2] * pz)), ha3 = fmaf(ha[3], px, fmaf(ha[4], py, ha[5] * pz));
+      const float hb2 = fmaf(ha[6], px, fmaf(ha[7], py, ha[8] * pz)), hb3 = fmaf(ha[9], px, fmaf(ha[10], py, ha[11] * pz));
+      const float hc2 = fmaf(ha[12], px, ha[13] * py), hc3 = fmaf(ha[15], px, ha[16] * py);
+      const float hd1 = fmaf(ha[18], px, fmaf(ha[19], py, ha[20] * pz)), hd2 = fmaf(ha[21], px, fmaf(ha[22], py, ha[23] * pz)),
+                  hd3 = fmaf(ha[24], px, fmaf(ha[25], py, ha[26] * pz));
+      const float he1 = fmaf(ha[27], px, ha[28] * py), he2 = fmaf(ha[30], px, ha[31] * py), he3 = fmaf(ha[33], px, ha[34] * py);
+      const float hf1 = fmaf(ha[36], px, ha[37] * py), hf2 = fmaf(ha[39], px, ha[40] * py), hf3 = fmaf(ha[42], px, ha[43] * py);
+      // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+      acc[8] += (double)E00;  acc[9] += (double)E01;  acc[10] += (double)E02;
+      acc[11] += (double)e3x; acc[12] += (double)e4x; acc[13] += (double)e5x;
+      acc[14] += (double)E11; acc[15] += (double)E12;
+      acc[16] += (double)e3y; acc[17] += (double)e4y; acc[18] += (double)e5y;
+      acc[19] += (double)E22;
+      acc[20] += (double)e3z; acc[21] += (double)e4z; acc[22] += (double)e5z;
+      acc[23] += (double)(fmaf(j_a, e3y, j_b * e3z) + fmaf(A1, ha2, A2 * ha3));                       // (3,3)
+      acc[24] += (double)(fmaf(j_a, e4y, j_b * e4z) + fmaf(A1, hb2, A2 * hb3));                       // (3,4)
+      acc[25] += (double)(fmaf(j_a, e5y, j_b * e5z) + fmaf(A1, hc2, A2 * hc3));                       // (3,5)
+      acc[26] += (double)(fmaf(j_c, e4x, fmaf(j_d, e4y, j_e * e4z)) + fmaf(A0, hd1, fmaf(A1, hd2, A2 * hd3)));  // (4,4)
+      acc[27] += (double)(fmaf(j_c, e5x, fmaf(j_d, e5y, j_e * e5z)) + fmaf(A0, he1, fmaf(A1, he2, A2 * he3)));  // (4,5)
+      acc[28] += (double)(fmaf(j_f, e5x, fmaf(j_g, e5y, j_h * e5z)) + fmaf(A0, hf1, fmaf(A1, hf2, A2 * hf3)));  // (5,5)
+    }
+  }
+
+  LSR_STAMP(2)
+  // ---- workgroup reduction: registers -> LDS transpose -> 8 segment sums per value -> partial row
+  const int nred = hess ? 29 : NDT_NRED_GRAD;
+#pragma unroll
+  for (int k = 0; k < 29; k++)
+    if (k < nred) s_part[k][tid] = acc[k];
+  __syncthreads();
+  double* prow = P.partials + (size_t)blockIdx.x * NDT_NRED;
+  {
+    const int v = tid >> 3, seg = tid & 7;  // 32 values x 8 interleaved segments
+    double t = 0.0;
+    if (v < nred) {
+#pragma unroll 8
+      for (int k = 0; k < NDT_THREADS / 8; k++) t += s_part[v][seg + 8 * k];
+    }
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 4, 64);
+    // write-through store so the row is visible to whichever workgroup arrives last
+    if (seg == 0 && v < nred) __hip_atomic_store(prow + v, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  LSR_STAMP(3)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  LSR_STAMP(4)
+  if (tid == 0) {
+    unsigned int prev = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (prev == (unsigned int)(P.nblocks - 1)) ? 1 : 0;
+  }
+  __syncthreads();
+  LSR_STAMP(5)
+  if (!s_last) return;
+
+  // ---- last workgroup: fixed-order sum of all partial rows + controller on an LDS copy of the state
+  constexpr int STATE_DW = (int)(sizeof(NdtState) / 4);
+  static_assert(sizeof(NdtState) % 4 == 0 && STATE_DW <= 2 * NDT_THREADS, "NdtState copy assumes <= 512 dwords");
+  double(*s_grp)[NDT_NRED] = reinterpret_cast<double(*)[NDT_NRED]>(s_raw);        // [8][32] doubles
+  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_raw + 8 * NDT_NRED);  // NdtState image
+  {
+    const unsigned int* gdw = reinterpret_cast<const unsigned int*>(S);
+    const unsigned int st0 = (tid < STATE_DW) ? gdw[tid] : 0u;
+    const unsigned int st1 = (tid + NDT_THREADS < STATE_DW) ? gdw[tid + NDT_THREADS] : 0u;
+    const int v = tid & 31, grp = tid >> 5;  // 8 groups x 32 values; group g owns rows g, g+8, g+16, ...
+    double sum = 0.0;
+    if (v < nred) {
+      const double* base = P.partials + v;
+      for (int b0 = grp; b0 < P.nblocks; b0 += 128) {  // 16 independent loads in flight, fixed summation tree
+        double r[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int b = b0 + 8 * k;
+          r[k] = (b < P.nblocks)
+                     ? __hip_atomic_load(base + (size_t)b * NDT_NRED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     : 0.0;
+        }
+        sum += (((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))) +
+               (((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15])));
+      }
+    }
+    __syncthreads();  // every thread is done with s_part before its bytes are re-used
+    s_grp[grp][v] = sum;
+    if (tid < STATE_DW) s_state[tid] = st0;
+    if (tid + NDT_THREADS < STATE_DW) s_state[tid + NDT_THREADS] = st1;
+    __syncthreads();
+    if (tid < NDT_NRED) {
+      double t = 0.0;
+      if (tid < nred)
+        for (int g2 = 0; g2 < NDT_THREADS / 32; g2++) t += s_grp[g2][tid];
+      s_sum[tid] = t;
+    }
+    __syncthreads();
+  }
+  LSR_STAMP(6)
+  if (tid == 0) {
+    __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ndt_controller((LdsState*)(s_state), (const LdsDouble*)s_sum);
+  }
+  __syncthreads();
+  build_request(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[1][0]));
+  {
+    unsigned int* gdw = reinterpret_cast<unsigned int*>(S);
+    if (tid < STATE_DW) gdw[tid] = s_state[tid];
+    if (tid + NDT_THREADS < STATE_DW) gdw[tid + NDT_THREADS] = s_state[tid + NDT_THREADS];
+  }
+  LSR_STAMP(7)
+}
+
+#ifdef LSR_TIMING
+}  // namespace
+extern "C" int lsr_debug_timing_buffer(long long** out) {
+  static long long* buf = nullptr;
+  if (!buf) {
+    if (hipMalloc((void**)&buf, 1024 * 32 * sizeof(long long)) != hipSuccess) return -1;
+    (void)hipMemset(buf, 0, 1024 * 32 * sizeof(long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lsr_timing), &buf, sizeof(buf));
+  }
+  *out = buf;
+  return 0;
+}
+namespace {
+#endif
+
+}  // namespace
+
+template <int NOFF>
+static void launch_one(bool byval, bool dense, dim3 grid, dim3 block, hipStream_t stream, const NdtProblem& pv,
+                       const NdtProblem* d_probs) {
+  if (byval) {
+    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, true>), grid, block, 0, stream, pv, d_probs);
+    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, false>), grid, block, 0, stream, pv, d_probs);
+  } else {
+    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, true>), grid, block, 0, stream, pv, d_probs);
+    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, false>), grid, block, 0, stream, pv, d_probs);
+  }
+}
+
+int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, int batch, int max_blocks, int neighborhood,
+                     bool dense, int count, hipStream_t stream) {
+  dim3 grid(max_blocks, batch), block(NDT_THREADS);
+  const bool byval = (batch == 1 && h_single != nullptr);
+  NdtProblem pv;
+  if (byval) pv = *h_single; else std::memset(&pv, 0, sizeof(pv));
+  for (int i = 0; i < count; i++) {
+    switch (neighborhood) {
+      case LSR_DIRECT1: launch_one<1>(byval, dense, grid, block, stream, pv, d_probs); break;
+      case LSR_DIRECT26: launch_one<27>(byval, dense, grid, block, stream, pv, d_probs); break;
+      default: launch_one<7>(byval, dense, grid, block, stream, pv, d_probs); break;
+    }
+  }
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+// ===========================================================================================
+// K1 / K2: voxel-covariance grid
+// ===========================================================================================
+namespace {
+
+__device__ __forceinline__ unsigned int f2ord(float f) {
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float ord2f(unsigned int u) {
+  unsigned int v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  float f;
+  std::memcpy(&f, &v, 4);
+  return f;
+}
+
+// bbox over finite points: ord[0..2] = min, ord[3..5] = max (order-preserving uint encoding), ord[6] = #finite
+__global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                   const float* __restrict__ z, int n, unsigned int* __restrict__ ord) {
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  unsigned int cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float p[3] = {x[i], y[i], z[i]};
+    if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
+    cnt++;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      mn[k] = fminf(mn[k], p[k]);
+      mx[k] = fmaxf(mx[k], p[k]);
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      mn[k] = fminf(mn[k], __shfl_xor(mn[k], m, 64));
+      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], m, 64));
+    }
+    cnt += __shfl_xor(cnt, m, 64);
+  }
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  __shared__ unsigned int s_cnt[4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 3; k++) { s_mn[w][k] = mn[k]; s_mx[w][k] = mx[k]; }
+    s_cnt[w] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (c) {
+      for (int k = 0; k < 3; k++) {
+        float a = fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k]));
+        float b = fmaxf(fmaxf(s_mx[0][k], s_mx[1][k]), fmaxf(s_mx[2][k], s_mx[3][k]));
+        atomicMin(&ord[k], f2ord(a));
+        atomicMax(&ord[3 + k], f2ord(b));
+      }
+      atomicAdd(&ord[6], c);
+    }
+  }
+}
+
+// key = linear leaf index exactly as VoxelGridCovariance computes it:
+// ijk = (int)(floor(p * inv_leaf) - (float)min_b)
+__global__ __launch_bounds__(256) void leaf_key_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ z, int n, float inv_leaf, int mb0, int mb1,
+                                                       int mb2, int mul1, int mul2, unsigned int* __restrict__ key,
+                                                       int* __restrict__ val) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float px = x[i], py = y[i], pz = z[i];
+  unsigned int k = 0xFFFFFFFFu;
+  if (isfinite(px) && isfinite(py) && isfinite(pz)) {
+    int i0 = (int)(floorf(px * inv_leaf) - (float)mb0);
+    int i1 = (int)(floorf(py * inv_leaf) - (float)mb1);
+    int i2 = (int)(floorf(pz * inv_leaf) - (float)mb2);
+    k = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
+  }
+  key[i] = k;
+  val[i] = i;
+}
+
+// K1: one wave per leaf; lanes stride the leaf's points (stable-sorted => ascending point index),
+// fp64 sums, fixed butterfly order => deterministic.  sums[leaf][9] = {Sx,Sy,Sz,Sxx,Sxy,Sxz,Syy,Syz,Szz}
+__global__ __launch_bounds__(256) void leaf_sum_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ z, const int* __restrict__ order,
+                                                       const int* __restrict__ run_off, const int* __restrict__ run_cnt,
+                                                       int n_runs, double* __restrict__ sums) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n_runs) return;
+  const int off = run_off[wave], cnt = run_cnt[wave];
+  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = lane; j < cnt; j += 64) {
+    const int pi = order[off + j];
+    const double px = (double)x[pi], py = (double)y[pi], pz = (double)z[pi];
+    s[0] += px; s[1] += py; s[2] += pz;
+    s[3] += px * px; s[4] += px * py; s[5] += px * pz;
+    s[6] += py * py; s[7] += py * pz; s[8] += pz * pz;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) s[k] = wave_sum(s[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) sums[(size_t)wave * 9 + k] = s[k];
+  }
+}
+
+// Symmetric 3x3 eigen-decomposition (cyclic Jacobi), eigenvalues ascending, eigenvectors in columns.
+__device__ void sym3_eigen_dev(const double* Ain, double* w, double* V) {
+  double a00 = Ain[0], a01 = Ain[1], a02 = Ain[2], a11 = Ain[4], a12 = Ain[5], a22 = Ain[8];
+  double q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 32; sweep++) {
+    double off = a01 * a01 + a02 * a02 + a12 * a12;
+    double diag = a00 * a00 + a11 * a11 + a22 * a22;
+    if (off <= 1e-300 || off <= 1e-34 * diag) break;
+#define LSR_JACOBI(app, aqq, apq, arp, arq, cp, cq)                                   \
+  if (apq != 0.0) {                                                                   \
+    double theta = (aqq - app) / (2.0 * apq);                                         \
+    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
+    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;                                    \
+    double npp = app - t * apq, nqq = aqq + t * apq;                                  \
+    double nrp = c * arp - s * arq, nrq = s * arp + c * arq;                          \
+    app = npp; aqq = nqq; apq = 0.0; arp = nrp; arq = nrq;                            \
+    for (int k = 0; k < 3; k++) {                                                     \
+      double qp = q[k * 3 + cp], qq = q[k * 3 + cq];                                  \
+      q[k * 3 + cp] = c * qp - s * qq;                                                \
+      q[k * 3 + cq] = s * qp + c * qq;                                                \
+    }                                                                                 \
+  }
+    LSR_JACOBI(a00, a11, a01, a02, a12, 0, 1)
+    LSR_JACOBI(a00, a22, a02, a01, a12, 0, 2)
+    LSR_JACOBI(a11, a22, a12, a01, a02, 1, 2)
+#undef LSR_JACOBI
+  }
+  double d[3] = {a00, a11, a22};
+  int i0 = 0, i1 = 1, i2 = 2;
+  if (d[i0] > d[i1]) { int t = i0; i0 = i1; i1 = t; }
+  if (d[i1] > d[i2]) { int t = i1; i1 = i2; i2 = t; }
+  if (d[i0] > d[i1]) { int t = i0; i0 = i1; i1 = t; }
+  int idx[3] = {i0, i1, i2};
+  for (int k = 0; k < 3; k++) {
+    w[k] = d[idx[k]];
+    for (int i = 0; i < 3; i++) V[i * 3 + k] = q[i * 3 + idx[k]];
+  }
+}
+
+__device__ bool sym3_inverse_dev(const double* A, double* Ai) {
+  double c00 = A[4] * A[8] - A[5] * A[7];
+  double c01 = A[5] * A[6] - A[3] * A[8];
+  double c02 = A[3] * A[7] - A[4] * A[6];
+  double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  double id = 1.0 / det;
+  Ai[0] = c00 * id;
+  Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id;
+  Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  Ai[3] = c01 * id;
+  Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id;
+  Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  Ai[6] = c02 * id;
+  Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+  Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+  bool ok = true;
+  for (int k = 0; k < 9; k++) ok = ok && isfinite(Ai[k]);
+  return ok;
+}
+
+// K2: one thread per leaf: mean, single-pass covariance, (n-1)/n, eigenvalue clamp, inverse.
+__global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __restrict__ sums, const unsigned int* __restrict__ run_key,
+                                                            const int* __restrict__ run_cnt, int n_runs, int min_points,
+                                                            double eig_mult, float4* __restrict__ rec,
+                                                            double* __restrict__ mean64, double* __restrict__ icov64,
+                                                            int* __restrict__ leaf_key, int* __restrict__ leaf_n,
+                                                            int* __restrict__ cell_slot, int* __restrict__ n_valid, int dense) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_runs) return;
+  const unsigned int key = run_key[r];
+  int n = run_cnt[r];
+  if (key == 0xFFFFFFFFu) {  // the run of non-finite points: not a leaf
+    leaf_key[r] = -1;
+    leaf_n[r] = 0;
+    return;
+  }
+  const double* s = sums + (size_t)r * 9;
+  const double nn = (double)n;
+  double mean[3] = {s[0] / nn, s[1] / nn, s[2] / nn};
+  double icov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool valid = false;
+  if (n >= min_points) {
+    const double sq[9] = {s[3], s[4], s[5], s[4], s[6], s[7], s[5], s[7], s[8]};
+    double cov[9];
+    const double f = (nn - 1.0) / nn;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b <= a; b++) {
+        double v = ((sq[a * 3 + b] - 2.0 * (s[a] * mean[b])) / nn + mean[a] * mean[b]) * f;
+        cov[a * 3 + b] = v;
+        cov[b * 3 + a] = v;
+      }
+    double w[3], V[9];
+    sym3_eigen_dev(cov, w, V);
+    if (!(w[0] < 0 || w[1] < 0 || w[2] <= 0)) {
+      const double lmin = eig_mult * w[2];
+      if (w[0] < lmin) {
+        w[0] = lmin;
+        if (w[1] < lmin) w[1] = lmin;
+        // cov = V diag(w) V^T  (V orthonormal: V^-1 = V^T)
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++)
+            cov[a * 3 + b] = V[a * 3 + 0] * w[0] * V[b * 3 + 0] + V[a * 3 + 1] * w[1] * V[b * 3 + 1] +
+                             V[a * 3 + 2] * w[2] * V[b * 3 + 2];
+      }
+      valid = sym3_inverse_dev(cov, icov);
+    }
+    if (!valid) n = -1;
+  }
+  leaf_key[r] = (int)key;
+  leaf_n[r] = n;
+  for (int k = 0; k < 3; k++) mean64[(size_t)r * 3 + k] = mean[k];
+  for (int k = 0; k < 9; k++) icov64[(size_t)r * 9 + k] = valid ? icov[k] : 0.0;
+  const size_t ri = dense ? (size_t)key : (size_t)r;  // dense: record lives at its cell index
+  rec[ri * 4 + 0] = make_float4((float)mean[0], (float)mean[1], (float)mean[2], (float)icov[0]);
+  rec[ri * 4 + 1] = make_float4((float)icov[1], (float)icov[2], (float)icov[4], (float)icov[5]);
+  rec[ri * 4 + 2] = make_float4((float)icov[8], (float)n, 0.f, 0.f);
+  rec[ri * 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  cell_slot[key] = valid ? (int)ri : -1;
+  if (valid) atomicAdd(n_valid, 1);
+}
+
+__global__ __launch_bounds__(256) void deinterleave_kernel(const unsigned char* __restrict__ aos, size_t stride, int n,
+                                                           float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = (const float*)(aos + (size_t)i * stride);
+  x[i] = p[0]; y[i] = p[1]; z[i] = p[2];
+}
+
+__global__ __launch_bounds__(256) void transform_strided_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ z, int n, const float* __restrict__ Tdev,
+                                                                unsigned char* __restrict__ out, size_t stride) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float px = x[i], py = y[i], pz = z[i];
+  float* o = (float*)(out + (size_t)i * stride);
+  o[0] = fmaf(Tdev[0], px, fmaf(Tdev[4], py, fmaf(Tdev[8], pz, Tdev[12])));
+  o[1] = fmaf(Tdev[1], px, fmaf(Tdev[5], py, fmaf(Tdev[9], pz, Tdev[13])));
+  o[2] = fmaf(Tdev[2], px, fmaf(Tdev[6], py, fmaf(Tdev[10], pz, Tdev[14])));
+}
+
+}  // namespace
+
+int deinterleave(const void* d_aos, size_t stride_bytes, size_t n, DeviceCloud& out, hipStream_t stream) {
+  int st = out.resize(n);
+  if (st) return st;
+  if (n == 0) return LSR_OK;
+  hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     (const unsigned char*)d_aos, stride_bytes, (int)n, out.x(), out.y(), out.z());
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+int transform_to_strided(const DeviceCloud& src, const float* d_T16, void* d_out, size_t stride_bytes, hipStream_t stream) {
+  if (src.n == 0) return LSR_OK;
+  hipLaunchKernelGGL(transform_strided_kernel, dim3((unsigned)((src.n + 255) / 256)), dim3(256), 0, stream, src.x(), src.y(),
+                     src.z(), (int)src.n, d_T16, (unsigned char*)d_out, stride_bytes);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  DevBuf<char>& temp = sc.temp;
+  DevBuf<unsigned int>& scratch = sc.words;
+  DevBuf<double>& sums = sc.sums;
+  const int n = (int)cloud.n;
+  grid.leaf = leaf;
+  grid.n_leaves = grid.n_valid = 0;
+  grid.ncells = 0;
+  for (int k = 0; k < 3; k++) { grid.min_b[k] = 0; grid.max_b[k] = -1; grid.div_b[k] = 0; }
+  if (n == 0) return LSR_OK;
+  const float inv_leaf = 1.0f / leaf;
+
+  // scratch carved from one allocation: ord[8] | key_in[n] | key_out[n] | val_in[n] | val_out[n] | run_key[n] | run_cnt[n] | run_off[n] | nruns | nvalid
+  size_t words = 16 + 7 * (size_t)n + 16;
+  int st = scratch.reserve(words);
+  if (st) return st;
+  unsigned int* ord = scratch.p;
+  unsigned int* key_in = ord + 16;
+  unsigned int* key_out = key_in + n;
+  int* val_in = (int*)(key_out + n);
+  int* val_out = val_in + n;
+  unsigned int* run_key = (unsigned int*)(val_out + n);
+  int* run_cnt = (int*)(run_key + n);
+  int* run_off = run_cnt + n;
+  int* d_nruns = run_off + n;
+  int* d_nvalid = d_nruns + 1;
+
+  unsigned int ord_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+  LSR_HIP(hipMemcpyAsync(ord, ord_init, sizeof(ord_init), hipMemcpyHostToDevice, stream));
+  int nb = std::min((n + 255) / 256, 512);
+  hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, ord);
+  unsigned int ord_h[8];
+  LSR_HIP(hipMemcpyAsync(ord_h, ord, sizeof(ord_h), hipMemcpyDeviceToHost, stream));
+  LSR_HIP(hipStreamSynchronize(stream));
+  if (ord_h[6] == 0) return LSR_OK;  // no finite point: empty grid
+  float mn[3], mx[3];
+  for (int k = 0; k < 3; k++) { mn[k] = ord2f(ord_h[k]); mx[k] = ord2f(ord_h[3 + k]); }
+  int64_t d[3];
+  for (int k = 0; k < 3; k++) d[k] = (int64_t)((mx[k] - mn[k]) * inv_leaf) + 1;
+  if (d[0] * d[1] * d[2] > (int64_t)INT32_MAX) {
+    set_last_error("voxel index space exceeds int32: leaf size too small for the target extent");
+    return LSR_ERR_INDEX_OVERFLOW;
+  }
+  for (int k = 0; k < 3; k++) {
+    grid.min_b[k] = (int)floorf(mn[k] * inv_leaf);
+    grid.max_b[k] = (int)floorf(mx[k] * inv_leaf);
+    grid.div_b[k] = grid.max_b[k] - grid.min_b[k] + 1;
+  }
+  const int mul1 = grid.div_b[0], mul2 = grid.div_b[0] * grid.div_b[1];
+  grid.ncells = (size_t)grid.div_b[0] * grid.div_b[1] * grid.div_b[2];
+  st = grid.cell_slot.reserve(grid.ncells);
+  if (st) return st;
+  LSR_HIP(hipMemsetAsync(grid.cell_slot.p, 0xFF, grid.ncells * sizeof(int), stream));
+
+  hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n,
+                     inv_leaf, grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, key_in, val_in);
+  // all 32 bits: the non-finite sentinel 0xFFFFFFFF must sort last
+  st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, 32, temp, stream);
+  if (st) return st;
+  st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, temp, stream);
+  if (st) return st;
+  int n_runs = 0;
+  LSR_HIP(hipMemcpyAsync(&n_runs, d_nruns, sizeof(int), hipMemcpyDeviceToHost, stream));
+  LSR_HIP(hipStreamSynchronize(stream));
+  st = exclusive_scan_i32(run_cnt, run_off, n_runs, temp, stream);
+  if (st) return st;
+
+  st = sums.reserve((size_t)n_runs * 9);
+  if (st) return st;
+  // Dense leaf records (64 B per grid cell) while the table stays <= 256 MiB; compact otherwise.
+  grid.dense = grid.ncells <= ((size_t)4 << 20);
+  if (grid.dense) {
+    if ((st = grid.rec.reserve(grid.ncells * 4))) return st;
+    LSR_HIP(hipMemsetAsync(grid.rec.p, 0, grid.ncells * 4 * sizeof(float4), stream));
+  } else {
+    if ((st = grid.rec.reserve((size_t)n_runs * 4))) return st;
+  }
+  if ((st = grid.mean64.reserve((size_t)n_runs * 3))) return st;
+  if ((st = grid.icov64.reserve((size_t)n_runs * 9))) return st;
+  if ((st = grid.leaf_key.reserve(n_runs))) return st;
+  if ((st = grid.leaf_n.reserve(n_runs))) return st;
+  LSR_HIP(hipMemsetAsync(d_nvalid, 0, sizeof(int), stream));
+  hipLaunchKernelGGL(leaf_sum_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), val_out,
+                     run_off, run_cnt, n_runs, sums.p);
+  hipLaunchKernelGGL(leaf_finalize_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, stream, sums.p, run_key, run_cnt, n_runs,
+                     6, 0.01, grid.rec.p, grid.mean64.p, grid.icov64.p, grid.leaf_key.p, grid.leaf_n.p, grid.cell_slot.p,
+                     d_nvalid, grid.dense ? 1 : 0);
+  LSR_HIP(hipGetLastError());
+  int n_valid = 0;
+  LSR_HIP(hipMemcpyAsync(&n_valid, d_nvalid, sizeof(int), hipMemcpyDeviceToHost, stream));
+  LSR_HIP(hipStreamSynchronize(stream));
+  grid.n_leaves = n_runs;  // includes the sentinel run if non-finite points exist (leaf_key = -1)
+  grid.n_valid = n_valid;
+  return LSR_OK;
+}
+
+}  // namespace lsr

@@ -1,0 +1,103 @@
+// NDT on gfx950: device-side structures and host entry points.
+//   K1/K2  voxel-covariance grid build        (replaces pclomp::VoxelGridCovariance::filter)
+//   K3     derivative pass                    (replaces NDT::computeDerivatives/updateDerivatives, a5/a7)
+//   K4     Newton + More-Thuente controller   (replaces NDT::computeTransformation/computeStepLengthMT, a4/a6)
+// K3 and K4 are ONE kernel: every workgroup reduces its points' score/gradient/Hessian, the last
+// workgroup to arrive sums the per-workgroup partials in fixed order and advances the controller,
+// leaving the next evaluation request in HBM for the next launch.  An align() is therefore a chain
+// of identical launches with no host round trip in between.
+#pragma once
+#include "common.hpp"
+
+namespace lsr {
+
+enum NdtPhase : int {
+  PH_INIT = 0,      // first derivative pass at the guess
+  PH_MT_FIRST = 1,  // first pass of a line search (with Hessian)
+  PH_MT_TRIAL = 2,  // More-Thuente trial (gradient only)
+  PH_MT_HESS = 3,   // Hessian recomputation after trials
+  PH_DIAG = 4       // lsr_ndt_derivatives: store sums and stop
+};
+
+constexpr int NDT_NRED = 32;       // doubles per partial row: [0]=score [1..6]=grad [7]=#pairs [8..28]=Hessian upper triangle
+constexpr int NDT_NRED_GRAD = 8;   // entries reduced on gradient-only passes
+constexpr int NDT_THREADS = 256;
+constexpr int NDT_MAX_BLOCKS = 1024;
+constexpr int NDT_RED_PITCH = 264;  // doubles per row of the LDS transpose buffer
+
+struct NdtState {
+  // ---- evaluation request, read by every workgroup of the next launch
+  float T[12];       // row-major 3x4 point transform
+  float jang[24];    // 8x3 angular Jacobian coefficient rows a..h       
+  float hang[48];    // 15x3 angular Hessian coefficient rows a2..f3 (+pad)
+  int want_hessian;
+  int done;
+  int phase;
+  int d1_sign;
+  // ---- constants of this align()
+  double d1, d2;
+  double step_max, step_min, eps;
+  int max_iter, n_points;
+  // ---- Newton state
+  double p[6], x_t[6], dir[6];
+  double score, g[6], H[36];
+  int nr_iterations, converged;
+  // ---- More-Thuente state
+  double phi_0, d_phi_0, a_l, f_l, g_l, a_u, f_u, g_u, a_t;
+  int open_interval, interval_converged, step_iterations, pad0;
+  // ---- results
+  float final_T[16];  // column-major 4x4
+  double trans_probability;
+  double last_pairs;
+  int n_evals, pad1;
+};
+
+// One registration problem as the kernels see it (array of these for batched launches).
+struct NdtProblem {
+  const float* sx;
+  const float* sy;
+  const float* sz;
+  int n;
+  int nblocks;              // workgroups assigned to this problem (partials rows)
+  const int* cell_slot;
+  const float4* rec;
+  int min_b[3];
+  int max_b[3];
+  int mul1, mul2;
+  float leaf;
+  int pad;
+  NdtState* st;
+  double* partials;         // [nblocks][NDT_NRED]
+  unsigned int* ticket;
+};
+
+struct NdtParamsHost {
+  double resolution = 1.0, step_size = 0.1, outlier_ratio = 0.55, trans_eps = 0.1;
+  int max_iterations = 35;
+  int neighborhood = LSR_DIRECT7;
+  int d1_sign = 1;
+};
+
+void ndt_gauss_constants(double resolution, double outlier_ratio, double* d1, double* d2);
+
+// K1/K2: build grid from the SoA cloud. Synchronises the stream (host needs the bbox + leaf count).
+int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
+
+// Launch `count` chained derivative+controller passes for `batch` problems.
+// h_single (nullable): host copy of the problem, passed by value when batch == 1.
+int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, int batch, int max_blocks, int neighborhood,
+                     bool dense, int count, hipStream_t stream);
+// Host: controller state at the entry of computeTransformation (guess nullable = identity).
+void ndt_fill_initial_state(NdtState& st, const float* guess16, const NdtParamsHost& prm, int n_points);
+// Fill a diagnostic request on the host (lsr_ndt_derivatives).
+void ndt_fill_diag_state(NdtState& st, const double* p6, const float* T16, int compute_hessian, const NdtParamsHost& prm,
+                         int n_points);
+// Host helper: default state constants for an align.
+void ndt_fill_align_constants(NdtState& st, const NdtParamsHost& prm, int n_points);
+
+// Transform cloud by a column-major 4x4 into a strided device buffer (align()'s `output`).
+int transform_to_strided(const DeviceCloud& src, const float* T16_host, void* d_out, size_t stride_bytes, hipStream_t stream);
+// AoS (strided xyz) -> SoA planes, device to device.
+int deinterleave(const void* d_aos, size_t stride_bytes, size_t n, DeviceCloud& out, hipStream_t stream);
+
+}  // namespace lsr

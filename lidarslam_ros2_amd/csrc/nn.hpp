@@ -1,0 +1,16 @@
+// Kd-tree-free exact nearest-neighbour search on a two-level hashed voxel grid
+// (replaces pcl::KdTreeFLANN behind getFitnessScore and GICP).
+#pragma once
+#include "common.hpp"
+
+struct lsr_handle_s;
+
+namespace lsr {
+float nn_pick_cell(size_t n, const lsr_handle_s* h);
+int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, BuildScratch& sc, hipStream_t stream);
+// mean squared 1-NN distance of T*source in the target, over pairs with d2 <= max_range.
+int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, double* out,
+                     BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream);
+int nn_search_host(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, int32_t* idx, float* d2,
+                   BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream);
+}  // namespace lsr

@@ -1,0 +1,311 @@
+"""Host-side mirror of the `pcl::Registration` surface the reference's two nodes call
+(SURVEY.md §8b), on top of the C ABI in include/lidarslam_reg.h.
+
+Method names, argument meaning and defaults follow pclomp / PCL so call sites read like the
+reference's: scanmatcher/src/scanmatcher_component.cpp:105-120,275,307,329,353-376 and
+graph_based_slam/src/graph_based_slam_component.cpp:64-82,181,227-231.
+
+Clouds may be numpy arrays (host) or torch CUDA tensors (already resident in HBM): shape (n, c)
+float32 with c >= 3 and xyz in the first three columns (c = 8 is pcl::PointXYZI's 32-byte record).
+4x4 transforms are numpy (4,4) float32, row/col indexed normally (converted to Eigen's
+column-major order at the boundary).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _capi as capi
+
+DIRECT7, DIRECT1, DIRECT26, KDTREE = capi.DIRECT7, capi.DIRECT1, capi.DIRECT26, capi.KDTREE
+
+
+def _is_torch_cuda(x) -> bool:
+    return hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+def _cloud_args(cloud):
+    """-> (pointer, stride_bytes, n, on_device, keepalive)"""
+    if _is_torch_cuda(cloud):
+        import torch
+
+        t = cloud
+        if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] < 3:
+            raise ValueError("device cloud must be float32 of shape (n, c>=3)")
+        if not t.is_contiguous():
+            t = t.contiguous()
+        return C.c_void_p(t.data_ptr()), t.shape[1] * 4, t.shape[0], True, t
+    a = np.asarray(cloud)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("cloud must have shape (n, c>=3)")
+    a = np.ascontiguousarray(a, np.float32)
+    return C.c_void_p(a.ctypes.data), a.shape[1] * 4, a.shape[0], False, a
+
+
+def _mat_to_col16(M) -> np.ndarray:
+    M = np.asarray(M, np.float32)
+    if M.shape != (4, 4):
+        raise ValueError("transform must be 4x4")
+    return np.ascontiguousarray(M.T).reshape(16)
+
+
+def _col16_to_mat(v) -> np.ndarray:
+    return np.asarray(v, np.float32).reshape(4, 4).T.copy()
+
+
+class Registration:
+    """pcl::Registration<PointXYZI, PointXYZI>-shaped base."""
+
+    _method = capi.METHOD_NDT
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = capi.load()
+        h = C.c_void_p()
+        capi.check(self._lib.lsr_create(self._method, device, C.c_void_p(stream) if stream else None, C.byref(h)),
+                   "lsr_create")
+        self._h = h
+        self._device = device
+        self._keep = {}
+        self._last = capi.Result()
+
+    # -- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lsr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setters exercised by the reference ---------------------------------------------------
+    def _setf(self, key, v, where):
+        capi.check(self._lib.lsr_set_f64(self._h, key, float(v)), where)
+
+    def _seti(self, key, v, where):
+        capi.check(self._lib.lsr_set_i32(self._h, key, int(v)), where)
+
+    def _getf(self, key):
+        v = C.c_double()
+        capi.check(self._lib.lsr_get_f64(self._h, key, C.byref(v)), "lsr_get_f64")
+        return v.value
+
+    def _geti(self, key):
+        v = C.c_int32()
+        capi.check(self._lib.lsr_get_i32(self._h, key, C.byref(v)), "lsr_get_i32")
+        return v.value
+
+    def setTransformationEpsilon(self, eps: float):  # scanmatcher_component.cpp:108,119
+        self._setf(capi.TRANSFORMATION_EPSILON, eps, "setTransformationEpsilon")
+
+    def getTransformationEpsilon(self) -> float:
+        return self._getf(capi.TRANSFORMATION_EPSILON)
+
+    def setMaximumIterations(self, n: int):  # graph_based_slam_component.cpp:66,77
+        self._seti(capi.MAX_ITERATIONS, n, "setMaximumIterations")
+
+    def getMaximumIterations(self) -> int:
+        return self._geti(capi.MAX_ITERATIONS)
+
+    def setMaxCorrespondenceDistance(self, d: float):  # scanmatcher_component.cpp:118
+        self._setf(capi.MAX_CORRESPONDENCE_DISTANCE, d, "setMaxCorrespondenceDistance")
+
+    def setEuclideanFitnessEpsilon(self, eps: float):  # graph_based_slam_component.cpp:80
+        self._setf(capi.EUCLIDEAN_FITNESS_EPSILON, eps, "setEuclideanFitnessEpsilon")
+
+    def setRANSACIterations(self, n: int):  # graph_based_slam_component.cpp:81
+        self._seti(capi.RANSAC_ITERATIONS, n, "setRANSACIterations")
+
+    # -- clouds ------------------------------------------------------------------------------
+    def setInputTarget(self, cloud):  # scanmatcher_component.cpp:275,307,315; graph_based_slam_component.cpp:227
+        p, stride, n, dev, keep = _cloud_args(cloud)
+        fn = self._lib.lsr_set_input_target_device if dev else self._lib.lsr_set_input_target
+        capi.check(fn(self._h, p, stride, n), "setInputTarget")
+        self._keep["target"] = None  # the core keeps its own SoA copy in HBM
+
+    def setInputSource(self, cloud):  # scanmatcher_component.cpp:329; graph_based_slam_component.cpp:181
+        p, stride, n, dev, keep = _cloud_args(cloud)
+        fn = self._lib.lsr_set_input_source_device if dev else self._lib.lsr_set_input_source
+        capi.check(fn(self._h, p, stride, n), "setInputSource")
+        self._n_source = n
+        self._keep["source"] = keep if dev else None  # device upload is asynchronous on the handle's stream
+
+    def shareTargetOf(self, other: "Registration"):
+        """Register against the target already resident in `other` (N keyframes vs one submap)."""
+        capi.check(self._lib.lsr_share_target(self._h, other._h), "shareTargetOf")
+
+    # -- align + accessors -------------------------------------------------------------------
+    def align(self, guess=None, output: bool = False):
+        """registration_->align(output, guess) (scanmatcher_component.cpp:353).  Returns the
+        transformed source as (n,3) fp32 when output=True, else None (both reference callers
+        discard it)."""
+        g = _mat_to_col16(guess) if guess is not None else None
+        gp = g.ctypes.data_as(C.POINTER(C.c_float)) if g is not None else None
+        fin = np.zeros(16, np.float32)
+        out = None
+        outp, stride = None, 0
+        if output:
+            out = np.zeros((self._n_source, 3), np.float32)
+            outp, stride = C.c_void_p(out.ctypes.data), 12
+        capi.check(self._lib.lsr_align(self._h, gp, fin.ctypes.data_as(C.POINTER(C.c_float)), C.byref(self._last), outp,
+                                       stride), "align")
+        return out
+
+    def getFinalTransformation(self) -> np.ndarray:  # scanmatcher_component.cpp:356
+        fin = np.zeros(16, np.float32)
+        capi.check(self._lib.lsr_get_final_transformation(self._h, fin.ctypes.data_as(C.POINTER(C.c_float))),
+                   "getFinalTransformation")
+        return _col16_to_mat(fin)
+
+    def hasConverged(self) -> bool:  # scanmatcher_component.cpp:375
+        v = C.c_int32()
+        capi.check(self._lib.lsr_has_converged(self._h, C.byref(v)), "hasConverged")
+        return bool(v.value)
+
+    def getFitnessScore(self, max_range: float = 1.7976931348623157e308) -> float:  # graph_based_slam_component.cpp:231
+        v = C.c_double()
+        capi.check(self._lib.lsr_get_fitness_score(self._h, float(max_range), C.byref(v)), "getFitnessScore")
+        return v.value
+
+    # -- extras (not part of the PCL surface) -------------------------------------------------
+    @property
+    def last_result(self) -> dict:
+        r = self._last
+        return dict(converged=bool(r.converged), iterations=int(r.iterations), score=float(r.score),
+                    n_evaluations=int(r.n_evaluations), n_correspondences=int(r.n_correspondences),
+                    gpu_ms=float(r.gpu_ms))
+
+    def getFinalNumIteration(self) -> int:
+        return int(self._last.iterations)
+
+    def nearestNeighbors(self, T=None):
+        idx = np.zeros(self._n_source, np.int32)
+        d2 = np.zeros(self._n_source, np.float32)
+        t = _mat_to_col16(T) if T is not None else None
+        capi.check(self._lib.lsr_nearest_neighbors(self._h, t.ctypes.data_as(C.POINTER(C.c_float)) if t is not None else None,
+                                                   idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                   d2.ctypes.data_as(C.POINTER(C.c_float))), "nearestNeighbors")
+        return idx, d2
+
+    def setProfiling(self, on: bool):
+        self._seti(capi.PROFILE, 1 if on else 0, "setProfiling")
+
+    def getProfile(self, reset: bool = False) -> dict:
+        p = capi.Profile()
+        capi.check(self._lib.lsr_get_profile(self._h, C.byref(p), 1 if reset else 0), "getProfile")
+        return dict(deriv_ms_total=p.deriv_ms_total, deriv_launches=p.deriv_launches, deriv_points=p.deriv_points,
+                    deriv_pairs=p.deriv_pairs)
+
+
+class NormalDistributionsTransform(Registration):
+    """pclomp::NormalDistributionsTransform<PointXYZI,PointXYZI> (scanmatcher_component.cpp:105-113)."""
+
+    _method = capi.METHOD_NDT
+
+    def setResolution(self, res: float):  # scanmatcher_component.cpp:107
+        self._setf(capi.RESOLUTION, res, "setResolution")
+
+    def getResolution(self) -> float:
+        return self._getf(capi.RESOLUTION)
+
+    def setStepSize(self, s: float):
+        self._setf(capi.STEP_SIZE, s, "setStepSize")
+
+    def getStepSize(self) -> float:
+        return self._getf(capi.STEP_SIZE)
+
+    def setOulierRatio(self, r: float):  # (sic) PCL spells it this way
+        self._setf(capi.OUTLIER_RATIO, r, "setOulierRatio")
+
+    setOutlierRatio = setOulierRatio
+
+    def setNeighborhoodSearchMethod(self, method: int):  # scanmatcher_component.cpp:110
+        self._seti(capi.NEIGHBORHOOD, method, "setNeighborhoodSearchMethod")
+
+    def setNumThreads(self, n: int):  # scanmatcher_component.cpp:111 — CPU hint, accepted and ignored
+        self._seti(capi.NUM_THREADS, n, "setNumThreads")
+
+    def setHessianD1Sign(self, sign: int):
+        self._seti(capi.HESSIAN_D1_SIGN, sign, "setHessianD1Sign")
+
+    def getTransformationProbability(self) -> float:
+        return float(self._last.score)
+
+    # inspection ----------------------------------------------------------------------------
+    def gridInfo(self) -> dict:
+        info = np.zeros(8, np.int32)
+        capi.check(self._lib.lsr_ndt_grid_info(self._h, info.ctypes.data_as(C.POINTER(C.c_int32))), "gridInfo")
+        return dict(min_b=info[0:3].copy(), max_b=info[3:6].copy(), n_leaves=int(info[6]), n_valid=int(info[7]))
+
+    def gridDump(self) -> dict:
+        n = self.gridInfo()["n_leaves"]
+        idx, npts = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        mean, icov = np.zeros((n, 3)), np.zeros((n, 3, 3))
+        capi.check(self._lib.lsr_ndt_grid_dump(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               npts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               mean.ctypes.data_as(C.POINTER(C.c_double)),
+                                               icov.ctypes.data_as(C.POINTER(C.c_double))), "gridDump")
+        return dict(idx=idx, n=npts, mean=mean, icov=icov)
+
+    def derivatives(self, p, T=None, compute_hessian: bool = True):
+        p = np.ascontiguousarray(p, np.float64)
+        t = _mat_to_col16(T) if T is not None else None
+        score = C.c_double()
+        g, H = np.zeros(6), np.zeros((6, 6))
+        capi.check(self._lib.lsr_ndt_derivatives(self._h, p.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 t.ctypes.data_as(C.POINTER(C.c_float)) if t is not None else None,
+                                                 1 if compute_hessian else 0, C.byref(score),
+                                                 g.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 H.ctypes.data_as(C.POINTER(C.c_double))), "derivatives")
+        return score.value, g, H
+
+
+class GeneralizedIterativeClosestPoint(Registration):
+    """pclomp::GeneralizedIterativeClosestPoint<PointXYZI,PointXYZI> (scanmatcher_component.cpp:115-120)."""
+
+    _method = capi.METHOD_GICP
+
+    def setRotationEpsilon(self, eps: float):
+        self._setf(capi.ROTATION_EPSILON, eps, "setRotationEpsilon")
+
+    def setCorrespondenceRandomness(self, k: int):
+        self._seti(capi.K_CORRESPONDENCES, k, "setCorrespondenceRandomness")
+
+    def setMaximumOptimizerIterations(self, n: int):
+        self._seti(capi.MAX_INNER_ITERATIONS, n, "setMaximumOptimizerIterations")
+
+    def covariances(self, which: str) -> np.ndarray:
+        w = 0 if which == "source" else 1
+        n = self._n_source if w == 0 else self._n_target
+        cov = np.zeros((n, 3, 3))
+        capi.check(self._lib.lsr_gicp_covariances(self._h, w, cov.ctypes.data_as(C.POINTER(C.c_double))), "covariances")
+        return cov
+
+    def setInputTarget(self, cloud):
+        super().setInputTarget(cloud)
+        self._n_target = _cloud_args(cloud)[2]
+
+
+def align_batch(regs: Sequence[Registration], guesses=None):
+    """Advance B registrations together in shared launches (BASELINE.json cfg 4).  Returns
+    (finals (B,4,4) fp32, list of result dicts)."""
+    lib = capi.load()
+    B = len(regs)
+    hs = (C.c_void_p * B)(*[r._h for r in regs])
+    g = None
+    if guesses is not None:
+        g = np.ascontiguousarray(np.stack([_mat_to_col16(x) for x in guesses]), np.float32)
+    fin = np.zeros((B, 16), np.float32)
+    res = (capi.Result * B)()
+    capi.check(lib.lsr_align_batch(hs, B, g.ctypes.data_as(C.POINTER(C.c_float)) if g is not None else None,
+                                   fin.ctypes.data_as(C.POINTER(C.c_float)), res), "align_batch")
+    finals = np.stack([_col16_to_mat(fin[b]) for b in range(B)])
+    out = []
+    for b, r in enumerate(regs):
+        r._last = capi.Result.from_buffer_copy(res[b])
+        out.append(r.last_result)
+    return finals, out

@@ -321,6 +321,7 @@ struct Ndt {
   int off[27][3];
   int noff;
   std::vector<float> trans;  // transformed cloud xyz
+  std::vector<double> sc, gr, he;  // per-point results (ndt_omp keeps scores[]/score_gradients[]/hessians[])
   NdtResult* res;
 };
 
@@ -343,7 +344,9 @@ void transform_cloud(Ndt& S, const float* M) {
 double compute_derivatives(Ndt& S, const double* p, bool compute_hessian, double* grad, double* hess) {
   compute_angle_derivatives(p, compute_hessian, S.prm.d1_sign, S.ang);
   const size_t n = S.n;
-  std::vector<double> sc(n), gr(n * 6), he(n * 36);
+  std::vector<double>&sc = S.sc, &gr = S.gr, &he = S.he;
+  if (sc.size() != n) { sc.resize(n); gr.resize(n * 6); }
+  if (compute_hessian && he.size() != n * 36) he.resize(n * 36);
   const float gd2 = (float)S.d2;
   const double gd1 = S.d1;
 #pragma omp parallel for schedule(guided, 8) num_threads(S.prm.num_threads > 0 ? S.prm.num_threads : omp_get_max_threads())
