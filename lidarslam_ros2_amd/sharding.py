@@ -1,0 +1,82 @@
+"""Multi-GPU sharding of a batch of independent registrations.
+
+The path shards at registration granularity: each (target, source, guess) triple is independent
+(the loop-closure candidate scan of graph_based_slam_component.cpp:190-231 generalised from arg-min
+to top-k, or N keyframes against a submap).  One process per GPU, static block partition of the
+batch, no collective on the data path; the only exchange is ONE all-gather of fixed 64-byte result
+records (3x4 pose fp32, score, iterations, converged, fitness) — `torch.distributed` backend "nccl"
+(= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  Splitting ONE registration over GPUs would need
+a 29-double all-reduce per derivative pass (hundreds per align): pure latency, so a single
+registration is "replicas only".
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import numpy as np
+
+RECORD_FLOATS = 16  # 64 bytes: T[:3,:4] (12) | score | iterations | converged | fitness
+
+
+def shard_range(n_items: int, world: int, rank: int) -> range:
+    """Static block partition: the first (n_items % world) ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def pack_record(T: np.ndarray, score: float, iterations: int, converged: bool, fitness: float = float("nan")) -> np.ndarray:
+    rec = np.zeros(RECORD_FLOATS, np.float32)
+    rec[:12] = np.asarray(T, np.float32)[:3, :4].reshape(-1)
+    rec[12:] = (score, iterations, 1.0 if converged else 0.0, fitness)
+    return rec
+
+
+def unpack_record(rec: np.ndarray) -> dict:
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :4] = np.asarray(rec[:12], np.float32).reshape(3, 4)
+    return dict(T=T, score=float(rec[12]), iterations=int(round(float(rec[13]))), converged=bool(rec[14] > 0.5),
+                fitness=float(rec[15]))
+
+
+def all_gather_records(local: np.ndarray, n_items: int, device=None) -> np.ndarray:
+    """All-gather the per-rank record blocks into the full (n_items, 16) table, in batch order.
+
+    Ranks may own different counts; blocks are padded to the largest shard so a single fixed-size
+    all_gather suffices (4 KiB for 64 candidates: latency-bound, ring order irrelevant)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        assert local.shape[0] == n_items
+        return np.asarray(local, np.float32).reshape(n_items, RECORD_FLOATS)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    max_count = max(len(shard_range(n_items, world, r)) for r in range(world))
+    buf = torch.zeros((max_count, RECORD_FLOATS), dtype=torch.float32)
+    mine = shard_range(n_items, world, rank)
+    if len(mine):
+        buf[: len(mine)] = torch.from_numpy(np.asarray(local, np.float32).reshape(len(mine), RECORD_FLOATS))
+    if device is not None:
+        buf = buf.to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    table = np.zeros((n_items, RECORD_FLOATS), np.float32)
+    for r in range(world):
+        rr = shard_range(n_items, world, r)
+        if len(rr):
+            table[rr.start:rr.stop] = out[r][: len(rr)].cpu().numpy()
+    return table
+
+
+def register_sharded(n_items: int, register_local: Callable[[Sequence[int]], List[np.ndarray]], device=None) -> List[dict]:
+    """Run `register_local(indices)` on this rank's shard (it returns one packed record per index) and
+    return the full list of results on every rank."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    mine = shard_range(n_items, world, rank)
+    recs = register_local(list(mine))
+    local = np.stack(recs).astype(np.float32) if len(recs) else np.zeros((0, RECORD_FLOATS), np.float32)
+    table = all_gather_records(local, n_items, device=device)
+    return [unpack_record(table[i]) for i in range(n_items)]
