@@ -110,14 +110,20 @@ struct VoxelGridDev {
   DevBuf<int> leaf_key, leaf_n;
 };
 
-// ---- NN hash grid over a cloud (fitness score, GICP) ------------------------------------------
+// ---- NN grid over a cloud (fitness score, GICP): two-level blocked voxel grid ------------------
+// Coarse cells (8x8x8 fine cells) are a dense int32 map -> block id; every occupied coarse cell owns a
+// 513-entry table of fine-cell start offsets into the cell-sorted point arrays.
 struct HashGridDev {
-  float cell = 1.f;
-  int mn[3] = {0, 0, 0}, dim[3] = {0, 0, 0};
-  size_t ncells = 0;
-  DevBuf<int> cell_start;  // [ncells + 1]
-  DeviceCloud sorted;      // points in cell order
-  DevBuf<int> order;       // sorted position -> original index
+  float cell = 0.5f;       // fine cell edge [m]; coarse edge = 8 * cell
+  int org[3] = {0, 0, 0};  // fine-cell coordinate of the grid origin (multiple of 8)
+  int cdim[3] = {0, 0, 0}; // coarse dims
+  int n_blocks = 0;        // occupied coarse cells
+  size_t n = 0;
+  DevBuf<int> coarse_block; // [cdim0*cdim1*cdim2] -> block id or -1
+  DevBuf<int> block_off;    // [n_blocks + 1] start of each block in the sorted arrays
+  DevBuf<int> fine_start;   // [n_blocks * 513] absolute start of each fine cell (+ end sentinel)
+  DeviceCloud sorted;       // points in (coarse, fine) cell order
+  DevBuf<int> order;        // sorted position -> original index
 };
 
 // Per-handle scratch for the target-side builders.

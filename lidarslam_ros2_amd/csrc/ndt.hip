@@ -1084,6 +1084,26 @@ int transform_to_strided(const DeviceCloud& src, const float* d_T16, void* d_out
   return LSR_OK;
 }
 
+// Bounding box over the finite points of a cloud (synchronises the stream).
+int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_finite, BuildScratch& sc, hipStream_t stream) {
+  const int n = (int)cloud.n;
+  int st = sc.words.reserve(16);
+  if (st) return st;
+  unsigned int* ord = sc.words.p;
+  unsigned int ord_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+  LSR_HIP(hipMemcpyAsync(ord, ord_init, sizeof(ord_init), hipMemcpyHostToDevice, stream));
+  if (n > 0) {
+    int nb = std::min((n + 255) / 256, 512);
+    hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, ord);
+  }
+  unsigned int ord_h[8];
+  LSR_HIP(hipMemcpyAsync(ord_h, ord, sizeof(ord_h), hipMemcpyDeviceToHost, stream));
+  LSR_HIP(hipStreamSynchronize(stream));
+  *n_finite = ord_h[6];
+  for (int k = 0; k < 3; k++) { mn[k] = ord2f(ord_h[k]); mx[k] = ord2f(ord_h[3 + k]); }
+  return LSR_OK;
+}
+
 int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
   DevBuf<char>& temp = sc.temp;
   DevBuf<unsigned int>& scratch = sc.words;

@@ -80,6 +80,8 @@ struct NdtParamsHost {
 
 void ndt_gauss_constants(double resolution, double outlier_ratio, double* d1, double* d2);
 
+int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_finite, BuildScratch& sc, hipStream_t stream);
+
 // K1/K2: build grid from the SoA cloud. Synchronises the stream (host needs the bbox + leaf count).
 int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
 

@@ -1,7 +1,455 @@
+// Kd-tree-free EXACT nearest-neighbour search for gfx950 (K8 fitness score, K5/K6 of GICP).
+// Replaces pcl::KdTreeFLANN behind pcl::Registration::getFitnessScore
+// (graph_based_slam/src/graph_based_slam_component.cpp:231, scanmatcher/src/scanmatcher_component.cpp:376)
+// and behind GICP's 1-NN correspondences / 20-NN covariances.
+//
+// Structure: a two-level blocked voxel grid.  Points are radix-sorted by (coarse cell, fine cell);
+// coarse cells (8x8x8 fine cells) are a dense int32 map to a block id, each block owns 513 fine-cell
+// start offsets.  A query first scans the (2R+1)^3 fine cells around it; if the k-th best distance is
+// not yet provably minimal it expands over coarse shells, pruning cells by box distance, until the
+// bound holds — so results equal a kd-tree's (ties broken by lowest point index), including for far
+// outliers, without ever touching a tree.  Distances use the reference's fp32 arithmetic
+// ((dx*dx + dy*dy) + dz*dz, no FMA contraction) so the CPU oracle and the GPU agree bit for bit.
 #include "handle.hpp"
+#include "sort.hpp"
+
 namespace lsr {
-float nn_pick_cell(size_t, const lsr_handle_s*) { return 0.5f; }
-int nn_build_hash(const DeviceCloud&, float, HashGridDev&, BuildScratch&, hipStream_t) { set_last_error("NN not implemented yet"); return LSR_ERR_NOT_IMPLEMENTED; }
-int nn_fitness_score(const DeviceCloud&, const float*, const HashGridDev&, double, double*, BuildScratch&, DevBuf<float>&, hipStream_t) { return LSR_ERR_NOT_IMPLEMENTED; }
-int nn_search_host(const DeviceCloud&, const float*, const HashGridDev&, int32_t*, float*, BuildScratch&, DevBuf<float>&, hipStream_t) { return LSR_ERR_NOT_IMPLEMENTED; }
+
+namespace {
+
+constexpr int NN_THREADS = 128;
+constexpr int FINE_PER_BLOCK = 512;
+constexpr int FINE_STRIDE = 513;
+
+struct NNGridView {
+  float cell, inv_cell;
+  int org[3];
+  int cdim[3];
+  const int* coarse_block;
+  const int* block_off;
+  const int* fine_start;
+  const float* x;
+  const float* y;
+  const float* z;
+  const int* order;
+};
+
+__device__ __forceinline__ float dist2_rn(float qx, float qy, float qz, float px, float py, float pz) {
+  const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
+
+// fp32 point transform in the reference's order: ((m0*x + m1*y) + m2*z) + m3, no contraction.
+__device__ __forceinline__ float xform_rn(float a, float b, float c, float d, float x, float y, float z) {
+  return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a, x), __fmul_rn(b, y)), __fmul_rn(c, z)), d);
+}
+
+// ---- top-K collectors --------------------------------------------------------------------------
+struct Best1 {
+  float d2;
+  int idx;
+  __device__ __forceinline__ void init() { d2 = INFINITY; idx = -1; }
+  __device__ __forceinline__ float worst() const { return d2; }
+  __device__ __forceinline__ bool full() const { return idx >= 0; }
+  __device__ __forceinline__ void offer(float d, int i) {
+    if (d < d2 || (d == d2 && i < idx)) { d2 = d; idx = i; }
+  }
+};
+
+// K-best list kept in LDS, column-major over threads ([slot][thread]) so lanes never collide.
+struct BestK {
+  float* d2;   // LDS base + tid
+  int* idx;    // LDS base + tid
+  int k, count;
+  __device__ __forceinline__ void init(float* d, int* i, int kk) {
+    d2 = d; idx = i; k = kk; count = 0;
+    for (int s = 0; s < kk; s++) { d2[s * NN_THREADS] = INFINITY; idx[s * NN_THREADS] = -1; }
+  }
+  __device__ __forceinline__ float worst() const { return d2[(k - 1) * NN_THREADS]; }
+  __device__ __forceinline__ bool full() const { return count >= k; }
+  __device__ __forceinline__ void offer(float d, int i) {
+    const float w = d2[(k - 1) * NN_THREADS];
+    const int wi = idx[(k - 1) * NN_THREADS];
+    if (!(d < w || (d == w && (wi < 0 || i < wi)))) return;
+    int s = k - 1;
+    while (s > 0) {
+      const float ps = d2[(s - 1) * NN_THREADS];
+      const int pi = idx[(s - 1) * NN_THREADS];
+      if (ps < d || (ps == d && pi >= 0 && pi < i)) break;
+      d2[s * NN_THREADS] = ps;
+      idx[s * NN_THREADS] = pi;
+      s--;
+    }
+    d2[s * NN_THREADS] = d;
+    idx[s * NN_THREADS] = i;
+    if (count < k) count++;
+  }
+};
+
+template <typename Coll>
+__device__ __forceinline__ void scan_range(const NNGridView& G, int beg, int end, float qx, float qy, float qz, Coll& c,
+                                           int self_skip) {
+  for (int s = beg; s < end; s++) {
+    const int oi = G.order[s];
+    if (oi == self_skip) continue;
+    const float d = dist2_rn(qx, qy, qz, G.x[s], G.y[s], G.z[s]);
+    c.offer(d, oi);
+  }
+}
+
+// Exact search for one query.  fine_rings: half-width of the first fine-cell block.
+template <typename Coll>
+__device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int fine_rings, float max_d2, Coll& c,
+                         int self_skip) {
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return;
+  const float fxf = floorf(qx * G.inv_cell), fyf = floorf(qy * G.inv_cell), fzf = floorf(qz * G.inv_cell);
+  if (!(fabsf(fxf) < 1.0e9f && fabsf(fyf) < 1.0e9f && fabsf(fzf) < 1.0e9f)) return;
+  const int fq[3] = {(int)fxf - G.org[0], (int)fyf - G.org[1], (int)fzf - G.org[2]};  // fine coords rel. to origin
+  const float q[3] = {qx, qy, qz};
+  const int fdim[3] = {G.cdim[0] * 8, G.cdim[1] * 8, G.cdim[2] * 8};
+
+  // ---- phase 1: (2R+1)^3 fine cells
+  bool any_fine = true;
+  for (int k = 0; k < 3; k++)
+    if (fq[k] + fine_rings < 0 || fq[k] - fine_rings >= fdim[k]) any_fine = false;
+  if (any_fine) {
+    for (int dz = -fine_rings; dz <= fine_rings; dz++) {
+      const int z = fq[2] + dz;
+      if (z < 0 || z >= fdim[2]) continue;
+      for (int dy = -fine_rings; dy <= fine_rings; dy++) {
+        const int y = fq[1] + dy;
+        if (y < 0 || y >= fdim[1]) continue;
+        for (int dx = -fine_rings; dx <= fine_rings; dx++) {
+          const int x = fq[0] + dx;
+          if (x < 0 || x >= fdim[0]) continue;
+          const int blk = G.coarse_block[(x >> 3) + G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3))];
+          if (blk < 0) continue;
+          const int f = (x & 7) | ((y & 7) << 3) | ((z & 7) << 6);
+          const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + f;
+          scan_range(G, fs[0], fs[1], qx, qy, qz, c, self_skip);
+        }
+      }
+    }
+  }
+  // every point outside the scanned fine block is at least `lo` away
+  float lo = INFINITY;
+  for (int k = 0; k < 3; k++) {
+    const float base = (float)(fq[k] + G.org[k]) * G.cell;
+    lo = fminf(lo, fminf(q[k] - (base - (float)fine_rings * G.cell), (base + (float)(fine_rings + 1) * G.cell) - q[k]));
+  }
+  lo = fmaxf(lo, 0.f);
+  float lo2 = lo * lo * 0.9999f;
+  if ((c.full() && c.worst() <= lo2) || lo2 > max_d2) return;
+
+  // ---- phase 2: coarse shells with box-distance pruning
+  const float C = G.cell * 8.f;
+  int cq[3];
+  for (int k = 0; k < 3; k++) cq[k] = (fq[k] >= 0) ? (fq[k] >> 3) : -(((-fq[k]) + 7) >> 3);
+  int rmax = 0;
+  for (int k = 0; k < 3; k++) rmax = max(rmax, max(cq[k], G.cdim[k] - 1 - cq[k]));
+  for (int r = 0; r <= rmax; r++) {
+    for (int dz = -r; dz <= r; dz++) {
+      const int z = cq[2] + dz;
+      if (z < 0 || z >= G.cdim[2]) continue;
+      for (int dy = -r; dy <= r; dy++) {
+        const int y = cq[1] + dy;
+        if (y < 0 || y >= G.cdim[1]) continue;
+        const bool shell_yz = (abs(dz) == r) || (abs(dy) == r);
+        const int step = shell_yz ? 1 : max(1, 2 * r);
+        for (int dx = -r; dx <= r; dx += step) {
+          const int x = cq[0] + dx;
+          if (x < 0 || x >= G.cdim[0]) continue;
+          const int blk = G.coarse_block[x + G.cdim[0] * (y + G.cdim[1] * z)];
+          if (blk < 0) continue;
+          // squared distance from q to the coarse cell's box
+          float bd2 = 0.f;
+          const int cc[3] = {x, y, z};
+          for (int k = 0; k < 3; k++) {
+            const float b0 = (float)(cc[k] * 8 + G.org[k]) * G.cell, b1 = b0 + C;
+            const float dd = fmaxf(fmaxf(b0 - q[k], q[k] - b1), 0.f);
+            bd2 += dd * dd;
+          }
+          bd2 *= 0.9999f;
+          if ((c.full() && bd2 > c.worst()) || bd2 > max_d2) continue;
+          scan_range(G, G.block_off[blk], G.block_off[blk + 1], qx, qy, qz, c, self_skip);
+        }
+      }
+    }
+    float loc = INFINITY;
+    for (int k = 0; k < 3; k++) {
+      const float b0 = (float)((cq[k] - r) * 8 + G.org[k]) * G.cell;
+      const float b1 = (float)((cq[k] + r + 1) * 8 + G.org[k]) * G.cell;
+      loc = fminf(loc, fminf(q[k] - b0, b1 - q[k]));
+    }
+    loc = fmaxf(loc, 0.f);
+    const float loc2 = loc * loc * 0.9999f;
+    if ((c.full() && c.worst() <= loc2) || loc2 > max_d2) return;
+  }
+}
+
+// ---- build kernels -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nn_key_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ z, int n, float inv_cell, int o0, int o1, int o2,
+                                                     int c0, int c1, unsigned int* __restrict__ key, int* __restrict__ val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned int k = 0xFFFFFFFFu;
+  const float px = x[i], py = y[i], pz = z[i];
+  if (isfinite(px) && isfinite(py) && isfinite(pz)) {
+    const int fx = (int)floorf(px * inv_cell) - o0, fy = (int)floorf(py * inv_cell) - o1, fz = (int)floorf(pz * inv_cell) - o2;
+    const unsigned int coarse = (unsigned int)((fx >> 3) + c0 * ((fy >> 3) + c1 * (fz >> 3)));
+    k = coarse * FINE_PER_BLOCK + (unsigned int)((fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6));
+  }
+  key[i] = k;
+  val[i] = i;
+}
+
+__global__ __launch_bounds__(256) void nn_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ z, const int* __restrict__ order, int n,
+                                                        float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = order[i];
+  sx[i] = x[o]; sy[i] = y[o]; sz[i] = z[o];
+}
+
+__global__ __launch_bounds__(256) void nn_coarse_key_kernel(const unsigned int* __restrict__ key_sorted, int n,
+                                                            unsigned int* __restrict__ ckey) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int k = key_sorted[i];
+  ckey[i] = (k == 0xFFFFFFFFu) ? 0xFFFFFFFFu : k / FINE_PER_BLOCK;
+}
+
+// one wave per occupied coarse cell: 513 fine-cell starts by counting (binary search over the sorted keys)
+__global__ __launch_bounds__(256) void nn_fine_table_kernel(const unsigned int* __restrict__ key_sorted,
+                                                            const unsigned int* __restrict__ run_key, const int* __restrict__ run_off,
+                                                            const int* __restrict__ run_cnt, int n_runs,
+                                                            int* __restrict__ coarse_block, int* __restrict__ block_off,
+                                                            int* __restrict__ fine_start) {
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (b >= n_runs) return;
+  const unsigned int ck = run_key[b];
+  if (ck == 0xFFFFFFFFu) return;  // run of non-finite points (always last)
+  const int beg = run_off[b], end = beg + run_cnt[b];
+  if (lane == 0) {
+    coarse_block[ck] = b;
+    block_off[b] = beg;
+    block_off[b + 1] = end;  // the next block (if any) rewrites the same value
+  }
+  for (int f = lane; f <= FINE_PER_BLOCK; f += 64) {
+    // first sorted position in [beg,end) whose fine id >= f
+    const unsigned int want = ck * FINE_PER_BLOCK + (unsigned int)f;
+    int lo = beg, hi = end;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (key_sorted[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    fine_start[(size_t)b * FINE_STRIDE + f] = (f == FINE_PER_BLOCK) ? end : lo;
+  }
+}
+
+// ---- query kernels -------------------------------------------------------------------------------
+__global__ __launch_bounds__(NN_THREADS) void nn1_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                         const float* __restrict__ qz, int n, const float* __restrict__ T16,
+                                                         int fine_rings, float max_d2, int* __restrict__ idx,
+                                                         float* __restrict__ d2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = qx[i], y = qy[i], z = qz[i];
+  float tx = x, ty = y, tz = z;
+  if (T16) {
+    tx = xform_rn(T16[0], T16[4], T16[8], T16[12], x, y, z);
+    ty = xform_rn(T16[1], T16[5], T16[9], T16[13], x, y, z);
+    tz = xform_rn(T16[2], T16[6], T16[10], T16[14], x, y, z);
+  }
+  Best1 c;
+  c.init();
+  nn_query(G, tx, ty, tz, fine_rings, max_d2, c, -1);
+  idx[i] = c.idx;
+  d2[i] = c.d2;
+}
+
+__global__ __launch_bounds__(NN_THREADS) void knn_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                         const float* __restrict__ qz, int n, int k, int fine_rings,
+                                                         int* __restrict__ idx, float* __restrict__ d2) {
+  extern __shared__ unsigned char smem[];
+  float* sd = reinterpret_cast<float*>(smem);
+  int* si = reinterpret_cast<int*>(smem + (size_t)k * NN_THREADS * sizeof(float));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  BestK c;
+  c.init(sd + threadIdx.x, si + threadIdx.x, k);
+  if (i < n) nn_query(G, qx[i], qy[i], qz[i], fine_rings, INFINITY, c, -1);
+  if (i < n)
+    for (int s = 0; s < k; s++) {
+      idx[(size_t)i * k + s] = si[s * NN_THREADS + threadIdx.x];
+      d2[(size_t)i * k + s] = sd[s * NN_THREADS + threadIdx.x];
+    }
+}
+
+// deterministic two-stage reduction of {sum d2, count} over pairs with d2 <= max_range
+__global__ __launch_bounds__(256) void fitness_partial_kernel(const int* __restrict__ idx, const float* __restrict__ d2, int n,
+                                                              double max_range, double* __restrict__ part) {
+  __shared__ double s_sum[256], s_cnt[256];
+  double sum = 0, cnt = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    if (idx[i] >= 0 && (double)d2[i] <= max_range) { sum += (double)d2[i]; cnt += 1.0; }
+  }
+  s_sum[threadIdx.x] = sum;
+  s_cnt[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { s_sum[threadIdx.x] += s_sum[threadIdx.x + s]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s_sum[0]; part[2 * blockIdx.x + 1] = s_cnt[0]; }
+}
+
+NNGridView make_view(const HashGridDev& g) {
+  NNGridView v;
+  v.cell = g.cell;
+  v.inv_cell = 1.0f / g.cell;
+  for (int k = 0; k < 3; k++) { v.org[k] = g.org[k]; v.cdim[k] = g.cdim[k]; }
+  v.coarse_block = g.coarse_block.p;
+  v.block_off = g.block_off.p;
+  v.fine_start = g.fine_start.p;
+  v.x = g.sorted.x(); v.y = g.sorted.y(); v.z = g.sorted.z();
+  v.order = g.order.p;
+  return v;
+}
+
+}  // namespace
+
+float nn_pick_cell(size_t, const lsr_handle_s*) { return 0.5f; }
+
+int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  const int n = (int)cloud.n;
+  grid.cell = cell;
+  grid.n = cloud.n;
+  grid.n_blocks = 0;
+  for (int k = 0; k < 3; k++) { grid.org[k] = 0; grid.cdim[k] = 0; }
+  if (n == 0) return LSR_OK;
+  float mn[3], mx[3];
+  unsigned int n_finite = 0;
+  int st = cloud_bbox(cloud, mn, mx, &n_finite, sc, stream);
+  if (st) return st;
+  if (n_finite == 0) return LSR_OK;
+  const float inv = 1.0f / cell;
+  size_t ccells = 1;
+  for (int k = 0; k < 3; k++) {
+    const int f0 = (int)floorf(mn[k] * inv), f1 = (int)floorf(mx[k] * inv);
+    const int o = (f0 >= 0) ? (f0 & ~7) : -(((-f0) + 7) & ~7);  // origin aligned down to a multiple of 8
+    grid.org[k] = o;
+    grid.cdim[k] = ((f1 - o) >> 3) + 1;
+    ccells *= (size_t)grid.cdim[k];
+  }
+  if (ccells * FINE_PER_BLOCK >= 0xFFFFFFFFull) {
+    set_last_error("cloud extent too large for the NN grid at this cell size");
+    return LSR_ERR_INDEX_OVERFLOW;
+  }
+  // scratch: key_in | key_out | val_in | ckey | run_key | run_cnt | run_off | nruns   (n words each)
+  if ((st = sc.words.reserve(32 + 7 * (size_t)n + 16))) return st;
+  unsigned int* key_in = sc.words.p + 32;
+  unsigned int* key_out = key_in + n;
+  int* val_in = (int*)(key_out + n);
+  unsigned int* ckey = (unsigned int*)(val_in + n);
+  unsigned int* run_key = ckey + n;
+  int* run_cnt = (int*)(run_key + n);
+  int* run_off = run_cnt + n;
+  int* d_nruns = run_off + n;
+  if ((st = grid.order.reserve(n))) return st;
+  if ((st = grid.sorted.resize(n))) return st;
+  if ((st = grid.coarse_block.reserve(ccells))) return st;
+  LSR_HIP(hipMemsetAsync(grid.coarse_block.p, 0xFF, ccells * sizeof(int), stream));
+  const int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(nn_key_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv, grid.org[0],
+                     grid.org[1], grid.org[2], grid.cdim[0], grid.cdim[1], key_in, val_in);
+  if ((st = sort_pairs_u32(key_in, key_out, val_in, grid.order.p, n, 32, sc.temp, stream))) return st;
+  hipLaunchKernelGGL(nn_gather_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), grid.order.p, n,
+                     grid.sorted.x(), grid.sorted.y(), grid.sorted.z());
+  hipLaunchKernelGGL(nn_coarse_key_kernel, dim3(nb), dim3(256), 0, stream, key_out, n, ckey);
+  if ((st = run_length_encode_u32(ckey, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
+  int n_runs = 0;
+  LSR_HIP(hipMemcpyAsync(&n_runs, d_nruns, sizeof(int), hipMemcpyDeviceToHost, stream));
+  LSR_HIP(hipStreamSynchronize(stream));
+  if ((st = exclusive_scan_i32(run_cnt, run_off, n_runs, sc.temp, stream))) return st;
+  if ((st = grid.block_off.reserve((size_t)n_runs + 1))) return st;
+  if ((st = grid.fine_start.reserve((size_t)n_runs * FINE_STRIDE))) return st;
+  hipLaunchKernelGGL(nn_fine_table_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream, key_out, run_key, run_off, run_cnt,
+                     n_runs, grid.coarse_block.p, grid.block_off.p, grid.fine_start.p);
+  LSR_HIP(hipGetLastError());
+  LSR_HIP(hipStreamSynchronize(stream));
+  grid.n_blocks = n_runs;  // a trailing run of non-finite points (if any) is never referenced by coarse_block
+  return LSR_OK;
+}
+
+int nn_search_device(const DeviceCloud& q, const float* d_T16, const HashGridDev& grid, int fine_rings, float max_d2,
+                     int* d_idx, float* d_d2, hipStream_t stream) {
+  const int n = (int)q.n;
+  if (n == 0) return LSR_OK;
+  if (grid.n_blocks == 0) {
+    LSR_HIP(hipMemsetAsync(d_idx, 0xFF, sizeof(int) * n, stream));
+    LSR_HIP(hipMemsetAsync(d_d2, 0x7F, sizeof(float) * n, stream));  // 0x7F7F7F7F ~ 3.4e38
+    return LSR_OK;
+  }
+  hipLaunchKernelGGL(nn1_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS), dim3(NN_THREADS), 0, stream, make_view(grid), q.x(),
+                     q.y(), q.z(), n, d_T16, fine_rings, max_d2, d_idx, d_d2);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+int knn_search_device(const DeviceCloud& q, const HashGridDev& grid, int k, int fine_rings, int* d_idx, float* d_d2,
+                      hipStream_t stream) {
+  const int n = (int)q.n;
+  if (n == 0) return LSR_OK;
+  const size_t smem = (size_t)k * NN_THREADS * (sizeof(float) + sizeof(int));
+  hipLaunchKernelGGL(knn_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS), dim3(NN_THREADS), smem, stream, make_view(grid), q.x(),
+                     q.y(), q.z(), n, k, fine_rings, d_idx, d_d2);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+static int nn_scratch(BuildScratch& sc, size_t n, int** d_idx, float** d_d2, double** d_part) {
+  int st = sc.words.reserve(32 + 2 * n + 16);
+  if (st) return st;
+  *d_idx = (int*)(sc.words.p + 32);
+  *d_d2 = (float*)(sc.words.p + 32 + n);
+  if ((st = sc.sums.reserve(2 * 256 + 8))) return st;
+  *d_part = sc.sums.p;
+  return LSR_OK;
+}
+
+int nn_search_host(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, int32_t* idx, float* d2,
+                   BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream) {
+  int* d_idx; float* d_d2; double* d_part;
+  int st = nn_scratch(sc, source.n, &d_idx, &d_d2, &d_part);
+  if (st) return st;
+  LSR_HIP(hipMemcpyAsync(d_T16.p, T16_host, 16 * sizeof(float), hipMemcpyHostToDevice, stream));
+  if ((st = nn_search_device(source, d_T16.p, grid, 1, INFINITY, d_idx, d_d2, stream))) return st;
+  LSR_HIP(hipMemcpyAsync(idx, d_idx, sizeof(int) * source.n, hipMemcpyDeviceToHost, stream));
+  LSR_HIP(hipMemcpyAsync(d2, d_d2, sizeof(float) * source.n, hipMemcpyDeviceToHost, stream));
+  LSR_HIP(hipStreamSynchronize(stream));
+  return LSR_OK;
+}
+
+int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, double* out,
+                     BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream) {
+  int* d_idx; float* d_d2; double* d_part;
+  int st = nn_scratch(sc, source.n, &d_idx, &d_d2, &d_part);
+  if (st) return st;
+  LSR_HIP(hipMemcpyAsync(d_T16.p, T16_host, 16 * sizeof(float), hipMemcpyHostToDevice, stream));
+  const float max_d2 = (max_range >= 3.0e38) ? INFINITY : (float)max_range * 1.0001f;
+  if ((st = nn_search_device(source, d_T16.p, grid, 1, max_d2, d_idx, d_d2, stream))) return st;
+  const int nb = 256;
+  hipLaunchKernelGGL(fitness_partial_kernel, dim3(nb), dim3(256), 0, stream, d_idx, d_d2, (int)source.n, max_range, d_part);
+  double part[2 * 256];
+  LSR_HIP(hipMemcpyAsync(part, d_part, sizeof(part), hipMemcpyDeviceToHost, stream));
+  LSR_HIP(hipStreamSynchronize(stream));
+  double sum = 0, cnt = 0;
+  for (int b = 0; b < nb; b++) { sum += part[2 * b]; cnt += part[2 * b + 1]; }
+  *out = (cnt > 0) ? sum / cnt : 1.7976931348623157e308;  // std::numeric_limits<double>::max()
+  return LSR_OK;
+}
+
+}  // namespace lsr
