@@ -1,5 +1,551 @@
+// GICP for gfx950 (replaces pclomp::GeneralizedIterativeClosestPoint).
+//   K5  gicp_cov_kernel      fused exact 20-NN (voxel-grid search, LDS top-k lists) + covariance +
+//                            3x3 symmetric eigen-decomposition + U diag(1,1,eps) U^T
+//   K6  gicp_corr_kernel     1-NN of (transformation_ * guess * src) in the target within corr_dist,
+//                            M_i = (R C1_i R^T + C2_j)^-1 in fp64, packed pair records for K7
+//   K7  gicp_gn_kernel       per-pair residual / Jacobian, 28 fp64 sums (cost, 6-gradient, 21-Hessian)
+//       gicp_update_kernel   fixed-order sum of the per-workgroup rows, 6x6 solve, state update
+// The reference minimises the same cost with BFGS; north_star asks for Gauss-Newton accumulation, so
+// the inner solver here is GN with the reference's stopping rule (|grad| < 1e-2 or max_inner
+// iterations).  Same cost and correspondences => same minimiser; the oracle carries both solvers.
 #include "handle.hpp"
+#include "nn_device.hpp"
+
 namespace lsr {
-int gicp_align(lsr_handle_s*, const float*, float*, lsr_result*) { set_last_error("GICP not implemented yet"); return LSR_ERR_NOT_IMPLEMENTED; }
-int gicp_get_covariances(lsr_handle_s*, int, double*) { return LSR_ERR_NOT_IMPLEMENTED; }
+
+using namespace nnd;
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_NRED = 28;  // [0] cost, [1..6] J^T M r, [7..27] upper triangle of J^T M J
+
+struct PairRec {      // one candidate correspondence, written by K6, streamed by K7
+  float q[3];         // target point
+  int valid;
+  double M[6];        // symmetric Mahalanobis matrix: 00 01 02 11 12 22
+};
+
+struct GnState {
+  double x[6];        // (t, phi, theta, psi): R = Rz(psi) Ry(theta) Rx(phi)
+  float T[12];        // row-major 3x4 of applyState(I, x), fp32 as the reference composes it
+  float pad0[4];
+  double dR[27];      // dR/dphi, dR/dtheta, dR/dpsi (row-major 3x3 each)
+  double f;           // mean cost at the last evaluated x
+  double gnorm;
+  int m;              // number of valid pairs
+  int inner_iter;
+  int inner_done;
+  int max_inner;
+};
+
+__host__ __device__ inline void gn_apply_state(GnState& S) {
+  const float a = (float)S.x[3], b = (float)S.x[4], c = (float)S.x[5];
+  const float ca = cosf(a), sa = sinf(a), cb = cosf(b), sb = sinf(b), cc = cosf(c), sc = sinf(c);
+  // A = Rz * Ry ; R = A * Rx   (float products, as Eigen::AngleAxisf chains them)
+  const float a00 = cc * cb, a01 = -sc, a02 = cc * sb;
+  const float a10 = sc * cb, a11 = cc, a12 = sc * sb;
+  const float a20 = -sb, a21 = 0.f, a22 = cb;
+  S.T[0] = a00; S.T[1] = a01 * ca + a02 * sa; S.T[2] = -a01 * sa + a02 * ca;
+  S.T[4] = a10; S.T[5] = a11 * ca + a12 * sa; S.T[6] = -a11 * sa + a12 * ca;
+  S.T[8] = a20; S.T[9] = a21 * ca + a22 * sa; S.T[10] = -a21 * sa + a22 * ca;
+  S.T[3] = (float)S.x[0]; S.T[7] = (float)S.x[1]; S.T[11] = (float)S.x[2];
+  const double phi = S.x[3], theta = S.x[4], psi = S.x[5];
+  const double cphi = cos(phi), sphi = sin(phi), ct = cos(theta), st = sin(theta), cpsi = cos(psi), spsi = sin(psi);
+  double* A = S.dR;
+  double* B = S.dR + 9;
+  double* Cc = S.dR + 18;
+  A[0] = 0; A[1] = sphi * spsi + cphi * cpsi * st;   A[2] = cphi * spsi - cpsi * sphi * st;
+  A[3] = 0; A[4] = -cpsi * sphi + cphi * spsi * st;  A[5] = -cphi * cpsi - sphi * spsi * st;
+  A[6] = 0; A[7] = cphi * ct;                        A[8] = -ct * sphi;
+  B[0] = -cpsi * st; B[1] = cpsi * ct * sphi; B[2] = cphi * cpsi * ct;
+  B[3] = -spsi * st; B[4] = ct * sphi * spsi; B[5] = cphi * ct * spsi;
+  B[6] = -ct;        B[7] = -sphi * st;       B[8] = -cphi * st;
+  Cc[0] = -ct * spsi; Cc[1] = -cphi * cpsi - sphi * spsi * st; Cc[2] = cpsi * sphi - cphi * spsi * st;
+  Cc[3] = cpsi * ct;  Cc[4] = -cphi * spsi + cpsi * sphi * st; Cc[5] = sphi * spsi + cphi * cpsi * st;
+  Cc[6] = 0; Cc[7] = 0; Cc[8] = 0;
 }
+
+// ---- small fp64 3x3 helpers ----------------------------------------------------------------------
+__device__ void sym3_eigen_k5(const double* Ain, double* w, double* V) {
+  double a00 = Ain[0], a01 = Ain[1], a02 = Ain[2], a11 = Ain[4], a12 = Ain[5], a22 = Ain[8];
+  double q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 32; sweep++) {
+    const double off = a01 * a01 + a02 * a02 + a12 * a12;
+    const double diag = a00 * a00 + a11 * a11 + a22 * a22;
+    if (off <= 1e-300 || off <= 1e-34 * diag) break;
+#define LSR_ROT(app, aqq, apq, arp, arq, cp, cq)                                            \
+  if (apq != 0.0) {                                                                         \
+    const double theta = (aqq - app) / (2.0 * apq);                                         \
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
+    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;                                    \
+    const double npp = app - t * apq, nqq = aqq + t * apq;                                  \
+    const double nrp = c * arp - s * arq, nrq = s * arp + c * arq;                          \
+    app = npp; aqq = nqq; apq = 0.0; arp = nrp; arq = nrq;                                  \
+    for (int k = 0; k < 3; k++) {                                                           \
+      const double qp = q[k * 3 + cp], qq = q[k * 3 + cq];                                  \
+      q[k * 3 + cp] = c * qp - s * qq;                                                      \
+      q[k * 3 + cq] = s * qp + c * qq;                                                      \
+    }                                                                                       \
+  }
+    LSR_ROT(a00, a11, a01, a02, a12, 0, 1)
+    LSR_ROT(a00, a22, a02, a01, a12, 0, 2)
+    LSR_ROT(a11, a22, a12, a01, a02, 1, 2)
+#undef LSR_ROT
+  }
+  w[0] = a00; w[1] = a11; w[2] = a22;
+  for (int k = 0; k < 9; k++) V[k] = q[k];
+}
+
+// K5: exact k-NN inside the cloud's own grid + covariance regularisation (computeCovariances)
+__global__ __launch_bounds__(NN_THREADS) void gicp_cov_kernel(NNGridView G, const float* __restrict__ px, const float* __restrict__ py,
+                                                              const float* __restrict__ pz, int n, int k, double gicp_eps,
+                                                              int fine_rings, double* __restrict__ cov) {
+  extern __shared__ unsigned char smem[];
+  float* sd = reinterpret_cast<float*>(smem);
+  int* si = reinterpret_cast<int*>(smem + (size_t)k * NN_THREADS * sizeof(float));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  BestK c;
+  c.init(sd + threadIdx.x, si + threadIdx.x, k);
+  if (i >= n) return;
+  nn_query(G, px[i], py[i], pz[i], fine_rings, INFINITY, c, -1);
+  double mean[3] = {0, 0, 0}, s00 = 0, s10 = 0, s11 = 0, s20 = 0, s21 = 0, s22 = 0;
+  for (int j = 0; j < k; j++) {
+    const int o = si[j * NN_THREADS + threadIdx.x];
+    if (o < 0) continue;  // cloud smaller than k (rejected on the host); keeps the kernel safe
+    const float x = px[o], y = py[o], z = pz[o];
+    mean[0] += (double)x; mean[1] += (double)y; mean[2] += (double)z;
+    // FLOAT products accumulated in double — the reference's `cov(0,0) += pt.x*pt.x`
+    s00 += (double)(x * x);
+    s10 += (double)(y * x); s11 += (double)(y * y);
+    s20 += (double)(z * x); s21 += (double)(z * y); s22 += (double)(z * z);
+  }
+  const double kk = (double)k;
+  mean[0] /= kk; mean[1] /= kk; mean[2] /= kk;
+  double C[9];
+  C[0] = s00 / kk - mean[0] * mean[0];
+  C[3] = s10 / kk - mean[1] * mean[0]; C[4] = s11 / kk - mean[1] * mean[1];
+  C[6] = s20 / kk - mean[2] * mean[0]; C[7] = s21 / kk - mean[2] * mean[1]; C[8] = s22 / kk - mean[2] * mean[2];
+  C[1] = C[3]; C[2] = C[6]; C[5] = C[7];
+  double w[3], V[9];
+  sym3_eigen_k5(C, w, V);
+  // singular values of a symmetric matrix are |eigenvalues|: the smallest one is replaced by eps
+  int small = 0;
+  if (fabs(w[1]) < fabs(w[small])) small = 1;
+  if (fabs(w[2]) < fabs(w[small])) small = 2;
+  double* out = cov + (size_t)i * 9;
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double s = 0;
+      for (int col = 0; col < 3; col++) s += ((col == small) ? gicp_eps : 1.0) * V[a * 3 + col] * V[b * 3 + col];
+      out[a * 3 + b] = s;
+    }
+}
+
+// output = guess * input (fp32, reference order of operations)
+__global__ __launch_bounds__(256) void gicp_apply_guess_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ z, int n, const float* __restrict__ G16,
+                                                               float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = x[i], b = y[i], c = z[i];
+  ox[i] = xform_rn(G16[0], G16[4], G16[8], G16[12], a, b, c);
+  oy[i] = xform_rn(G16[1], G16[5], G16[9], G16[13], a, b, c);
+  oz[i] = xform_rn(G16[2], G16[6], G16[10], G16[14], a, b, c);
+}
+
+// K6: correspondences + Mahalanobis matrices.  Rm = rotation of (transformation_ * guess) in double.
+__global__ __launch_bounds__(NN_THREADS) void gicp_corr_kernel(NNGridView G, const float* __restrict__ ox, const float* __restrict__ oy,
+                                                               const float* __restrict__ oz, int n, const float* __restrict__ T16,
+                                                               const double* __restrict__ Rm, float thr2, const double* __restrict__ C1,
+                                                               const double* __restrict__ C2, const float* __restrict__ tx,
+                                                               const float* __restrict__ ty, const float* __restrict__ tz,
+                                                               PairRec* __restrict__ pairs, int* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = ox[i], b = oy[i], c = oz[i];
+  const float qx = xform_rn(T16[0], T16[4], T16[8], T16[12], a, b, c);
+  const float qy = xform_rn(T16[1], T16[5], T16[9], T16[13], a, b, c);
+  const float qz = xform_rn(T16[2], T16[6], T16[10], T16[14], a, b, c);
+  Best1 best;
+  best.init();
+  nn_query(G, qx, qy, qz, 1, thr2, best, -1);
+  PairRec r;
+  r.valid = 0;
+  r.q[0] = r.q[1] = r.q[2] = 0.f;
+  for (int k = 0; k < 6; k++) r.M[k] = 0.0;
+  if (best.idx >= 0 && best.d2 < thr2) {
+    const int j = best.idx;
+    const double* c1 = C1 + (size_t)i * 9;
+    const double* c2 = C2 + (size_t)j * 9;
+    double RC[9], S[9];
+    for (int u = 0; u < 3; u++)
+      for (int v = 0; v < 3; v++) RC[u * 3 + v] = Rm[u * 3] * c1[v] + Rm[u * 3 + 1] * c1[3 + v] + Rm[u * 3 + 2] * c1[6 + v];
+    for (int u = 0; u < 3; u++)
+      for (int v = 0; v < 3; v++)
+        S[u * 3 + v] = RC[u * 3] * Rm[v * 3] + RC[u * 3 + 1] * Rm[v * 3 + 1] + RC[u * 3 + 2] * Rm[v * 3 + 2] + c2[u * 3 + v];
+    // general 3x3 inverse by cofactors (what temp.inverse() does)
+    const double k00 = S[4] * S[8] - S[5] * S[7], k01 = S[5] * S[6] - S[3] * S[8], k02 = S[3] * S[7] - S[4] * S[6];
+    const double det = S[0] * k00 + S[1] * k01 + S[2] * k02;
+    const double id = 1.0 / det;
+    r.M[0] = k00 * id;
+    r.M[1] = (S[2] * S[7] - S[1] * S[8]) * id;
+    r.M[2] = (S[1] * S[5] - S[2] * S[4]) * id;
+    r.M[3] = (S[0] * S[8] - S[2] * S[6]) * id;
+    r.M[4] = (S[2] * S[3] - S[0] * S[5]) * id;
+    r.M[5] = (S[0] * S[4] - S[1] * S[3]) * id;
+    r.q[0] = tx[j]; r.q[1] = ty[j]; r.q[2] = tz[j];
+    r.valid = 1;
+    atomicAdd(count, 1);
+  }
+  pairs[i] = r;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// K7: one Gauss-Newton accumulation pass at the state's x.
+__global__ __launch_bounds__(GN_THREADS) void gicp_gn_kernel(const float* __restrict__ ox, const float* __restrict__ oy,
+                                                             const float* __restrict__ oz, int n, const PairRec* __restrict__ pairs,
+                                                             const GnState* __restrict__ S, double* __restrict__ partials) {
+  if (S->inner_done) return;
+  __shared__ double s_red[GN_THREADS / 64][GN_NRED];
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = S->T[k];
+  double acc[GN_NRED];
+#pragma unroll
+  for (int k = 0; k < GN_NRED; k++) acc[k] = 0.0;
+  for (int i = blockIdx.x * GN_THREADS + threadIdx.x; i < n; i += gridDim.x * GN_THREADS) {
+    const PairRec r = pairs[i];
+    if (!r.valid) continue;
+    const float a = ox[i], b = oy[i], c = oz[i];
+    // transformation_matrix * p_src in float, residual promoted to double (OptimizationFunctorWithIndices)
+    const float ppx = xform_rn(T[0], T[1], T[2], T[3], a, b, c);
+    const float ppy = xform_rn(T[4], T[5], T[6], T[7], a, b, c);
+    const float ppz = xform_rn(T[8], T[9], T[10], T[11], a, b, c);
+    const double res[3] = {(double)(ppx - r.q[0]), (double)(ppy - r.q[1]), (double)(ppz - r.q[2])};
+    const double p[3] = {(double)a, (double)b, (double)c};
+    const double M00 = r.M[0], M01 = r.M[1], M02 = r.M[2], M11 = r.M[3], M12 = r.M[4], M22 = r.M[5];
+    double J[3][3];  // rotation columns: dR_k * p
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double* D = S->dR + 9 * k;
+#pragma unroll
+      for (int u = 0; u < 3; u++) J[u][k] = D[u * 3] * p[0] + D[u * 3 + 1] * p[1] + D[u * 3 + 2] * p[2];
+    }
+    const double Mr0 = M00 * res[0] + M01 * res[1] + M02 * res[2];
+    const double Mr1 = M01 * res[0] + M11 * res[1] + M12 * res[2];
+    const double Mr2 = M02 * res[0] + M12 * res[1] + M22 * res[2];
+    acc[0] += res[0] * Mr0 + res[1] * Mr1 + res[2] * Mr2;
+    acc[1] += Mr0; acc[2] += Mr1; acc[3] += Mr2;
+    double MJ[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      acc[4 + k] += J[0][k] * Mr0 + J[1][k] * Mr1 + J[2][k] * Mr2;
+      MJ[0][k] = M00 * J[0][k] + M01 * J[1][k] + M02 * J[2][k];
+      MJ[1][k] = M01 * J[0][k] + M11 * J[1][k] + M12 * J[2][k];
+      MJ[2][k] = M02 * J[0][k] + M12 * J[1][k] + M22 * J[2][k];
+    }
+    // upper triangle of J^T M J with J = [I | Jr]: rows 0..2 (tt, tr), rows 3..5 (rr)
+    acc[7] += M00; acc[8] += M01; acc[9] += M02; acc[10] += MJ[0][0]; acc[11] += MJ[0][1]; acc[12] += MJ[0][2];
+    acc[13] += M11; acc[14] += M12; acc[15] += MJ[1][0]; acc[16] += MJ[1][1]; acc[17] += MJ[1][2];
+    acc[18] += M22; acc[19] += MJ[2][0]; acc[20] += MJ[2][1]; acc[21] += MJ[2][2];
+    acc[22] += J[0][0] * MJ[0][0] + J[1][0] * MJ[1][0] + J[2][0] * MJ[2][0];
+    acc[23] += J[0][0] * MJ[0][1] + J[1][0] * MJ[1][1] + J[2][0] * MJ[2][1];
+    acc[24] += J[0][0] * MJ[0][2] + J[1][0] * MJ[1][2] + J[2][0] * MJ[2][2];
+    acc[25] += J[0][1] * MJ[0][1] + J[1][1] * MJ[1][1] + J[2][1] * MJ[2][1];
+    acc[26] += J[0][1] * MJ[0][2] + J[1][1] * MJ[1][2] + J[2][1] * MJ[2][2];
+    acc[27] += J[0][2] * MJ[0][2] + J[1][2] * MJ[1][2] + J[2][2] * MJ[2][2];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < GN_NRED; k++) {
+    const double v = wave_sum_d(acc[k]);
+    if (lane == 0) s_red[wid][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < GN_NRED) {
+    double v = s_red[0][threadIdx.x];
+    for (int w = 1; w < GN_THREADS / 64; w++) v += s_red[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * 32 + threadIdx.x] = v;
+  }
+}
+
+// delta = H^{-1} b, Gaussian elimination with partial pivoting (registers)
+__device__ void solve6_gn(const double* H, const double* b, double* x) {
+  double A[6][7];
+  for (int i = 0; i < 6; i++) {
+    for (int j = 0; j < 6; j++) A[i][j] = H[i * 6 + j];
+    A[i][6] = b[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double best = fabs(A[k][k]);
+    int piv = k;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double v = fabs(A[i][k]);
+      if (v > best) { best = v; piv = i; }
+    }
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const bool sw = (piv == i);
+#pragma unroll
+      for (int j = k; j < 7; j++) {
+        const double a = A[k][j], c = A[i][j];
+        A[k][j] = sw ? c : a;
+        A[i][j] = sw ? a : c;
+      }
+    }
+    const double inv = 1.0 / A[k][k];
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double f = A[i][k] * inv;
+#pragma unroll
+      for (int j = k + 1; j < 7; j++) A[i][j] -= f * A[k][j];
+    }
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; k--) {
+    double s = A[k][6];
+#pragma unroll
+    for (int j = k + 1; j < 6; j++) s -= A[k][j] * x[j];
+    x[k] = s / A[k][k];
+  }
+}
+
+__global__ __launch_bounds__(64) void gicp_update_kernel(GnState* __restrict__ S, const double* __restrict__ partials, int nblocks) {
+  if (S->inner_done) return;
+  __shared__ double s_sum[GN_NRED];
+  const int t = threadIdx.x;
+  if (t < GN_NRED) {
+    double v = 0.0;
+    for (int b = 0; b < nblocks; b++) v += partials[(size_t)b * 32 + t];  // fixed order
+    s_sum[t] = v;
+  }
+  __syncthreads();
+  if (t != 0) return;
+  const double m = (double)S->m;
+  double g[6], H[36];
+  S->f = s_sum[0] / m;
+  for (int k = 0; k < 6; k++) g[k] = 2.0 * s_sum[1 + k] / m;
+  int idx = 7;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      H[i * 6 + j] = H[j * 6 + i] = 2.0 * s_sum[idx] / m;
+      idx++;
+    }
+  double gn = 0;
+  for (int k = 0; k < 6; k++) gn += g[k] * g[k];
+  gn = sqrt(gn);
+  S->gnorm = gn;
+  if (gn < 1e-2 || S->inner_iter >= S->max_inner || !(gn == gn)) {  // BFGS testGradient(1e-2) / max_inner_iterations_
+    S->inner_done = 1;
+    return;
+  }
+  double neg[6], dx[6];
+  for (int k = 0; k < 6; k++) neg[k] = -g[k];
+  solve6_gn(H, neg, dx);
+  for (int k = 0; k < 6; k++) S->x[k] += dx[k];
+  S->inner_iter++;
+  gn_apply_state(*S);
+}
+
+void mat4_mul_f(const float* A, const float* B, float* C) {  // column-major fp32 product
+  float T[16];
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) {
+      float s = 0;
+      for (int k = 0; k < 4; k++) s += A[k * 4 + r] * B[c * 4 + k];
+      T[c * 4 + r] = s;
+    }
+  std::memcpy(C, T, sizeof(T));
+}
+
+int compute_covariances(lsr_handle_s* h, const DeviceCloud& cloud, const HashGridDev& grid, DevBuf<double>& cov) {
+  const int n = (int)cloud.n;
+  int st = cov.reserve((size_t)n * 9);
+  if (st) return st;
+  if (n == 0) return LSR_OK;
+  const int k = h->gicp.k;
+  const size_t smem = (size_t)k * NN_THREADS * (sizeof(float) + sizeof(int));
+  hipLaunchKernelGGL(gicp_cov_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS), dim3(NN_THREADS), smem, h->stream, make_view(grid),
+                     cloud.x(), cloud.y(), cloud.z(), n, k, h->gicp.gicp_eps, 2, cov.p);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+int ensure_covariances(lsr_handle_s* h) {
+  TargetData& t = *h->target;
+  int st;
+  if ((int)t.n < h->gicp.k || (int)h->source.n < h->gicp.k) {
+    set_last_error("GICP: cloud has fewer points than k_correspondences");
+    return LSR_ERR_TOO_FEW_POINTS;
+  }
+  if (!t.has_hash) {
+    if ((st = nn_build_hash(t.cloud, nn_pick_cell(t.cloud.n, h), t.hash, h->scratch, h->stream))) return st;
+    t.has_hash = true;
+  }
+  if (!t.has_cov || t.cov_k != h->gicp.k || t.cov_eps != h->gicp.gicp_eps) {
+    if ((st = compute_covariances(h, t.cloud, t.hash, t.cov))) return st;
+    t.has_cov = true;
+    t.cov_k = h->gicp.k;
+    t.cov_eps = h->gicp.gicp_eps;
+  }
+  if (!h->source_cov_valid) {
+    if ((st = nn_build_hash(h->source, nn_pick_cell(h->source.n, h), h->source_hash, h->scratch, h->stream))) return st;
+    if ((st = compute_covariances(h, h->source, h->source_hash, h->source_cov))) return st;
+    h->source_cov_valid = true;
+  }
+  return LSR_OK;
+}
+
+}  // namespace
+
+int gicp_get_covariances(lsr_handle_s* h, int which, double* cov) {
+  if (!h->target || h->target->n == 0) return LSR_ERR_NO_TARGET;
+  if (!h->has_source) return LSR_ERR_NO_SOURCE;
+  int st = ensure_covariances(h);
+  if (st) return st;
+  const DevBuf<double>& c = which == 0 ? h->source_cov : h->target->cov;
+  const size_t n = which == 0 ? h->source.n : h->target->n;
+  LSR_HIP(hipMemcpyAsync(cov, c.p, sizeof(double) * 9 * n, hipMemcpyDeviceToHost, h->stream));
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
+int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res) {
+  if (!h->target || h->target->n == 0) { set_last_error("align before setInputTarget"); return LSR_ERR_NO_TARGET; }
+  if (!h->has_source) { set_last_error("align before setInputSource"); return LSR_ERR_NO_SOURCE; }
+  int st = ensure_covariances(h);
+  if (st) return st;
+  hipStream_t s = h->stream;
+  const int n = (int)h->source.n;
+  const TargetData& t = *h->target;
+  float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float* G = guess ? guess : I16;
+
+  // workspace: out cloud | pairs | partials | state | count | T16 + G16 | Rm
+  const int nblocks = std::max(1, std::min((n + GN_THREADS - 1) / GN_THREADS, 512));
+  GicpWorkspace& ws = h->gicp_ws;
+  if ((st = ws.out.resize(n))) return st;
+  if ((st = ws.pairs.reserve((size_t)n * sizeof(PairRec)))) return st;
+  if ((st = ws.buf.reserve((size_t)nblocks * 32 + 64))) return st;
+  if ((st = ws.state.reserve(sizeof(GnState) + 256))) return st;
+  double* d_partials = ws.buf.p;
+  double* d_Rm = ws.buf.p + (size_t)nblocks * 32;
+  GnState* d_state = reinterpret_cast<GnState*>(ws.state.p);
+  int* d_count = reinterpret_cast<int*>(ws.state.p + sizeof(GnState) + 16);
+  float* d_T16 = reinterpret_cast<float*>(ws.state.p + sizeof(GnState) + 64);
+  float* d_G16 = d_T16 + 16;
+  PairRec* d_pairs = reinterpret_cast<PairRec*>(ws.pairs.p);
+
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  LSR_HIP(hipEventCreate(&e0));
+  LSR_HIP(hipEventCreate(&e1));
+  LSR_HIP(hipEventRecord(e0, s));
+  LSR_HIP(hipMemcpyAsync(d_G16, G, 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gicp_apply_guess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->source.x(), h->source.y(), h->source.z(),
+                     n, d_G16, ws.out.x(), ws.out.y(), ws.out.z());
+
+  float trans[16], prev[16];
+  std::memcpy(trans, I16, sizeof(I16));
+  std::memcpy(prev, I16, sizeof(I16));
+  const float thr2 = (float)(h->gicp.max_corr_dist * h->gicp.max_corr_dist);
+  int nr_iterations = 0, last_cnt = 0, gn_steps = 0;
+  bool converged = false;
+  double last_cost = 0;
+  GnState hs;
+  while (!converged) {
+    double Rm[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double v = 0;
+        for (int k = 0; k < 4; k++) v += (double)trans[k * 4 + i] * (double)G[j * 4 + k];
+        Rm[i * 3 + j] = v;
+      }
+    std::memset(&hs, 0, sizeof(hs));
+    hs.x[0] = trans[12]; hs.x[1] = trans[13]; hs.x[2] = trans[14];
+    hs.x[3] = atan2((double)trans[6], (double)trans[10]);
+    hs.x[4] = asin(-(double)trans[2]);
+    hs.x[5] = atan2((double)trans[1], (double)trans[0]);
+    hs.max_inner = h->gicp.max_inner;
+    gn_apply_state(hs);
+    LSR_HIP(hipMemcpyAsync(d_T16, trans, 16 * sizeof(float), hipMemcpyHostToDevice, s));
+    LSR_HIP(hipMemcpyAsync(d_Rm, Rm, sizeof(Rm), hipMemcpyHostToDevice, s));
+    LSR_HIP(hipMemsetAsync(d_count, 0, sizeof(int), s));
+    hipLaunchKernelGGL(gicp_corr_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS), dim3(NN_THREADS), 0, s, make_view(t.hash),
+                       ws.out.x(), ws.out.y(), ws.out.z(), n, d_T16, d_Rm, thr2, h->source_cov.p, t.cov.p, t.cloud.x(),
+                       t.cloud.y(), t.cloud.z(), d_pairs, d_count);
+    int cnt = 0;
+    LSR_HIP(hipMemcpyAsync(&cnt, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    LSR_HIP(hipStreamSynchronize(s));
+    last_cnt = cnt;
+    std::memcpy(prev, trans, sizeof(prev));
+    if (cnt < 4) break;  // reference: NotEnoughPointsException is caught, loop left unconverged
+    hs.m = cnt;
+    LSR_HIP(hipMemcpyAsync(d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, s));
+    // inner Gauss-Newton chain: launches past convergence exit on the done flag
+    int launched = 0;
+    while (true) {
+      const int chunk = std::min(4, h->gicp.max_inner + 1 - launched);
+      for (int it = 0; it < chunk; it++) {
+        hipLaunchKernelGGL(gicp_gn_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, ws.out.x(), ws.out.y(), ws.out.z(), n, d_pairs,
+                           d_state, d_partials);
+        hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_partials, nblocks);
+      }
+      launched += chunk;
+      LSR_HIP(hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, s));
+      LSR_HIP(hipStreamSynchronize(s));
+      if (hs.inner_done || launched >= h->gicp.max_inner + 1) break;
+    }
+    gn_steps += hs.inner_iter;
+    last_cost = hs.f;
+    if (!(hs.gnorm == hs.gnorm)) break;  // NaN: the reference's solver exception path
+    // transformation_ = applyState(identity, x)
+    {
+      GnState tmp = hs;
+      gn_apply_state(tmp);
+      trans[0] = tmp.T[0]; trans[4] = tmp.T[1]; trans[8] = tmp.T[2];  trans[12] = tmp.T[3];
+      trans[1] = tmp.T[4]; trans[5] = tmp.T[5]; trans[9] = tmp.T[6];  trans[13] = tmp.T[7];
+      trans[2] = tmp.T[8]; trans[6] = tmp.T[9]; trans[10] = tmp.T[10]; trans[14] = tmp.T[11];
+      trans[3] = trans[7] = trans[11] = 0.f; trans[15] = 1.f;
+    }
+    double delta = 0;
+    for (int k = 0; k < 4; k++)
+      for (int l = 0; l < 4; l++) {
+        const double ratio = (k < 3 && l < 3) ? 1. / h->gicp.rot_eps : 1. / h->gicp.trans_eps;
+        const double c_delta = ratio * std::fabs((double)prev[l * 4 + k] - (double)trans[l * 4 + k]);
+        if (c_delta > delta) delta = c_delta;
+      }
+    nr_iterations++;
+    if (nr_iterations >= h->gicp.max_iterations || delta < 1) {
+      converged = true;
+      std::memcpy(prev, trans, sizeof(prev));
+    }
+  }
+  LSR_HIP(hipEventRecord(e1, s));
+  LSR_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  LSR_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  mat4_mul_f(prev, G, h->final_T);  // final_transformation_ = previous_transformation_ * guess
+  h->converged = converged ? 1 : 0;
+  if (final_T) std::memcpy(final_T, h->final_T, sizeof(float) * 16);
+  if (res) {
+    res->converged = h->converged;
+    res->iterations = nr_iterations;
+    res->score = last_cost;
+    res->n_evaluations = gn_steps;
+    res->n_correspondences = last_cnt;
+    res->gpu_ms = ms;
+  }
+  return LSR_OK;
+}
+
+}  // namespace lsr

@@ -18,7 +18,10 @@ struct GicpParamsHost {
 };
 
 struct GicpWorkspace {
-  DevBuf<double> buf;
+  DeviceCloud out;               // guess * source ("output" of the reference's align)
+  DevBuf<unsigned char> pairs;   // PairRec[n]
+  DevBuf<double> buf;            // per-workgroup partial rows + Rm
+  DevBuf<unsigned char> state;   // GnState + counters + small matrices
 };
 
 int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res);

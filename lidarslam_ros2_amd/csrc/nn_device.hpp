@@ -1,0 +1,211 @@
+// Device-side pieces of the kd-tree-free NN grid shared by nn.hip (1-NN, fitness) and gicp.hip
+// (20-NN covariances, correspondences).  Translation units including this header are compiled with
+// -ffp-contract=off so the fp32 distance arithmetic matches the reference bit for bit.
+#pragma once
+#include "common.hpp"
+
+namespace lsr {
+namespace nnd {
+
+constexpr int NN_THREADS = 128;
+constexpr int FINE_PER_BLOCK = 512;
+constexpr int FINE_STRIDE = 513;
+
+struct NNGridView {
+  float cell, inv_cell;
+  int org[3];
+  int cdim[3];
+  const int* coarse_block;
+  const int* block_off;
+  const int* fine_start;
+  const float* x;
+  const float* y;
+  const float* z;
+  const int* order;
+};
+
+__device__ __forceinline__ float dist2_rn(float qx, float qy, float qz, float px, float py, float pz) {
+  const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// fp32 point transform in the reference's order: ((m0*x + m1*y) + m2*z) + m3, no contraction.
+__device__ __forceinline__ float xform_rn(float a, float b, float c, float d, float x, float y, float z) {
+  return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a, x), __fmul_rn(b, y)), __fmul_rn(c, z)), d);
+}
+
+// ---- top-K collectors --------------------------------------------------------------------------
+struct Best1 {
+  float d2;
+  int idx;
+  __device__ __forceinline__ void init() { d2 = INFINITY; idx = -1; }
+  __device__ __forceinline__ float worst() const { return d2; }
+  __device__ __forceinline__ bool full() const { return idx >= 0; }
+  __device__ __forceinline__ void offer(float d, int i) {
+    if (d < d2 || (d == d2 && i < idx)) { d2 = d; idx = i; }
+  }
+};
+
+// K-best list kept in LDS, column-major over threads ([slot][thread]) so lanes never collide.
+struct BestK {
+  float* d2;   // LDS base + tid
+  int* idx;    // LDS base + tid
+  int k, count;
+  __device__ __forceinline__ void init(float* d, int* i, int kk) {
+    d2 = d; idx = i; k = kk; count = 0;
+    for (int s = 0; s < kk; s++) { d2[s * NN_THREADS] = INFINITY; idx[s * NN_THREADS] = -1; }
+  }
+  __device__ __forceinline__ float worst() const { return d2[(k - 1) * NN_THREADS]; }
+  __device__ __forceinline__ bool full() const { return count >= k; }
+  __device__ __forceinline__ void offer(float d, int i) {
+    const float w = d2[(k - 1) * NN_THREADS];
+    const int wi = idx[(k - 1) * NN_THREADS];
+    if (!(d < w || (d == w && (wi < 0 || i < wi)))) return;
+    int s = k - 1;
+    while (s > 0) {
+      const float ps = d2[(s - 1) * NN_THREADS];
+      const int pi = idx[(s - 1) * NN_THREADS];
+      if (ps < d || (ps == d && pi >= 0 && pi < i)) break;
+      d2[s * NN_THREADS] = ps;
+      idx[s * NN_THREADS] = pi;
+      s--;
+    }
+    d2[s * NN_THREADS] = d;
+    idx[s * NN_THREADS] = i;
+    if (count < k) count++;
+  }
+};
+
+template <typename Coll>
+__device__ __forceinline__ void scan_range(const NNGridView& G, int beg, int end, float qx, float qy, float qz, Coll& c,
+                                           int self_skip) {
+  for (int s = beg; s < end; s++) {
+    const int oi = G.order[s];
+    if (oi == self_skip) continue;
+    const float d = dist2_rn(qx, qy, qz, G.x[s], G.y[s], G.z[s]);
+    c.offer(d, oi);
+  }
+}
+
+// Exact search for one query.  fine_rings: half-width of the first fine-cell block.
+template <typename Coll>
+__device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int fine_rings, float max_d2, Coll& c,
+                         int self_skip) {
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return;
+  const float fxf = floorf(qx * G.inv_cell), fyf = floorf(qy * G.inv_cell), fzf = floorf(qz * G.inv_cell);
+  if (!(fabsf(fxf) < 1.0e9f && fabsf(fyf) < 1.0e9f && fabsf(fzf) < 1.0e9f)) return;
+  const int fq[3] = {(int)fxf - G.org[0], (int)fyf - G.org[1], (int)fzf - G.org[2]};  // fine coords rel. to origin
+  const float q[3] = {qx, qy, qz};
+  const int fdim[3] = {G.cdim[0] * 8, G.cdim[1] * 8, G.cdim[2] * 8};
+
+  // ---- phase 1: (2R+1)^3 fine cells
+  bool any_fine = true;
+  for (int k = 0; k < 3; k++)
+    if (fq[k] + fine_rings < 0 || fq[k] - fine_rings >= fdim[k]) any_fine = false;
+  if (any_fine) {
+    for (int dz = -fine_rings; dz <= fine_rings; dz++) {
+      const int z = fq[2] + dz;
+      if (z < 0 || z >= fdim[2]) continue;
+      for (int dy = -fine_rings; dy <= fine_rings; dy++) {
+        const int y = fq[1] + dy;
+        if (y < 0 || y >= fdim[1]) continue;
+        for (int dx = -fine_rings; dx <= fine_rings; dx++) {
+          const int x = fq[0] + dx;
+          if (x < 0 || x >= fdim[0]) continue;
+          const int blk = G.coarse_block[(x >> 3) + G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3))];
+          if (blk < 0) continue;
+          const int f = (x & 7) | ((y & 7) << 3) | ((z & 7) << 6);
+          const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + f;
+          scan_range(G, fs[0], fs[1], qx, qy, qz, c, self_skip);
+        }
+      }
+    }
+  }
+  // every point outside the scanned fine block is at least `lo` away
+  float lo = INFINITY;
+  for (int k = 0; k < 3; k++) {
+    const float base = (float)(fq[k] + G.org[k]) * G.cell;
+    lo = fminf(lo, fminf(q[k] - (base - (float)fine_rings * G.cell), (base + (float)(fine_rings + 1) * G.cell) - q[k]));
+  }
+  lo = fmaxf(lo, 0.f);
+  float lo2 = lo * lo * 0.9999f;
+  if ((c.full() && c.worst() <= lo2) || lo2 > max_d2) return;
+
+  // ---- phase 2: coarse shells with box-distance pruning
+  const float C = G.cell * 8.f;
+  int cq[3];
+  for (int k = 0; k < 3; k++) cq[k] = (fq[k] >= 0) ? (fq[k] >> 3) : -(((-fq[k]) + 7) >> 3);
+  int rmax = 0;
+  for (int k = 0; k < 3; k++) rmax = max(rmax, max(cq[k], G.cdim[k] - 1 - cq[k]));
+  for (int r = 0; r <= rmax; r++) {
+    for (int dz = -r; dz <= r; dz++) {
+      const int z = cq[2] + dz;
+      if (z < 0 || z >= G.cdim[2]) continue;
+      for (int dy = -r; dy <= r; dy++) {
+        const int y = cq[1] + dy;
+        if (y < 0 || y >= G.cdim[1]) continue;
+        const bool shell_yz = (abs(dz) == r) || (abs(dy) == r);
+        const int step = shell_yz ? 1 : max(1, 2 * r);
+        for (int dx = -r; dx <= r; dx += step) {
+          const int x = cq[0] + dx;
+          if (x < 0 || x >= G.cdim[0]) continue;
+          const int blk = G.coarse_block[x + G.cdim[0] * (y + G.cdim[1] * z)];
+          if (blk < 0) continue;
+          // squared distance from q to the coarse cell's box
+          float bd2 = 0.f;
+          const int cc[3] = {x, y, z};
+          for (int k = 0; k < 3; k++) {
+            const float b0 = (float)(cc[k] * 8 + G.org[k]) * G.cell, b1 = b0 + C;
+            const float dd = fmaxf(fmaxf(b0 - q[k], q[k] - b1), 0.f);
+            bd2 += dd * dd;
+          }
+          bd2 *= 0.9999f;
+          if ((c.full() && bd2 > c.worst()) || bd2 > max_d2) continue;
+          // fine cells already visited in phase 1 must not be offered twice (a k-best list would keep
+          // the duplicate): walk the block cell by cell where it overlaps the phase-1 box
+          bool overlap = any_fine;
+          for (int k = 0; k < 3; k++)
+            if (cc[k] * 8 + 7 < fq[k] - fine_rings || cc[k] * 8 > fq[k] + fine_rings) overlap = false;
+          if (!overlap) {
+            scan_range(G, G.block_off[blk], G.block_off[blk + 1], qx, qy, qz, c, self_skip);
+          } else {
+            const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE;
+            for (int f = 0; f < FINE_PER_BLOCK; f++) {
+              const int beg = fs[f], end = fs[f + 1];
+              if (beg == end) continue;
+              const int gx = x * 8 + (f & 7), gy = y * 8 + ((f >> 3) & 7), gz = z * 8 + (f >> 6);
+              const bool seen = (abs(gx - fq[0]) <= fine_rings) && (abs(gy - fq[1]) <= fine_rings) && (abs(gz - fq[2]) <= fine_rings);
+              if (!seen) scan_range(G, beg, end, qx, qy, qz, c, self_skip);
+            }
+          }
+        }
+      }
+    }
+    float loc = INFINITY;
+    for (int k = 0; k < 3; k++) {
+      const float b0 = (float)((cq[k] - r) * 8 + G.org[k]) * G.cell;
+      const float b1 = (float)((cq[k] + r + 1) * 8 + G.org[k]) * G.cell;
+      loc = fminf(loc, fminf(q[k] - b0, b1 - q[k]));
+    }
+    loc = fmaxf(loc, 0.f);
+    const float loc2 = loc * loc * 0.9999f;
+    if ((c.full() && c.worst() <= loc2) || loc2 > max_d2) return;
+  }
+}
+
+
+inline NNGridView make_view(const HashGridDev& g) {
+  NNGridView v;
+  v.cell = g.cell;
+  v.inv_cell = 1.0f / g.cell;
+  for (int k = 0; k < 3; k++) { v.org[k] = g.org[k]; v.cdim[k] = g.cdim[k]; }
+  v.coarse_block = g.coarse_block.p;
+  v.block_off = g.block_off.p;
+  v.fine_start = g.fine_start.p;
+  v.x = g.sorted.x(); v.y = g.sorted.y(); v.z = g.sorted.z();
+  v.order = g.order.p;
+  return v;
+}
+
+}  // namespace nnd
+}  // namespace lsr

@@ -1,0 +1,120 @@
+"""GPU parity for GICP (K5 covariances, K6 correspondences, K7 Gauss-Newton) vs the CPU oracle.
+Final-pose tolerance from BASELINE.json north_star: <= 1e-3 m, <= 1e-4 rad."""
+import numpy as np
+import pytest
+
+from lidarslam_ros2_amd import synth
+from lidarslam_ros2_amd.posemath import pose_delta
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def case():
+    c = synth.small_case(n_source=4000, n_keyframes=3)
+    # the GICP frontend re-filters the target at vg_size_for_input (scanmatcher_component.cpp:309-315)
+    c.target = synth.voxel_downsample(c.target, 0.4)
+    return c
+
+
+def make_gicp(corr=5.0, eps=1e-8):
+    from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
+
+    g = GeneralizedIterativeClosestPoint(device=0)
+    g.setMaxCorrespondenceDistance(corr)      # scanmatcher_component.cpp:118
+    g.setTransformationEpsilon(eps)           # scanmatcher_component.cpp:119
+    return g
+
+
+def test_covariances_match_oracle(O, case):
+    g = make_gicp()
+    g.setInputTarget(synth.as_pointxyzi(case.target))
+    g.setInputSource(synth.as_pointxyzi(case.source))
+    for which, pts in (("target", case.target), ("source", case.source)):
+        cov = g.covariances(which)
+        ref = O.gicp_covariances(O.NearestNeighbour(pts, 1.0), pts)
+        # every regularised covariance has eigenvalues (eps, 1, 1)
+        w = np.linalg.eigvalsh(cov)
+        assert np.allclose(w, [1e-3, 1, 1], atol=1e-9)
+        # exact same 20 neighbours; eigenvectors of the same fp64 matrix by two Jacobi codes.  The plane
+        # normal of a near-isotropic neighbourhood is ill-conditioned, so compare the bulk tightly and the
+        # worst case loosely.
+        err = np.abs(cov - ref).max(axis=(1, 2))
+        assert np.quantile(err, 0.99) < 1e-6
+        assert err.max() < 1e-2
+
+
+def test_plane_covariance_is_diag_in_plane_frame(O):
+    g = make_gicp()
+    rng = np.random.default_rng(0)
+    xy = rng.uniform(-5, 5, (3000, 2))
+    plane = np.c_[xy, 0.25 * xy[:, 0] + 1.0].astype(np.float32)     # tilted plane
+    g.setInputTarget(plane)
+    g.setInputSource(plane[:500])
+    cov = g.covariances("target")
+    nrm = np.array([-0.25, 0, 1.0]) / np.linalg.norm([-0.25, 0, 1.0])
+    # normal direction carries epsilon, in-plane directions carry 1
+    assert np.allclose(np.einsum("i,nij,j->n", nrm, cov, nrm), 1e-3, atol=1e-4)
+    assert np.allclose(np.trace(cov, axis1=1, axis2=2), 2.001, atol=1e-6)
+
+
+@pytest.mark.parametrize("corr", [5.0, 30.0])
+def test_align_matches_oracle(O, case, corr):
+    g = make_gicp(corr)
+    g.setInputTarget(synth.as_pointxyzi(case.target))
+    g.setInputSource(synth.as_pointxyzi(case.source))
+    out = g.align(case.guess, output=True)
+    T = g.getFinalTransformation()
+    nt, ns = O.NearestNeighbour(case.target, 1.0), O.NearestNeighbour(case.source, 1.0)
+    ct, cs = O.gicp_covariances(nt, case.target), O.gicp_covariances(ns, case.source)
+    ref_gn = O.gicp_align(nt, case.target, ct, case.source, cs, case.guess, max_corr_dist=corr, trans_eps=1e-8, solver=1)
+    ref_bfgs = O.gicp_align(nt, case.target, ct, case.source, cs, case.guess, max_corr_dist=corr, trans_eps=1e-8, solver=0)
+    # same algorithm (Gauss-Newton inner solver) on CPU: tight
+    dt, ang = pose_delta(T, ref_gn["final"])
+    assert dt <= 1e-4 and ang <= 1e-5, (dt, ang, g.last_result, ref_gn)
+    assert g.last_result["n_correspondences"] == ref_gn["n_correspondences"]
+    # reference schedule (BFGS inner solver): north_star tolerance
+    dt, ang = pose_delta(T, ref_bfgs["final"])
+    assert dt <= 1e-3 and ang <= 1e-4, (dt, ang)
+    assert g.hasConverged() and ref_bfgs["converged"]
+    # registered: close to ground truth, output = T * source
+    gt, _ = pose_delta(T, case.truth)
+    assert gt < 0.05
+    assert np.abs(out - (case.source @ T[:3, :3].T + T[:3, 3])).max() < 1e-4
+    assert g.getFitnessScore() < 0.5
+
+
+def test_identical_planar_patches_zero_cost(O):
+    g = make_gicp()
+    rng = np.random.default_rng(1)
+    pts = np.c_[rng.uniform(-4, 4, (2000, 2)), np.zeros(2000)].astype(np.float32)
+    pts[:, 2] += (0.01 * rng.standard_normal(2000)).astype(np.float32)
+    g.setInputTarget(pts)
+    g.setInputSource(pts)
+    g.align()
+    assert np.allclose(g.getFinalTransformation(), np.eye(4), atol=1e-6)
+    assert g.last_result["score"] < 1e-12 and g.last_result["n_correspondences"] == 2000
+
+
+def test_too_few_points_and_no_correspondences(O, case):
+    from lidarslam_ros2_amd import _capi
+
+    g = make_gicp()
+    g.setInputTarget(case.target[:10])
+    g.setInputSource(case.source)
+    with pytest.raises(_capi.RegistrationError) as ei:
+        g.align()
+    assert ei.value.status == -8
+    g = make_gicp(corr=0.5)
+    g.setInputTarget(case.target)
+    g.setInputSource(case.source + np.float32(500.0))
+    g.align()                                   # < 4 correspondences: loop left, not converged, pose = guess
+    assert not g.hasConverged()
+    assert np.allclose(g.getFinalTransformation(), np.eye(4))
