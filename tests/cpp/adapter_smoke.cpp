@@ -1,0 +1,50 @@
+// Compiles the pcl::Registration-shaped adapter without PCL (stand-in point/cloud types with PCL's
+// layout) and exercises the exact call sequence of ScanMatcherComponent
+// (scanmatcher/src/scanmatcher_component.cpp:105-113,275,329,353,356,375).
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+#include "lidarslam_reg/registration.hpp"
+
+struct alignas(16) PointXYZI {  // pcl::PointXYZI: 32 bytes
+  float x, y, z, pad;
+  float intensity, p1, p2, p3;
+};
+static_assert(sizeof(PointXYZI) == 32, "PCL layout");
+struct Cloud {
+  std::vector<PointXYZI> points;
+};
+using NDT = lidarslam_reg::NormalDistributionsTransform<PointXYZI, PointXYZI, Cloud, Cloud>;
+using Reg = lidarslam_reg::Registration<PointXYZI, PointXYZI, Cloud, Cloud>;
+
+int main() {
+  std::shared_ptr<Reg> registration_;
+  try {
+    std::shared_ptr<NDT> ndt(new NDT());
+    ndt->setResolution(5.0f);
+    ndt->setTransformationEpsilon(0.01);
+    ndt->setNeighborhoodSearchMethod(lidarslam_reg::DIRECT7);
+    ndt->setNumThreads(2);
+    registration_ = ndt;
+  } catch (const std::exception& e) {
+    std::printf("NO_DEVICE %s\n", e.what());
+    return 0;  // expected on a CPU-only host: the core has no CPU path
+  }
+  auto tgt = std::make_shared<Cloud>();
+  auto src = std::make_shared<Cloud>();
+  for (int i = 0; i < 4000; i++) {
+    float u = (i % 64) * 0.3f, v = (i / 64) * 0.3f;
+    tgt->points.push_back({u, v, 0.02f * ((i * 7) % 5), 1.f, 0, 0, 0, 0});
+    tgt->points.push_back({u, 0.05f * ((i * 3) % 7), v, 1.f, 0, 0, 0, 0});
+    if (i % 3 == 0) src->points.push_back({u + 0.2f, v - 0.1f, 0.02f * ((i * 7) % 5), 1.f, 0, 0, 0, 0});
+  }
+  registration_->setInputTarget(tgt);
+  registration_->setInputSource(src);
+  Cloud output;
+  registration_->align(output, lidarslam_reg::Matrix4f::Identity());
+  auto T = registration_->getFinalTransformation();
+  std::printf("OK converged=%d iters=%d t=(%.3f %.3f %.3f) fitness=%.4f out=%zu\n", (int)registration_->hasConverged(),
+              registration_->getFinalNumIteration(), T(0, 3), T(1, 3), T(2, 3), registration_->getFitnessScore(), output.points.size());
+  return 0;
+}
