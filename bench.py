@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="registrations per shared launch in the 'batched' leg")
+    ap.add_argument("--batch", type=int, default=64, help="registrations per shared launch in the 'batched' leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()

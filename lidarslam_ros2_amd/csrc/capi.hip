@@ -64,13 +64,13 @@ int upload_cloud(lsr_handle h, const void* pts, size_t stride, size_t n, bool on
 }
 
 // Workgroups per registration.  A single registration spreads one point per thread over as many CUs as
-// it can (latency); a batch wants ~2 resident workgroups per CU in total and lets every thread stride
+// it can (latency); a batch wants ~4 resident workgroups per CU in total and lets every thread stride
 // over several points, which amortises the reduction and the partial-row traffic (throughput).
 int ndt_nblocks(size_t n, int batch = 1) {
   int nb = (int)((n + NDT_THREADS - 1) / NDT_THREADS);
   nb = std::max(1, std::min(nb, NDT_MAX_BLOCKS));
   if (batch > 1) {
-    int per = std::max(4, (2 * 256 + batch - 1) / batch);
+    int per = std::max(4, (4 * 256 + batch - 1) / batch);  // the batch kernel runs 4 workgroups per CU
     nb = std::min(nb, per);
   }
   return nb;

@@ -502,6 +502,15 @@ __device__ long long* g_lsr_timing = nullptr;  // [blocks][16] {wall, shader} pa
 #define LSR_STAMP(k)
 #endif
 
+// sum partner inside a quad of lanes via DPP quad_perm (no LDS traffic): CTRL 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1]
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad_xor(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 template <int NOFF>
 struct Offsets;
 template <>
@@ -525,13 +534,72 @@ struct Offsets<27> {
   }
 };
 
+// Epilogue of a derivative pass, executed by ONE workgroup per registration: fixed-order sum of all
+// partial rows, controller on an LDS image of the state, request build, write-back.
+__device__ __forceinline__ void ndt_epilogue(const NdtProblem& P, NdtState* __restrict__ S, const int nred, double* s_raw,
+                                             double* s_sum, double (*s_lu)[8]) {
+  const int tid = threadIdx.x;
+  // ---- last workgroup: fixed-order sum of all partial rows + controller on an LDS copy of the state
+  constexpr int STATE_DW = (int)(sizeof(NdtState) / 4);
+  static_assert(sizeof(NdtState) % 4 == 0 && STATE_DW <= 2 * NDT_THREADS, "NdtState copy assumes <= 512 dwords");
+  double(*s_grp)[NDT_NRED] = reinterpret_cast<double(*)[NDT_NRED]>(s_raw);        // [8][32] doubles
+  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_raw + 8 * NDT_NRED);  // NdtState image
+  {
+    const unsigned int* gdw = reinterpret_cast<const unsigned int*>(S);
+    const unsigned int st0 = (tid < STATE_DW) ? gdw[tid] : 0u;
+    const unsigned int st1 = (tid + NDT_THREADS < STATE_DW) ? gdw[tid + NDT_THREADS] : 0u;
+    const int v = tid & 31, grp = tid >> 5;  // 8 groups x 32 values; group g owns rows g, g+8, g+16, ...
+    double sum = 0.0;
+    if (v < nred) {
+      const double* base = P.partials + v;
+      for (int b0 = grp; b0 < P.nblocks; b0 += 128) {  // 16 independent loads in flight, fixed summation tree
+        double r[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int b = b0 + 8 * k;
+          r[k] = (b < P.nblocks)
+                     ? __hip_atomic_load(base + (size_t)b * NDT_NRED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     : 0.0;
+        }
+        sum += (((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))) +
+               (((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15])));
+      }
+    }
+    __syncthreads();  // every thread is done with s_part before its bytes are re-used
+    s_grp[grp][v] = sum;
+    if (tid < STATE_DW) s_state[tid] = st0;
+    if (tid + NDT_THREADS < STATE_DW) s_state[tid + NDT_THREADS] = st1;
+    __syncthreads();
+    if (tid < NDT_NRED) {
+      double t = 0.0;
+      if (tid < nred)
+        for (int g2 = 0; g2 < NDT_THREADS / 32; g2++) t += s_grp[g2][tid];
+      s_sum[tid] = t;
+    }
+    __syncthreads();
+  }
+  LSR_STAMP(6)
+  if (tid == 0) ndt_controller((LdsState*)(s_state), (const LdsDouble*)s_sum);
+  __syncthreads();
+  build_request(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[1][0]));
+  {
+    unsigned int* gdw = reinterpret_cast<unsigned int*>(S);
+    if (tid < STATE_DW) gdw[tid] = s_state[tid];
+    if (tid + NDT_THREADS < STATE_DW) gdw[tid + NDT_THREADS] = s_state[tid + NDT_THREADS];
+  }
+}
+
 // One derivative pass (K3) with the fused controller epilogue (K4).
 //  BYVAL: a single-registration launch carries its NdtProblem in the kernel arguments, which removes
 //         one dependent memory round trip from the latency chain of every pass.
 //  DENSE: leaf records are stored per grid cell (no cell->slot indirection): one dependent gather
 //         less per point; chosen when the dense table is small enough (ndt_build_grid).
-template <int NOFF, bool BYVAL, bool DENSE>
-__global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs) {
+//  FUSED: the last-arriving workgroup runs the controller inside this launch (lowest latency, used for
+//         a single registration).  Batched launches are NOT fused: every workgroup just leaves its
+//         partial row and a one-workgroup-per-registration ndt_controller_kernel follows — that keeps
+//         this kernel at <=128 VGPRs / 17 KB LDS (4 workgroups per CU) for throughput.
+template <int NOFF, bool BYVAL, bool DENSE, bool FUSED>
+__global__ __launch_bounds__(NDT_THREADS, FUSED ? 1 : 4) void ndt_eval_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs) {
   const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
   if ((int)blockIdx.x >= P.nblocks) return;
   NdtState* __restrict__ S = P.st;
@@ -541,7 +609,7 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   // LDS: [value][thread] transpose buffer (row pitch 264 doubles: column writes and the strided row
   // reads below are both bank-conflict free for ds_*_b64).  The epilogue of the last workgroup
   // re-uses the same bytes for its row sums and for an LDS copy of the controller state.
-  __shared__ double s_raw[29 * NDT_RED_PITCH];
+  __shared__ double s_raw[29 * NDT_RED_PITCH];  // 29 x 72 doubles = 16.7 KB
   __shared__ double s_sum[NDT_NRED];
   __shared__ double s_lu[8][8];  // rows 0-5: LU scratch, 6: -g, 7: delta
   __shared__ int s_last;
@@ -684,19 +752,25 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   }
 
   LSR_STAMP(2)
-  // ---- workgroup reduction: registers -> LDS transpose -> 8 segment sums per value -> partial row
+  // ---- workgroup reduction: quad sum in registers (DPP) -> LDS transpose [value][64 quads] ->
+  //      8 interleaved segment sums per value -> one partial row
   const int nred = hess ? 29 : NDT_NRED_GRAD;
 #pragma unroll
   for (int k = 0; k < 29; k++)
-    if (k < nred) s_part[k][tid] = acc[k];
+    if (k < nred) {
+      double v = acc[k];
+      v += dpp_quad_xor<0xB1>(v);  // lanes {0<->1, 2<->3}
+      v += dpp_quad_xor<0x4E>(v);  // lanes {0<->2, 1<->3}
+      if ((tid & 3) == 0) s_part[k][tid >> 2] = v;
+    }
   __syncthreads();
   double* prow = P.partials + (size_t)blockIdx.x * NDT_NRED;
   {
-    const int v = tid >> 3, seg = tid & 7;  // 32 values x 8 interleaved segments
+    const int v = tid >> 3, seg = tid & 7;  // 32 values x 8 interleaved segments of the 64 quad sums
     double t = 0.0;
     if (v < nred) {
-#pragma unroll 8
-      for (int k = 0; k < NDT_THREADS / 8; k++) t += s_part[v][seg + 8 * k];
+#pragma unroll
+      for (int k = 0; k < NDT_THREADS / 32; k++) t += s_part[v][seg + 8 * k];
     }
     t += __shfl_xor(t, 1, 64);
     t += __shfl_xor(t, 2, 64);
@@ -704,6 +778,7 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
     // write-through store so the row is visible to whichever workgroup arrives last
     if (seg == 0 && v < nred) __hip_atomic_store(prow + v, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (!FUSED) return;  // the controller kernel that follows sums the rows (kernel boundary = visibility)
   LSR_STAMP(3)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -715,59 +790,21 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   __syncthreads();
   LSR_STAMP(5)
   if (!s_last) return;
-
-  // ---- last workgroup: fixed-order sum of all partial rows + controller on an LDS copy of the state
-  constexpr int STATE_DW = (int)(sizeof(NdtState) / 4);
-  static_assert(sizeof(NdtState) % 4 == 0 && STATE_DW <= 2 * NDT_THREADS, "NdtState copy assumes <= 512 dwords");
-  double(*s_grp)[NDT_NRED] = reinterpret_cast<double(*)[NDT_NRED]>(s_raw);        // [8][32] doubles
-  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_raw + 8 * NDT_NRED);  // NdtState image
-  {
-    const unsigned int* gdw = reinterpret_cast<const unsigned int*>(S);
-    const unsigned int st0 = (tid < STATE_DW) ? gdw[tid] : 0u;
-    const unsigned int st1 = (tid + NDT_THREADS < STATE_DW) ? gdw[tid + NDT_THREADS] : 0u;
-    const int v = tid & 31, grp = tid >> 5;  // 8 groups x 32 values; group g owns rows g, g+8, g+16, ...
-    double sum = 0.0;
-    if (v < nred) {
-      const double* base = P.partials + v;
-      for (int b0 = grp; b0 < P.nblocks; b0 += 128) {  // 16 independent loads in flight, fixed summation tree
-        double r[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          const int b = b0 + 8 * k;
-          r[k] = (b < P.nblocks)
-                     ? __hip_atomic_load(base + (size_t)b * NDT_NRED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                     : 0.0;
-        }
-        sum += (((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))) +
-               (((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15])));
-      }
-    }
-    __syncthreads();  // every thread is done with s_part before its bytes are re-used
-    s_grp[grp][v] = sum;
-    if (tid < STATE_DW) s_state[tid] = st0;
-    if (tid + NDT_THREADS < STATE_DW) s_state[tid + NDT_THREADS] = st1;
-    __syncthreads();
-    if (tid < NDT_NRED) {
-      double t = 0.0;
-      if (tid < nred)
-        for (int g2 = 0; g2 < NDT_THREADS / 32; g2++) t += s_grp[g2][tid];
-      s_sum[tid] = t;
-    }
-    __syncthreads();
-  }
-  LSR_STAMP(6)
-  if (tid == 0) {
-    __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ndt_controller((LdsState*)(s_state), (const LdsDouble*)s_sum);
-  }
-  __syncthreads();
-  build_request(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[1][0]));
-  {
-    unsigned int* gdw = reinterpret_cast<unsigned int*>(S);
-    if (tid < STATE_DW) gdw[tid] = s_state[tid];
-    if (tid + NDT_THREADS < STATE_DW) gdw[tid + NDT_THREADS] = s_state[tid + NDT_THREADS];
-  }
+  if (tid == 0) __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ndt_epilogue(P, S, nred, s_raw, s_sum, s_lu);
   LSR_STAMP(7)
+}
+
+// One workgroup per registration: the epilogue of a non-fused (batched) derivative pass.
+__global__ __launch_bounds__(NDT_THREADS) void ndt_controller_kernel(const NdtProblem* __restrict__ probs) {
+  const NdtProblem& P = probs[blockIdx.x];
+  NdtState* __restrict__ S = P.st;
+  if (S->done) return;
+  __shared__ double s_raw[29 * NDT_RED_PITCH];
+  __shared__ double s_sum[NDT_NRED];
+  __shared__ double s_lu[8][8];
+  const int nred = (S->want_hessian != 0) ? 29 : NDT_NRED_GRAD;
+  ndt_epilogue(P, S, nred, s_raw, s_sum, s_lu);
 }
 
 #ifdef LSR_TIMING
@@ -790,12 +827,13 @@ namespace {
 template <int NOFF>
 static void launch_one(bool byval, bool dense, dim3 grid, dim3 block, hipStream_t stream, const NdtProblem& pv,
                        const NdtProblem* d_probs) {
-  if (byval) {
-    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, true>), grid, block, 0, stream, pv, d_probs);
-    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, false>), grid, block, 0, stream, pv, d_probs);
-  } else {
-    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, true>), grid, block, 0, stream, pv, d_probs);
-    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, false>), grid, block, 0, stream, pv, d_probs);
+  if (byval) {  // single registration: fused controller, problem in the kernel arguments
+    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, true, true>), grid, block, 0, stream, pv, d_probs);
+    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, false, true>), grid, block, 0, stream, pv, d_probs);
+  } else {      // batch: throughput variant + one controller workgroup per registration
+    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, true, false>), grid, block, 0, stream, pv, d_probs);
+    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, false, false>), grid, block, 0, stream, pv, d_probs);
+    hipLaunchKernelGGL(ndt_controller_kernel, dim3(grid.y), block, 0, stream, d_probs);
   }
 }
 

@@ -23,7 +23,7 @@ constexpr int NDT_NRED = 32;       // doubles per partial row: [0]=score [1..6]=
 constexpr int NDT_NRED_GRAD = 8;   // entries reduced on gradient-only passes
 constexpr int NDT_THREADS = 256;
 constexpr int NDT_MAX_BLOCKS = 1024;
-constexpr int NDT_RED_PITCH = 264;  // doubles per row of the LDS transpose buffer
+constexpr int NDT_RED_PITCH = 72;   // doubles per row of the LDS transpose buffer (64 quad sums + pad)
 
 struct NdtState {
   // ---- evaluation request, read by every workgroup of the next launch
