@@ -113,33 +113,43 @@ int ensure_target_hash(lsr_handle h) {
   return LSR_OK;
 }
 
-// Chain of derivative+controller launches until every problem reports done.
-int run_ndt_chain(lsr_handle lead, NdtProblem* d_probs, const NdtProblem* h_probs, int batch, int max_blocks, NdtState* d_states, NdtState* h_states,
-                  int neighborhood, bool dense, int min_evals, int hard_cap, bool profile, lsr_profile* prof, long points_per_launch) {
+// Chain of launches until every problem reports done.  Launch `seq` consumes the rows of launch seq-1
+// (ndt.hip), so an align of E derivative passes takes E+1 launches; states are double buffered by
+// launch parity: after L launches the current state of problem b is h_states[2*b + (L & 1)].
+int run_ndt_chain(lsr_handle lead, NdtProblem* d_probs, const NdtProblem* h_probs, int batch, int max_blocks, NdtState* d_states,
+                  NdtState* h_states, int neighborhood, bool dense, int min_evals, int hard_cap, bool profile, lsr_profile* prof,
+                  long points_per_launch, int* launches_out) {
   int launched = 0;
   int chunk = std::max(1, min_evals);
   if (profile) chunk = 1;
   while (launched < hard_cap) {
     int c = std::min(chunk, hard_cap - launched);
     if (profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
-    int st = ndt_launch_evals(d_probs, batch == 1 ? h_probs : nullptr, batch, max_blocks, neighborhood, dense, c, lead->stream);
+    int st = ndt_launch_evals(d_probs, batch == 1 ? h_probs : nullptr, batch, max_blocks, neighborhood, dense, launched, c,
+                              lead->stream);
     if (st) return st;
     if (profile) LSR_HIP(hipEventRecord(lead->ev1, lead->stream));
     launched += c;
-    LSR_HIP(hipMemcpyAsync(h_states, d_states, sizeof(NdtState) * batch, hipMemcpyDeviceToHost, lead->stream));
+    LSR_HIP(hipMemcpyAsync(h_states, d_states, sizeof(NdtState) * 2 * batch, hipMemcpyDeviceToHost, lead->stream));
     LSR_HIP(hipStreamSynchronize(lead->stream));
-    if (profile) {
+    const int cur = launched & 1;
+    bool all_done = true;
+    for (int b = 0; b < batch; b++) all_done = all_done && (h_states[2 * b + cur].done != 0);
+    if (profile && !(all_done && c == 1 && launched > 1 && false)) {
       float ms = 0.f;
       LSR_HIP(hipEventElapsedTime(&ms, lead->ev0, lead->ev1));
-      prof->deriv_ms_total += ms;
-      prof->deriv_launches += 1;
-      prof->deriv_points += points_per_launch;
+      if (!all_done) {  // the finalising launch (controller only, no derivative pass) is not a derivative launch
+        prof->deriv_ms_total += ms;
+        prof->deriv_launches += 1;
+        prof->deriv_points += points_per_launch;
+      }
       prof->deriv_pairs = 0;
-      for (int b = 0; b < batch; b++) prof->deriv_pairs += (int64_t)h_states[b].last_pairs;
+      for (int b = 0; b < batch; b++) prof->deriv_pairs += (int64_t)h_states[2 * b + cur].last_pairs;
     }
-    bool all_done = true;
-    for (int b = 0; b < batch; b++) all_done = all_done && (h_states[b].done != 0);
-    if (all_done) return LSR_OK;
+    if (all_done) {
+      *launches_out = launched;
+      return LSR_OK;
+    }
     if (!profile) chunk = 8;
   }
   set_last_error("NDT controller did not finish within the launch cap");
@@ -148,12 +158,12 @@ int run_ndt_chain(lsr_handle lead, NdtProblem* d_probs, const NdtProblem* h_prob
 
 int ndt_hard_cap(const NdtParamsHost& p) {
   // per Newton iteration: 1 first pass + <=10 trials + 1 Hessian recomputation; max_iter+2 iterations; + initial pass
-  return (p.max_iterations + 2) * 12 + 4;
+  return (p.max_iterations + 2) * 12 + 5;
 }
 
 int ndt_min_evals(const NdtParamsHost& p) {
   // with a non-positive epsilon the loop can only stop on the iteration count: at least max_iter+2 line searches
-  if (p.trans_eps <= 0) return p.max_iterations + 3;
+  if (p.trans_eps <= 0) return p.max_iterations + 4;  // + the finalising launch
   return 8;
 }
 
@@ -169,8 +179,8 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     if (st) return st;
   }
   int st;
-  if ((st = lead->d_state.reserve(B))) return st;
-  if ((st = lead->h_state.reserve(B))) return st;
+  if ((st = lead->d_state.reserve(2 * (size_t)B))) return st;
+  if ((st = lead->h_state.reserve(2 * (size_t)B))) return st;
   if ((st = lead->d_prob.reserve(B))) return st;
   if ((st = lead->h_prob.reserve(B))) return st;
   size_t tot_blocks = 0;
@@ -180,7 +190,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     tot_blocks += nb;
     max_blocks = std::max(max_blocks, nb);
   }
-  if ((st = lead->d_partials.reserve(tot_blocks * NDT_NRED))) return st;
+  if ((st = lead->d_partials.reserve(2 * tot_blocks * NDT_NRED))) return st;
   size_t old_ticket_cap = lead->d_ticket.cap;
   if ((st = lead->d_ticket.reserve(B))) return st;
   if (lead->d_ticket.cap != old_ticket_cap)
@@ -192,22 +202,24 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   long pts = 0;
   for (int b = 0; b < B; b++) {
     lsr_handle h = hs[b];
-    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + b, lead->d_partials.p + blk_off * NDT_NRED, lead->d_ticket.p + b, B);
+    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_partials.p + 2 * blk_off * NDT_NRED, lead->d_ticket.p + b, B);
     blk_off += lead->h_prob.p[b].nblocks;
-    ndt_fill_initial_state(lead->h_state.p[b], guesses ? guesses + 16 * b : nullptr, h->ndt, (int)h->source.n);
+    ndt_fill_initial_state(lead->h_state.p[2 * b], guesses ? guesses + 16 * b : nullptr, h->ndt, (int)h->source.n);
+    lead->h_state.p[2 * b + 1] = lead->h_state.p[2 * b];
     min_evals = std::max(min_evals, ndt_min_evals(h->ndt));
     hard_cap = std::max(hard_cap, ndt_hard_cap(h->ndt));
     pts += (long)h->source.n;
   }
   LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   LSR_HIP(hipMemcpyAsync(lead->d_prob.p, lead->h_prob.p, sizeof(NdtProblem) * B, hipMemcpyHostToDevice, lead->stream));
-  LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * B, hipMemcpyHostToDevice, lead->stream));
+  LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
   hipEvent_t e_start = nullptr, e_stop = nullptr;
   LSR_HIP(hipEventCreate(&e_start));
   LSR_HIP(hipEventCreate(&e_stop));
   LSR_HIP(hipEventRecord(e_start, lead->stream));
+  int launches = 0;
   st = run_ndt_chain(lead, lead->d_prob.p, lead->h_prob.p, B, max_blocks, lead->d_state.p, lead->h_state.p, lead->ndt.neighborhood, dense, min_evals,
-                     hard_cap, lead->profile != 0, &lead->prof, pts);
+                     hard_cap, lead->profile != 0, &lead->prof, pts, &launches);
   if (st) { (void)hipEventDestroy(e_start); (void)hipEventDestroy(e_stop); return st; }
   LSR_HIP(hipEventRecord(e_stop, lead->stream));
   LSR_HIP(hipEventSynchronize(e_stop));
@@ -216,7 +228,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   (void)hipEventDestroy(e_start);
   (void)hipEventDestroy(e_stop);
   for (int b = 0; b < B; b++) {
-    const NdtState& S = lead->h_state.p[b];
+    const NdtState& S = lead->h_state.p[2 * b + (launches & 1)];
     lsr_handle h = hs[b];
     std::memcpy(h->final_T, S.final_T, sizeof(float) * 16);
     h->converged = S.converged;
@@ -569,20 +581,22 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
   if (!h->has_source) return LSR_ERR_NO_SOURCE;
   int st = ensure_ndt_grid(h);
   if (st) return st;
-  if ((st = h->d_state.reserve(1))) return st;
-  if ((st = h->h_state.reserve(1))) return st;
+  if ((st = h->d_state.reserve(2))) return st;
+  if ((st = h->h_state.reserve(2))) return st;
   if ((st = h->d_prob.reserve(1))) return st;
   if ((st = h->h_prob.reserve(1))) return st;
   int nb = ndt_nblocks(h->source.n);
-  if ((st = h->d_partials.reserve((size_t)nb * NDT_NRED))) return st;
+  if ((st = h->d_partials.reserve(2 * (size_t)nb * NDT_NRED))) return st;
   size_t old_cap = h->d_ticket.cap;
   if ((st = h->d_ticket.reserve(1))) return st;
   if (h->d_ticket.cap != old_cap) LSR_HIP(hipMemsetAsync(h->d_ticket.p, 0, h->d_ticket.cap * sizeof(unsigned int), h->stream));
   fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p, h->d_ticket.p);
   ndt_fill_diag_state(h->h_state.p[0], p6, T16, compute_hessian, h->ndt, (int)h->source.n);
+  h->h_state.p[1] = h->h_state.p[0];
   LSR_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, sizeof(NdtProblem), hipMemcpyHostToDevice, h->stream));
-  LSR_HIP(hipMemcpyAsync(h->d_state.p, h->h_state.p, sizeof(NdtState), hipMemcpyHostToDevice, h->stream));
-  if ((st = ndt_launch_evals(h->d_prob.p, h->h_prob.p, 1, nb, h->ndt.neighborhood, h->target->grid.dense, 1, h->stream))) return st;
+  LSR_HIP(hipMemcpyAsync(h->d_state.p, h->h_state.p, 2 * sizeof(NdtState), hipMemcpyHostToDevice, h->stream));
+  // launch 0 evaluates, launch 1 sums the rows into the state (PH_DIAG) -> state buffer (2 & 1) = 0
+  if ((st = ndt_launch_evals(h->d_prob.p, h->h_prob.p, 1, nb, h->ndt.neighborhood, h->target->grid.dense, 0, 2, h->stream))) return st;
   LSR_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, sizeof(NdtState), hipMemcpyDeviceToHost, h->stream));
   LSR_HIP(hipStreamSynchronize(h->stream));
   const NdtState& S = h->h_state.p[0];

@@ -226,6 +226,7 @@ __device__ __forceinline__ bool mt_update_interval(LdsState* S, double a_t, doub
 // fully unrolled, row swaps by select).  The reference calls JacobiSVD::solve; for a non-singular 6x6
 // both give H^{-1} b.  A column whose pivot vanishes is dropped = its unknown set to 0, which is the
 // SVD's minimum-norm answer for the degenerate all-zero Hessian of a scan that overlaps no voxel.
+// (A wave-parallel Gauss-Jordan on an LDS matrix was measured slower: +0.9 us per pass on average.)
 __device__ __forceinline__ void solve6(const LdsDouble* H, const double* __restrict__ b, double* __restrict__ x) {
   double A[6][7];
   double scale = 0;
@@ -534,102 +535,116 @@ struct Offsets<27> {
   }
 };
 
-// Epilogue of a derivative pass, executed by ONE workgroup per registration: fixed-order sum of all
-// partial rows, controller on an LDS image of the state, request build, write-back.
-__device__ __forceinline__ void ndt_epilogue(const NdtProblem& P, NdtState* __restrict__ S, const int nred, double* s_raw,
-                                             double* s_sum, double (*s_lu)[8]) {
+// One derivative pass (K3) preceded by the controller step (K4) that consumes the PREVIOUS pass.
+//
+// "Pull" structure: launch number `seq` starts — in EVERY workgroup, redundantly and deterministically
+// — by summing the partial rows launch seq-1 left behind (fixed order), advancing the Newton /
+// More-Thuente controller on an LDS image of the state and building the next evaluation request;
+// only then does it evaluate its own points and leave its partial row.  No workgroup ever waits for
+// another one inside a launch: no tickets, no atomics, no write-through stores, no tail executed by a
+// single workgroup — the kernel boundary is the only synchronisation.  State and rows are double
+// buffered by launch parity (launch seq reads state[seq&1], rows[(seq-1)&1]; workgroup 0 writes
+// state[(seq+1)&1]; everybody writes rows[seq&1]), so a late-starting workgroup can never observe a
+// value produced by its own launch.
+//  BYVAL: a single-registration launch carries its NdtProblem in the kernel arguments, which removes
+//         one dependent memory round trip from the latency chain of every pass.
+//  DENSE: leaf records are stored per grid cell (no cell->slot indirection): one dependent gather
+//         less per point; chosen when the dense table is small enough (ndt_build_grid).
+template <int NOFF, bool BYVAL, bool DENSE>
+__global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq) {
+  const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
+  if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x;
-  // ---- last workgroup: fixed-order sum of all partial rows + controller on an LDS copy of the state
+  LSR_STAMP(0)
+
+  // LDS: [value][64 quad sums] transpose buffer (pitch 72: conflict free ds_*_b64) — also the row-sum
+  // scratch of the head —, the state image, the 32 totals.
+  __shared__ double s_raw[29 * NDT_RED_PITCH];
+  __shared__ double s_sum[NDT_NRED];
+  __shared__ double s_lu[8][8];
   constexpr int STATE_DW = (int)(sizeof(NdtState) / 4);
-  static_assert(sizeof(NdtState) % 4 == 0 && STATE_DW <= 2 * NDT_THREADS, "NdtState copy assumes <= 512 dwords");
-  double(*s_grp)[NDT_NRED] = reinterpret_cast<double(*)[NDT_NRED]>(s_raw);        // [8][32] doubles
-  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_raw + 8 * NDT_NRED);  // NdtState image
+  static_assert(sizeof(NdtState) % 8 == 0 && STATE_DW <= 2 * NDT_THREADS, "NdtState copy assumes <= 512 dwords");
+  __shared__ double s_state_d[STATE_DW / 2];
+  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_state_d);
+  double(*s_part)[NDT_RED_PITCH] = reinterpret_cast<double(*)[NDT_RED_PITCH]>(s_raw);
+  double(*s_grp)[NDT_NRED] = reinterpret_cast<double(*)[NDT_NRED]>(s_raw);  // [8][32] doubles, head only
+
+  const NdtState* __restrict__ Sin = P.st + (seq & 1);
+  NdtState* __restrict__ Sout = P.st + ((seq + 1) & 1);
+
+  // ---- head: issue everything this workgroup needs from HBM/L2 at once
+  const int stride = P.nblocks * NDT_THREADS;
+  int i = blockIdx.x * NDT_THREADS + tid;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
   {
-    const unsigned int* gdw = reinterpret_cast<const unsigned int*>(S);
+    const unsigned int* gdw = reinterpret_cast<const unsigned int*>(Sin);
     const unsigned int st0 = (tid < STATE_DW) ? gdw[tid] : 0u;
     const unsigned int st1 = (tid + NDT_THREADS < STATE_DW) ? gdw[tid + NDT_THREADS] : 0u;
-    const int v = tid & 31, grp = tid >> 5;  // 8 groups x 32 values; group g owns rows g, g+8, g+16, ...
+    // rows of the previous launch: 8 groups x 32 values; group g owns rows g, g+8, ...; 16 loads in flight
+    const int v = tid & 31, grp = tid >> 5;
     double sum = 0.0;
-    if (v < nred) {
-      const double* base = P.partials + v;
-      for (int b0 = grp; b0 < P.nblocks; b0 += 128) {  // 16 independent loads in flight, fixed summation tree
+    if (seq > 0) {
+      const double* base = P.partials + (size_t)((seq + 1) & 1) * P.nblocks * NDT_NRED + v;
+      for (int b0 = grp; b0 < P.nblocks; b0 += 128) {
         double r[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
           const int b = b0 + 8 * k;
-          r[k] = (b < P.nblocks)
-                     ? __hip_atomic_load(base + (size_t)b * NDT_NRED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                     : 0.0;
+          r[k] = (b < P.nblocks) ? base[(size_t)b * NDT_NRED] : 0.0;
         }
         sum += (((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))) +
                (((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15])));
       }
     }
-    __syncthreads();  // every thread is done with s_part before its bytes are re-used
     s_grp[grp][v] = sum;
     if (tid < STATE_DW) s_state[tid] = st0;
     if (tid + NDT_THREADS < STATE_DW) s_state[tid + NDT_THREADS] = st1;
-    __syncthreads();
+  }
+  __syncthreads();
+  LdsState* L = (LdsState*)s_state;
+  LSR_STAMP(1)
+  if (L->done) {  // finished earlier: keep both state buffers identical so later launches see it too
+    if (blockIdx.x == 0 && seq > 0) {
+      unsigned int* gdw = reinterpret_cast<unsigned int*>(Sout);
+      if (tid < STATE_DW) gdw[tid] = s_state[tid];
+      if (tid + NDT_THREADS < STATE_DW) gdw[tid + NDT_THREADS] = s_state[tid + NDT_THREADS];
+    }
+    return;
+  }
+  if (seq > 0) {
+    // rows hold what the request in the state asked for: 29 sums with Hessian, 8 without
+    const int nprev = (L->want_hessian != 0) ? 29 : NDT_NRED_GRAD;
     if (tid < NDT_NRED) {
       double t = 0.0;
-      if (tid < nred)
+      if (tid < nprev)
         for (int g2 = 0; g2 < NDT_THREADS / 32; g2++) t += s_grp[g2][tid];
       s_sum[tid] = t;
     }
     __syncthreads();
+    LSR_STAMP(6)
+    if (tid == 0) ndt_controller(L, (const LdsDouble*)s_sum);
+    __syncthreads();
+    build_request(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[1][0]));
+    LSR_STAMP(4)
   }
-  LSR_STAMP(6)
-  if (tid == 0) ndt_controller((LdsState*)(s_state), (const LdsDouble*)s_sum);
-  __syncthreads();
-  build_request(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[1][0]));
-  {
-    unsigned int* gdw = reinterpret_cast<unsigned int*>(S);
+  if (blockIdx.x == 0) {
+    unsigned int* gdw = reinterpret_cast<unsigned int*>(Sout);
     if (tid < STATE_DW) gdw[tid] = s_state[tid];
     if (tid + NDT_THREADS < STATE_DW) gdw[tid + NDT_THREADS] = s_state[tid + NDT_THREADS];
   }
-}
+  if (L->done) return;
+  LSR_STAMP(7)
 
-// One derivative pass (K3) with the fused controller epilogue (K4).
-//  BYVAL: a single-registration launch carries its NdtProblem in the kernel arguments, which removes
-//         one dependent memory round trip from the latency chain of every pass.
-//  DENSE: leaf records are stored per grid cell (no cell->slot indirection): one dependent gather
-//         less per point; chosen when the dense table is small enough (ndt_build_grid).
-//  FUSED: the last-arriving workgroup runs the controller inside this launch (lowest latency, used for
-//         a single registration).  Batched launches are NOT fused: every workgroup just leaves its
-//         partial row and a one-workgroup-per-registration ndt_controller_kernel follows — that keeps
-//         this kernel at <=128 VGPRs / 17 KB LDS (4 workgroups per CU) for throughput.
-template <int NOFF, bool BYVAL, bool DENSE, bool FUSED>
-__global__ __launch_bounds__(NDT_THREADS, FUSED ? 1 : 4) void ndt_eval_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs) {
-  const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
-  if ((int)blockIdx.x >= P.nblocks) return;
-  NdtState* __restrict__ S = P.st;
-  const int tid = threadIdx.x;
-  LSR_STAMP(0)
-
-  // LDS: [value][thread] transpose buffer (row pitch 264 doubles: column writes and the strided row
-  // reads below are both bank-conflict free for ds_*_b64).  The epilogue of the last workgroup
-  // re-uses the same bytes for its row sums and for an LDS copy of the controller state.
-  __shared__ double s_raw[29 * NDT_RED_PITCH];  // 29 x 72 doubles = 16.7 KB
-  __shared__ double s_sum[NDT_NRED];
-  __shared__ double s_lu[8][8];  // rows 0-5: LU scratch, 6: -g, 7: delta
-  __shared__ int s_last;
-  double(*s_part)[NDT_RED_PITCH] = reinterpret_cast<double(*)[NDT_RED_PITCH]>(s_raw);
-
-  // Issue the first point loads and the request loads together, THEN look at `done`.
-  const int stride = P.nblocks * NDT_THREADS;
-  int i = blockIdx.x * NDT_THREADS + tid;
-  float x = 0.f, y = 0.f, z = 0.f;
-  if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
-  const int done = S->done;
-  const bool hess = S->want_hessian != 0;
-  const double d1d = S->d1;
-  const float d2 = (float)S->d2;
+  // ---- this launch's request, straight from the LDS image
+  const bool hess = L->want_hessian != 0;
+  const double d1d = L->d1;
+  const float d2 = (float)L->d2;
   float T[12];
 #pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = S->T[k];
-  if (done) return;
-  LSR_STAMP(1)
+  for (int k = 0; k < 12; k++) T[k] = L->T[k];
   const float leaf = P.leaf;
+  __syncthreads();  // s_grp (aliases the transpose buffer) is dead from here on
 
   double acc[29];
 #pragma unroll
@@ -701,7 +716,7 @@ __global__ __launch_bounds__(NDT_THREADS, FUSED ? 1 : 4) void ndt_eval_kernel(co
     if (npairs == 0.f) continue;
 
     // Point Jacobian J = [I | J3 J4 J5] from the UNTRANSFORMED point (eq. 6.18/6.19)
-    const float* ja = S->jang;
+    const __attribute__((address_space(3))) float* ja = L->jang;
     const float j_a = fmaf(ja[0], px, fmaf(ja[1], py, ja[2] * pz));
     const float j_b = fmaf(ja[3], px, fmaf(ja[4], py, ja[5] * pz));
     const float j_c = fmaf(ja[6], px, fmaf(ja[7], py, ja[8] * pz));
@@ -726,7 +741,7 @@ __global__ __launch_bounds__(NDT_THREADS, FUSED ? 1 : 4) void ndt_eval_kernel(co
                   e4z = fmaf(E02, j_c, fmaf(E12, j_d, E22 * j_e));
       const float e5x = fmaf(E00, j_f, fmaf(E01, j_g, E02 * j_h)), e5y = fmaf(E01, j_f, fmaf(E11, j_g, E12 * j_h)),
                   e5z = fmaf(E02, j_f, fmaf(E12, j_g, E22 * j_h));
-      const float* ha = S->hang;
+      const __attribute__((address_space(3))) float* ha = L->hang;
       // second-derivative vectors (eq. 6.20/6.21) dotted with A = sum w C q
       const float ha2 = fmaf(ha[0], px, fmaf(ha[1], py, ha[2] * pz)), ha3 = fmaf(ha[3], px, fmaf(ha[4], py, ha[5] * pz));
       const float hb2 = fmaf(ha[6], px, fmaf(ha[7], py, ha[8] * pz)), hb3 = fmaf(ha[9], px, fmaf(ha[10], py, ha[11] * pz));
@@ -764,7 +779,7 @@ __global__ __launch_bounds__(NDT_THREADS, FUSED ? 1 : 4) void ndt_eval_kernel(co
       if ((tid & 3) == 0) s_part[k][tid >> 2] = v;
     }
   __syncthreads();
-  double* prow = P.partials + (size_t)blockIdx.x * NDT_NRED;
+  double* prow = P.partials + ((size_t)(seq & 1) * P.nblocks + blockIdx.x) * NDT_NRED;
   {
     const int v = tid >> 3, seg = tid & 7;  // 32 values x 8 interleaved segments of the 64 quad sums
     double t = 0.0;
@@ -775,36 +790,9 @@ __global__ __launch_bounds__(NDT_THREADS, FUSED ? 1 : 4) void ndt_eval_kernel(co
     t += __shfl_xor(t, 1, 64);
     t += __shfl_xor(t, 2, 64);
     t += __shfl_xor(t, 4, 64);
-    // write-through store so the row is visible to whichever workgroup arrives last
-    if (seg == 0 && v < nred) __hip_atomic_store(prow + v, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seg == 0 && v < nred) prow[v] = t;  // consumed by EVERY workgroup at the head of the next launch
   }
-  if (!FUSED) return;  // the controller kernel that follows sums the rows (kernel boundary = visibility)
   LSR_STAMP(3)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  LSR_STAMP(4)
-  if (tid == 0) {
-    unsigned int prev = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (prev == (unsigned int)(P.nblocks - 1)) ? 1 : 0;
-  }
-  __syncthreads();
-  LSR_STAMP(5)
-  if (!s_last) return;
-  if (tid == 0) __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  ndt_epilogue(P, S, nred, s_raw, s_sum, s_lu);
-  LSR_STAMP(7)
-}
-
-// One workgroup per registration: the epilogue of a non-fused (batched) derivative pass.
-__global__ __launch_bounds__(NDT_THREADS) void ndt_controller_kernel(const NdtProblem* __restrict__ probs) {
-  const NdtProblem& P = probs[blockIdx.x];
-  NdtState* __restrict__ S = P.st;
-  if (S->done) return;
-  __shared__ double s_raw[29 * NDT_RED_PITCH];
-  __shared__ double s_sum[NDT_NRED];
-  __shared__ double s_lu[8][8];
-  const int nred = (S->want_hessian != 0) ? 29 : NDT_NRED_GRAD;
-  ndt_epilogue(P, S, nred, s_raw, s_sum, s_lu);
 }
 
 #ifdef LSR_TIMING
@@ -826,28 +814,28 @@ namespace {
 
 template <int NOFF>
 static void launch_one(bool byval, bool dense, dim3 grid, dim3 block, hipStream_t stream, const NdtProblem& pv,
-                       const NdtProblem* d_probs) {
-  if (byval) {  // single registration: fused controller, problem in the kernel arguments
-    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, true, true>), grid, block, 0, stream, pv, d_probs);
-    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, false, true>), grid, block, 0, stream, pv, d_probs);
-  } else {      // batch: throughput variant + one controller workgroup per registration
-    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, true, false>), grid, block, 0, stream, pv, d_probs);
-    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, false, false>), grid, block, 0, stream, pv, d_probs);
-    hipLaunchKernelGGL(ndt_controller_kernel, dim3(grid.y), block, 0, stream, d_probs);
+                       const NdtProblem* d_probs, int seq) {
+  if (byval) {
+    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, true>), grid, block, 0, stream, pv, d_probs, seq);
+    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, false>), grid, block, 0, stream, pv, d_probs, seq);
+  } else {
+    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, true>), grid, block, 0, stream, pv, d_probs, seq);
+    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, false>), grid, block, 0, stream, pv, d_probs, seq);
   }
 }
 
+// Launches seq0 .. seq0+count-1 of the chain (launch seq consumes the rows of launch seq-1).
 int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, int batch, int max_blocks, int neighborhood,
-                     bool dense, int count, hipStream_t stream) {
+                     bool dense, int seq0, int count, hipStream_t stream) {
   dim3 grid(max_blocks, batch), block(NDT_THREADS);
   const bool byval = (batch == 1 && h_single != nullptr);
   NdtProblem pv;
   if (byval) pv = *h_single; else std::memset(&pv, 0, sizeof(pv));
   for (int i = 0; i < count; i++) {
     switch (neighborhood) {
-      case LSR_DIRECT1: launch_one<1>(byval, dense, grid, block, stream, pv, d_probs); break;
-      case LSR_DIRECT26: launch_one<27>(byval, dense, grid, block, stream, pv, d_probs); break;
-      default: launch_one<7>(byval, dense, grid, block, stream, pv, d_probs); break;
+      case LSR_DIRECT1: launch_one<1>(byval, dense, grid, block, stream, pv, d_probs, seq0 + i); break;
+      case LSR_DIRECT26: launch_one<27>(byval, dense, grid, block, stream, pv, d_probs, seq0 + i); break;
+      default: launch_one<7>(byval, dense, grid, block, stream, pv, d_probs, seq0 + i); break;
     }
   }
   LSR_HIP(hipGetLastError());

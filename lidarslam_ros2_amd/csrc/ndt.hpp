@@ -2,10 +2,11 @@
 //   K1/K2  voxel-covariance grid build        (replaces pclomp::VoxelGridCovariance::filter)
 //   K3     derivative pass                    (replaces NDT::computeDerivatives/updateDerivatives, a5/a7)
 //   K4     Newton + More-Thuente controller   (replaces NDT::computeTransformation/computeStepLengthMT, a4/a6)
-// K3 and K4 are ONE kernel: every workgroup reduces its points' score/gradient/Hessian, the last
-// workgroup to arrive sums the per-workgroup partials in fixed order and advances the controller,
-// leaving the next evaluation request in HBM for the next launch.  An align() is therefore a chain
-// of identical launches with no host round trip in between.
+// K3 and K4 are ONE kernel in a "pull" arrangement: every workgroup of launch n first sums the
+// per-workgroup partial rows launch n-1 left behind (fixed order) and advances the controller —
+// redundantly and deterministically in every workgroup —, then evaluates its own points and leaves its
+// partial row for launch n+1.  No intra-launch synchronisation between workgroups; an align() is a
+// chain of identical launches with no host round trip in between.
 #pragma once
 #include "common.hpp"
 
@@ -66,9 +67,9 @@ struct NdtProblem {
   int mul1, mul2;
   float leaf;
   int pad;
-  NdtState* st;
-  double* partials;         // [nblocks][NDT_NRED]
-  unsigned int* ticket;
+  NdtState* st;             // [2] double buffered by launch parity
+  double* partials;         // [2][nblocks][NDT_NRED]
+  unsigned int* ticket;     // unused (kept for layout stability)
 };
 
 struct NdtParamsHost {
@@ -88,7 +89,7 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
 // Launch `count` chained derivative+controller passes for `batch` problems.
 // h_single (nullable): host copy of the problem, passed by value when batch == 1.
 int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, int batch, int max_blocks, int neighborhood,
-                     bool dense, int count, hipStream_t stream);
+                     bool dense, int seq0, int count, hipStream_t stream);
 // Host: controller state at the entry of computeTransformation (guess nullable = identity).
 void ndt_fill_initial_state(NdtState& st, const float* guess16, const NdtParamsHost& prm, int n_points);
 // Fill a diagnostic request on the host (lsr_ndt_derivatives).
