@@ -1,0 +1,157 @@
+"""GPU tests at BASELINE.json's full sizes (cfg 1/2: 30k-pt scan vs 10-frame submap; cfg 3: GICP on the
+same scan; cfg 4: candidate batch; cfg 5: 120k-pt 64-line scan vs 20-frame submap).  Direct oracle
+comparison where the oracle finishes in seconds, plus size-independent properties: recovery of a known
+rigid offset, invariance to source permutation, idempotence (re-aligning from the answer stays put)."""
+import numpy as np
+import pytest
+
+from lidarslam_ros2_amd import synth
+from lidarslam_ros2_amd.posemath import pose_delta
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def cfg12():
+    return synth.cfg_ndt_30k()
+
+
+def make_ndt(res, eps, max_iter=None):
+    from lidarslam_ros2_amd import DIRECT7, NormalDistributionsTransform
+
+    r = NormalDistributionsTransform(device=0)
+    r.setResolution(res)
+    r.setTransformationEpsilon(eps)
+    r.setNeighborhoodSearchMethod(DIRECT7)
+    if max_iter is not None:
+        r.setMaximumIterations(max_iter)
+    return r
+
+
+@pytest.mark.parametrize("eps,max_iter", [(0.01, None), (0.0, 30)])
+def test_cfg1_cfg2_match_oracle(O, cfg12, eps, max_iter):
+    """cfg 1 (reference settings, eps 0.01) and cfg 2 (fixed 30 iterations) on the full workload."""
+    c = cfg12
+    ndt = make_ndt(5.0, eps, max_iter)
+    ndt.setInputTarget(synth.as_pointxyzi(c.target))
+    ndt.setInputSource(synth.as_pointxyzi(c.source))
+    ndt.align(c.guess)
+    T = ndt.getFinalTransformation()
+    ref = O.ndt_align(O.VoxelGridCovariance(c.target, 5.0), c.source, c.guess, resolution=5.0, trans_eps=eps,
+                      max_iterations=max_iter or 35, num_threads=min(32, O.max_threads()))
+    dt, ang = pose_delta(T, ref["final"])
+    assert dt <= 1e-3 and ang <= 1e-4, (dt, ang)
+    assert ndt.getFinalNumIteration() == ref["iterations"]
+    assert ndt.hasConverged() and ref["converged"]
+    gt_dt, gt_ang = pose_delta(T, c.truth)
+    assert gt_dt < 0.05 and gt_ang < 2e-3
+    # voxel table of the 661k-point submap: same leaf set as the CPU path
+    g = O.VoxelGridCovariance(c.target, 5.0)
+    info = ndt.gridInfo()
+    assert info["n_leaves"] == g.n_leaves and info["n_valid"] == g.n_valid
+
+
+def test_cfg2_properties(cfg12):
+    c = cfg12
+    ndt = make_ndt(5.0, 1e-6, 30)
+    ndt.setInputTarget(c.target)
+    ndt.setInputSource(c.source)
+    ndt.align(c.guess)
+    T = ndt.getFinalTransformation()
+    # permutation invariance: only the fp64 summation order changes
+    rng = np.random.default_rng(0)
+    ndt.setInputSource(c.source[rng.permutation(c.source.shape[0])])
+    ndt.align(c.guess)
+    dt, ang = pose_delta(ndt.getFinalTransformation(), T)
+    assert dt < 1e-4 and ang < 1e-5
+    # idempotence: starting from the answer, the answer does not move
+    ndt.align(T)
+    dt, ang = pose_delta(ndt.getFinalTransformation(), T)
+    assert dt < 2e-3 and ang < 2e-4
+    # rigid-motion recovery: move the source by a known transform, the estimate moves by its inverse
+    D = synth.pose_matrix(0.15, -0.1, 0.02, 0.01).astype(np.float32)
+    moved = (c.source - D[:3, 3]) @ D[:3, :3]          # D^-1 applied to the scan
+    ndt.setInputSource(moved.astype(np.float32))
+    ndt.align((c.guess.astype(np.float64) @ D.astype(np.float64)).astype(np.float32))
+    dt, ang = pose_delta(ndt.getFinalTransformation(), T.astype(np.float64) @ D.astype(np.float64))
+    assert dt < 5e-3 and ang < 5e-4
+
+
+def test_cfg3_gicp_matches_oracle(O):
+    from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
+
+    c = synth.cfg_gicp_30k()
+    g = GeneralizedIterativeClosestPoint(device=0)
+    g.setMaxCorrespondenceDistance(5.0)
+    g.setTransformationEpsilon(1e-8)
+    g.setInputTarget(synth.as_pointxyzi(c.target))
+    g.setInputSource(synth.as_pointxyzi(c.source))
+    g.align(c.guess)
+    T = g.getFinalTransformation()
+    th = min(32, O.max_threads())
+    nt, ns = O.NearestNeighbour(c.target, 1.0), O.NearestNeighbour(c.source, 1.0)
+    ct, cs = O.gicp_covariances(nt, c.target, num_threads=th), O.gicp_covariances(ns, c.source, num_threads=th)
+    ref = O.gicp_align(nt, c.target, ct, c.source, cs, c.guess, max_corr_dist=5.0, trans_eps=1e-8, solver=0, num_threads=th)
+    dt, ang = pose_delta(T, ref["final"])           # vs the reference schedule (BFGS)
+    assert dt <= 1e-3 and ang <= 1e-4, (dt, ang, g.last_result, ref)
+    assert g.hasConverged()
+    gt_dt, gt_ang = pose_delta(T, c.truth)
+    assert gt_dt < 0.03 and gt_ang < 1e-3
+
+
+def test_cfg4_candidate_batch_sharded_single_rank(O):
+    """One GPU's share of cfg 4 (64 candidates / 8 GPUs = 8): per candidate setInputTarget +
+    setInputSource + align + getFitnessScore (graph_based_slam_component.cpp:181-231), run as one batch,
+    gathered through the sharding layer (world size 1 here)."""
+    from lidarslam_ros2_amd import align_batch
+    from lidarslam_ros2_amd.sharding import pack_record, register_sharded
+
+    n_cand = 8
+    cases = [synth.cfg_loop_candidate(c) for c in range(n_cand)]
+
+    def register_local(indices):
+        regs = []
+        for i in indices:
+            r = make_ndt(5.0, 0.01, 100)               # backend: setMaximumIterations(100)
+            r.setInputTarget(cases[i].target)
+            r.setInputSource(cases[i].source)
+            regs.append(r)
+        finals, results = align_batch(regs, [cases[i].guess for i in indices])
+        return [pack_record(finals[k], results[k]["score"], results[k]["iterations"], results[k]["converged"],
+                            regs[k].getFitnessScore()) for k in range(len(indices))]
+
+    out = register_sharded(n_cand, register_local)
+    assert len(out) == n_cand
+    for i, r in enumerate(out):
+        dt, ang = pose_delta(r["T"], cases[i].truth)
+        assert r["converged"] and dt < 0.08 and ang < 3e-3, (i, dt, ang)
+        assert r["fitness"] < 0.2                      # a closed loop passes the reference's gate (score < 0.3 default region)
+    # one candidate against the oracle
+    ref = O.ndt_align(O.VoxelGridCovariance(cases[3].target, 5.0), cases[3].source, cases[3].guess, resolution=5.0,
+                      trans_eps=0.01, max_iterations=100, num_threads=min(32, O.max_threads()))
+    dt, ang = pose_delta(out[3]["T"], ref["final"])
+    assert dt <= 1e-3 and ang <= 1e-4
+
+
+def test_cfg5_dense_scan_matches_oracle(O):
+    c = synth.cfg_dense_120k()
+    assert c.source.shape == (120000, 3)
+    ndt = make_ndt(2.0, 0.01)
+    ndt.setInputTarget(c.target)
+    ndt.setInputSource(c.source)
+    ndt.align(c.guess)
+    T = ndt.getFinalTransformation()
+    g = O.VoxelGridCovariance(c.target, 2.0)
+    info = ndt.gridInfo()
+    assert info["n_leaves"] == g.n_leaves and info["n_valid"] == g.n_valid
+    ref = O.ndt_align(g, c.source, c.guess, resolution=2.0, trans_eps=0.01, num_threads=min(32, O.max_threads()))
+    dt, ang = pose_delta(T, ref["final"])
+    assert dt <= 1e-3 and ang <= 1e-4, (dt, ang, ndt.last_result, ref["iterations"])
+    assert ndt.getFinalNumIteration() == ref["iterations"]
