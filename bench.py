@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+PMC_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 553.2 + 12.16) * 1024)  # single 30k-pt pass, see roofline.traffic_source
 
 
 def main():
@@ -147,7 +148,12 @@ def main():
         achieved = alg_bytes / (avg_us * 1e-6) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "ndt_eval_kernel<7> (derivative pass + fused Newton/More-Thuente controller)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_us,
+                           # HBM bytes per launch from rocprofv3 PMC passes of this kernel on this workload
+                           # (profiles/r01_pmc_ndt_eval_a.md): FETCH_SIZE 553 KB x2 (gfx950 reports half of wide
+                           # coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE 12 KB.  bench.py cannot collect
+                           # PMCs itself; re-measure with tools/pmc_run.sh when the kernel changes.
+                           "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "profiles/r01_pmc_ndt_eval_a.md",
+                           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_us,
                            "valid_pairs_per_point": pairs / n_src,
                            "compulsory_bytes_per_launch": n_src * 12 + grid["n_valid"] * 36,
                            "note": "single 30k-pt scan = 118 workgroups on 256 CUs: latency-bound, voxel table is L2-resident; "
@@ -184,6 +190,39 @@ def main():
                           "roofline": {"bound": "hbm", "achieved": b_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": b_ach / HBM_PEAK_GBS, "avg_launch_us": b_us,
                                        "algorithmic_bytes_per_launch": b_bytes}}
+
+        # ---- GICP leg (BASELINE cfg 3): same scan, target re-filtered at 0.2, corr dist 5.0, eps 1e-8
+        try:
+            from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
+
+            gc = synth.cfg_gicp_30k(seed=rank)
+            gicp = GeneralizedIterativeClosestPoint(device=local_rank, stream=stream)
+            gicp.setMaxCorrespondenceDistance(5.0)
+            gicp.setTransformationEpsilon(1e-8)
+            g_tgt = torch.from_numpy(synth.as_pointxyzi(gc.target)).cuda()
+            g_src = torch.from_numpy(synth.as_pointxyzi(gc.source)).cuda()
+            tg = time.perf_counter()
+            gicp.setInputTarget(g_tgt)
+            gicp.setInputSource(g_src)
+            gicp.align(gc.guess)                       # first align also pays the target covariances (K5)
+            torch.cuda.synchronize()
+            t_first = time.perf_counter() - tg
+            tg = time.perf_counter()
+            ng = 5
+            for _ in range(ng):
+                gicp.setInputSource(g_src)             # source covariances are recomputed per scan, as in the reference
+                gicp.align(gc.guess)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            gdt, gang = pose_delta(gicp.getFinalTransformation(), gc.truth)
+            out["gicp_cfg3"] = {"value": ng / tg, "unit": "registrations/s", "ms_per_registration": 1e3 * tg / ng,
+                                "first_registration_ms_incl_target_setup": 1e3 * t_first,
+                                "target_points": int(gc.target.shape[0]), "outer_iterations": gicp.last_result["iterations"],
+                                "gauss_newton_steps": gicp.last_result["n_evaluations"],
+                                "correspondences": gicp.last_result["n_correspondences"],
+                                "error_vs_truth": {"translation_m": gdt, "rotation_rad": gang}}
+        except Exception as e:  # the headline line must still be printed
+            out["gicp_cfg3"] = {"error": repr(e)}
 
         # ---- CPU baseline: the oracle (restatement of ndt_omp) on this box's host cores, bounded sample
         if not args.no_cpu:

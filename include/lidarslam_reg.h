@@ -111,6 +111,16 @@ int lsr_set_input_target_device(lsr_handle h, const void* dev_pts, size_t stride
 /* registration_->setInputSource(cloud)   scanmatcher_component.cpp:329; graph_based_slam_component.cpp:181 */
 int lsr_set_input_source(lsr_handle h, const void* pts, size_t stride_bytes, size_t n);
 int lsr_set_input_source_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n);
+/* pcl::VoxelGrid<PointXYZI>::filter (centroid per occupied leaf, output ordered by leaf index) fused with
+ * setInputSource: the frontend's per-scan `voxel_grid.filter(*filtered); registration_->setInputSource(filtered)`
+ * (scanmatcher_component.cpp:324-329) without the filtered cloud ever leaving HBM.  on_device != 0: `pts` is a
+ * HIP device pointer.  n_out (nullable) receives the number of points kept. */
+int lsr_set_input_source_filtered(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, float leaf, int on_device,
+                                  size_t* n_out);
+/* The same filter as a stand-alone operation, host in / host out (map side: scanmatcher_component.cpp:266-269,
+ * 443-447; graph_based_slam_component.cpp:224-226).  Writes xyz at offset 0 of each out_stride_bytes record. */
+int lsr_voxel_grid_filter(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, float leaf, void* out_pts,
+                          size_t out_stride_bytes, size_t out_capacity, size_t* n_out);
 /* Let `h` register against the target already resident in `owner` (N keyframes vs ONE submap):
  * no copy, the voxel grid / target structures are reference counted. */
 int lsr_share_target(lsr_handle h, lsr_handle owner);

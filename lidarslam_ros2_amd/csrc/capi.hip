@@ -439,6 +439,42 @@ int lsr_set_input_source_device(lsr_handle h, const void* dev_pts, size_t stride
   return set_source_impl(h, dev_pts, stride_bytes, n, true);
 }
 
+// pcl::VoxelGrid::filter + registration_->setInputSource, without the cloud leaving HBM
+// (scanmatcher_component.cpp:324-329)
+int lsr_set_input_source_filtered(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, float leaf, int on_device,
+                                  size_t* n_out) {
+  LSR_CHECK_HANDLE(h);
+  if (!(leaf > 0)) { set_last_error("leaf size must be > 0"); return LSR_ERR_INVALID_ARGUMENT; }
+  int st = upload_cloud(h, pts, stride_bytes, n, on_device != 0, h->raw);
+  if (st) return st;
+  if ((st = voxel_grid_filter(h->raw, leaf, h->source, h->scratch, h->stream))) return st;
+  h->has_source = true;
+  h->source_cov_valid = false;
+  if (n_out) *n_out = h->source.n;
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
+// pcl::VoxelGrid::filter as a stand-alone device operation (host in, host out)
+int lsr_voxel_grid_filter(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, float leaf, void* out_pts,
+                          size_t out_stride_bytes, size_t out_capacity, size_t* n_out) {
+  LSR_CHECK_HANDLE(h);
+  if (!(leaf > 0) || !n_out || out_stride_bytes < 12 || (out_stride_bytes % 4)) { set_last_error("bad argument"); return LSR_ERR_INVALID_ARGUMENT; }
+  int st = upload_cloud(h, pts, stride_bytes, n, false, h->raw);
+  if (st) return st;
+  if ((st = voxel_grid_filter(h->raw, leaf, h->filtered, h->scratch, h->stream))) return st;
+  *n_out = h->filtered.n;
+  if (h->filtered.n > out_capacity) { set_last_error("output buffer too small"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (h->filtered.n == 0) return LSR_OK;
+  const size_t bytes = h->filtered.n * out_stride_bytes;
+  if ((st = h->staging.reserve(bytes))) return st;
+  LSR_HIP(hipMemsetAsync(h->staging.p, 0, bytes, h->stream));
+  if ((st = interleave(h->filtered, h->staging.p, out_stride_bytes, h->stream))) return st;
+  LSR_HIP(hipMemcpyAsync(out_pts, h->staging.p, bytes, hipMemcpyDeviceToHost, h->stream));
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
 int lsr_share_target(lsr_handle h, lsr_handle owner) {
   LSR_CHECK_HANDLE(h);
   if (!owner || !owner->target) { set_last_error("owner has no target"); return LSR_ERR_NO_TARGET; }

@@ -27,6 +27,7 @@ struct lsr_handle_s {
 
   std::shared_ptr<TargetData> target;
   DeviceCloud source;
+  DeviceCloud raw, filtered;  // N1: unfiltered upload / stand-alone filter result
   bool has_source = false;
   bool source_cov_valid = false;
   DevBuf<double> source_cov;  // GICP

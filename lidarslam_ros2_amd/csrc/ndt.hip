@@ -1130,6 +1130,98 @@ int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_f
   return LSR_OK;
 }
 
+// ---- N1: pcl::VoxelGrid::filter (centroid per occupied leaf, output ordered by leaf index) -------------
+// scanmatcher/src/scanmatcher_component.cpp:324-328 (every scan, vg_size_for_input), :266-269, :443-447
+// (map side, vg_size_for_map), graph_based_slam/src/graph_based_slam_component.cpp:224-226.
+// Same key/sort machinery as K1; one thread per leaf sums its (few) points in ascending point order in
+// fp64 and rounds the centroid to fp32 (PCL accumulates in fp32 in std::sort order, which is not
+// reproducible; the fp64 sum is within an ulp or two of it and deterministic).
+namespace {
+__global__ __launch_bounds__(256) void leaf_centroid_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ z, const int* __restrict__ order,
+                                                            const unsigned int* __restrict__ run_key, const int* __restrict__ run_off,
+                                                            const int* __restrict__ run_cnt, int n_runs, float* __restrict__ ox,
+                                                            float* __restrict__ oy, float* __restrict__ oz) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_runs) return;
+  if (run_key[r] == 0xFFFFFFFFu) return;  // the run of non-finite points (always last) is dropped
+  const int off = run_off[r], cnt = run_cnt[r];
+  double sx = 0, sy = 0, sz = 0;
+  for (int j = 0; j < cnt; j++) {
+    const int pi = order[off + j];
+    sx += (double)x[pi]; sy += (double)y[pi]; sz += (double)z[pi];
+  }
+  const double inv = 1.0 / (double)cnt;
+  ox[r] = (float)(sx * inv); oy[r] = (float)(sy * inv); oz[r] = (float)(sz * inv);
+}
+}  // namespace
+
+int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, BuildScratch& sc, hipStream_t stream) {
+  const int n = (int)cloud.n;
+  out.n = 0;
+  if (n == 0) return out.resize(0);
+  float mn[3], mx[3];
+  unsigned int n_finite = 0;
+  int st = cloud_bbox(cloud, mn, mx, &n_finite, sc, stream);
+  if (st) return st;
+  if (n_finite == 0) return out.resize(0);
+  const float inv_leaf = 1.0f / leaf;
+  int64_t d[3];
+  for (int k = 0; k < 3; k++) d[k] = (int64_t)((mx[k] - mn[k]) * inv_leaf) + 1;
+  if (d[0] * d[1] * d[2] > (int64_t)INT32_MAX) {  // PCL: "Leaf size is too small for the input dataset"
+    set_last_error("voxel index space exceeds int32: leaf size too small for the cloud extent");
+    return LSR_ERR_INDEX_OVERFLOW;
+  }
+  int min_b[3], div_b[3];
+  for (int k = 0; k < 3; k++) {
+    min_b[k] = (int)floorf(mn[k] * inv_leaf);
+    div_b[k] = (int)floorf(mx[k] * inv_leaf) - min_b[k] + 1;
+  }
+  if ((st = sc.words.reserve(32 + 7 * (size_t)n + 16))) return st;
+  unsigned int* key_in = sc.words.p + 32;
+  unsigned int* key_out = key_in + n;
+  int* val_in = (int*)(key_out + n);
+  int* val_out = val_in + n;
+  unsigned int* run_key = (unsigned int*)(val_out + n);
+  int* run_cnt = (int*)(run_key + n);
+  int* run_off = run_cnt + n;
+  int* d_nruns = run_off + n;
+  hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
+                     min_b[0], min_b[1], min_b[2], div_b[0], div_b[0] * div_b[1], key_in, val_in);
+  if ((st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, 32, sc.temp, stream))) return st;
+  if ((st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
+  int n_runs = 0;
+  LSR_HIP(hipMemcpyAsync(&n_runs, d_nruns, sizeof(int), hipMemcpyDeviceToHost, stream));
+  LSR_HIP(hipStreamSynchronize(stream));
+  if ((st = exclusive_scan_i32(run_cnt, run_off, n_runs, sc.temp, stream))) return st;
+  const int n_out = n_runs - ((n_finite < (unsigned int)n) ? 1 : 0);  // minus the sentinel run
+  if ((st = out.resize(n_out))) return st;
+  hipLaunchKernelGGL(leaf_centroid_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(),
+                     val_out, run_key, run_off, run_cnt, n_runs, out.x(), out.y(), out.z());
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+// SoA planes -> strided xyz records (device to device)
+namespace {
+__global__ __launch_bounds__(256) void interleave_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, int n, unsigned char* __restrict__ out,
+                                                         size_t stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float* o = (float*)(out + (size_t)i * stride);
+  o[0] = x[i]; o[1] = y[i]; o[2] = z[i];
+}
+}  // namespace
+
+int interleave(const DeviceCloud& in, void* d_out, size_t stride_bytes, hipStream_t stream) {
+  if (in.n == 0) return LSR_OK;
+  hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)((in.n + 255) / 256)), dim3(256), 0, stream, in.x(), in.y(), in.z(),
+                     (int)in.n, (unsigned char*)d_out, stride_bytes);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
 int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
   DevBuf<char>& temp = sc.temp;
   DevBuf<unsigned int>& scratch = sc.words;

@@ -98,6 +98,10 @@ void ndt_fill_diag_state(NdtState& st, const double* p6, const float* T16, int c
 // Host helper: default state constants for an align.
 void ndt_fill_align_constants(NdtState& st, const NdtParamsHost& prm, int n_points);
 
+// N1: pcl::VoxelGrid::filter on the device (centroid per leaf, leaf-index order).
+int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, BuildScratch& sc, hipStream_t stream);
+int interleave(const DeviceCloud& in, void* d_out, size_t stride_bytes, hipStream_t stream);
+
 // Transform cloud by a column-major 4x4 into a strided device buffer (align()'s `output`).
 int transform_to_strided(const DeviceCloud& src, const float* T16_host, void* d_out, size_t stride_bytes, hipStream_t stream);
 // AoS (strided xyz) -> SoA planes, device to device.

@@ -134,6 +134,27 @@ class Registration:
         self._n_source = n
         self._keep["source"] = keep if dev else None  # device upload is asynchronous on the handle's stream
 
+    def setInputSourceFiltered(self, cloud, leaf: float) -> int:
+        """pcl::VoxelGrid(leaf).filter + setInputSource on the device (scanmatcher_component.cpp:324-329);
+        returns the number of points kept."""
+        p, stride, n, dev, keep = _cloud_args(cloud)
+        n_out = C.c_size_t()
+        capi.check(self._lib.lsr_set_input_source_filtered(self._h, p, stride, n, C.c_float(leaf), 1 if dev else 0,
+                                                           C.byref(n_out)), "setInputSourceFiltered")
+        self._n_source = int(n_out.value)
+        return self._n_source
+
+    def voxelGridFilter(self, cloud, leaf: float) -> np.ndarray:
+        """Stand-alone pcl::VoxelGrid(leaf).filter on the device; host (n,c>=3) in, (m,3) fp32 out."""
+        p, stride, n, dev, keep = _cloud_args(cloud)
+        if dev:
+            raise ValueError("voxelGridFilter takes a host array")
+        out = np.zeros((max(n, 1), 3), np.float32)
+        n_out = C.c_size_t()
+        capi.check(self._lib.lsr_voxel_grid_filter(self._h, p, stride, n, C.c_float(leaf), C.c_void_p(out.ctypes.data), 12,
+                                                   out.shape[0], C.byref(n_out)), "voxelGridFilter")
+        return out[: n_out.value].copy()
+
     def shareTargetOf(self, other: "Registration"):
         """Register against the target already resident in `other` (N keyframes vs one submap)."""
         capi.check(self._lib.lsr_share_target(self._h, other._h), "shareTargetOf")

@@ -747,6 +747,57 @@ int orc_ndt_align(void* gp, const float* src, size_t stride_floats, size_t n, co
   return 0;
 }
 
+// pcl::VoxelGrid<PointT>::applyFilter restatement (PCL 1.12 voxel_grid.hpp; call sites
+// scanmatcher_component.cpp:324-328,266-269,443-447; graph_based_slam_component.cpp:224-226): leaf index as
+// in VoxelGridCovariance, points sorted by leaf index, centroid per leaf accumulated in FLOAT
+// (CentroidPoint's AccumulatorXYZ is Eigen::Vector3f), output in ascending leaf order.  std::sort's order
+// inside a leaf is unspecified upstream; ascending point index is used here.
+int orc_voxel_grid_filter(const float* pts, size_t stride_f, size_t n, float leaf, float* out_xyz) {
+  const float inv = 1.0f / leaf;
+  float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+  float mx[3] = {-mn[0], -mn[1], -mn[2]};
+  size_t finite = 0;
+  for (size_t i = 0; i < n; i++) {
+    const float* p = pts + i * stride_f;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    finite++;
+    for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], p[k]); mx[k] = std::max(mx[k], p[k]); }
+  }
+  if (!finite) return 0;
+  int min_b[3], div_b[3];
+  for (int k = 0; k < 3; k++) {
+    min_b[k] = (int)std::floor(mn[k] * inv);
+    div_b[k] = (int)std::floor(mx[k] * inv) - min_b[k] + 1;
+  }
+  std::vector<std::pair<unsigned int, unsigned int>> iv;
+  iv.reserve(finite);
+  for (size_t i = 0; i < n; i++) {
+    const float* p = pts + i * stride_f;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    int i0 = (int)(std::floor(p[0] * inv) - (float)min_b[0]);
+    int i1 = (int)(std::floor(p[1] * inv) - (float)min_b[1]);
+    int i2 = (int)(std::floor(p[2] * inv) - (float)min_b[2]);
+    iv.emplace_back((unsigned int)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]), (unsigned int)i);
+  }
+  std::sort(iv.begin(), iv.end());
+  int cnt = 0;
+  size_t a = 0;
+  while (a < iv.size()) {
+    size_t b = a;
+    float acc[3] = {0, 0, 0};
+    while (b < iv.size() && iv[b].first == iv[a].first) {
+      const float* p = pts + (size_t)iv[b].second * stride_f;
+      acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
+      b++;
+    }
+    float m = (float)(b - a);
+    out_xyz[3 * cnt] = acc[0] / m; out_xyz[3 * cnt + 1] = acc[1] / m; out_xyz[3 * cnt + 2] = acc[2] / m;
+    cnt++;
+    a = b;
+  }
+  return cnt;
+}
+
 int orc_max_threads() {
 #ifdef _OPENMP
   return omp_get_max_threads();

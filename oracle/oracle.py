@@ -68,6 +68,8 @@ def lib():
         L.orc_ndt_align.argtypes = [vp, fp, C.c_size_t, C.c_size_t, fp, C.POINTER(NdtParams), C.POINTER(NdtResult),
                                     dp, C.c_int]
         L.orc_max_threads.restype = C.c_int
+        L.orc_voxel_grid_filter.restype = C.c_int
+        L.orc_voxel_grid_filter.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_float, fp]
         if hasattr(L, "orc_nn_build"):
             L.orc_nn_build.restype = vp
             L.orc_nn_build.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_float]
@@ -122,6 +124,14 @@ def matrix_to_pose(M) -> np.ndarray:
     p = np.zeros(6, np.float64)
     lib().orc_matrix_to_pose(Mc.ctypes.data_as(C.POINTER(C.c_float)), _f64p(p))
     return p
+
+
+def voxel_grid_filter(pts: np.ndarray, leaf: float) -> np.ndarray:
+    """CPU restatement of pcl::VoxelGrid::filter (centroid per leaf, leaf-index order)."""
+    a, ap = _f32(pts)
+    out = np.zeros((a.shape[0], 3), np.float32)
+    n = lib().orc_voxel_grid_filter(ap, a.shape[1], a.shape[0], C.c_float(leaf), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:n].copy()
 
 
 class VoxelGridCovariance:
