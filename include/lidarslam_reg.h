@@ -108,6 +108,13 @@ int lsr_get_i32(lsr_handle h, int key, int* value);
  * Host-memory (`pts` readable by the CPU) and device-memory (`pts` a HIP device pointer) forms. */
 int lsr_set_input_target(lsr_handle h, const void* pts, size_t stride_bytes, size_t n);
 int lsr_set_input_target_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n);
+/* Submap assembly fused with setInputTarget: frame f (strided xyz, counts[f] points) is moved by poses16[16*f ..]
+ * (column-major 4x4, pcl::transformPointCloud's fp32 arithmetic) and the frames are concatenated in order — what
+ * updateMap() does on the host before setInputTarget (scanmatcher_component.cpp:449-464,307) and searchLoop() for a
+ * loop candidate window (graph_based_slam_component.cpp:208-227).  on_device != 0: frame pointers are HIP device
+ * pointers (keyframes kept resident in HBM); the assembled target never visits the host. */
+int lsr_set_input_target_frames(lsr_handle h, int n_frames, const void* const* frames, const size_t* counts, size_t stride_bytes,
+                                const float* poses16, int on_device);
 /* registration_->setInputSource(cloud)   scanmatcher_component.cpp:329; graph_based_slam_component.cpp:181 */
 int lsr_set_input_source(lsr_handle h, const void* pts, size_t stride_bytes, size_t n);
 int lsr_set_input_source_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n);

@@ -415,6 +415,47 @@ static int set_target_impl(lsr_handle h, const void* pts, size_t stride, size_t 
   return LSR_OK;
 }
 
+// Submap assembly + setInputTarget without a host round trip of the assembled cloud
+// (scanmatcher_component.cpp:449-464,307; graph_based_slam_component.cpp:208-227)
+int lsr_set_input_target_frames(lsr_handle h, int n_frames, const void* const* frames, const size_t* counts, size_t stride_bytes,
+                                const float* poses16, int on_device) {
+  LSR_CHECK_HANDLE(h);
+  if (n_frames <= 0 || !frames || !counts || !poses16 || stride_bytes < 12 || (stride_bytes % 4)) {
+    set_last_error("bad frame list");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  size_t total = 0, biggest = 0;
+  for (int f = 0; f < n_frames; f++) {
+    if (counts[f] > 0 && !frames[f]) { set_last_error("null frame pointer"); return LSR_ERR_INVALID_ARGUMENT; }
+    total += counts[f];
+    biggest = std::max(biggest, counts[f]);
+  }
+  if (total > (size_t)INT32_MAX / 2) { set_last_error("cloud too large"); return LSR_ERR_INVALID_ARGUMENT; }
+  auto t = std::make_shared<TargetData>();
+  int st = t->cloud.resize(total);
+  if (st) return st;
+  if ((st = h->d_poses.reserve((size_t)n_frames * 16))) return st;
+  LSR_HIP(hipMemcpyAsync(h->d_poses.p, poses16, sizeof(float) * 16 * n_frames, hipMemcpyHostToDevice, h->stream));
+  if (!on_device && (st = h->staging.reserve(biggest * stride_bytes))) return st;
+  size_t off = 0;
+  for (int f = 0; f < n_frames; f++) {
+    const void* d_aos = frames[f];
+    if (!on_device && counts[f] > 0) {
+      LSR_HIP(hipMemcpyAsync(h->staging.p, frames[f], counts[f] * stride_bytes, hipMemcpyHostToDevice, h->stream));
+      d_aos = h->staging.p;
+    }
+    if ((st = transform_append(d_aos, stride_bytes, counts[f], h->d_poses.p + 16 * f, t->cloud, off, h->stream))) return st;
+    if (!on_device) LSR_HIP(hipStreamSynchronize(h->stream));  // the staging buffer is reused by the next frame
+    off += counts[f];
+  }
+  t->n = total;
+  h->target = t;
+  st = (h->method == LSR_METHOD_NDT) ? ensure_ndt_grid(h) : ensure_target_hash(h);
+  if (st) { h->target.reset(); return st; }
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
 int lsr_set_input_target(lsr_handle h, const void* pts, size_t stride_bytes, size_t n) {
   return set_target_impl(h, pts, stride_bytes, n, false);
 }

@@ -44,6 +44,7 @@ struct lsr_handle_s {
   PinBuf<NdtState> h_state;
   PinBuf<NdtProblem> h_prob;
   DevBuf<float> d_T16;
+  DevBuf<float> d_poses;  // N2: keyframe poses
 
   GicpWorkspace gicp_ws;
 

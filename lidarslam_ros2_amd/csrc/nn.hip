@@ -141,6 +141,33 @@ __global__ __launch_bounds__(256) void fitness_partial_kernel(const int* __restr
 
 }  // namespace
 
+// ---- N2: submap assembly — pcl::transformPointCloud per keyframe + concatenation, on the device ----------
+// scanmatcher/src/scanmatcher_component.cpp:449-464 (frontend target = newest frame + previous submaps, each
+// moved by its pose); graph_based_slam/src/graph_based_slam_component.cpp:208-222 (loop candidate window).
+// fp32 arithmetic in the reference's order ((m00*x + m01*y) + m02*z) + m03, no FMA contraction (this TU).
+namespace {
+__global__ __launch_bounds__(256) void transform_append_kernel(const unsigned char* __restrict__ aos, size_t stride, int n,
+                                                               const float* __restrict__ T16, float* __restrict__ ox,
+                                                               float* __restrict__ oy, float* __restrict__ oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = (const float*)(aos + (size_t)i * stride);
+  const float x = p[0], y = p[1], z = p[2];
+  ox[i] = xform_rn(T16[0], T16[4], T16[8], T16[12], x, y, z);
+  oy[i] = xform_rn(T16[1], T16[5], T16[9], T16[13], x, y, z);
+  oz[i] = xform_rn(T16[2], T16[6], T16[10], T16[14], x, y, z);
+}
+}  // namespace
+
+int transform_append(const void* d_aos, size_t stride_bytes, size_t n, const float* d_T16, DeviceCloud& out, size_t offset,
+                     hipStream_t stream) {
+  if (n == 0) return LSR_OK;
+  hipLaunchKernelGGL(transform_append_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     (const unsigned char*)d_aos, stride_bytes, (int)n, d_T16, out.x() + offset, out.y() + offset, out.z() + offset);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
 float nn_pick_cell(size_t, const lsr_handle_s*) { return 0.5f; }
 
 int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, BuildScratch& sc, hipStream_t stream) {

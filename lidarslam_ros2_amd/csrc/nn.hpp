@@ -6,6 +6,9 @@
 struct lsr_handle_s;
 
 namespace lsr {
+// N2: transform one keyframe (strided xyz, device) by a column-major 4x4 and write it at `offset` of `out`.
+int transform_append(const void* d_aos, size_t stride_bytes, size_t n, const float* d_T16, DeviceCloud& out, size_t offset,
+                     hipStream_t stream);
 float nn_pick_cell(size_t n, const lsr_handle_s* h);
 int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, BuildScratch& sc, hipStream_t stream);
 // mean squared 1-NN distance of T*source in the target, over pairs with d2 <= max_range.

@@ -127,6 +127,22 @@ class Registration:
         capi.check(fn(self._h, p, stride, n), "setInputTarget")
         self._keep["target"] = None  # the core keeps its own SoA copy in HBM
 
+    def setInputTargetFrames(self, frames, poses):
+        """Submap assembly on the device: frame f transformed by poses[f] (4x4), concatenated, then
+        setInputTarget (scanmatcher_component.cpp:449-464,307).  Frames: host arrays or CUDA tensors, same layout."""
+        args = [_cloud_args(f) for f in frames]
+        dev = args[0][3]
+        if any(a[3] != dev for a in args) or any(a[1] != args[0][1] for a in args):
+            raise ValueError("frames must all be host or all device, with one record stride")
+        nf = len(args)
+        ptrs = (C.c_void_p * nf)(*[a[0] for a in args])
+        counts = (C.c_size_t * nf)(*[a[2] for a in args])
+        P = np.ascontiguousarray(np.stack([_mat_to_col16(p) for p in poses]), np.float32)
+        capi.check(self._lib.lsr_set_input_target_frames(self._h, nf, ptrs, counts, args[0][1],
+                                                         P.ctypes.data_as(C.POINTER(C.c_float)), 1 if dev else 0),
+                   "setInputTargetFrames")
+        self._n_target = int(sum(a[2] for a in args))
+
     def setInputSource(self, cloud):  # scanmatcher_component.cpp:329; graph_based_slam_component.cpp:181
         p, stride, n, dev, keep = _cloud_args(cloud)
         fn = self._lib.lsr_set_input_source_device if dev else self._lib.lsr_set_input_source

@@ -57,3 +57,33 @@ def test_filtered_source_feeds_align(O, scan):
     dt, ang = pose_delta(a.getFinalTransformation(), b.getFinalTransformation())
     assert dt < 1e-4 and ang < 1e-5
     assert pose_delta(a.getFinalTransformation(), case.truth)[0] < 0.1
+
+
+def test_submap_assembly_on_device_matches_host_assembly(O):
+    """'Next' row N2: transformPointCloud per keyframe + concat on the device == assembling on the host
+    (scanmatcher_component.cpp:449-464) — same voxel table, bit-exact leaf set."""
+    from lidarslam_ros2_amd import NormalDistributionsTransform
+
+    world, sensor = synth.make_world(), synth.Sensor(16, -20.0, 12.0, 600)
+    rng = np.random.default_rng(3)
+    frames, poses = [], []
+    for k in range(4):
+        T = synth.trajectory_pose(1.5 * k)
+        frames.append(synth.voxel_downsample(synth.raycast(world, sensor, T, rng), 0.2))
+        poses.append(T.astype(np.float32))
+    # host assembly with pcl::transformPointCloud's fp32 arithmetic: ((m00 x + m01 y) + m02 z) + m03
+    chunks = []
+    for f, T in zip(frames, poses):
+        cols = [((T[r, 0] * f[:, 0] + T[r, 1] * f[:, 1]) + T[r, 2] * f[:, 2]) + T[r, 3] for r in range(3)]
+        chunks.append(np.stack(cols, 1).astype(np.float32))
+    host = np.concatenate(chunks)
+    a, b = NormalDistributionsTransform(device=0), NormalDistributionsTransform(device=0)
+    for r in (a, b):
+        r.setResolution(2.0)
+    a.setInputTargetFrames([synth.as_pointxyzi(f) for f in frames], poses)
+    b.setInputTarget(host)
+    da, db = a.gridDump(), b.gridDump()
+    assert np.array_equal(da["idx"], db["idx"]) and np.array_equal(da["n"], db["n"])
+    assert np.array_equal(da["mean"], db["mean"]) and np.array_equal(da["icov"], db["icov"])   # bit-identical clouds
+    ref = O.VoxelGridCovariance(host, 2.0)
+    assert a.gridInfo()["n_valid"] == ref.n_valid
