@@ -124,6 +124,12 @@ int lsr_set_input_source_device(lsr_handle h, const void* dev_pts, size_t stride
  * HIP device pointer.  n_out (nullable) receives the number of points kept. */
 int lsr_set_input_source_filtered(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, float leaf, int on_device,
                                   size_t* n_out);
+/* The frontend's whole per-scan preprocessing on the device: min-max range filter
+ * (`scan_min_range < sqrt(x^2+y^2) < scan_max_range`, scanmatcher_component.cpp:210-218) -> VoxelGrid
+ * (vg_size_for_input, :324-328) -> setInputSource (:329).  A sensor_msgs/PointCloud2 payload with x@0,y@4,z@8
+ * (point_step = stride_bytes, e.g. 32 for the PointXYZI layout pcl::toROSMsg writes) can be passed as is. */
+int lsr_set_input_source_frontend(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, double scan_min_range,
+                                  double scan_max_range, float vg_size_for_input, int on_device, size_t* n_out);
 /* The same filter as a stand-alone operation, host in / host out (map side: scanmatcher_component.cpp:266-269,
  * 443-447; graph_based_slam_component.cpp:224-226).  Writes xyz at offset 0 of each out_stride_bytes record. */
 int lsr_voxel_grid_filter(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, float leaf, void* out_pts,

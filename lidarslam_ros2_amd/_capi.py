@@ -24,7 +24,7 @@ KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
 EXPORTED_SYMBOLS = [
     "lsr_version", "lsr_status_string", "lsr_last_error", "lsr_device_count", "lsr_create", "lsr_destroy",
     "lsr_set_f64", "lsr_set_i32", "lsr_get_f64", "lsr_get_i32", "lsr_set_input_target", "lsr_set_input_target_device",
-    "lsr_set_input_target_frames", "lsr_set_input_source", "lsr_set_input_source_device", "lsr_set_input_source_filtered", "lsr_voxel_grid_filter",
+    "lsr_set_input_target_frames", "lsr_set_input_source", "lsr_set_input_source_device", "lsr_set_input_source_filtered", "lsr_set_input_source_frontend", "lsr_voxel_grid_filter",
     "lsr_share_target", "lsr_align", "lsr_align_batch",
     "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_ndt_grid_info",
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
@@ -81,6 +81,8 @@ def load() -> C.CDLL:
     L.lsr_share_target.argtypes = [vp, vp]
     L.lsr_set_input_target_frames.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, fp, C.c_int]
     L.lsr_set_input_source_filtered.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.POINTER(C.c_size_t)]
+    L.lsr_set_input_source_frontend.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_float, C.c_int,
+                                                C.POINTER(C.c_size_t)]
     L.lsr_voxel_grid_filter.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_float, vp, C.c_size_t, C.c_size_t,
                                         C.POINTER(C.c_size_t)]
     L.lsr_align.argtypes = [vp, fp, fp, C.POINTER(Result), vp, C.c_size_t]

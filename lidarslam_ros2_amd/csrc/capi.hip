@@ -496,6 +496,23 @@ int lsr_set_input_source_filtered(lsr_handle h, const void* pts, size_t stride_b
   return LSR_OK;
 }
 
+// The frontend's whole per-scan preprocessing in one call, on the device: min-max range filter
+// (scanmatcher_component.cpp:210-218) -> VoxelGrid(vg_size_for_input) (:324-328) -> setInputSource (:329).
+int lsr_set_input_source_frontend(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, double scan_min_range,
+                                  double scan_max_range, float vg_size_for_input, int on_device, size_t* n_out) {
+  LSR_CHECK_HANDLE(h);
+  if (!(vg_size_for_input > 0)) { set_last_error("leaf size must be > 0"); return LSR_ERR_INVALID_ARGUMENT; }
+  int st = upload_cloud(h, pts, stride_bytes, n, on_device != 0, h->raw);
+  if (st) return st;
+  if ((st = range_mask(h->raw, scan_min_range, scan_max_range, h->stream))) return st;
+  if ((st = voxel_grid_filter(h->raw, vg_size_for_input, h->source, h->scratch, h->stream))) return st;
+  h->has_source = true;
+  h->source_cov_valid = false;
+  if (n_out) *n_out = h->source.n;
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
 // pcl::VoxelGrid::filter as a stand-alone device operation (host in, host out)
 int lsr_voxel_grid_filter(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, float leaf, void* out_pts,
                           size_t out_stride_bytes, size_t out_capacity, size_t* n_out) {

@@ -1156,6 +1156,29 @@ __global__ __launch_bounds__(256) void leaf_centroid_kernel(const float* __restr
 }
 }  // namespace
 
+// N4: the frontend's min-max range filter (scanmatcher_component.cpp:210-218): keep p iff
+// scan_min_range < sqrt(x^2 + y^2) < scan_max_range (double arithmetic, as pow(p.x, 2.0) promotes).
+// Rejected points are overwritten with NaN in the handle's private copy, so the voxel filter that
+// follows drops them exactly like non-finite input.
+namespace {
+__global__ __launch_bounds__(256) void range_mask_kernel(float* __restrict__ x, const float* __restrict__ y, int n, double rmin,
+                                                         double rmax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double px = (double)x[i], py = (double)y[i];
+  const double r = sqrt(px * px + py * py);
+  if (!(rmin < r && r < rmax)) x[i] = __int_as_float(0x7FC00000);
+}
+}  // namespace
+
+int range_mask(DeviceCloud& cloud, double rmin, double rmax, hipStream_t stream) {
+  if (cloud.n == 0) return LSR_OK;
+  hipLaunchKernelGGL(range_mask_kernel, dim3((unsigned)((cloud.n + 255) / 256)), dim3(256), 0, stream, cloud.x(), cloud.y(),
+                     (int)cloud.n, rmin, rmax);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
 int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, BuildScratch& sc, hipStream_t stream) {
   const int n = (int)cloud.n;
   out.n = 0;

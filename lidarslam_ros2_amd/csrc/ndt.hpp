@@ -100,6 +100,7 @@ void ndt_fill_align_constants(NdtState& st, const NdtParamsHost& prm, int n_poin
 
 // N1: pcl::VoxelGrid::filter on the device (centroid per leaf, leaf-index order).
 int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, BuildScratch& sc, hipStream_t stream);
+int range_mask(DeviceCloud& cloud, double rmin, double rmax, hipStream_t stream);
 int interleave(const DeviceCloud& in, void* d_out, size_t stride_bytes, hipStream_t stream);
 
 // Transform cloud by a column-major 4x4 into a strided device buffer (align()'s `output`).

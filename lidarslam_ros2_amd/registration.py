@@ -160,6 +160,17 @@ class Registration:
         self._n_source = int(n_out.value)
         return self._n_source
 
+    def setInputSourceFrontend(self, cloud, scan_min_range: float, scan_max_range: float, vg_size_for_input: float) -> int:
+        """Range filter (scanmatcher_component.cpp:210-218) + VoxelGrid (:324-328) + setInputSource (:329) on the
+        device; returns the number of points kept."""
+        p, stride, n, dev, keep = _cloud_args(cloud)
+        n_out = C.c_size_t()
+        capi.check(self._lib.lsr_set_input_source_frontend(self._h, p, stride, n, float(scan_min_range), float(scan_max_range),
+                                                           C.c_float(vg_size_for_input), 1 if dev else 0, C.byref(n_out)),
+                   "setInputSourceFrontend")
+        self._n_source = int(n_out.value)
+        return self._n_source
+
     def voxelGridFilter(self, cloud, leaf: float) -> np.ndarray:
         """Stand-alone pcl::VoxelGrid(leaf).filter on the device; host (n,c>=3) in, (m,3) fp32 out."""
         p, stride, n, dev, keep = _cloud_args(cloud)

@@ -87,3 +87,25 @@ def test_submap_assembly_on_device_matches_host_assembly(O):
     assert np.array_equal(da["mean"], db["mean"]) and np.array_equal(da["icov"], db["icov"])   # bit-identical clouds
     ref = O.VoxelGridCovariance(host, 2.0)
     assert a.gridInfo()["n_valid"] == ref.n_valid
+
+
+def test_frontend_preprocessing_range_filter_then_voxelgrid(O, scan):
+    """'Next' row N4: min-max range filter (scanmatcher_component.cpp:210-218) + VoxelGrid + setInputSource in one
+    device call == doing the two filters on the host."""
+    from lidarslam_ros2_amd import NormalDistributionsTransform
+
+    rmin, rmax, leaf = 2.0, 60.0, 0.2
+    r64 = np.sqrt(scan[:, 0].astype(np.float64) ** 2 + scan[:, 1].astype(np.float64) ** 2)
+    kept = scan[(rmin < r64) & (r64 < rmax)]
+    assert 0 < kept.shape[0] < scan.shape[0]
+    ref = O.voxel_grid_filter(kept, leaf)
+    case = synth.small_case(n_source=1000, n_keyframes=2)
+    a = NormalDistributionsTransform(device=0)
+    a.setResolution(5.0)
+    a.setInputTarget(case.target)
+    n = a.setInputSourceFrontend(synth.as_pointxyzi(scan), rmin, rmax, leaf)   # PointCloud2-style 32-byte records
+    assert n == ref.shape[0]
+    out = a.align(np.eye(4, dtype=np.float32), output=True)                   # output = T * filtered source
+    T = a.getFinalTransformation()
+    back = (out - T[:3, 3]) @ T[:3, :3]                                        # undo T: recovers the filtered cloud
+    assert np.abs(back - ref).max() < 2e-3
