@@ -1,0 +1,162 @@
+"""GPU edge cases of the C ABI: empty / ragged / non-finite inputs, record strides, device-pointer inputs,
+neighbourhood variants, lazy grid rebuild, error codes (the reference has no tests — SURVEY.md §4 — these
+pin the behaviour SURVEY.md §8b/§9 describes)."""
+import numpy as np
+import pytest
+
+from lidarslam_ros2_amd import synth
+from lidarslam_ros2_amd.posemath import pose_delta
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def case():
+    return synth.small_case(n_source=3000, n_keyframes=3)
+
+
+def make_ndt(res=5.0, eps=0.01):
+    from lidarslam_ros2_amd import NormalDistributionsTransform
+
+    r = NormalDistributionsTransform(device=0)
+    r.setResolution(res)
+    r.setTransformationEpsilon(eps)
+    return r
+
+
+def test_record_strides_and_device_pointers_are_equivalent(case):
+    import torch
+
+    finals = []
+    for fmt in ("xyz12", "xyzw16", "xyzi32", "device32"):
+        r = make_ndt()
+        if fmt == "xyz12":
+            t, s = case.target, case.source
+        elif fmt == "xyzw16":
+            t, s = np.c_[case.target, np.ones(len(case.target), np.float32)], np.c_[case.source, np.ones(len(case.source), np.float32)]
+        else:
+            t, s = synth.as_pointxyzi(case.target), synth.as_pointxyzi(case.source)
+        if fmt == "device32":
+            t, s = torch.from_numpy(t).cuda(), torch.from_numpy(s).cuda()
+        r.setInputTarget(t)
+        r.setInputSource(s)
+        r.align(case.guess)
+        finals.append(r.getFinalTransformation())
+    for f in finals[1:]:
+        assert np.array_equal(f, finals[0])      # same SoA planes in HBM -> bit-identical registration
+
+
+def test_empty_and_missing_inputs(case):
+    from lidarslam_ros2_amd import _capi
+
+    r = make_ndt()
+    with pytest.raises(_capi.RegistrationError) as ei:
+        r.align()
+    assert ei.value.status == -4                                   # LSR_ERR_NO_TARGET
+    r.setInputTarget(np.zeros((0, 3), np.float32))                 # empty target: accepted, align refuses
+    r.setInputSource(case.source)
+    with pytest.raises(_capi.RegistrationError) as ei:
+        r.align()
+    assert ei.value.status == -4
+    r.setInputTarget(case.target)
+    r.setInputSource(np.zeros((0, 3), np.float32))                 # empty source: nothing to match, pose = guess
+    r.align(case.guess)
+    assert np.array_equal(r.getFinalTransformation(), case.guess)
+    assert r.getFinalNumIteration() == 0
+    with pytest.raises(_capi.RegistrationError):
+        r.setResolution(0.0)
+    with pytest.raises(ValueError):
+        r.setInputSource(np.zeros((5, 2), np.float32))             # fewer than 3 columns
+
+
+def test_nonfinite_points_are_ignored(O, case):
+    src = np.concatenate([case.source, np.array([[np.nan, 0, 0], [0, np.inf, 0], [1e30, 1e30, 1e30]], np.float32)])
+    tgt = np.concatenate([case.target, np.array([[np.nan, np.nan, np.nan]], np.float32)])
+    a, b = make_ndt(), make_ndt()
+    a.setInputTarget(case.target); a.setInputSource(case.source); a.align(case.guess)
+    b.setInputTarget(tgt); b.setInputSource(src); b.align(case.guess)
+    dt, ang = pose_delta(a.getFinalTransformation(), b.getFinalTransformation())
+    assert dt < 1e-6 and ang < 1e-7
+    # trans_probability is score / N with N = all source points, as in the reference
+    assert b.getTransformationProbability() == pytest.approx(a.getTransformationProbability() * len(case.source) / len(src), rel=1e-6)
+
+
+@pytest.mark.parametrize("method,search", [("DIRECT1", 1), ("DIRECT7", 7), ("DIRECT26", 26)])
+def test_neighbourhood_variants_match_oracle(O, case, method, search):
+    import lidarslam_ros2_amd as L
+
+    r = make_ndt(4.0)
+    r.setNeighborhoodSearchMethod(getattr(L, method))
+    r.setInputTarget(case.target)
+    r.setInputSource(case.source)
+    grid = O.VoxelGridCovariance(case.target, 4.0)
+    p = O.matrix_to_pose(case.guess) + np.array([0.1, -0.05, 0.02, 0.002, -0.003, 0.004])
+    s, g, H = r.derivatives(p)
+    rs, rg, rH = O.ndt_derivatives(grid, case.source, p, resolution=4.0, search=search)
+    assert abs(s - rs) <= 1e-5 * abs(rs)
+    assert np.abs(g - rg).max() <= 2e-5 * np.abs(rg).max() and np.abs(H - rH).max() <= 2e-5 * np.abs(rH).max()
+    r.align(case.guess)
+    ref = O.ndt_align(grid, case.source, case.guess, resolution=4.0, search=search)
+    dt, ang = pose_delta(r.getFinalTransformation(), ref["final"])
+    assert dt <= 1e-3 and ang <= 1e-4
+
+
+def test_kdtree_neighbourhood_is_refused():
+    import lidarslam_ros2_amd as L
+    from lidarslam_ros2_amd import _capi
+
+    r = make_ndt()
+    with pytest.raises(_capi.RegistrationError) as ei:
+        r.setNeighborhoodSearchMethod(L.KDTREE)
+    assert ei.value.status == -6                                   # LSR_ERR_NOT_IMPLEMENTED
+
+
+def test_hessian_d1_sign_option_matches_oracle(O, case):
+    grid = O.VoxelGridCovariance(case.target, 5.0)
+    p = O.matrix_to_pose(case.guess) + np.array([0.05, 0.02, -0.01, 0.003, 0.02, -0.004])
+    for sign in (+1, -1):
+        r = make_ndt()
+        r.setHessianD1Sign(sign)
+        r.setInputTarget(case.target)
+        r.setInputSource(case.source)
+        _, _, H = r.derivatives(p)
+        _, _, rH = O.ndt_derivatives(grid, case.source, p, resolution=5.0, d1_sign=sign)
+        assert np.abs(H - rH).max() <= 2e-5 * np.abs(rH).max()
+
+
+def test_resolution_change_rebuilds_grid_lazily(O, case):
+    r = make_ndt(5.0)
+    r.setInputTarget(case.target)
+    n5 = r.gridInfo()["n_leaves"]
+    r.setResolution(2.0)                                            # pclomp re-inits the grid on the next use
+    info = r.gridInfo()
+    assert info["n_leaves"] == O.VoxelGridCovariance(case.target, 2.0).n_leaves != n5
+    r.setInputSource(case.source)
+    r.align(case.guess)
+    ref = O.ndt_align(O.VoxelGridCovariance(case.target, 2.0), case.source, case.guess, resolution=2.0)
+    dt, ang = pose_delta(r.getFinalTransformation(), ref["final"])
+    assert dt <= 1e-3 and ang <= 1e-4
+
+
+def test_max_iterations_zero_and_repeatability(O, case):
+    r = make_ndt(5.0, 1e-6)
+    r.setMaximumIterations(0)
+    r.setInputTarget(case.target)
+    r.setInputSource(case.source)
+    r.align(case.guess)
+    ref = O.ndt_align(O.VoxelGridCovariance(case.target, 5.0), case.source, case.guess, resolution=5.0, trans_eps=1e-6,
+                      max_iterations=0)
+    assert r.getFinalNumIteration() == ref["iterations"] == 2      # `iter > max_iter` is strict: two passes
+    dt, ang = pose_delta(r.getFinalTransformation(), ref["final"])
+    assert dt <= 1e-3 and ang <= 1e-4
+    # run-to-run reproducibility: fixed-order reductions, no float atomics
+    T1 = r.getFinalTransformation()
+    r.align(case.guess)
+    assert np.array_equal(T1, r.getFinalTransformation())
