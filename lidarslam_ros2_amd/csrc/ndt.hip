@@ -503,6 +503,15 @@ __device__ long long* g_lsr_timing = nullptr;  // [blocks][16] {wall, shader} pa
 #define LSR_STAMP(k)
 #endif
 
+// Values read from the LDS state image are wave-uniform; telling the compiler (v_readfirstlane -> SGPR)
+// turns the branches on them into scalar branches and keeps them out of the vector register file.
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uniform_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // sum partner inside a quad of lanes via DPP quad_perm (no LDS traffic): CTRL 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1]
 template <int CTRL>
 __device__ __forceinline__ double dpp_quad_xor(double v) {
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   __syncthreads();
   LdsState* L = (LdsState*)s_state;
   LSR_STAMP(1)
-  if (L->done) {  // finished earlier: keep both state buffers identical so later launches see it too
+  if (uniform_i(L->done)) {  // finished earlier: keep both state buffers identical so later launches see it too
     if (blockIdx.x == 0 && seq > 0) {
       unsigned int* gdw = reinterpret_cast<unsigned int*>(Sout);
       if (tid < STATE_DW) gdw[tid] = s_state[tid];
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   }
   if (seq > 0) {
     // rows hold what the request in the state asked for: 29 sums with Hessian, 8 without
-    const int nprev = (L->want_hessian != 0) ? 29 : NDT_NRED_GRAD;
+    const int nprev = (uniform_i(L->want_hessian) != 0) ? 29 : NDT_NRED_GRAD;
     if (tid < NDT_NRED) {
       double t = 0.0;
       if (tid < nprev)
@@ -633,16 +642,16 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
     if (tid < STATE_DW) gdw[tid] = s_state[tid];
     if (tid + NDT_THREADS < STATE_DW) gdw[tid + NDT_THREADS] = s_state[tid + NDT_THREADS];
   }
-  if (L->done) return;
+  if (uniform_i(L->done)) return;
   LSR_STAMP(7)
 
   // ---- this launch's request, straight from the LDS image
-  const bool hess = L->want_hessian != 0;
-  const double d1d = L->d1;
-  const float d2 = (float)L->d2;
+  const bool hess = uniform_i(L->want_hessian) != 0;
+  const double d1d = uniform_d(L->d1);
+  const float d2 = uniform_f((float)L->d2);
   float T[12];
 #pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = L->T[k];
+  for (int k = 0; k < 12; k++) T[k] = uniform_f(L->T[k]);
   const float leaf = P.leaf;
   __syncthreads();  // s_grp (aliases the transpose buffer) is dead from here on
 
@@ -660,7 +669,10 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
     const bool finite_ok = (fabsf(fx) < 1.0e9f) && (fabsf(fy) < 1.0e9f) && (fabsf(fz) < 1.0e9f);
     const int ci = finite_ok ? (int)fx : INT_MIN / 2, cj = finite_ok ? (int)fy : INT_MIN / 2, ck = finite_ok ? (int)fz : INT_MIN / 2;
 
-    int slot[NOFF];
+    // Branch-free neighbourhood: every record load is issued up front (out-of-range neighbours read
+    // cell 0 and are masked), so a point costs ONE gather round trip instead of one per neighbour.
+    bool valid[NOFF];
+    size_t ridx[NOFF];
 #pragma unroll
     for (int o = 0; o < NOFF; o++) {
       int dx, dy, dz;
@@ -668,12 +680,22 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
       const int a = ci + dx, b = cj + dy, c = ck + dz;
       const bool in = (a >= P.min_b[0]) & (a <= P.max_b[0]) & (b >= P.min_b[1]) & (b <= P.max_b[1]) &
                       (c >= P.min_b[2]) & (c <= P.max_b[2]);
-      int sidx = -1;
-      if (in) {
-        const int cell = (a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2;
-        sidx = DENSE ? cell : P.cell_slot[cell];
+      const int cell = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
+      if (DENSE) {
+        valid[o] = in;
+        ridx[o] = (size_t)cell;
+      } else {
+        const int sl = P.cell_slot[cell];
+        valid[o] = in & (sl >= 0);
+        ridx[o] = (size_t)(sl >= 0 ? sl : 0);
       }
-      slot[o] = sidx;
+    }
+    float4 r0[NOFF], r1[NOFF], r2[NOFF];
+#pragma unroll
+    for (int o = 0; o < NOFF; o++) {
+      r0[o] = P.rec[ridx[o] * 4 + 0];
+      r1[o] = P.rec[ridx[o] * 4 + 1];
+      r2[o] = P.rec[ridx[o] * 4 + 2];
     }
 
     float score = 0.f, npairs = 0.f;
@@ -681,33 +703,31 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
     float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;  // sum w * (C - d2 Cq Cq^T)
 #pragma unroll
     for (int o = 0; o < NOFF; o++) {
-      if (slot[o] < 0) continue;
-      const float4 r0 = P.rec[(size_t)slot[o] * 4 + 0];
-      const float4 r1 = P.rec[(size_t)slot[o] * 4 + 1];
-      const float4 r2 = P.rec[(size_t)slot[o] * 4 + 2];
-      if (DENSE && !(r2.y >= 6.f)) continue;  // empty / under-populated / invalidated cell
-      const float q0 = tx - r0.x, q1 = ty - r0.y, q2 = tz - r0.z;
-      const float c00 = r0.w, c01 = r1.x, c02 = r1.y, c11 = r1.z, c12 = r1.w, c22 = r2.x;
+      const bool leaf_ok = valid[o] & (r2[o].y >= 6.f);  // empty / under-populated / invalidated cells carry n < 6
+      const float q0 = tx - r0[o].x, q1 = ty - r0[o].y, q2 = tz - r0[o].z;
+      const float c00 = r0[o].w, c01 = r1[o].x, c02 = r1[o].y, c11 = r1[o].z, c12 = r1[o].w, c22 = r2[o].x;
       const float Cq0 = fmaf(c00, q0, fmaf(c01, q1, c02 * q2));
       const float Cq1 = fmaf(c01, q0, fmaf(c11, q1, c12 * q2));
       const float Cq2 = fmaf(c02, q0, fmaf(c12, q1, c22 * q2));
       const float qCq = fmaf(q0, Cq0, fmaf(q1, Cq1, q2 * Cq2));
       const float e = expf(-d2 * qCq * 0.5f);
-      float w = d2 * e;
+      const float w0 = d2 * e;
       // ndt_omp drops the whole pair (score included) when d2*e is outside [0,1] or NaN
-      if (!(w <= 1.f) || !(w >= 0.f)) continue;
-      score += (float)(-d1d * (double)e);
-      npairs += 1.f;
-      w = (float)((double)w * d1d);
-      A0 = fmaf(w, Cq0, A0); A1 = fmaf(w, Cq1, A1); A2 = fmaf(w, Cq2, A2);
+      const bool ok = leaf_ok & (w0 <= 1.f) & (w0 >= 0.f);
+      score += ok ? (float)(-d1d * (double)e) : 0.f;
+      npairs += ok ? 1.f : 0.f;
+      const float w = (float)((double)w0 * d1d);
+      A0 = ok ? fmaf(w, Cq0, A0) : A0;
+      A1 = ok ? fmaf(w, Cq1, A1) : A1;
+      A2 = ok ? fmaf(w, Cq2, A2) : A2;
       if (hess) {
         const float wd = -w * d2;
-        E00 += fmaf(wd * Cq0, Cq0, w * c00);
-        E01 += fmaf(wd * Cq0, Cq1, w * c01);
-        E02 += fmaf(wd * Cq0, Cq2, w * c02);
-        E11 += fmaf(wd * Cq1, Cq1, w * c11);
-        E12 += fmaf(wd * Cq1, Cq2, w * c12);
-        E22 += fmaf(wd * Cq2, Cq2, w * c22);
+        E00 = ok ? E00 + fmaf(wd * Cq0, Cq0, w * c00) : E00;
+        E01 = ok ? E01 + fmaf(wd * Cq0, Cq1, w * c01) : E01;
+        E02 = ok ? E02 + fmaf(wd * Cq0, Cq2, w * c02) : E02;
+        E11 = ok ? E11 + fmaf(wd * Cq1, Cq1, w * c11) : E11;
+        E12 = ok ? E12 + fmaf(wd * Cq1, Cq2, w * c12) : E12;
+        E22 = ok ? E22 + fmaf(wd * Cq2, Cq2, w * c22) : E22;
       }
     }
     const float px = x, py = y, pz = z;
@@ -770,14 +790,23 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   // ---- workgroup reduction: quad sum in registers (DPP) -> LDS transpose [value][64 quads] ->
   //      8 interleaved segment sums per value -> one partial row
   const int nred = hess ? 29 : NDT_NRED_GRAD;
+  if (hess) {
 #pragma unroll
-  for (int k = 0; k < 29; k++)
-    if (k < nred) {
+    for (int k = 0; k < 29; k++) {
       double v = acc[k];
       v += dpp_quad_xor<0xB1>(v);  // lanes {0<->1, 2<->3}
       v += dpp_quad_xor<0x4E>(v);  // lanes {0<->2, 1<->3}
       if ((tid & 3) == 0) s_part[k][tid >> 2] = v;
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NDT_NRED_GRAD; k++) {
+      double v = acc[k];
+      v += dpp_quad_xor<0xB1>(v);
+      v += dpp_quad_xor<0x4E>(v);
+      if ((tid & 3) == 0) s_part[k][tid >> 2] = v;
+    }
+  }
   __syncthreads();
   double* prow = P.partials + ((size_t)(seq & 1) * P.nblocks + blockIdx.x) * NDT_NRED;
   {

@@ -6,7 +6,7 @@ case = synth.cfg_ndt_30k()
 def mk():
     r = NormalDistributionsTransform(0); r.setResolution(5.0); r.setTransformationEpsilon(0.0); r.setMaximumIterations(30); return r
 lead = mk(); lead.setInputTarget(case.target)
-for B in (1, 4, 16, 64):
+for B in [int(b) for b in os.environ.get("LSR_BS", "1,4,16,64").split(",")]:
     regs = [lead] + [mk() for _ in range(B - 1)]
     for r in regs[1:]: r.shareTargetOf(lead)
     for r in regs: r.setInputSource(case.source)
