@@ -318,13 +318,22 @@ __device__ void solve6_gn(const double* H, const double* b, double* x) {
   }
 }
 
-__global__ __launch_bounds__(64) void gicp_update_kernel(GnState* __restrict__ S, const double* __restrict__ partials, int nblocks) {
+__global__ __launch_bounds__(256) void gicp_update_kernel(GnState* __restrict__ S, const double* __restrict__ partials, int nblocks) {
   if (S->inner_done) return;
-  __shared__ double s_sum[GN_NRED];
+  __shared__ double s_grp[8][32];
+  __shared__ double s_sum[32];
   const int t = threadIdx.x;
-  if (t < GN_NRED) {
+  {
+    const int v = t & 31, grp = t >> 5;  // 8 groups x 32 values, fixed order
+    double acc = 0.0;
+    if (v < GN_NRED)
+      for (int b = grp; b < nblocks; b += 8) acc += partials[(size_t)b * 32 + v];
+    s_grp[grp][v] = acc;
+  }
+  __syncthreads();
+  if (t < 32) {
     double v = 0.0;
-    for (int b = 0; b < nblocks; b++) v += partials[(size_t)b * 32 + t];  // fixed order
+    for (int g2 = 0; g2 < 8; g2++) v += s_grp[g2][t];
     s_sum[t] = v;
   }
   __syncthreads();
@@ -496,7 +505,7 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
       for (int it = 0; it < chunk; it++) {
         hipLaunchKernelGGL(gicp_gn_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, ws.out.x(), ws.out.y(), ws.out.z(), n, d_pairs,
                            d_state, d_partials);
-        hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_partials, nblocks);
+        hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(256), 0, s, d_state, d_partials, nblocks);
       }
       launched += chunk;
       LSR_HIP(hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, s));

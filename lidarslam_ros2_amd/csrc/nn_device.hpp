@@ -10,6 +10,7 @@ namespace nnd {
 constexpr int NN_THREADS = 128;
 constexpr int FINE_PER_BLOCK = 512;
 constexpr int FINE_STRIDE = 513;
+constexpr int NN_MAX_FINE_RINGS = 4;  // fine-cell shells tried before falling back to coarse shells
 
 struct NNGridView {
   float cell, inv_cell;
@@ -98,38 +99,45 @@ __device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int 
   const float q[3] = {qx, qy, qz};
   const int fdim[3] = {G.cdim[0] * 8, G.cdim[1] * 8, G.cdim[2] * 8};
 
-  // ---- phase 1: (2R+1)^3 fine cells
+  // ---- phase 1: fine-cell shells 0..NN_MAX_FINE_RINGS around the query; after shell R every point outside
+  //      the (2R+1)^3 block is at least `lo` away, so the search stops as soon as the k-th best is closer.
+  //      (`fine_rings` = shells scanned before the first bound test: 1 for 1-NN, 2 for 20-NN.)
   bool any_fine = true;
   for (int k = 0; k < 3; k++)
-    if (fq[k] + fine_rings < 0 || fq[k] - fine_rings >= fdim[k]) any_fine = false;
+    if (fq[k] + NN_MAX_FINE_RINGS < 0 || fq[k] - NN_MAX_FINE_RINGS >= fdim[k]) any_fine = false;
   if (any_fine) {
-    for (int dz = -fine_rings; dz <= fine_rings; dz++) {
-      const int z = fq[2] + dz;
-      if (z < 0 || z >= fdim[2]) continue;
-      for (int dy = -fine_rings; dy <= fine_rings; dy++) {
-        const int y = fq[1] + dy;
-        if (y < 0 || y >= fdim[1]) continue;
-        for (int dx = -fine_rings; dx <= fine_rings; dx++) {
-          const int x = fq[0] + dx;
-          if (x < 0 || x >= fdim[0]) continue;
-          const int blk = G.coarse_block[(x >> 3) + G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3))];
-          if (blk < 0) continue;
-          const int f = (x & 7) | ((y & 7) << 3) | ((z & 7) << 6);
-          const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + f;
-          scan_range(G, fs[0], fs[1], qx, qy, qz, c, self_skip);
+    for (int r = 0; r <= NN_MAX_FINE_RINGS; r++) {
+      for (int dz = -r; dz <= r; dz++) {
+        const int z = fq[2] + dz;
+        if (z < 0 || z >= fdim[2]) continue;
+        for (int dy = -r; dy <= r; dy++) {
+          const int y = fq[1] + dy;
+          if (y < 0 || y >= fdim[1]) continue;
+          const bool shell_yz = (abs(dz) == r) || (abs(dy) == r);
+          const int step = shell_yz ? 1 : max(1, 2 * r);
+          for (int dx = -r; dx <= r; dx += step) {
+            const int x = fq[0] + dx;
+            if (x < 0 || x >= fdim[0]) continue;
+            const int blk = G.coarse_block[(x >> 3) + G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3))];
+            if (blk < 0) continue;
+            const int f = (x & 7) | ((y & 7) << 3) | ((z & 7) << 6);
+            const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + f;
+            scan_range(G, fs[0], fs[1], qx, qy, qz, c, self_skip);
+          }
         }
       }
+      if (r < fine_rings) continue;
+      float lo = INFINITY;
+      for (int k = 0; k < 3; k++) {
+        const float base = (float)(fq[k] + G.org[k]) * G.cell;
+        lo = fminf(lo, fminf(q[k] - (base - (float)r * G.cell), (base + (float)(r + 1) * G.cell) - q[k]));
+      }
+      lo = fmaxf(lo, 0.f);
+      const float lo2 = lo * lo * 0.9999f;
+      if ((c.full() && c.worst() <= lo2) || lo2 > max_d2) return;
     }
   }
-  // every point outside the scanned fine block is at least `lo` away
-  float lo = INFINITY;
-  for (int k = 0; k < 3; k++) {
-    const float base = (float)(fq[k] + G.org[k]) * G.cell;
-    lo = fminf(lo, fminf(q[k] - (base - (float)fine_rings * G.cell), (base + (float)(fine_rings + 1) * G.cell) - q[k]));
-  }
-  lo = fmaxf(lo, 0.f);
-  float lo2 = lo * lo * 0.9999f;
-  if ((c.full() && c.worst() <= lo2) || lo2 > max_d2) return;
+  fine_rings = NN_MAX_FINE_RINGS;  // what phase 2 must not offer again
 
   // ---- phase 2: coarse shells with box-distance pruning
   const float C = G.cell * 8.f;
