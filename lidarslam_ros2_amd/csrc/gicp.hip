@@ -39,6 +39,12 @@ struct GnState {
   int max_inner;
 };
 
+struct IterBlock {    // uploaded once per outer iteration
+  GnState st;
+  float T16[16];      // transformation_ (column-major)
+  double Rm[9];       // rotation of transformation_ * guess, fp64
+};
+
 __host__ __device__ inline void gn_apply_state(GnState& S) {
   const float a = (float)S.x[3], b = (float)S.x[4], c = (float)S.x[5];
   const float ca = cosf(a), sa = sinf(a), cb = cosf(b), sb = sinf(b), cc = cosf(c), sc = sinf(c);
@@ -318,7 +324,8 @@ __device__ void solve6_gn(const double* H, const double* b, double* x) {
   }
 }
 
-__global__ __launch_bounds__(256) void gicp_update_kernel(GnState* __restrict__ S, const double* __restrict__ partials, int nblocks) {
+__global__ __launch_bounds__(256) void gicp_update_kernel(GnState* __restrict__ S, const double* __restrict__ partials, int nblocks,
+                                                          const int* __restrict__ count) {
   if (S->inner_done) return;
   __shared__ double s_grp[8][32];
   __shared__ double s_sum[32];
@@ -338,6 +345,13 @@ __global__ __launch_bounds__(256) void gicp_update_kernel(GnState* __restrict__ 
   }
   __syncthreads();
   if (t != 0) return;
+  if (S->inner_iter == 0 && S->m == 0) {  // first step of this outer iteration: adopt K6's pair count
+    S->m = *count;
+    if (S->m < 4) {  // the reference's NotEnoughPointsException: leave x alone, the host ends the outer loop
+      S->inner_done = 1;
+      return;
+    }
+  }
   const double m = (double)S->m;
   double g[6], H[36];
   S->f = s_sum[0] / m;
@@ -444,13 +458,12 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   if ((st = ws.out.resize(n))) return st;
   if ((st = ws.pairs.reserve((size_t)n * sizeof(PairRec)))) return st;
   if ((st = ws.buf.reserve((size_t)nblocks * 32 + 64))) return st;
-  if ((st = ws.state.reserve(sizeof(GnState) + 256))) return st;
+  if ((st = ws.state.reserve(sizeof(IterBlock) + 256))) return st;
+  if ((st = ws.pin.reserve(sizeof(IterBlock) + 64))) return st;
   double* d_partials = ws.buf.p;
-  double* d_Rm = ws.buf.p + (size_t)nblocks * 32;
-  GnState* d_state = reinterpret_cast<GnState*>(ws.state.p);
-  int* d_count = reinterpret_cast<int*>(ws.state.p + sizeof(GnState) + 16);
-  float* d_T16 = reinterpret_cast<float*>(ws.state.p + sizeof(GnState) + 64);
-  float* d_G16 = d_T16 + 16;
+  IterBlock* d_blk = reinterpret_cast<IterBlock*>(ws.state.p);
+  int* d_count = reinterpret_cast<int*>(ws.state.p + sizeof(IterBlock) + 16);
+  float* d_G16 = reinterpret_cast<float*>(ws.state.p + sizeof(IterBlock) + 64);
   PairRec* d_pairs = reinterpret_cast<PairRec*>(ws.pairs.p);
 
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -484,34 +497,34 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
     hs.x[5] = atan2((double)trans[1], (double)trans[0]);
     hs.max_inner = h->gicp.max_inner;
     gn_apply_state(hs);
-    LSR_HIP(hipMemcpyAsync(d_T16, trans, 16 * sizeof(float), hipMemcpyHostToDevice, s));
-    LSR_HIP(hipMemcpyAsync(d_Rm, Rm, sizeof(Rm), hipMemcpyHostToDevice, s));
+    // one pinned block per outer iteration: {GnState | T16 | Rm}, one H2D copy, one sync at the end
+    IterBlock* hb = reinterpret_cast<IterBlock*>(h->gicp_ws.pin.p);
+    hb->st = hs;
+    std::memcpy(hb->T16, trans, sizeof(hb->T16));
+    std::memcpy(hb->Rm, Rm, sizeof(hb->Rm));
+    LSR_HIP(hipMemcpyAsync(d_blk, hb, sizeof(IterBlock), hipMemcpyHostToDevice, s));
     LSR_HIP(hipMemsetAsync(d_count, 0, sizeof(int), s));
     hipLaunchKernelGGL(gicp_corr_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS), dim3(NN_THREADS), 0, s, make_view(t.hash),
-                       ws.out.x(), ws.out.y(), ws.out.z(), n, d_T16, d_Rm, thr2, h->source_cov.p, t.cov.p, t.cloud.x(),
+                       ws.out.x(), ws.out.y(), ws.out.z(), n, d_blk->T16, d_blk->Rm, thr2, h->source_cov.p, t.cov.p, t.cloud.x(),
                        t.cloud.y(), t.cloud.z(), d_pairs, d_count);
-    int cnt = 0;
-    LSR_HIP(hipMemcpyAsync(&cnt, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
-    LSR_HIP(hipStreamSynchronize(s));
-    last_cnt = cnt;
     std::memcpy(prev, trans, sizeof(prev));
-    if (cnt < 4) break;  // reference: NotEnoughPointsException is caught, loop left unconverged
-    hs.m = cnt;
-    LSR_HIP(hipMemcpyAsync(d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, s));
     // inner Gauss-Newton chain: launches past convergence exit on the done flag
     int launched = 0;
     while (true) {
       const int chunk = std::min(4, h->gicp.max_inner + 1 - launched);
       for (int it = 0; it < chunk; it++) {
         hipLaunchKernelGGL(gicp_gn_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, ws.out.x(), ws.out.y(), ws.out.z(), n, d_pairs,
-                           d_state, d_partials);
-        hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(256), 0, s, d_state, d_partials, nblocks);
+                           &d_blk->st, d_partials);
+        hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(256), 0, s, &d_blk->st, d_partials, nblocks, d_count);
       }
       launched += chunk;
-      LSR_HIP(hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, s));
+      LSR_HIP(hipMemcpyAsync(&hb->st, &d_blk->st, sizeof(GnState), hipMemcpyDeviceToHost, s));
       LSR_HIP(hipStreamSynchronize(s));
+      hs = hb->st;
       if (hs.inner_done || launched >= h->gicp.max_inner + 1) break;
     }
+    last_cnt = hs.m;
+    if (hs.m < 4) break;  // reference: NotEnoughPointsException is caught, loop left unconverged
     gn_steps += hs.inner_iter;
     last_cost = hs.f;
     if (!(hs.gnorm == hs.gnorm)) break;  // NaN: the reference's solver exception path

@@ -21,7 +21,8 @@ struct GicpWorkspace {
   DeviceCloud out;               // guess * source ("output" of the reference's align)
   DevBuf<unsigned char> pairs;   // PairRec[n]
   DevBuf<double> buf;            // per-workgroup partial rows + Rm
-  DevBuf<unsigned char> state;   // GnState + counters + small matrices
+  DevBuf<unsigned char> state;   // per-iteration block {GnState, T16, Rm} + counters
+  PinBuf<unsigned char> pin;     // pinned host mirror of the per-iteration block
 };
 
 int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res);
