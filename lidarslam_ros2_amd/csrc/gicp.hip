@@ -402,6 +402,10 @@ int compute_covariances(lsr_handle_s* h, const DeviceCloud& cloud, const HashGri
   return LSR_OK;
 }
 
+// The 20-NN of a voxel-filtered LiDAR cloud reach ~2 m along far-range scan rings; a 1 m cell keeps them
+// inside the first two fine shells (the 1-NN correspondence grid stays at 0.5 m).
+constexpr float GICP_COV_CELL = 1.0f;
+
 int ensure_covariances(lsr_handle_s* h) {
   TargetData& t = *h->target;
   int st;
@@ -414,13 +418,15 @@ int ensure_covariances(lsr_handle_s* h) {
     t.has_hash = true;
   }
   if (!t.has_cov || t.cov_k != h->gicp.k || t.cov_eps != h->gicp.gicp_eps) {
-    if ((st = compute_covariances(h, t.cloud, t.hash, t.cov))) return st;
+    if ((st = nn_build_hash(t.cloud, GICP_COV_CELL, h->source_hash, h->scratch, h->stream))) return st;  // borrowed, rebuilt below
+    if ((st = compute_covariances(h, t.cloud, h->source_hash, t.cov))) return st;
     t.has_cov = true;
     t.cov_k = h->gicp.k;
     t.cov_eps = h->gicp.gicp_eps;
+    h->source_cov_valid = false;
   }
   if (!h->source_cov_valid) {
-    if ((st = nn_build_hash(h->source, nn_pick_cell(h->source.n, h), h->source_hash, h->scratch, h->stream))) return st;
+    if ((st = nn_build_hash(h->source, GICP_COV_CELL, h->source_hash, h->scratch, h->stream))) return st;
     if ((st = compute_covariances(h, h->source, h->source_hash, h->source_cov))) return st;
     h->source_cov_valid = true;
   }
