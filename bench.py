@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 553.2 + 12.16) * 1024)  # single 30k-pt pass, see roofline.traffic_source
+PMC_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 780.1 + 8.44) * 1024)  # single 30k-pt pass, see roofline.traffic_source
 
 
 def main():
@@ -149,10 +149,10 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "ndt_eval_kernel<7> (derivative pass + fused Newton/More-Thuente controller)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            # HBM bytes per launch from rocprofv3 PMC passes of this kernel on this workload
-                           # (profiles/r01_pmc_ndt_eval_a.md): FETCH_SIZE 553 KB x2 (gfx950 reports half of wide
-                           # coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE 12 KB.  bench.py cannot collect
+                           # (profiles/r01_pmc_ndt_eval_final.md): FETCH_SIZE 780 KB x2 (gfx950 reports half of wide
+                           # coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE 8 KB.  bench.py cannot collect
                            # PMCs itself; re-measure with tools/pmc_run.sh when the kernel changes.
-                           "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "profiles/r01_pmc_ndt_eval_a.md",
+                           "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "profiles/r01_pmc_ndt_eval_final.md",
                            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_us,
                            "valid_pairs_per_point": pairs / n_src,
                            "compulsory_bytes_per_launch": n_src * 12 + grid["n_valid"] * 36,

@@ -76,7 +76,7 @@ int ndt_nblocks(size_t n, int batch = 1) {
   return nb;
 }
 
-void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_partials, unsigned int* d_ticket, int batch = 1) {
+void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_partials, int batch = 1) {
   const VoxelGridDev& g = h->target->grid;
   P.sx = h->source.x(); P.sy = h->source.y(); P.sz = h->source.z();
   P.n = (int)h->source.n;
@@ -90,7 +90,7 @@ void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_part
   P.pad = 0;
   P.st = d_state;
   P.partials = d_partials;
-  P.ticket = d_ticket;
+  P.reserved = nullptr;
 }
 
 int ensure_ndt_grid(lsr_handle h) {
@@ -191,10 +191,6 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     max_blocks = std::max(max_blocks, nb);
   }
   if ((st = lead->d_partials.reserve(2 * tot_blocks * NDT_NRED))) return st;
-  size_t old_ticket_cap = lead->d_ticket.cap;
-  if ((st = lead->d_ticket.reserve(B))) return st;
-  if (lead->d_ticket.cap != old_ticket_cap)
-    LSR_HIP(hipMemsetAsync(lead->d_ticket.p, 0, lead->d_ticket.cap * sizeof(unsigned int), lead->stream));
   size_t blk_off = 0;
   int min_evals = 1, hard_cap = 1;
   bool dense = true;
@@ -202,7 +198,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   long pts = 0;
   for (int b = 0; b < B; b++) {
     lsr_handle h = hs[b];
-    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_partials.p + 2 * blk_off * NDT_NRED, lead->d_ticket.p + b, B);
+    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_partials.p + 2 * blk_off * NDT_NRED, B);
     blk_off += lead->h_prob.p[b].nblocks;
     ndt_fill_initial_state(lead->h_state.p[2 * b], guesses ? guesses + 16 * b : nullptr, h->ndt, (int)h->source.n);
     lead->h_state.p[2 * b + 1] = lead->h_state.p[2 * b];
@@ -681,10 +677,7 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
   if ((st = h->h_prob.reserve(1))) return st;
   int nb = ndt_nblocks(h->source.n);
   if ((st = h->d_partials.reserve(2 * (size_t)nb * NDT_NRED))) return st;
-  size_t old_cap = h->d_ticket.cap;
-  if ((st = h->d_ticket.reserve(1))) return st;
-  if (h->d_ticket.cap != old_cap) LSR_HIP(hipMemsetAsync(h->d_ticket.p, 0, h->d_ticket.cap * sizeof(unsigned int), h->stream));
-  fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p, h->d_ticket.p);
+  fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p);
   ndt_fill_diag_state(h->h_state.p[0], p6, T16, compute_hessian, h->ndt, (int)h->source.n);
   h->h_state.p[1] = h->h_state.p[0];
   LSR_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, sizeof(NdtProblem), hipMemcpyHostToDevice, h->stream));

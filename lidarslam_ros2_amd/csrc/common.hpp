@@ -16,10 +16,6 @@ namespace lsr {
 
 void set_last_error(const std::string& s);
 
-struct HipError {
-  hipError_t code;
-};
-
 #define LSR_HIP(expr)                                                                                         \
   do {                                                                                                        \
     hipError_t _e = (expr);                                                                                   \

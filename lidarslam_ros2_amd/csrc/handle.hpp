@@ -39,7 +39,6 @@ struct lsr_handle_s {
   // NDT run-time buffers (batch-capable: the leader of a batch owns arrays for all members)
   DevBuf<NdtState> d_state;
   DevBuf<double> d_partials;
-  DevBuf<unsigned int> d_ticket;
   DevBuf<NdtProblem> d_prob;
   PinBuf<NdtState> h_state;
   PinBuf<NdtProblem> h_prob;

@@ -69,7 +69,7 @@ struct NdtProblem {
   int pad;
   NdtState* st;             // [2] double buffered by launch parity
   double* partials;         // [2][nblocks][NDT_NRED]
-  unsigned int* ticket;     // unused (kept for layout stability)
+  void* reserved;
 };
 
 struct NdtParamsHost {
