@@ -56,12 +56,24 @@ def main():
         raise SystemExit("bench.py needs a GPU: the registration core has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LSR_BENCH_FORCE_DIST"):  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when the communicator is created; stdout must carry exactly one
+        # JSON line, so C-level stdout is pointed at stderr until the first collective has run.
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from lidarslam_ros2_amd import DIRECT7, NormalDistributionsTransform, align_batch, synth
     from lidarslam_ros2_amd.posemath import pose_delta
