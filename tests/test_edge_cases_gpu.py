@@ -160,3 +160,32 @@ def test_max_iterations_zero_and_repeatability(O, case):
     T1 = r.getFinalTransformation()
     r.align(case.guess)
     assert np.array_equal(T1, r.getFinalTransformation())
+
+
+def test_compact_leaf_table_path_for_huge_extents(O, case):
+    """Targets whose dense cell table would exceed 4 Mi cells use the compact table + cell->slot indirection
+    (ndt_build_grid): same answers as the oracle, also for a registration 3.9 km from the origin."""
+    off = np.float32([3000.0, 2500.0, 0.0])
+    tgt = np.concatenate([case.target, case.target + off])               # a second copy of the scene ~3.9 km away
+    res = 1.5
+    r = make_ndt(res)
+    r.setInputTarget(tgt)
+    info = r.gridInfo()
+    cells = np.prod((info["max_b"] - info["min_b"] + 1).astype(np.int64))
+    assert cells > 4 * 2**20                                             # really on the compact path
+    ref_grid = O.VoxelGridCovariance(tgt, res)
+    assert info["n_leaves"] == ref_grid.n_leaves and info["n_valid"] == ref_grid.n_valid
+    r.setInputSource(case.source)
+    for shift in (np.zeros(3, np.float32), off):
+        G = case.guess.copy()
+        G[:3, 3] += shift
+        p = O.matrix_to_pose(G)
+        s, g, H = r.derivatives(p)
+        rs, rg, rH = O.ndt_derivatives(ref_grid, case.source, p, resolution=res)
+        tol = 1e-5 if not shift.any() else 1e-3      # 3.9 km away the fp32 leaf means carry ~1e-4 m of rounding
+        assert abs(s - rs) <= tol * abs(rs) and np.abs(g - rg).max() <= 20 * tol * np.abs(rg).max()
+        r.align(G)
+        ref = O.ndt_align(ref_grid, case.source, G, resolution=res)
+        dt, ang = pose_delta(r.getFinalTransformation(), ref["final"])
+        assert dt <= 1e-3 and ang <= 1e-4, (shift, dt, ang)
+        assert r.hasConverged() == ref["converged"]
