@@ -135,7 +135,7 @@ int run_ndt_chain(lsr_handle lead, NdtProblem* d_probs, const NdtProblem* h_prob
     const int cur = launched & 1;
     bool all_done = true;
     for (int b = 0; b < batch; b++) all_done = all_done && (h_states[2 * b + cur].done != 0);
-    if (profile && !(all_done && c == 1 && launched > 1 && false)) {
+    if (profile) {
       float ms = 0.f;
       LSR_HIP(hipEventElapsedTime(&ms, lead->ev0, lead->ev1));
       if (!all_done) {  // the finalising launch (controller only, no derivative pass) is not a derivative launch
@@ -206,23 +206,18 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     hard_cap = std::max(hard_cap, ndt_hard_cap(h->ndt));
     pts += (long)h->source.n;
   }
-  LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   LSR_HIP(hipMemcpyAsync(lead->d_prob.p, lead->h_prob.p, sizeof(NdtProblem) * B, hipMemcpyHostToDevice, lead->stream));
   LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
-  hipEvent_t e_start = nullptr, e_stop = nullptr;
-  LSR_HIP(hipEventCreate(&e_start));
-  LSR_HIP(hipEventCreate(&e_stop));
+  hipEvent_t e_start = lead->ev2, e_stop = lead->ev3;  // persistent per-handle events
   LSR_HIP(hipEventRecord(e_start, lead->stream));
   int launches = 0;
   st = run_ndt_chain(lead, lead->d_prob.p, lead->h_prob.p, B, max_blocks, lead->d_state.p, lead->h_state.p, lead->ndt.neighborhood, dense, min_evals,
                      hard_cap, lead->profile != 0, &lead->prof, pts, &launches);
-  if (st) { (void)hipEventDestroy(e_start); (void)hipEventDestroy(e_stop); return st; }
+  if (st) return st;
   LSR_HIP(hipEventRecord(e_stop, lead->stream));
   LSR_HIP(hipEventSynchronize(e_stop));
   float ms = 0.f;
   LSR_HIP(hipEventElapsedTime(&ms, e_start, e_stop));
-  (void)hipEventDestroy(e_start);
-  (void)hipEventDestroy(e_stop);
   for (int b = 0; b < B; b++) {
     const NdtState& S = lead->h_state.p[2 * b + (launches & 1)];
     lsr_handle h = hs[b];
@@ -300,7 +295,8 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return LSR_ERR_HIP; }
     h->own_stream = true;
   }
-  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return LSR_ERR_HIP; }
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->ev2) != hipSuccess ||
+      hipEventCreate(&h->ev3) != hipSuccess) { delete h; return LSR_ERR_HIP; }
   if (h->d_T16.reserve(16)) { delete h; return LSR_ERR_HIP; }
   *out = h;
   return LSR_OK;
@@ -312,6 +308,8 @@ int lsr_destroy(lsr_handle h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->ev3) (void)hipEventDestroy(h->ev3);
   h->target.reset();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;

@@ -472,9 +472,7 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   float* d_G16 = reinterpret_cast<float*>(ws.state.p + sizeof(IterBlock) + 64);
   PairRec* d_pairs = reinterpret_cast<PairRec*>(ws.pairs.p);
 
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  LSR_HIP(hipEventCreate(&e0));
-  LSR_HIP(hipEventCreate(&e1));
+  hipEvent_t e0 = h->ev2, e1 = h->ev3;  // persistent per-handle events
   LSR_HIP(hipEventRecord(e0, s));
   LSR_HIP(hipMemcpyAsync(d_G16, G, 16 * sizeof(float), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(gicp_apply_guess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->source.x(), h->source.y(), h->source.z(),
@@ -560,8 +558,6 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   LSR_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
   LSR_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   mat4_mul_f(prev, G, h->final_T);  // final_transformation_ = previous_transformation_ * guess
   h->converged = converged ? 1 : 0;
   if (final_T) std::memcpy(final_T, h->final_T, sizeof(float) * 16);

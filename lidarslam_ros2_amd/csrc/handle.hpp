@@ -15,7 +15,7 @@ struct lsr_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 
   NdtParamsHost ndt;
   GicpParamsHost gicp;
