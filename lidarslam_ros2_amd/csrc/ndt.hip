@@ -937,12 +937,12 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ x, 
 // ijk = (int)(floor(p * inv_leaf) - (float)min_b)
 __global__ __launch_bounds__(256) void leaf_key_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ z, int n, float inv_leaf, int mb0, int mb1,
-                                                       int mb2, int mul1, int mul2, unsigned int* __restrict__ key,
-                                                       int* __restrict__ val) {
+                                                       int mb2, int mul1, int mul2, unsigned int sentinel,
+                                                       unsigned int* __restrict__ key, int* __restrict__ val) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float px = x[i], py = y[i], pz = z[i];
-  unsigned int k = 0xFFFFFFFFu;
+  unsigned int k = sentinel;  // non-finite points: one past the last cell, sorts last
   if (isfinite(px) && isfinite(py) && isfinite(pz)) {
     int i0 = (int)(floorf(px * inv_leaf) - (float)mb0);
     int i1 = (int)(floorf(py * inv_leaf) - (float)mb1);
@@ -964,7 +964,8 @@ __global__ __launch_bounds__(256) void leaf_sum_kernel(const float* __restrict__
   if (wave >= n_runs) return;
   const int off = run_off[wave], cnt = run_cnt[wave];
   double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int j = lane; j < cnt; j += 64) {
+#pragma unroll 4
+  for (int j = lane; j < cnt; j += 64) {  // unrolled: several gathers in flight, additions stay in index order
     const int pi = order[off + j];
     const double px = (double)x[pi], py = (double)y[pi], pz = (double)z[pi];
     s[0] += px; s[1] += py; s[2] += pz;
@@ -1044,12 +1045,13 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __rest
                                                             double eig_mult, float4* __restrict__ rec,
                                                             double* __restrict__ mean64, double* __restrict__ icov64,
                                                             int* __restrict__ leaf_key, int* __restrict__ leaf_n,
-                                                            int* __restrict__ cell_slot, int* __restrict__ n_valid, int dense) {
+                                                            int* __restrict__ cell_slot, int* __restrict__ n_valid, int dense,
+                                                            unsigned int sentinel) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_runs) return;
   const unsigned int key = run_key[r];
   int n = run_cnt[r];
-  if (key == 0xFFFFFFFFu) {  // the run of non-finite points: not a leaf
+  if (key == sentinel) {  // the run of non-finite points: not a leaf
     leaf_key[r] = -1;
     leaf_n[r] = 0;
     return;
@@ -1148,7 +1150,7 @@ int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_f
   unsigned int ord_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
   LSR_HIP(hipMemcpyAsync(ord, ord_init, sizeof(ord_init), hipMemcpyHostToDevice, stream));
   if (n > 0) {
-    int nb = std::min((n + 255) / 256, 512);
+    int nb = std::min((n + 255) / 256, 96);  // one atomic set per workgroup: keep the contention low
     hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, ord);
   }
   unsigned int ord_h[8];
@@ -1157,6 +1159,12 @@ int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_f
   *n_finite = ord_h[6];
   for (int k = 0; k < 3; k++) { mn[k] = ord2f(ord_h[k]); mx[k] = ord2f(ord_h[3 + k]); }
   return LSR_OK;
+}
+
+static int bits_for(unsigned int max_key) {  // radix bits needed to order keys in [0, max_key]
+  int b = 1;
+  while (b < 32 && (max_key >> b) != 0) b++;
+  return b;
 }
 
 // ---- N1: pcl::VoxelGrid::filter (centroid per occupied leaf, output ordered by leaf index) -------------
@@ -1169,11 +1177,11 @@ namespace {
 __global__ __launch_bounds__(256) void leaf_centroid_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ z, const int* __restrict__ order,
                                                             const unsigned int* __restrict__ run_key, const int* __restrict__ run_off,
-                                                            const int* __restrict__ run_cnt, int n_runs, float* __restrict__ ox,
-                                                            float* __restrict__ oy, float* __restrict__ oz) {
+                                                            const int* __restrict__ run_cnt, int n_runs, unsigned int sentinel,
+                                                            float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_runs) return;
-  if (run_key[r] == 0xFFFFFFFFu) return;  // the run of non-finite points (always last) is dropped
+  if (run_key[r] == sentinel) return;  // the run of non-finite points (always last) is dropped
   const int off = run_off[r], cnt = run_cnt[r];
   double sx = 0, sy = 0, sz = 0;
   for (int j = 0; j < cnt; j++) {
@@ -1238,9 +1246,10 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
   int* run_cnt = (int*)(run_key + n);
   int* run_off = run_cnt + n;
   int* d_nruns = run_off + n;
+  const unsigned int sentinel = (unsigned int)((int64_t)div_b[0] * div_b[1] * div_b[2]);  // one past the last leaf index
   hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
-                     min_b[0], min_b[1], min_b[2], div_b[0], div_b[0] * div_b[1], key_in, val_in);
-  if ((st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, 32, sc.temp, stream))) return st;
+                     min_b[0], min_b[1], min_b[2], div_b[0], div_b[0] * div_b[1], sentinel, key_in, val_in);
+  if ((st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), sc.temp, stream))) return st;
   if ((st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
   int n_runs = 0;
   LSR_HIP(hipMemcpyAsync(&n_runs, d_nruns, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1249,7 +1258,7 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
   const int n_out = n_runs - ((n_finite < (unsigned int)n) ? 1 : 0);  // minus the sentinel run
   if ((st = out.resize(n_out))) return st;
   hipLaunchKernelGGL(leaf_centroid_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(),
-                     val_out, run_key, run_off, run_cnt, n_runs, out.x(), out.y(), out.z());
+                     val_out, run_key, run_off, run_cnt, n_runs, sentinel, out.x(), out.y(), out.z());
   LSR_HIP(hipGetLastError());
   return LSR_OK;
 }
@@ -1303,7 +1312,7 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
 
   unsigned int ord_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
   LSR_HIP(hipMemcpyAsync(ord, ord_init, sizeof(ord_init), hipMemcpyHostToDevice, stream));
-  int nb = std::min((n + 255) / 256, 512);
+  int nb = std::min((n + 255) / 256, 96);
   hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, ord);
   unsigned int ord_h[8];
   LSR_HIP(hipMemcpyAsync(ord_h, ord, sizeof(ord_h), hipMemcpyDeviceToHost, stream));
@@ -1327,11 +1336,12 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
   st = grid.cell_slot.reserve(grid.ncells);
   if (st) return st;
   LSR_HIP(hipMemsetAsync(grid.cell_slot.p, 0xFF, grid.ncells * sizeof(int), stream));
+  const unsigned int sentinel = (unsigned int)grid.ncells;  // non-finite points: one past the last leaf index
 
   hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n,
-                     inv_leaf, grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, key_in, val_in);
-  // all 32 bits: the non-finite sentinel 0xFFFFFFFF must sort last
-  st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, 32, temp, stream);
+                     inv_leaf, grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, sentinel, key_in, val_in);
+  // keys live in [0, ncells]: only that many radix bits are sorted (12 at res 5.0 instead of 32)
+  st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), temp, stream);
   if (st) return st;
   st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, temp, stream);
   if (st) return st;
@@ -1360,7 +1370,7 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
                      run_off, run_cnt, n_runs, sums.p);
   hipLaunchKernelGGL(leaf_finalize_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, stream, sums.p, run_key, run_cnt, n_runs,
                      6, 0.01, grid.rec.p, grid.mean64.p, grid.icov64.p, grid.leaf_key.p, grid.leaf_n.p, grid.cell_slot.p,
-                     d_nvalid, grid.dense ? 1 : 0);
+                     d_nvalid, grid.dense ? 1 : 0, sentinel);
   LSR_HIP(hipGetLastError());
   int n_valid = 0;
   LSR_HIP(hipMemcpyAsync(&n_valid, d_nvalid, sizeof(int), hipMemcpyDeviceToHost, stream));

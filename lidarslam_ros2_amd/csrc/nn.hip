@@ -23,10 +23,11 @@ using namespace nnd;
 // ---- build kernels -------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nn_key_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                      const float* __restrict__ z, int n, float inv_cell, int o0, int o1, int o2,
-                                                     int c0, int c1, unsigned int* __restrict__ key, int* __restrict__ val) {
+                                                     int c0, int c1, unsigned int sentinel, unsigned int* __restrict__ key,
+                                                     int* __restrict__ val) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  unsigned int k = 0xFFFFFFFFu;
+  unsigned int k = sentinel;  // non-finite points: one past the last (coarse, fine) key, sorts last
   const float px = x[i], py = y[i], pz = z[i];
   if (isfinite(px) && isfinite(py) && isfinite(pz)) {
     const int fx = (int)floorf(px * inv_cell) - o0, fy = (int)floorf(py * inv_cell) - o1, fz = (int)floorf(pz * inv_cell) - o2;
@@ -46,12 +47,12 @@ __global__ __launch_bounds__(256) void nn_gather_kernel(const float* __restrict_
   sx[i] = x[o]; sy[i] = y[o]; sz[i] = z[o];
 }
 
-__global__ __launch_bounds__(256) void nn_coarse_key_kernel(const unsigned int* __restrict__ key_sorted, int n,
+__global__ __launch_bounds__(256) void nn_coarse_key_kernel(const unsigned int* __restrict__ key_sorted, int n, unsigned int sentinel,
                                                             unsigned int* __restrict__ ckey) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned int k = key_sorted[i];
-  ckey[i] = (k == 0xFFFFFFFFu) ? 0xFFFFFFFFu : k / FINE_PER_BLOCK;
+  ckey[i] = (k == sentinel) ? 0xFFFFFFFFu : k / FINE_PER_BLOCK;
 }
 
 // one wave per occupied coarse cell: 513 fine-cell starts by counting (binary search over the sorted keys)
@@ -210,12 +211,15 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
   if ((st = grid.coarse_block.reserve(ccells))) return st;
   LSR_HIP(hipMemsetAsync(grid.coarse_block.p, 0xFF, ccells * sizeof(int), stream));
   const int nb = (n + 255) / 256;
+  const unsigned int sentinel = (unsigned int)(ccells * FINE_PER_BLOCK);
   hipLaunchKernelGGL(nn_key_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv, grid.org[0],
-                     grid.org[1], grid.org[2], grid.cdim[0], grid.cdim[1], key_in, val_in);
-  if ((st = sort_pairs_u32(key_in, key_out, val_in, grid.order.p, n, 32, sc.temp, stream))) return st;
+                     grid.org[1], grid.org[2], grid.cdim[0], grid.cdim[1], sentinel, key_in, val_in);
+  int bits = 1;
+  while (bits < 32 && (sentinel >> bits) != 0) bits++;  // only the bits the keys can use are sorted
+  if ((st = sort_pairs_u32(key_in, key_out, val_in, grid.order.p, n, bits, sc.temp, stream))) return st;
   hipLaunchKernelGGL(nn_gather_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), grid.order.p, n,
                      grid.sorted.x(), grid.sorted.y(), grid.sorted.z());
-  hipLaunchKernelGGL(nn_coarse_key_kernel, dim3(nb), dim3(256), 0, stream, key_out, n, ckey);
+  hipLaunchKernelGGL(nn_coarse_key_kernel, dim3(nb), dim3(256), 0, stream, key_out, n, sentinel, ckey);
   if ((st = run_length_encode_u32(ckey, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
   int n_runs = 0;
   LSR_HIP(hipMemcpyAsync(&n_runs, d_nruns, sizeof(int), hipMemcpyDeviceToHost, stream));
