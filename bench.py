@@ -103,9 +103,22 @@ def main():
     torch.cuda.synchronize()
     t_tgt = (time.perf_counter() - t_tgt) / 3
 
+    # The timed loop drives the C ABI directly (what a C++ caller does): no per-step numpy conversions.
+    import ctypes as C
+
+    from lidarslam_ros2_amd import _capi
+
+    lib = _capi.load()
+    fptr = C.POINTER(C.c_float)
+    g16 = np.ascontiguousarray(case.guess.T, np.float32).reshape(16)
+    fin16 = np.zeros(16, np.float32)
+    src_ptr, n_src_pts = C.c_void_p(src_dev.data_ptr()), int(src_dev.shape[0])
+
     def step():
-        ndt.setInputSource(src_dev)
-        ndt.align(case.guess)
+        _capi.check(lib.lsr_set_input_source_device(ndt._h, src_ptr, 32, n_src_pts), "lsr_set_input_source_device")
+        _capi.check(lib.lsr_align(ndt._h, g16.ctypes.data_as(fptr), fin16.ctypes.data_as(fptr), C.byref(ndt._last), None, 0),
+                    "lsr_align")
+        ndt._n_source = n_src_pts
 
     for _ in range(args.warmup):
         step()
@@ -113,13 +126,15 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    rec_np = np.zeros((args.steps, 16), np.float32)   # 64-byte result records: column-major 4x4, bottom row reused
     t0 = time.perf_counter()
-    records = []
-    for _ in range(args.steps):
+    for k in range(args.steps):
         step()
-        T = ndt.getFinalTransformation()
-        records.append(np.r_[T[:3, :4].reshape(-1), ndt.getTransformationProbability(), ndt.getFinalNumIteration(), 0, 0])
-    rec = torch.tensor(np.asarray(records, np.float32), device="cuda")     # K x 16 floats = 64-byte records
+        rec_np[k] = fin16   # final transformation (column-major) straight into the record
+        rec_np[k, 3] = ndt._last.score
+        rec_np[k, 7] = ndt._last.iterations
+        rec_np[k, 11] = ndt._last.converged
+    rec = torch.from_numpy(rec_np).cuda()
     if dist is not None:
         gathered = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(gathered, rec)                                      # C1: pose all-gather over xGMI
