@@ -189,3 +189,42 @@ def test_compact_leaf_table_path_for_huge_extents(O, case):
         dt, ang = pose_delta(r.getFinalTransformation(), ref["final"])
         assert dt <= 1e-3 and ang <= 1e-4, (shift, dt, ang)
         assert r.hasConverged() == ref["converged"]
+
+
+def test_points_exactly_on_voxel_faces(O, case):
+    """SURVEY.md §8c KAT 7: source points whose transformed coordinates sit exactly on leaf faces take the
+    reference's cell assignment (fp32 floor(x'/leaf) at lookup, floor(x*inv_leaf) at build)."""
+    res = 2.5
+    grid = O.VoxelGridCovariance(case.target, res)
+    lo, hi = grid.min_b * res, (grid.max_b + 1) * res
+    rng = np.random.default_rng(2)
+    n = 4000
+    pts = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    # snap one (random) coordinate of every point onto a face k*res — exactly representable in fp32
+    ax = rng.integers(0, 3, n)
+    pts[np.arange(n), ax] = (np.round(pts[np.arange(n), ax] / res) * res).astype(np.float32)
+    r = make_ndt(res)
+    r.setInputTarget(case.target)
+    r.setInputSource(pts)
+    p = np.zeros(6)
+    s, g, H = r.derivatives(p, T=np.eye(4, dtype=np.float32))
+    rs, rg, rH = O.ndt_derivatives(grid, pts, p, T=np.eye(4, dtype=np.float32), resolution=res)
+    assert rs > 0
+    assert abs(s - rs) <= 1e-5 * abs(rs)
+    assert np.abs(g - rg).max() <= 2e-5 * np.abs(rg).max() and np.abs(H - rH).max() <= 2e-5 * np.abs(rH).max()
+
+
+def test_d1_quirk_does_not_move_the_fixed_point(case):
+    """the h_ang d1 sign only perturbs the Hessian (step direction), never the gradient, so in
+    tight-epsilon mode both settings converge to the same pose."""
+    finals = []
+    for sign in (+1, -1):
+        r = make_ndt(5.0, 1e-6)
+        r.setMaximumIterations(30)
+        r.setHessianD1Sign(sign)
+        r.setInputTarget(case.target)
+        r.setInputSource(case.source)
+        r.align(case.guess)
+        finals.append(r.getFinalTransformation())
+    dt, ang = pose_delta(finals[0], finals[1])
+    assert dt <= 1e-3 and ang <= 1e-4
