@@ -17,7 +17,9 @@ The JSON line also carries
                 G*224) / hipEvent-measured launch duration, vs 8 TB/s HBM peak;
   cpu_baseline  the CPU oracle (C++/OpenMP restatement of ndt_omp — NOT ndt_omp itself) timed on this
                 box's host cores on a bounded sample of the same workload;
-  batched       the same registrations advanced B at a time in shared launches (cfg 4 style).
+  batched       the same registrations advanced B at a time in shared launches (cfg 4 style);
+  gicp_cfg3     GICP frontend registration (cfg 3);
+  loop_gate     the backend's searchLoop() compute (lsr_search_loop) on a synthetic route that closes a loop.
 """
 from __future__ import annotations
 
@@ -259,6 +261,37 @@ def main():
         except Exception as e:  # the headline line must still be printed
             out["gicp_cfg3"] = {"error": repr(e)}
 
+        # ---- loop-closure gate: searchLoop() compute on HBM-resident submaps
+        route = None
+        try:
+            from lidarslam_ros2_amd import LoopClosureParams, SubMap, search_loop
+
+            route = synth.make_loop_route()
+            sms = [SubMap(torch.from_numpy(synth.as_pointxyzi(s["cloud"])).cuda(), s["position"], s["orientation"], s["distance"])
+                   for s in route]
+            lp = dict(threshold_loop_closure_score=1.0, distance_loop_closure=20.0, range_of_searching_loop_closure=10.0,
+                      search_submap_num=2, voxel_leaf_size=0.2)
+            back = NormalDistributionsTransform(device=local_rank, stream=stream)   # graph_based_slam_component.cpp:64-72
+            back.setMaximumIterations(100)
+            back.setResolution(5.0)
+            back.setTransformationEpsilon(0.01)
+            edges = search_loop(back, sms, LoopClosureParams(**lp))
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            nl = 10
+            for _ in range(nl):
+                edges = search_loop(back, sms, LoopClosureParams(**lp))
+            torch.cuda.synchronize()
+            tl = (time.perf_counter() - tl) / nl
+            out["loop_gate"] = {"ms_per_search": 1e3 * tl, "submaps": len(route), "edge": list(edges[0].pair_id),
+                                "fitness_score": edges[0].fitness_score, "accepted": edges[0].accepted,
+                                "target_points": edges[0].n_target_points, "source_points": int(route[-1]["cloud"].shape[0]),
+                                "newton_iterations": edges[0].iterations,
+                                "what": "source transform + 5-submap window transform/concat + VoxelGrid(0.2) + "
+                                        "setInputTarget + align + getFitnessScore + gate, clouds resident in HBM"}
+        except Exception as e:
+            out["loop_gate"] = {"error": repr(e)}
+
         # ---- CPU baseline: the oracle (restatement of ndt_omp) on this box's host cores, bounded sample
         if not args.no_cpu:
             from oracle import oracle as O
@@ -288,6 +321,14 @@ def main():
                                    "ms_per_derivative_pass": 1e3 * best,
                                    "note": "C++/OpenMP restatement of ndt_omp (oracle/), not ndt_omp itself"}
             out["parity_vs_cpu"] = {"translation_m": dt, "rotation_rad": ang}
+            if route is not None and "error" not in out.get("loop_gate", {}):
+                tq = time.perf_counter()
+                ref_edges = O.search_loop(route, **lp, ndt_resolution=5.0, trans_eps=0.01, max_iterations=100, num_threads=cores)
+                tq = time.perf_counter() - tq
+                ldt, lang = pose_delta(edges[0].relative_pose, ref_edges[0]["relative_pose"])
+                out["loop_gate"]["cpu_port_ms_per_search"] = 1e3 * tq
+                out["loop_gate"]["parity_vs_cpu"] = {"same_edge": list(ref_edges[0]["pair_id"]) == list(edges[0].pair_id),
+                                                     "translation_m": ldt, "rotation_rad": lang}
         print(json.dumps(out), flush=True)
 
     if dist is not None:

@@ -156,6 +156,48 @@ int lsr_has_converged(lsr_handle h, int* out);
 /* registration_->getFitnessScore(max_range = DBL_MAX)  graph_based_slam_component.cpp:231; scanmatcher_component.cpp:376 */
 int lsr_get_fitness_score(lsr_handle h, double max_range, double* out);
 
+/* ---- loop-closure gate -------------------------------------------------- */
+/* One lidarslam_msgs/msg/SubMap (SubMap.msg:1-4): accumulated travel distance, geometry_msgs/Pose, and the
+ * PointCloud2 payload (xyz fp32 at offset 0 of every record of stride_bytes; pose-local coordinates). */
+typedef struct lsr_submap {
+  double position[3];           /* pose.position x,y,z */
+  double orientation[4];        /* pose.orientation x,y,z,w */
+  double distance;              /* SubMap.distance */
+  const void* cloud;            /* host or HIP device pointer (see on_device) */
+  size_t n_points;
+} lsr_submap;
+/* graph_based_slam parameters used by searchLoop() (graph_based_slam_component.cpp:23-38, defaults in brackets) */
+typedef struct lsr_loop_params {
+  double threshold_loop_closure_score;     /* [1.0]  accept when fitness < threshold        (:233) */
+  double distance_loop_closure;            /* [20.0] minimum travel since the candidate      (:195) */
+  double range_of_searching_loop_closure;  /* [20.0] maximum Euclidean distance to candidate (:196) */
+  int search_submap_num;                   /* [3]    half-width of the target window         (:209) */
+  float voxel_leaf_size;                   /* [0.2]  voxelgrid_ leaf of the assembled target (:61,224-226) */
+  int top_k;                               /* 1 = the reference (nearest candidate only); >1 = k nearest candidates */
+  int reserved;
+} lsr_loop_params;
+typedef struct lsr_loop_edge {
+  int id_from;                  /* LoopEdge.pair_id.first  = candidate submap index (:240) */
+  int id_to;                    /* LoopEdge.pair_id.second = num_submaps - 1 */
+  int accepted;                 /* fitness_score < threshold_loop_closure_score */
+  int converged;
+  int iterations;
+  int n_target_points;          /* size of the filtered target window */
+  double candidate_distance;    /* |latest - candidate| position distance */
+  double fitness_score;         /* getFitnessScore() after align (:231) */
+  double relative_pose[16];     /* from^-1 * (final * init), column-major 4x4 fp64 (:241-245) */
+  float final_transformation[16];
+} lsr_loop_edge;
+/* GraphBasedSlamComponent::searchLoop() from `latest_submap` on (graph_based_slam_component.cpp:164-252): the latest
+ * submap moved by its pose becomes the source (:171-181), candidates are gated on travelled distance and range and the
+ * nearest one is picked (:188-205), its window of 2*search_submap_num+1 submaps is moved, concatenated, voxel filtered and
+ * set as target (:207-227), then align() without guess (:230), getFitnessScore() (:231), the threshold (:233) and the
+ * relative pose of the edge (:236-245) — clouds stay in HBM from the first transform to the fitness sum.
+ * edges: up to edge_capacity entries, nearest candidate first; *n_evaluated = candidates registered (0 = no candidate).
+ * The pose-graph optimisation that follows (doPoseAdjustment, g2o) is the caller's. */
+int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, size_t stride_bytes, int on_device,
+                    const lsr_loop_params* params, lsr_loop_edge* edges, int edge_capacity, int* n_evaluated);
+
 /* ---- inspection (parity tests / profiling; not used by the ROS nodes) ------------------- */
 /* NDT voxel grid: info[0..2]=min_b, [3..5]=max_b, [6]=#leaves (any point count), [7]=#leaves usable (n>=6, valid cov) */
 int lsr_ndt_grid_info(lsr_handle h, int32_t* info8);

@@ -6,6 +6,8 @@ include/lidarslam_reg.h.  See DESIGN.md.
 """
 from .registration import (DIRECT1, DIRECT7, DIRECT26, KDTREE, GeneralizedIterativeClosestPoint,
                            NormalDistributionsTransform, Registration, align_batch)
+from .loop_closure import LoopClosureParams, LoopEdge, SubMap, search_loop
 
 __all__ = ["Registration", "NormalDistributionsTransform", "GeneralizedIterativeClosestPoint", "align_batch",
+           "SubMap", "LoopClosureParams", "LoopEdge", "search_loop",
            "DIRECT1", "DIRECT7", "DIRECT26", "KDTREE"]

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "lsr_set_f64", "lsr_set_i32", "lsr_get_f64", "lsr_get_i32", "lsr_set_input_target", "lsr_set_input_target_device",
     "lsr_set_input_target_frames", "lsr_set_input_source", "lsr_set_input_source_device", "lsr_set_input_source_filtered", "lsr_set_input_source_frontend", "lsr_voxel_grid_filter",
     "lsr_share_target", "lsr_align", "lsr_align_batch",
-    "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_ndt_grid_info",
+    "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_search_loop", "lsr_ndt_grid_info",
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
 ]
 
@@ -39,6 +39,23 @@ class Result(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("deriv_ms_total", C.c_double), ("deriv_launches", C.c_int64), ("deriv_points", C.c_int64),
                 ("deriv_pairs", C.c_int64)]
+
+
+class SubMap(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("orientation", C.c_double * 4), ("distance", C.c_double),
+                ("cloud", C.c_void_p), ("n_points", C.c_size_t)]
+
+
+class LoopParams(C.Structure):
+    _fields_ = [("threshold_loop_closure_score", C.c_double), ("distance_loop_closure", C.c_double),
+                ("range_of_searching_loop_closure", C.c_double), ("search_submap_num", C.c_int),
+                ("voxel_leaf_size", C.c_float), ("top_k", C.c_int), ("reserved", C.c_int)]
+
+
+class LoopEdge(C.Structure):
+    _fields_ = [("id_from", C.c_int), ("id_to", C.c_int), ("accepted", C.c_int), ("converged", C.c_int),
+                ("iterations", C.c_int), ("n_target_points", C.c_int), ("candidate_distance", C.c_double),
+                ("fitness_score", C.c_double), ("relative_pose", C.c_double * 16), ("final_transformation", C.c_float * 16)]
 
 
 class RegistrationError(RuntimeError):
@@ -90,6 +107,8 @@ def load() -> C.CDLL:
     L.lsr_get_final_transformation.argtypes = [vp, fp]
     L.lsr_has_converged.argtypes = [vp, ip]
     L.lsr_get_fitness_score.argtypes = [vp, C.c_double, dp]
+    L.lsr_search_loop.argtypes = [vp, C.POINTER(SubMap), C.c_int, C.c_size_t, C.c_int, C.POINTER(LoopParams),
+                                  C.POINTER(LoopEdge), C.c_int, ip]
     L.lsr_ndt_grid_info.argtypes = [vp, ip]
     L.lsr_ndt_grid_dump.argtypes = [vp, ip, ip, dp, dp]
     L.lsr_ndt_derivatives.argtypes = [vp, dp, fp, C.c_int, dp, dp, dp]

@@ -411,13 +411,9 @@ static int set_target_impl(lsr_handle h, const void* pts, size_t stride, size_t 
 
 // Submap assembly + setInputTarget without a host round trip of the assembled cloud
 // (scanmatcher_component.cpp:449-464,307; graph_based_slam_component.cpp:208-227)
-int lsr_set_input_target_frames(lsr_handle h, int n_frames, const void* const* frames, const size_t* counts, size_t stride_bytes,
-                                const float* poses16, int on_device) {
-  LSR_CHECK_HANDLE(h);
-  if (n_frames <= 0 || !frames || !counts || !poses16 || stride_bytes < 12 || (stride_bytes % 4)) {
-    set_last_error("bad frame list");
-    return LSR_ERR_INVALID_ARGUMENT;
-  }
+// Move every frame by its pose and concatenate them in order into `out` (device SoA).
+static int assemble_frames(lsr_handle h, int n_frames, const void* const* frames, const size_t* counts, size_t stride_bytes,
+                           const float* poses16, bool on_device, DeviceCloud& out) {
   size_t total = 0, biggest = 0;
   for (int f = 0; f < n_frames; f++) {
     if (counts[f] > 0 && !frames[f]) { set_last_error("null frame pointer"); return LSR_ERR_INVALID_ARGUMENT; }
@@ -425,8 +421,7 @@ int lsr_set_input_target_frames(lsr_handle h, int n_frames, const void* const* f
     biggest = std::max(biggest, counts[f]);
   }
   if (total > (size_t)INT32_MAX / 2) { set_last_error("cloud too large"); return LSR_ERR_INVALID_ARGUMENT; }
-  auto t = std::make_shared<TargetData>();
-  int st = t->cloud.resize(total);
+  int st = out.resize(total);
   if (st) return st;
   if ((st = h->d_poses.reserve((size_t)n_frames * 16))) return st;
   LSR_HIP(hipMemcpyAsync(h->d_poses.p, poses16, sizeof(float) * 16 * n_frames, hipMemcpyHostToDevice, h->stream));
@@ -438,11 +433,26 @@ int lsr_set_input_target_frames(lsr_handle h, int n_frames, const void* const* f
       LSR_HIP(hipMemcpyAsync(h->staging.p, frames[f], counts[f] * stride_bytes, hipMemcpyHostToDevice, h->stream));
       d_aos = h->staging.p;
     }
-    if ((st = transform_append(d_aos, stride_bytes, counts[f], h->d_poses.p + 16 * f, t->cloud, off, h->stream))) return st;
+    if ((st = transform_append(d_aos, stride_bytes, counts[f], h->d_poses.p + 16 * f, out, off, h->stream))) return st;
     if (!on_device) LSR_HIP(hipStreamSynchronize(h->stream));  // the staging buffer is reused by the next frame
     off += counts[f];
   }
-  t->n = total;
+  // poses16 is caller memory read by an asynchronous copy: it must have landed before we return to the caller
+  if (on_device) LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
+int lsr_set_input_target_frames(lsr_handle h, int n_frames, const void* const* frames, const size_t* counts, size_t stride_bytes,
+                                const float* poses16, int on_device) {
+  LSR_CHECK_HANDLE(h);
+  if (n_frames <= 0 || !frames || !counts || !poses16 || stride_bytes < 12 || (stride_bytes % 4)) {
+    set_last_error("bad frame list");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  auto t = std::make_shared<TargetData>();
+  int st = assemble_frames(h, n_frames, frames, counts, stride_bytes, poses16, on_device != 0, t->cloud);
+  if (st) return st;
+  t->n = t->cloud.n;
   h->target = t;
   st = (h->method == LSR_METHOD_NDT) ? ensure_ndt_grid(h) : ensure_target_hash(h);
   if (st) { h->target.reset(); return st; }
@@ -605,6 +615,143 @@ int lsr_get_fitness_score(lsr_handle h, double max_range, double* out) {
   int st = ensure_target_hash(h);
   if (st) return st;
   return nn_fitness_score(h->source, h->final_T, h->target->hash, max_range, out, h->scratch, h->d_T16, h->stream);
+}
+
+// ---- N3: loop-closure gate ---------------------------------------------------------------------
+namespace {
+// tf2::fromMsg(geometry_msgs::Pose) -> Eigen::Affine3d = Translation * Quaterniond (Eigen's toRotationMatrix, no
+// normalisation), column-major 4x4 (graph_based_slam_component.cpp:171,177,219,236-238)
+void submap_pose_matrix(const lsr_submap& s, double M[16]) {
+  const double x = s.orientation[0], y = s.orientation[1], z = s.orientation[2], w = s.orientation[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
+               tzz = tz * z;
+  M[0] = 1 - (tyy + tzz); M[4] = txy - twz;       M[8] = txz + twy;        M[12] = s.position[0];
+  M[1] = txy + twz;       M[5] = 1 - (txx + tzz); M[9] = tyz - twx;        M[13] = s.position[1];
+  M[2] = txz - twy;       M[6] = tyz + twx;       M[10] = 1 - (txx + tyy); M[14] = s.position[2];
+  M[3] = 0; M[7] = 0; M[11] = 0; M[15] = 1;
+}
+void mat4_mul(const double* A, const double* B, double* C) {  // column-major C = A * B
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) {
+      double acc = 0;
+      for (int k = 0; k < 4; k++) acc += A[r + 4 * k] * B[k + 4 * c];
+      C[r + 4 * c] = acc;
+    }
+}
+void isometry_inverse(const double* M, double* I) {  // Eigen::Isometry3d::inverse(): [R^T | -R^T t]
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) I[r + 4 * c] = M[c + 4 * r];
+  for (int r = 0; r < 3; r++) I[r + 12] = -(I[r] * M[12] + I[r + 4] * M[13] + I[r + 8] * M[14]);
+  I[3] = I[7] = I[11] = 0; I[15] = 1;
+}
+}  // namespace
+
+int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, size_t stride_bytes, int on_device,
+                    const lsr_loop_params* params, lsr_loop_edge* edges, int edge_capacity, int* n_evaluated) {
+  LSR_CHECK_HANDLE(h);
+  if (!submaps || num_submaps <= 0 || !params || !n_evaluated || stride_bytes < 12 || (stride_bytes % 4) ||
+      (edge_capacity > 0 && !edges) || edge_capacity < 0) {
+    set_last_error("bad argument");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  if (!(params->voxel_leaf_size > 0) || params->search_submap_num < 0) {
+    set_last_error("voxel_leaf_size must be > 0 and search_submap_num >= 0");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  *n_evaluated = 0;
+  const lsr_submap& latest = submaps[num_submaps - 1];
+  if (latest.n_points == 0 || !latest.cloud) { set_last_error("latest submap has no points"); return LSR_ERR_NO_SOURCE; }
+
+  // source = latest submap moved by its own pose (:171-181)
+  double init_M[16];
+  submap_pose_matrix(latest, init_M);
+  float pose_f[16];
+  for (int k = 0; k < 16; k++) pose_f[k] = (float)init_M[k];
+  {
+    const void* fr[1] = {latest.cloud};
+    const size_t cn[1] = {latest.n_points};
+    int st = assemble_frames(h, 1, fr, cn, stride_bytes, pose_f, on_device != 0, h->source);
+    if (st) return st;
+    h->has_source = true;
+    h->source_cov_valid = false;
+  }
+
+  // candidates (:188-205): enough travel since, close enough now; nearest first (ties: lower index, as the
+  // strict `dist < min_dist` of the reference keeps the first minimum)
+  std::vector<std::pair<double, int>> cand;
+  for (int i = 0; i < num_submaps; i++) {
+    const double dx = latest.position[0] - submaps[i].position[0], dy = latest.position[1] - submaps[i].position[1],
+                 dz = latest.position[2] - submaps[i].position[2];
+    const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
+    if (latest.distance - submaps[i].distance > params->distance_loop_closure && dist < params->range_of_searching_loop_closure)
+      cand.emplace_back(dist, i);
+  }
+  if (cand.empty()) return LSR_OK;
+  std::stable_sort(cand.begin(), cand.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+  const int k_eval = std::min({std::max(params->top_k, 1), (int)cand.size(), edge_capacity});
+
+  std::vector<const void*> frames;
+  std::vector<size_t> counts;
+  std::vector<float> poses;
+  for (int e = 0; e < k_eval; e++) {
+    const int id_min = cand[e].second;
+    // target window (:207-222).  The reference only guards the lower end; an index past the last submap would
+    // read out of bounds there, so it is skipped here.
+    frames.clear(); counts.clear(); poses.clear();
+    for (int j = 0; j <= 2 * params->search_submap_num; j++) {
+      const int idx = id_min + j - params->search_submap_num;
+      if (idx < 0 || idx >= num_submaps) continue;
+      double M[16];
+      submap_pose_matrix(submaps[idx], M);
+      frames.push_back(submaps[idx].cloud);
+      counts.push_back(submaps[idx].n_points);
+      for (int k = 0; k < 16; k++) poses.push_back((float)M[k]);
+    }
+    int st = assemble_frames(h, (int)frames.size(), frames.data(), counts.data(), stride_bytes, poses.data(), on_device != 0, h->raw);
+    if (st) return st;
+    // voxelgrid_.filter + setInputTarget (:224-227)
+    auto t = std::make_shared<TargetData>();
+    if ((st = voxel_grid_filter(h->raw, params->voxel_leaf_size, t->cloud, h->scratch, h->stream))) return st;
+    t->n = t->cloud.n;
+    h->target = t;
+    st = (h->method == LSR_METHOD_NDT) ? ensure_ndt_grid(h) : ensure_target_hash(h);
+    if (st) { h->target.reset(); return st; }
+    // align(output) without guess (:230) and getFitnessScore() (:231)
+    lsr_loop_edge& E = edges[e];
+    std::memset(&E, 0, sizeof(E));
+    lsr_result res;
+    std::memset(&res, 0, sizeof(res));
+    if (h->method == LSR_METHOD_NDT) {
+      lsr_handle hs[1] = {h};
+      st = align_ndt_batch(hs, 1, nullptr, E.final_transformation, &res);
+    } else {
+      st = gicp_align(h, nullptr, E.final_transformation, &res);
+    }
+    if (st) return st;
+    if ((st = ensure_target_hash(h))) return st;
+    double fitness = 0;
+    if ((st = nn_fitness_score(h->source, h->final_T, h->target->hash, 1.7976931348623157e308, &fitness, h->scratch, h->d_T16,
+                               h->stream)))
+      return st;
+    E.id_from = id_min;
+    E.id_to = num_submaps - 1;
+    E.converged = res.converged;
+    E.iterations = res.iterations;
+    E.n_target_points = (int)t->n;
+    E.candidate_distance = cand[e].first;
+    E.fitness_score = fitness;
+    E.accepted = fitness < params->threshold_loop_closure_score ? 1 : 0;
+    // relative pose of the loop edge (:236-245): from^-1 * (final * init)
+    double fin[16], to[16], from[16], from_inv[16];
+    for (int k = 0; k < 16; k++) fin[k] = (double)E.final_transformation[k];
+    mat4_mul(fin, init_M, to);
+    submap_pose_matrix(submaps[id_min], from);
+    isometry_inverse(from, from_inv);
+    mat4_mul(from_inv, to, E.relative_pose);
+    (*n_evaluated)++;
+  }
+  return LSR_OK;
 }
 
 int lsr_nearest_neighbors(lsr_handle h, const float* T16, int32_t* idx, float* d2) {

@@ -272,3 +272,39 @@ def as_pointxyzi(pts: np.ndarray) -> np.ndarray:
     out[:, :3] = pts
     out[:, 3] = 1.0
     return out
+
+
+# ---- loop-closure route ------------------------------------------------------
+def make_loop_route(spacing: float = 3.0, length: float = 24.0, lane: float = 1.25, sensor: Sensor | None = None,
+                    vg_map: float = 0.2, drift: tuple = (0.35, -0.25, 0.04, 0.01), seed: int = 0,
+                    world: World | None = None) -> list:
+    """A route that returns to its start, as a lidarslam_msgs/MapArray stand-in: out along the corridor on the lane
+    y = -lane, a turn, back on y = +lane, and a final submap next to the first one.  Each submap is one scan
+    (VoxelGrid(vg_map), pose-local coordinates) with its ESTIMATED pose; the estimate drifts linearly with travelled
+    distance up to `drift` = (dx, dy, dz, dyaw) at the end, which is what a loop edge has to correct.
+    Returns a list of dicts: cloud (n,3) f32, position (3), orientation (x,y,z,w), distance, truth (4x4 f64)."""
+    sensor = sensor or Sensor(32, -25.0, 15.0, 900)
+    world = world or make_world()
+    rng = np.random.default_rng(WORLD_SEED + 104729 * seed + 5)
+    n_leg = int(round(length / spacing))
+    way = [(spacing * k, -lane, 0.0) for k in range(n_leg + 1)]                      # out, heading +x
+    way += [(length + 0.5 * spacing, 0.0, 0.5 * math.pi)]                            # turn
+    way += [(length - spacing * k, lane, math.pi) for k in range(n_leg + 1)]         # back, heading -x
+    way += [(-0.5 * spacing, 0.2, 1.5 * math.pi), (0.4 * spacing, -lane + 0.3, 2.0 * math.pi)]  # turn, re-visit of the start
+    out = []
+    dist = 0.0
+    for k, (x, y, yaw) in enumerate(way):
+        if k:
+            dist += math.hypot(x - way[k - 1][0], y - way[k - 1][1])
+        out.append(dict(xyyaw=(x, y, yaw), distance=dist))
+    total = max(dist, 1e-9)
+    for sm in out:
+        x, y, yaw = sm.pop("xyyaw")
+        T = pose_matrix(x, y, 0.0, yaw)
+        f = sm["distance"] / total
+        est_yaw = yaw + drift[3] * f
+        sm["truth"] = T
+        sm["cloud"] = voxel_downsample(raycast(world, sensor, T, rng), vg_map)
+        sm["position"] = (x + drift[0] * f, y + drift[1] * f, drift[2] * f)
+        sm["orientation"] = (0.0, 0.0, math.sin(0.5 * est_yaw), math.cos(0.5 * est_yaw))
+    return out

@@ -268,3 +268,84 @@ def gicp_align(nn_tgt: NearestNeighbour, tgt: np.ndarray, tgt_cov: np.ndarray, s
     return dict(final=np.array(res.final_transformation, np.float32).reshape(4, 4).T.copy(),
                 converged=bool(res.converged), iterations=int(res.iterations),
                 n_correspondences=int(res.n_correspondences), final_cost=float(res.final_cost))
+
+
+# ---- loop-closure gate: GraphBasedSlamComponent::searchLoop -------------------
+def pose_msg_to_matrix(position, orientation) -> np.ndarray:
+    """tf2::fromMsg(geometry_msgs::Pose) -> Eigen::Affine3d (graph_based_slam_component.cpp:171,219):
+    Translation * Quaterniond(w,x,y,z) with Eigen's un-normalised toRotationMatrix()."""
+    x, y, z, w = [float(v) for v in orientation]
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    M = np.eye(4)
+    M[:3, :3] = [[1 - (tyy + tzz), txy - twz, txz + twy],
+                 [txy + twz, 1 - (txx + tzz), tyz - twx],
+                 [txz - twy, tyz + twx, 1 - (txx + tyy)]]
+    M[:3, 3] = [float(v) for v in position]
+    return M
+
+
+def transform_point_cloud(pts: np.ndarray, M) -> np.ndarray:
+    """pcl::transformPointCloud(in, out, Matrix4f) for finite points: fp32 ((m0 x + m1 y) + m2 z) + m3."""
+    a = np.asarray(pts, np.float32)[:, :3]
+    m = np.asarray(M, np.float32)
+    x, y, z = a[:, 0], a[:, 1], a[:, 2]
+    out = np.empty((a.shape[0], 3), np.float32)
+    for r in range(3):
+        out[:, r] = ((m[r, 0] * x + m[r, 1] * y) + m[r, 2] * z) + m[r, 3]
+    return out
+
+
+def search_loop(submaps, *, threshold_loop_closure_score=1.0, distance_loop_closure=20.0,
+                range_of_searching_loop_closure=20.0, search_submap_num=3, voxel_leaf_size=0.2, top_k=1,
+                method="ndt", ndt_resolution=1.0, trans_eps=0.01, max_iterations=100, step_size=0.1, num_threads=0,
+                gicp_corr_dist=5.0, gicp_trans_eps=1e-8):
+    """CPU restatement of searchLoop() from `latest_submap` on (graph_based_slam_component.cpp:164-252).
+    submaps: sequence of dicts {cloud (n,>=3) f32, position (3), orientation (4, xyzw), distance}.
+    Returns one dict per evaluated candidate (nearest first): pair_id, fitness_score, accepted, relative_pose, final."""
+    n = len(submaps)
+    latest = submaps[n - 1]
+    init = pose_msg_to_matrix(latest["position"], latest["orientation"])                     # :169-171
+    source = transform_point_cloud(latest["cloud"], init.astype(np.float32))                 # :176-181
+    lp = np.asarray(latest["position"], np.float64)
+    cand = []
+    for i, sm in enumerate(submaps):                                                         # :188-205
+        dist = float(np.linalg.norm(lp - np.asarray(sm["position"], np.float64)))
+        if latest["distance"] - sm["distance"] > distance_loop_closure and dist < range_of_searching_loop_closure:
+            cand.append((dist, i))
+    cand.sort(key=lambda c: c[0])  # stable: first minimum wins, like the strict `dist < min_dist`
+    out = []
+    for dist, id_min in cand[:max(1, top_k)]:
+        parts = []
+        for j in range(2 * search_submap_num + 1):                                          # :209-222
+            idx = id_min + j - search_submap_num
+            if idx < 0 or idx >= n:  # (the reference guards the lower end only)
+                continue
+            sm = submaps[idx]
+            if len(sm["cloud"]):
+                parts.append(transform_point_cloud(sm["cloud"], pose_msg_to_matrix(sm["position"], sm["orientation"]).astype(np.float32)))
+        window = np.concatenate(parts) if parts else np.zeros((0, 3), np.float32)
+        target = voxel_grid_filter(window, voxel_leaf_size)                                  # :224-226
+        if method == "ndt":
+            grid = VoxelGridCovariance(target, ndt_resolution)                               # :227
+            r = ndt_align(grid, source, None, trans_eps=trans_eps, max_iterations=max_iterations, step_size=step_size,
+                          num_threads=num_threads)                                           # :230
+        else:
+            nn_t = NearestNeighbour(target)
+            nn_s = NearestNeighbour(source)
+            r = gicp_align(nn_t, target, gicp_covariances(nn_t, target, num_threads=num_threads), source,
+                           gicp_covariances(nn_s, source, num_threads=num_threads), None, max_corr_dist=gicp_corr_dist,
+                           trans_eps=gicp_trans_eps, max_iterations=max_iterations, solver=1, num_threads=num_threads)
+        fitness = NearestNeighbour(target).fitness_score(source, r["final"], num_threads=num_threads)   # :231
+        frm = pose_msg_to_matrix(submaps[id_min]["position"], submaps[id_min]["orientation"])
+        to = r["final"].astype(np.float64) @ init                                           # :241-243
+        inv = np.eye(4)
+        inv[:3, :3] = frm[:3, :3].T
+        inv[:3, 3] = -frm[:3, :3].T @ frm[:3, 3]                                             # Isometry3d::inverse()
+        out.append(dict(pair_id=(id_min, n - 1), fitness_score=float(fitness),
+                        accepted=bool(fitness < threshold_loop_closure_score), relative_pose=inv @ to,
+                        final=r["final"], iterations=r["iterations"], converged=r["converged"],
+                        n_target_points=int(target.shape[0]), candidate_distance=dist))
+    return out

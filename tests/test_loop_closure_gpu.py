@@ -1,0 +1,135 @@
+"""'Next' row N3: the loop-closure gate of GraphBasedSlamComponent::searchLoop()
+(graph_based_slam_component.cpp:164-252) on the device, through the C ABI (`lsr_search_loop`), against the CPU
+restatement oracle.search_loop on the same synthetic route."""
+import numpy as np
+import pytest
+
+from lidarslam_ros2_amd import (GeneralizedIterativeClosestPoint, LoopClosureParams, NormalDistributionsTransform, SubMap,
+                                search_loop, synth)
+from lidarslam_ros2_amd.posemath import pose_delta
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL_T, TOL_R = 1e-3, 1e-4  # north_star: metres / radians
+
+
+@pytest.fixture(scope="module")
+def route():
+    return synth.make_loop_route()
+
+
+def _submaps(route, device=False):
+    out = []
+    for sm in route:
+        cloud = synth.as_pointxyzi(sm["cloud"])
+        if device:
+            import torch
+            cloud = torch.from_numpy(cloud).cuda()
+        out.append(SubMap(cloud, sm["position"], sm["orientation"], sm["distance"]))
+    return out
+
+
+def _backend_ndt():
+    ndt = NormalDistributionsTransform(0)  # graph_based_slam_component.cpp:64-72
+    ndt.setMaximumIterations(100)
+    ndt.setResolution(5.0)
+    ndt.setTransformationEpsilon(0.01)
+    ndt.setNeighborhoodSearchMethod(synth_direct7())
+    return ndt
+
+
+def synth_direct7():
+    from lidarslam_ros2_amd import DIRECT7
+    return DIRECT7
+
+
+PARAMS = dict(threshold_loop_closure_score=1.0, distance_loop_closure=20.0, range_of_searching_loop_closure=10.0,
+              search_submap_num=2, voxel_leaf_size=0.2)
+
+
+def _check_edge(e, o):
+    assert e.pair_id == o["pair_id"]
+    assert e.n_target_points == o["n_target_points"]
+    assert e.accepted == o["accepted"]
+    assert e.candidate_distance == pytest.approx(o["candidate_distance"], rel=1e-12)
+    dt, dr = pose_delta(e.final_transformation, o["final"])
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    dt, dr = pose_delta(e.relative_pose, o["relative_pose"])
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    assert e.fitness_score == pytest.approx(o["fitness_score"], rel=1e-3)
+
+
+def test_search_loop_matches_the_oracle_ndt(route):
+    edges = search_loop(_backend_ndt(), _submaps(route), LoopClosureParams(**PARAMS))
+    ref = oracle.search_loop(route, **PARAMS, ndt_resolution=5.0, trans_eps=0.01, max_iterations=100,
+                             num_threads=min(32, oracle.max_threads()))
+    assert len(edges) == len(ref) == 1
+    _check_edge(edges[0], ref[0])
+    e = edges[0]
+    assert e.accepted and e.pair_id[1] == len(route) - 1
+    # the edge undoes the drift: relative pose == ground-truth relative pose of the two submaps
+    truth = np.linalg.inv(route[e.pair_id[0]]["truth"]) @ route[-1]["truth"]
+    dt, dr = pose_delta(e.relative_pose, truth)
+    assert dt < 0.03 and dr < 2e-3, (dt, dr)
+
+
+def test_search_loop_top_k_and_device_resident_clouds(route):
+    p = dict(PARAMS, top_k=3)
+    host = search_loop(_backend_ndt(), _submaps(route), LoopClosureParams(**p))
+    dev = search_loop(_backend_ndt(), _submaps(route, device=True), LoopClosureParams(**p))
+    ref = oracle.search_loop(route, **p, ndt_resolution=5.0, trans_eps=0.01, max_iterations=100,
+                             num_threads=min(32, oracle.max_threads()))
+    assert len(host) == len(dev) == len(ref) == 3
+    assert [e.pair_id for e in host] == [o["pair_id"] for o in ref]
+    assert sorted(e.candidate_distance for e in host) == [e.candidate_distance for e in host]
+    for e, d, o in zip(host, dev, ref):
+        _check_edge(e, o)
+        # HBM-resident submaps take the same kernels: identical bits
+        assert np.array_equal(e.final_transformation, d.final_transformation)
+        assert e.fitness_score == d.fitness_score
+        assert np.array_equal(e.relative_pose, d.relative_pose)
+
+
+def test_search_loop_gates(route):
+    sm = _submaps(route)
+    # not enough travel since any submap -> no candidate, nothing registered
+    assert search_loop(_backend_ndt(), sm, LoopClosureParams(**dict(PARAMS, distance_loop_closure=1e6))) == []
+    # nothing within range
+    assert search_loop(_backend_ndt(), sm, LoopClosureParams(**dict(PARAMS, range_of_searching_loop_closure=0.5))) == []
+    # a threshold nobody meets: evaluated but rejected (graph_based_slam_component.cpp:233,251)
+    e = search_loop(_backend_ndt(), sm, LoopClosureParams(**dict(PARAMS, threshold_loop_closure_score=1e-6)))
+    assert len(e) == 1 and not e[0].accepted and e[0].fitness_score > 1e-6
+    # a single submap cannot close a loop
+    assert search_loop(_backend_ndt(), sm[:1], LoopClosureParams(**PARAMS)) == []
+
+
+def test_search_loop_window_is_clipped_at_both_ends(route):
+    # candidate 0 is the nearest when the re-visit lands on it: window -2..2 keeps 0,1,2 only
+    r = [dict(s) for s in route]
+    r[-1] = dict(r[-1], position=(r[0]["position"][0] + 0.3, r[0]["position"][1] + 0.2, 0.0))
+    sm = [SubMap(synth.as_pointxyzi(s["cloud"]), s["position"], s["orientation"], s["distance"]) for s in r]
+    edges = search_loop(_backend_ndt(), sm, LoopClosureParams(**PARAMS))
+    ref = oracle.search_loop(r, **PARAMS, ndt_resolution=5.0, num_threads=min(32, oracle.max_threads()))
+    assert edges[0].pair_id == ref[0]["pair_id"] == (0, len(r) - 1)
+    assert edges[0].n_target_points == ref[0]["n_target_points"]
+
+
+def test_search_loop_gicp(route):
+    gicp = GeneralizedIterativeClosestPoint(0)  # graph_based_slam_component.cpp:74-82
+    gicp.setMaxCorrespondenceDistance(30)
+    gicp.setMaximumIterations(100)
+    gicp.setTransformationEpsilon(1e-8)
+    gicp.setEuclideanFitnessEpsilon(1e-6)
+    gicp.setRANSACIterations(0)
+    edges = search_loop(gicp, _submaps(route), LoopClosureParams(**PARAMS))
+    ref = oracle.search_loop(route, **PARAMS, method="gicp", gicp_corr_dist=30.0, gicp_trans_eps=1e-8, max_iterations=100,
+                             num_threads=min(32, oracle.max_threads()))
+    assert len(edges) == len(ref) == 1
+    e, o = edges[0], ref[0]
+    assert e.pair_id == o["pair_id"] and e.n_target_points == o["n_target_points"] and e.accepted == o["accepted"]
+    dt, dr = pose_delta(e.final_transformation, o["final"])
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    truth = np.linalg.inv(route[e.pair_id[0]]["truth"]) @ route[-1]["truth"]
+    dt, dr = pose_delta(e.relative_pose, truth)
+    assert dt < 0.03 and dr < 2e-3, (dt, dr)

@@ -219,3 +219,38 @@ def test_oracle_reproduces_golden():
     assert np.allclose(g, gold["grad"], rtol=1e-10, atol=1e-9) and np.allclose(H, gold["hess"], rtol=1e-10, atol=1e-7)
     r = O.ndt_align(grid, case.source, case.guess, resolution=float(gold["res"]), trans_eps=0.01, num_threads=1)
     assert np.allclose(r["final"], gold["final_eps001"], atol=1e-6) and r["iterations"] == int(gold["iters_eps001"])
+
+
+# ---- loop-closure gate ---------------------------------------------------------
+def test_pose_msg_to_matrix_is_the_quaternion_rotation():
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(5)
+    for _ in range(5):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        t = rng.normal(size=3)
+        M = O.pose_msg_to_matrix(t, q)
+        assert np.allclose(M[:3, :3], Rotation.from_quat(q).as_matrix(), atol=1e-14)
+        assert np.array_equal(M[:3, 3], t) and np.array_equal(M[3], [0, 0, 0, 1])
+
+
+def test_search_loop_oracle_closes_a_synthetic_loop():
+    route = synth.make_loop_route(sensor=synth.Sensor(16, -20.0, 12.0, 450), vg_map=0.4)
+    nt = min(16, O.max_threads())
+    kw = dict(distance_loop_closure=20.0, range_of_searching_loop_closure=10.0, search_submap_num=2, voxel_leaf_size=0.4,
+              ndt_resolution=5.0, num_threads=nt)
+    out = O.search_loop(route, **kw)
+    assert len(out) == 1 and out[0]["accepted"] and out[0]["pair_id"][1] == len(route) - 1
+    # candidates respect both gates (graph_based_slam_component.cpp:195-196) and the nearest one is taken (:199)
+    lp = np.asarray(route[-1]["position"])
+    d = [np.linalg.norm(lp - np.asarray(s["position"])) for s in route]
+    ok = [i for i, s in enumerate(route) if route[-1]["distance"] - s["distance"] > 20.0 and d[i] < 10.0]
+    assert out[0]["pair_id"][0] == min(ok, key=lambda i: d[i])
+    # the edge recovers the true relative pose although the estimates drifted by ~0.4 m
+    truth = np.linalg.inv(route[out[0]["pair_id"][0]]["truth"]) @ route[-1]["truth"]
+    dt, dr = pose_delta(out[0]["relative_pose"], truth)
+    assert dt < 0.05 and dr < 3e-3, (dt, dr)
+    assert O.search_loop(route, **dict(kw, distance_loop_closure=1e6)) == []
+    top3 = O.search_loop(route, **dict(kw, top_k=3))
+    assert len(top3) == 3 and top3[0]["pair_id"] == out[0]["pair_id"]
+    assert [e["candidate_distance"] for e in top3] == sorted(e["candidate_distance"] for e in top3)

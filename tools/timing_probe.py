@@ -21,8 +21,11 @@ for rep in range(3):
     nb = 118
     w = host[:nb, 0::2].astype(np.float64) * 10.0
     h0 = w[:, 0].min()
-    print("rep", rep, "HEAD: state+rows in LDS %.0f ns after entry | finalising launch: totals->controller done %.0f ns, request built +%.0f ns" % (
-        np.median(w[:, 1]) - h0, np.median(w[:, 5] - w[:, 6]), np.median(w[:, 4] - w[:, 5])))
+    print("rep", rep, "HEAD: state+rows in LDS %.0f ns after entry | finalising launch: row totals +%.0f ns, controller+request +%.0f ns" % (
+        np.median(w[:, 1]) - h0, np.median(w[:, 6] - w[:, 1]), np.median(w[:, 4] - w[:, 6])))
+    if w[:, 8].max() > 0:
+        print("        MAIN detail (last loop iteration of each block): loads issued at +%.0f, pair loop done +%.0f ns after main start" % (
+            np.median(w[:, 8] - w[:, 7]), np.median(w[:, 9] - w[:, 7])))
     m0 = np.median(w[:, 7])
     print("        MAIN  (last pass): points done +%.0f  row written +%.0f ns (medians from main start); max row written +%.0f" % (
         np.median(w[:, 2]) - m0, np.median(w[:, 3]) - m0, w[:, 3].max() - m0))
