@@ -150,7 +150,7 @@ int run_ndt_chain(lsr_handle lead, NdtProblem* d_probs, const NdtProblem* h_prob
       *launches_out = launched;
       return LSR_OK;
     }
-    if (!profile) chunk = 8;
+    if (!profile) chunk = 8;  // measured (tools/latency_probe.py): 8/8 .. 12/12 are equivalent, larger chunks only add idle launches
   }
   set_last_error("NDT controller did not finish within the launch cap");
   return LSR_ERR_HIP;
@@ -206,7 +206,8 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     hard_cap = std::max(hard_cap, ndt_hard_cap(h->ndt));
     pts += (long)h->source.n;
   }
-  LSR_HIP(hipMemcpyAsync(lead->d_prob.p, lead->h_prob.p, sizeof(NdtProblem) * B, hipMemcpyHostToDevice, lead->stream));
+  if (B > 1)  // a single registration carries its NdtProblem in the kernel arguments
+    LSR_HIP(hipMemcpyAsync(lead->d_prob.p, lead->h_prob.p, sizeof(NdtProblem) * B, hipMemcpyHostToDevice, lead->stream));
   LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
   hipEvent_t e_start = lead->ev2, e_stop = lead->ev3;  // persistent per-handle events
   LSR_HIP(hipEventRecord(e_start, lead->stream));

@@ -46,5 +46,20 @@ int main() {
   auto T = registration_->getFinalTransformation();
   std::printf("OK converged=%d iters=%d t=(%.3f %.3f %.3f) fitness=%.4f out=%zu\n", (int)registration_->hasConverged(),
               registration_->getFinalNumIteration(), T(0, 3), T(1, 3), T(2, 3), registration_->getFitnessScore(), output.points.size());
+
+  // searchLoop() through the C ABI: four "submaps" sharing the target cloud; the last one has
+  // travelled far enough and sits next to the first, so exactly one candidate (id 0) is registered.
+  std::vector<lsr_submap> sm(4);
+  const double xs[4] = {0.0, 15.0, 30.0, 0.1};
+  for (int i = 0; i < 4; i++) {
+    sm[i] = lsr_submap{{xs[i], 0.0, 0.0}, {0.0, 0.0, 0.0, 1.0}, 15.0 * i, tgt->points.data(), tgt->points.size()};
+  }
+  sm[3].position[0] = 0.1;
+  lsr_loop_params lp = {1.0, 20.0, 5.0, 0, 0.2f, 1, 0};
+  lsr_loop_edge edge;
+  int n_eval = -1;
+  int st = lsr_search_loop(registration_->handle(), sm.data(), 4, sizeof(PointXYZI), 0, &lp,
+                           &edge, 1, &n_eval);
+  std::printf("LOOP st=%d n=%d from=%d to=%d accepted=%d\n", st, n_eval, edge.id_from, edge.id_to, edge.accepted);
   return 0;
 }

@@ -1,0 +1,37 @@
+// Host emulation of nn_device.hpp (debug only)
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <cstring>
+#include <cstdint>
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __global__
+#define __restrict__
+#define LSR_HOST_EMU 1
+using std::min; using std::max; using std::isfinite; using std::abs;
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+// minimal stand-ins for what nn_device.hpp needs from common.hpp
+namespace lsr { template <typename T> struct DevBuf { T* p = nullptr; };
+struct DeviceCloud { float* x() const { return nullptr; } float* y() const { return nullptr; } float* z() const { return nullptr; } };
+struct HashGridDev { float cell; int org[3]; int cdim[3]; DevBuf<int> coarse_block, block_off, fine_start, order; DeviceCloud sorted; }; }
+#define LSR_COMMON_HPP_STUB
+#include "nn_device_emu.hpp"
+using namespace lsr::nnd;
+extern "C" long run_knn(float cell, const int* org, const int* cdim, const int* coarse_block, const int* block_off, const int* fine_start,
+             const float* sx, const float* sy, const float* sz, const int* order, const float* qx, const float* qy, const float* qz, int nq, int k, int fine_rings, int* out_idx, float* out_d2) {
+  NNGridView G; G.cell = cell; G.inv_cell = 1.0f / cell;
+  for (int a = 0; a < 3; a++) { G.org[a] = org[a]; G.cdim[a] = cdim[a]; }
+  G.coarse_block = coarse_block; G.block_off = block_off; G.fine_start = fine_start; G.x = sx; G.y = sy; G.z = sz; G.order = order;
+  float* sd = (float*)malloc(sizeof(float) * k * NN_THREADS); int* si = (int*)malloc(sizeof(int) * k * NN_THREADS);
+  for (int i = 0; i < nq; i++) {
+    BestK c; c.init(sd, si, k);
+    nn_query(G, qx[i], qy[i], qz[i], fine_rings, INFINITY, c, -1);
+    for (int j = 0; j < k; j++) { out_idx[i * k + j] = si[j * NN_THREADS]; out_d2[i * k + j] = sd[j * NN_THREADS]; }
+  }
+  return 0;
+}
