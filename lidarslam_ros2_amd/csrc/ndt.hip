@@ -499,8 +499,16 @@ __device__ long long* g_lsr_timing = nullptr;  // [blocks][16] {wall, shader} pa
     g_lsr_timing[blockIdx.x * 32 + 2 * (k)] = (long long)wall_clock64();                \
     g_lsr_timing[blockIdx.x * 32 + 2 * (k) + 1] = (long long)clock64();                 \
   }
+#define LSR_SPAN_BEGIN(seq)                                                                                   \
+  if (threadIdx.x == 0 && g_lsr_timing && blockIdx.y == 0)                                                     \
+    atomicMin((unsigned long long*)&g_lsr_timing[(512 + ((seq) & 255)) * 32 + 0], (unsigned long long)wall_clock64());
+#define LSR_SPAN_END(seq)                                                                                     \
+  if (threadIdx.x == 0 && g_lsr_timing && blockIdx.y == 0)                                                     \
+    atomicMax((unsigned long long*)&g_lsr_timing[(512 + ((seq) & 255)) * 32 + 1], (unsigned long long)wall_clock64());
 #else
 #define LSR_STAMP(k)
+#define LSR_SPAN_BEGIN(seq)
+#define LSR_SPAN_END(seq)
 #endif
 
 // Values read from the LDS state image are wave-uniform; telling the compiler (v_readfirstlane -> SGPR)
@@ -565,6 +573,7 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x;
   LSR_STAMP(0)
+  LSR_SPAN_BEGIN(seq)
 
   // LDS: [value][64 quad sums] transpose buffer (pitch 72: conflict free ds_*_b64) — also the row-sum
   // scratch of the head —, the state image, the 32 totals.
@@ -822,6 +831,7 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
     if (seg == 0 && v < nred) prow[v] = t;  // consumed by EVERY workgroup at the head of the next launch
   }
   LSR_STAMP(3)
+  LSR_SPAN_END(seq)
 }
 
 #ifdef LSR_TIMING
