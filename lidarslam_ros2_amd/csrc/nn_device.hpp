@@ -4,6 +4,10 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef LSR_NN_COUNT   // host-emulation statistics hook (tools/nn_host_emu); compiles to nothing in the product
+#define LSR_NN_COUNT(what, n)
+#endif
+
 namespace lsr {
 namespace nnd {
 
@@ -77,14 +81,31 @@ struct BestK {
   }
 };
 
+// Candidates [beg, end) of the cell-sorted arrays.  Coordinates are fetched four at a time (independent loads in
+// flight: with one wave per SIMD nothing else hides the latency); the original index is only fetched for a
+// candidate that can enter the list (needed for the (distance, index) tie-break).
 template <typename Coll>
 __device__ __forceinline__ void scan_range(const NNGridView& G, int beg, int end, float qx, float qy, float qz, Coll& c,
                                            int self_skip) {
-  for (int s = beg; s < end; s++) {
-    const int oi = G.order[s];
-    if (oi == self_skip) continue;
-    const float d = dist2_rn(qx, qy, qz, G.x[s], G.y[s], G.z[s]);
-    c.offer(d, oi);
+  LSR_NN_COUNT(ranges, 1);
+  LSR_NN_COUNT(candidates, end - beg);
+  for (int s = beg; s < end; s += 4) {
+    float X[4], Y[4], Z[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int su = min(s + u, end - 1);
+      X[u] = G.x[su]; Y[u] = G.y[su]; Z[u] = G.z[su];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (s + u < end) {
+        const float d = dist2_rn(qx, qy, qz, X[u], Y[u], Z[u]);
+        if (!(d > c.worst())) {
+          const int oi = G.order[s + u];
+          if (oi != self_skip) c.offer(d, oi);
+        }
+      }
+    }
   }
 }
 
@@ -119,6 +140,7 @@ __device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int 
             const int x = fq[0] + dx;
             if (x < 0 || x >= fdim[0]) continue;
             const int blk = G.coarse_block[(x >> 3) + G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3))];
+            LSR_NN_COUNT(fine_probes, 1);
             if (blk < 0) continue;
             const int f = (x & 7) | ((y & 7) << 3) | ((z & 7) << 6);
             const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + f;
@@ -138,6 +160,7 @@ __device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int 
     }
   }
   fine_rings = NN_MAX_FINE_RINGS;  // what phase 2 must not offer again
+  LSR_NN_COUNT(phase2_queries, 1);
 
   // ---- phase 2: coarse shells with box-distance pruning
   const float C = G.cell * 8.f;
@@ -169,6 +192,7 @@ __device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int 
           }
           bd2 *= 0.9999f;
           if ((c.full() && bd2 > c.worst()) || bd2 > max_d2) continue;
+          LSR_NN_COUNT(coarse_blocks, 1);
           // fine cells already visited in phase 1 must not be offered twice (a k-best list would keep
           // the duplicate): walk the block cell by cell where it overlaps the phase-1 box
           bool overlap = any_fine;

@@ -20,8 +20,11 @@ namespace lsr { template <typename T> struct DevBuf { T* p = nullptr; };
 struct DeviceCloud { float* x() const { return nullptr; } float* y() const { return nullptr; } float* z() const { return nullptr; } };
 struct HashGridDev { float cell; int org[3]; int cdim[3]; DevBuf<int> coarse_block, block_off, fine_start, order; DeviceCloud sorted; }; }
 #define LSR_COMMON_HPP_STUB
+struct Counters { long ranges, candidates, fine_probes, phase2_queries, coarse_blocks, offers_taken, shifts; } g_cnt;
+#define LSR_NN_COUNT(what, n) (g_cnt.what += (n))
 #include "nn_device_emu.hpp"
 using namespace lsr::nnd;
+extern "C" void get_counters(long* out) { memcpy(out, &g_cnt, sizeof(g_cnt)); memset(&g_cnt, 0, sizeof(g_cnt)); }
 extern "C" long run_knn(float cell, const int* org, const int* cdim, const int* coarse_block, const int* block_off, const int* fine_start,
              const float* sx, const float* sy, const float* sz, const int* order, const float* qx, const float* qy, const float* qz, int nq, int k, int fine_rings, int* out_idx, float* out_d2) {
   NNGridView G; G.cell = cell; G.inv_cell = 1.0f / cell;
