@@ -103,35 +103,26 @@ __device__ void sym3_eigen_k5(const double* Ain, double* w, double* V) {
   for (int k = 0; k < 9; k++) V[k] = q[k];
 }
 
-// K5: exact k-NN inside the cloud's own grid + covariance regularisation (computeCovariances)
-__global__ __launch_bounds__(NN_THREADS) void gicp_cov_kernel(NNGridView G, const float* __restrict__ px, const float* __restrict__ py,
-                                                              const float* __restrict__ pz, int n, int k, double gicp_eps,
-                                                              int fine_rings, double* __restrict__ cov) {
-  extern __shared__ unsigned char smem[];
-  float* sd = reinterpret_cast<float*>(smem);
-  int* si = reinterpret_cast<int*>(smem + (size_t)k * NN_THREADS * sizeof(float));
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  BestK c;
-  c.init(sd + threadIdx.x, si + threadIdx.x, k);
-  if (i >= n) return;
-  nn_query(G, px[i], py[i], pz[i], fine_rings, INFINITY, c, -1);
+// Regularised covariance of one point from the sums over its k neighbours (computeCovariances)
+struct CovSums {
   double mean[3] = {0, 0, 0}, s00 = 0, s10 = 0, s11 = 0, s20 = 0, s21 = 0, s22 = 0;
-  for (int j = 0; j < k; j++) {
-    const int o = si[j * NN_THREADS + threadIdx.x];
-    if (o < 0) continue;  // cloud smaller than k (rejected on the host); keeps the kernel safe
-    const float x = px[o], y = py[o], z = pz[o];
+  __device__ __forceinline__ void add(float x, float y, float z) {
     mean[0] += (double)x; mean[1] += (double)y; mean[2] += (double)z;
     // FLOAT products accumulated in double — the reference's `cov(0,0) += pt.x*pt.x`
     s00 += (double)(x * x);
     s10 += (double)(y * x); s11 += (double)(y * y);
     s20 += (double)(z * x); s21 += (double)(z * y); s22 += (double)(z * z);
   }
+};
+
+__device__ void cov_finish(CovSums& S, int k, double gicp_eps, double* __restrict__ out) {
   const double kk = (double)k;
+  double* mean = S.mean;
   mean[0] /= kk; mean[1] /= kk; mean[2] /= kk;
   double C[9];
-  C[0] = s00 / kk - mean[0] * mean[0];
-  C[3] = s10 / kk - mean[1] * mean[0]; C[4] = s11 / kk - mean[1] * mean[1];
-  C[6] = s20 / kk - mean[2] * mean[0]; C[7] = s21 / kk - mean[2] * mean[1]; C[8] = s22 / kk - mean[2] * mean[2];
+  C[0] = S.s00 / kk - mean[0] * mean[0];
+  C[3] = S.s10 / kk - mean[1] * mean[0]; C[4] = S.s11 / kk - mean[1] * mean[1];
+  C[6] = S.s20 / kk - mean[2] * mean[0]; C[7] = S.s21 / kk - mean[2] * mean[1]; C[8] = S.s22 / kk - mean[2] * mean[2];
   C[1] = C[3]; C[2] = C[6]; C[5] = C[7];
   double w[3], V[9];
   sym3_eigen_k5(C, w, V);
@@ -139,13 +130,61 @@ __global__ __launch_bounds__(NN_THREADS) void gicp_cov_kernel(NNGridView G, cons
   int small = 0;
   if (fabs(w[1]) < fabs(w[small])) small = 1;
   if (fabs(w[2]) < fabs(w[small])) small = 2;
-  double* out = cov + (size_t)i * 9;
   for (int a = 0; a < 3; a++)
     for (int b = 0; b < 3; b++) {
       double s = 0;
       for (int col = 0; col < 3; col++) s += ((col == small) ? gicp_eps : 1.0) * V[a * 3 + col] * V[b * 3 + col];
       out[a * 3 + b] = s;
     }
+}
+
+// K5: exact k-NN inside the cloud's own grid + covariance regularisation (computeCovariances).
+// One thread per point walks fine shells 0..ring_cap; a point whose k-th neighbour is not proven by then goes to
+// `work_list` and is finished by gicp_cov_coop_kernel (one wave per point) — otherwise the rare sparse points
+// would drag every wave through hundreds of dependent cell probes (that tail was ~90 % of this kernel's time).
+__global__ __launch_bounds__(NN_THREADS) void gicp_cov_kernel(NNGridView G, const float* __restrict__ px, const float* __restrict__ py,
+                                                              const float* __restrict__ pz, int n, int k, double gicp_eps,
+                                                              int fine_rings, int ring_cap, int* __restrict__ work_count,
+                                                              int* __restrict__ work_list, double* __restrict__ cov) {
+  extern __shared__ unsigned char smem[];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  BestK c;
+  c.init(smem, threadIdx.x, k);
+  if (i >= n) return;
+  if (!nn_query(G, px[i], py[i], pz[i], fine_rings, INFINITY, c, -1, ring_cap)) {
+    work_list[atomicAdd(work_count, 1)] = i;
+    return;
+  }
+  c.finalize();
+  CovSums S;
+  for (int j = 0; j < k; j++) {
+    const int o = c.index(j);
+    if (o < 0) continue;  // cloud smaller than k (rejected on the host); keeps the kernel safe
+    S.add(px[o], py[o], pz[o]);
+  }
+  cov_finish(S, k, gicp_eps, cov + (size_t)i * 9);
+}
+
+// K5 tail: one wave per deferred point (k <= 64).  Same neighbours, same summation order as the per-thread kernel.
+__global__ __launch_bounds__(256) void gicp_cov_coop_kernel(NNGridView G, const float* __restrict__ px, const float* __restrict__ py,
+                                                            const float* __restrict__ pz, int k, double gicp_eps,
+                                                            const int* __restrict__ work_count, const int* __restrict__ work_list,
+                                                            double* __restrict__ cov) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int n_work = *work_count;
+  for (int w = wave; w < n_work; w += n_waves) {
+    const int i = work_list[w];
+    CoopList mine;
+    coop_knn(G, px[i], py[i], pz[i], k, INFINITY, -1, mine);
+    CovSums S;
+    for (int j = 0; j < k; j++) {
+      const int o = __shfl(mine.i, j, 64);
+      if (o == INT_MAX) continue;
+      S.add(px[o], py[o], pz[o]);
+    }
+    if (lane == 0) cov_finish(S, k, gicp_eps, cov + (size_t)i * 9);
+  }
 }
 
 // output = guess * input (fp32, reference order of operations)
@@ -395,10 +434,21 @@ int compute_covariances(lsr_handle_s* h, const DeviceCloud& cloud, const HashGri
   if (st) return st;
   if (n == 0) return LSR_OK;
   const int k = h->gicp.k;
-  const size_t smem = (size_t)k * NN_THREADS * (sizeof(float) + sizeof(int));
+  const size_t smem = BestK::lds_bytes(k);
+  // deferred-point list: [0] = count, [1..n] = point indices
+  if ((st = h->gicp_ws.work.reserve((size_t)n + 1))) return st;
+  int* work = h->gicp_ws.work.p;
+  const bool coop = (k <= 64);
+  const int ring_cap = coop ? 2 : -1;  // k > 64 does not fit one wave: the per-thread walk finishes everything
+  LSR_HIP(hipMemsetAsync(work, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(gicp_cov_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS), dim3(NN_THREADS), smem, h->stream, make_view(grid),
-                     cloud.x(), cloud.y(), cloud.z(), n, k, h->gicp.gicp_eps, 2, cov.p);
+                     cloud.x(), cloud.y(), cloud.z(), n, k, h->gicp.gicp_eps, 2, ring_cap, work, work + 1, cov.p);
   LSR_HIP(hipGetLastError());
+  if (coop) {
+    hipLaunchKernelGGL(gicp_cov_coop_kernel, dim3(1024), dim3(256), 0, h->stream, make_view(grid), cloud.x(), cloud.y(), cloud.z(),
+                       k, h->gicp.gicp_eps, work, work + 1, cov.p);
+    LSR_HIP(hipGetLastError());
+  }
   return LSR_OK;
 }
 

@@ -23,6 +23,7 @@ struct GicpWorkspace {
   DevBuf<double> buf;            // per-workgroup partial rows + Rm
   DevBuf<unsigned char> state;   // per-iteration block {GnState, T16, Rm} + counters
   PinBuf<unsigned char> pin;     // pinned host mirror of the per-iteration block
+  DevBuf<int> work;              // K5: count + indices of the points deferred to the wave-cooperative search
 };
 
 int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res);

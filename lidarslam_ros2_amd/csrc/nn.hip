@@ -109,17 +109,17 @@ __global__ __launch_bounds__(NN_THREADS) void knn_kernel(NNGridView G, const flo
                                                          const float* __restrict__ qz, int n, int k, int fine_rings,
                                                          int* __restrict__ idx, float* __restrict__ d2) {
   extern __shared__ unsigned char smem[];
-  float* sd = reinterpret_cast<float*>(smem);
-  int* si = reinterpret_cast<int*>(smem + (size_t)k * NN_THREADS * sizeof(float));
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   BestK c;
-  c.init(sd + threadIdx.x, si + threadIdx.x, k);
-  if (i < n) nn_query(G, qx[i], qy[i], qz[i], fine_rings, INFINITY, c, -1);
-  if (i < n)
+  c.init(smem, threadIdx.x, k);
+  if (i < n) {
+    nn_query(G, qx[i], qy[i], qz[i], fine_rings, INFINITY, c, -1);
+    c.finalize();
     for (int s = 0; s < k; s++) {
-      idx[(size_t)i * k + s] = si[s * NN_THREADS + threadIdx.x];
-      d2[(size_t)i * k + s] = sd[s * NN_THREADS + threadIdx.x];
+      idx[(size_t)i * k + s] = c.index(s);
+      d2[(size_t)i * k + s] = c.dist(s);
     }
+  }
 }
 
 // deterministic two-stage reduction of {sum d2, count} over pairs with d2 <= max_range
@@ -254,7 +254,7 @@ int knn_search_device(const DeviceCloud& q, const HashGridDev& grid, int k, int 
                       hipStream_t stream) {
   const int n = (int)q.n;
   if (n == 0) return LSR_OK;
-  const size_t smem = (size_t)k * NN_THREADS * (sizeof(float) + sizeof(int));
+  const size_t smem = BestK::lds_bytes(k);
   hipLaunchKernelGGL(knn_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS), dim3(NN_THREADS), smem, stream, make_view(grid), q.x(),
                      q.y(), q.z(), n, k, fine_rings, d_idx, d_d2);
   LSR_HIP(hipGetLastError());

@@ -49,35 +49,101 @@ struct Best1 {
   __device__ __forceinline__ void offer(float d, int i) {
     if (d < d2 || (d == d2 && i < idx)) { d2 = d; idx = i; }
   }
+  __device__ __forceinline__ void finalize() {}
 };
 
-// K-best list kept in LDS, column-major over threads ([slot][thread]) so lanes never collide.
+// K-best list kept in LDS, column-major over threads ([slot][thread]) so lanes never collide.  The list is
+// UNSORTED while the search runs: the current worst entry (value, index, slot) lives in registers, so rejecting a
+// candidate touches no memory, and accepting one overwrites the worst slot and re-scans the k entries with
+// independent LDS reads — a wave pays for an insertion whenever ANY of its 64 lanes inserts, so the insertion must
+// not be a chain of dependent shifts.  finalize() sorts ascending by (distance, index) once at the end.
+#ifdef LSR_HOST_EMU
+#define LSR_LDS_PTR(T) T*
+#define LSR_NOINLINE
+#else
+#define LSR_LDS_PTR(T) __attribute__((address_space(3))) T*
+#define LSR_NOINLINE __attribute__((noinline))
+#endif
+
 struct BestK {
-  float* d2;   // LDS base + tid
-  int* idx;    // LDS base + tid
-  int k, count;
-  __device__ __forceinline__ void init(float* d, int* i, int kk) {
-    d2 = d; idx = i; k = kk; count = 0;
-    for (int s = 0; s < kk; s++) { d2[s * NN_THREADS] = INFINITY; idx[s * NN_THREADS] = -1; }
+  typedef unsigned long long Key;  // (distance bits << 32) | index: distances are >= 0, so (distance, index) order == integer order
+  LSR_LDS_PTR(Key) e;              // LDS base + tid, one ds_read_b64 per slot
+  int k, count, wslot;
+  Key wkey;                        // worst key in the list (the empty key until the list is full)
+  float w;                         // its distance (inf until the list is full)
+  static constexpr Key EMPTY = 0x7F800000FFFFFFFFull;  // (inf, -1)
+  static __host__ __device__ __forceinline__ size_t lds_bytes(int kk) { return (size_t)kk * NN_THREADS * sizeof(Key); }
+  static __device__ __forceinline__ Key key(float d, int i) { return ((Key)(unsigned int)__float_as_int(d) << 32) | (unsigned int)i; }
+  __device__ __forceinline__ void init(void* lds_base, int tid, int kk) {
+    e = (LSR_LDS_PTR(Key))lds_base + tid; k = kk; count = 0; w = INFINITY; wkey = EMPTY; wslot = 0;
+    for (int s = 0; s < kk; s++) e[s * NN_THREADS] = EMPTY;
   }
-  __device__ __forceinline__ float worst() const { return d2[(k - 1) * NN_THREADS]; }
+  __device__ __forceinline__ float dist(int s) const { return __int_as_float((int)(e[s * NN_THREADS] >> 32)); }
+  __device__ __forceinline__ int index(int s) const { return (int)(unsigned int)e[s * NN_THREADS]; }
+  __device__ __forceinline__ float worst() const { return w; }
   __device__ __forceinline__ bool full() const { return count >= k; }
-  __device__ __forceinline__ void offer(float d, int i) {
-    const float w = d2[(k - 1) * NN_THREADS];
-    const int wi = idx[(k - 1) * NN_THREADS];
-    if (!(d < w || (d == w && (wi < 0 || i < wi)))) return;
-    int s = k - 1;
-    while (s > 0) {
-      const float ps = d2[(s - 1) * NN_THREADS];
-      const int pi = idx[(s - 1) * NN_THREADS];
-      if (ps < d || (ps == d && pi >= 0 && pi < i)) break;
-      d2[s * NN_THREADS] = ps;
-      idx[s * NN_THREADS] = pi;
-      s--;
+  template <int K>
+  __device__ __forceinline__ void rescan_fixed() {
+    Key v[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) v[s] = e[s * NN_THREADS];   // K independent ds_read_b64 in flight
+    Key bw = v[0];
+    int bs = 0;
+#pragma unroll
+    for (int s = 1; s < K; s++) {
+      const bool worse = v[s] > bw;
+      bw = worse ? v[s] : bw; bs = worse ? s : bs;
     }
-    d2[s * NN_THREADS] = d;
-    idx[s * NN_THREADS] = i;
-    if (count < k) count++;
+    wkey = bw; wslot = bs;
+  }
+  // One copy of this code per kernel (noinline): the candidate scan is instantiated at several call sites and an
+  // inlined, unrolled rescan pushed nn_query past the instruction cache.
+  __device__ LSR_NOINLINE void replace_worst(Key nk) {
+    e[wslot * NN_THREADS] = nk;
+    if (k == 20) {   // PCL's default k_correspondences
+      rescan_fixed<20>();
+    } else {
+      Key bw = e[0];
+      int bs = 0;
+#pragma unroll 4
+      for (int s = 1; s < k; s++) {
+        const Key v = e[s * NN_THREADS];
+        const bool worse = v > bw;
+        bw = worse ? v : bw; bs = worse ? s : bs;
+      }
+      wkey = bw; wslot = bs;
+    }
+    w = __int_as_float((int)(wkey >> 32));
+  }
+  __device__ __forceinline__ void offer(float d, int i) {
+    if (!(d <= INFINITY)) return;  // NaN never enters
+    const Key nk = key(d, i);
+    if (count < k) {                // filling: slot `count`; the last fill goes through replace_worst to set the worst
+      wslot = count;
+      if (++count == k) replace_worst(nk);
+      else e[wslot * NN_THREADS] = nk;
+      return;
+    }
+    if (!(nk < wkey)) return;
+    replace_worst(nk);
+  }
+  // ascending (distance, index) order in slots 0..count-1 (selection sort: every pass is a run of independent reads)
+  __device__ LSR_NOINLINE void finalize() {
+    for (int a = 0; a + 1 < count; a++) {
+      const Key av = e[a * NN_THREADS];
+      Key bk = av;
+      int bs = a;
+#pragma unroll 4
+      for (int s = a + 1; s < count; s++) {
+        const Key v = e[s * NN_THREADS];
+        const bool better = v < bk;
+        bk = better ? v : bk; bs = better ? s : bs;
+      }
+      if (bs != a) {
+        e[bs * NN_THREADS] = av;
+        e[a * NN_THREADS] = bk;
+      }
+    }
   }
 };
 
@@ -110,12 +176,16 @@ __device__ __forceinline__ void scan_range(const NNGridView& G, int beg, int end
 }
 
 // Exact search for one query.  fine_rings: half-width of the first fine-cell block.
+// ring_cap < 0 (default): the search always completes (fine shells, then coarse shells) and true is returned.
+// ring_cap >= fine_rings: only fine shells 0..ring_cap are walked; false is returned when that was not enough to
+// prove the result — the caller hands such a query to the wave-cooperative search (coop_knn) instead of letting
+// one lane drag its whole wave through hundreds of dependent cell probes.
 template <typename Coll>
-__device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int fine_rings, float max_d2, Coll& c,
-                         int self_skip) {
-  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return;
+__device__ bool nn_query(const NNGridView& G, float qx, float qy, float qz, int fine_rings, float max_d2, Coll& c,
+                         int self_skip, int ring_cap = -1) {
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return true;
   const float fxf = floorf(qx * G.inv_cell), fyf = floorf(qy * G.inv_cell), fzf = floorf(qz * G.inv_cell);
-  if (!(fabsf(fxf) < 1.0e9f && fabsf(fyf) < 1.0e9f && fabsf(fzf) < 1.0e9f)) return;
+  if (!(fabsf(fxf) < 1.0e9f && fabsf(fyf) < 1.0e9f && fabsf(fzf) < 1.0e9f)) return true;
   const int fq[3] = {(int)fxf - G.org[0], (int)fyf - G.org[1], (int)fzf - G.org[2]};  // fine coords rel. to origin
   const float q[3] = {qx, qy, qz};
   const int fdim[3] = {G.cdim[0] * 8, G.cdim[1] * 8, G.cdim[2] * 8};
@@ -126,8 +196,10 @@ __device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int 
   bool any_fine = true;
   for (int k = 0; k < 3; k++)
     if (fq[k] + NN_MAX_FINE_RINGS < 0 || fq[k] - NN_MAX_FINE_RINGS >= fdim[k]) any_fine = false;
+  const int last_ring = (ring_cap >= 0) ? min(ring_cap, NN_MAX_FINE_RINGS) : NN_MAX_FINE_RINGS;
+  if (ring_cap >= 0 && !any_fine) return false;
   if (any_fine) {
-    for (int r = 0; r <= NN_MAX_FINE_RINGS; r++) {
+    for (int r = 0; r <= last_ring; r++) {
       for (int dz = -r; dz <= r; dz++) {
         const int z = fq[2] + dz;
         if (z < 0 || z >= fdim[2]) continue;
@@ -156,9 +228,10 @@ __device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int 
       }
       lo = fmaxf(lo, 0.f);
       const float lo2 = lo * lo * 0.9999f;
-      if ((c.full() && c.worst() <= lo2) || lo2 > max_d2) return;
+      if ((c.full() && c.worst() <= lo2) || lo2 > max_d2) return true;
     }
   }
+  if (ring_cap >= 0) return false;
   fine_rings = NN_MAX_FINE_RINGS;  // what phase 2 must not offer again
   LSR_NN_COUNT(phase2_queries, 1);
 
@@ -221,9 +294,105 @@ __device__ void nn_query(const NNGridView& G, float qx, float qy, float qz, int 
     }
     loc = fmaxf(loc, 0.f);
     const float loc2 = loc * loc * 0.9999f;
-    if ((c.full() && c.worst() <= loc2) || loc2 > max_d2) return;
+    if ((c.full() && c.worst() <= loc2) || loc2 > max_d2) return true;
+  }
+  return true;
+}
+
+#ifndef LSR_HOST_EMU   // (wave intrinsics: not part of the host emulation in tools/nn_host_emu)
+// ---- wave-cooperative exact k-NN (k <= 64) for the queries the per-thread walk gave up on ---------------------
+// One 64-lane wave per query.  The k best (distance, index) pairs live one per lane, sorted ascending in lanes
+// 0..k-1 (empty = (inf, INT_MAX)); coarse cells are visited shell by shell with the same box-distance pruning and
+// termination bound as nn_query's phase 2, but every cell's points are read 64 at a time, coalesced, and a
+// candidate enters the list with one ballot + one shuffle.  Same (distance, index) ordering as BestK, same fp32
+// distance arithmetic: the result is identical to nn_query's.
+struct CoopList {
+  float d;
+  int i;
+};
+
+__device__ __forceinline__ void coop_knn(const NNGridView& G, float qx, float qy, float qz, int k, float max_d2, int self_skip,
+                                         CoopList& mine) {
+  const int lane = threadIdx.x & 63;
+  mine.d = INFINITY;
+  mine.i = INT_MAX;
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return;
+  const float fxf = floorf(qx * G.inv_cell), fyf = floorf(qy * G.inv_cell), fzf = floorf(qz * G.inv_cell);
+  if (!(fabsf(fxf) < 1.0e9f && fabsf(fyf) < 1.0e9f && fabsf(fzf) < 1.0e9f)) return;
+  const int fq[3] = {(int)fxf - G.org[0], (int)fyf - G.org[1], (int)fzf - G.org[2]};
+  const float q[3] = {qx, qy, qz};
+  float worst = INFINITY;
+  int worst_i = INT_MAX;
+  const float C = G.cell * 8.f;
+  int cq[3];
+  for (int a = 0; a < 3; a++) cq[a] = (fq[a] >= 0) ? (fq[a] >> 3) : -(((-fq[a]) + 7) >> 3);
+  int rmax = 0;
+  for (int a = 0; a < 3; a++) rmax = max(rmax, max(cq[a], G.cdim[a] - 1 - cq[a]));
+  for (int r = 0; r <= rmax; r++) {
+    for (int dz = -r; dz <= r; dz++) {
+      const int z = cq[2] + dz;
+      if (z < 0 || z >= G.cdim[2]) continue;
+      for (int dy = -r; dy <= r; dy++) {
+        const int y = cq[1] + dy;
+        if (y < 0 || y >= G.cdim[1]) continue;
+        const bool shell_yz = (abs(dz) == r) || (abs(dy) == r);
+        const int step = shell_yz ? 1 : max(1, 2 * r);
+        for (int dx = -r; dx <= r; dx += step) {
+          const int x = cq[0] + dx;
+          if (x < 0 || x >= G.cdim[0]) continue;
+          const int blk = G.coarse_block[x + G.cdim[0] * (y + G.cdim[1] * z)];
+          if (blk < 0) continue;
+          float bd2 = 0.f;
+          const int cc[3] = {x, y, z};
+          for (int a = 0; a < 3; a++) {
+            const float b0 = (float)(cc[a] * 8 + G.org[a]) * G.cell, b1 = b0 + C;
+            const float dd = fmaxf(fmaxf(b0 - q[a], q[a] - b1), 0.f);
+            bd2 += dd * dd;
+          }
+          bd2 *= 0.9999f;
+          if ((worst_i != INT_MAX && bd2 > worst) || bd2 > max_d2) continue;   // list full <=> last slot filled
+          const int beg = G.block_off[blk], end = G.block_off[blk + 1];
+          for (int s0 = beg; s0 < end; s0 += 64) {
+            const int s = s0 + lane;
+            const bool valid = s < end;
+            const int sl = valid ? s : end - 1;
+            const float d = dist2_rn(qx, qy, qz, G.x[sl], G.y[sl], G.z[sl]);
+            const int oi = G.order[sl];
+            bool qual = valid && (oi != self_skip) && (d < worst || (d == worst && oi < worst_i));
+            unsigned long long mask = __ballot(qual);
+            while (mask) {
+              const int src = __ffsll((long long)mask) - 1;
+              mask &= mask - 1;
+              const float dn = __shfl(d, src, 64);
+              const int in = __shfl(oi, src, 64);
+              if (!(dn < worst || (dn == worst && in < worst_i))) continue;
+              const unsigned long long before = __ballot(lane < k && (mine.d < dn || (mine.d == dn && mine.i < in)));
+              const int pos = __popcll(before);
+              const float up_d = __shfl_up(mine.d, 1, 64);
+              const int up_i = __shfl_up(mine.i, 1, 64);
+              if (lane < k) {
+                if (lane > pos) { mine.d = up_d; mine.i = up_i; }
+                else if (lane == pos) { mine.d = dn; mine.i = in; }
+              }
+              worst = __shfl(mine.d, k - 1, 64);
+              worst_i = __shfl(mine.i, k - 1, 64);
+            }
+          }
+        }
+      }
+    }
+    float loc = INFINITY;
+    for (int a = 0; a < 3; a++) {
+      const float b0 = (float)((cq[a] - r) * 8 + G.org[a]) * G.cell;
+      const float b1 = (float)((cq[a] + r + 1) * 8 + G.org[a]) * G.cell;
+      loc = fminf(loc, fminf(q[a] - b0, b1 - q[a]));
+    }
+    loc = fmaxf(loc, 0.f);
+    const float loc2 = loc * loc * 0.9999f;
+    if ((worst_i != INT_MAX && worst <= loc2) || loc2 > max_d2) return;
   }
 }
+#endif  // LSR_HOST_EMU
 
 
 inline NNGridView make_view(const HashGridDev& g) {

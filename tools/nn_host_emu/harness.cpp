@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdint>
+#include <climits>
 #define __device__
 #define __host__
 #define __forceinline__ inline
@@ -15,6 +16,10 @@ using std::min; using std::max; using std::isfinite; using std::abs;
 static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+struct int2 { int x, y; };
+static inline int2 make_int2(int a, int b) { int2 r; r.x = a; r.y = b; return r; }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 // minimal stand-ins for what nn_device.hpp needs from common.hpp
 namespace lsr { template <typename T> struct DevBuf { T* p = nullptr; };
 struct DeviceCloud { float* x() const { return nullptr; } float* y() const { return nullptr; } float* z() const { return nullptr; } };
@@ -30,11 +35,12 @@ extern "C" long run_knn(float cell, const int* org, const int* cdim, const int* 
   NNGridView G; G.cell = cell; G.inv_cell = 1.0f / cell;
   for (int a = 0; a < 3; a++) { G.org[a] = org[a]; G.cdim[a] = cdim[a]; }
   G.coarse_block = coarse_block; G.block_off = block_off; G.fine_start = fine_start; G.x = sx; G.y = sy; G.z = sz; G.order = order;
-  float* sd = (float*)malloc(sizeof(float) * k * NN_THREADS); int* si = (int*)malloc(sizeof(int) * k * NN_THREADS);
+  void* lds = malloc(BestK::lds_bytes(k));
   for (int i = 0; i < nq; i++) {
-    BestK c; c.init(sd, si, k);
+    BestK c; c.init(lds, 0, k);
     nn_query(G, qx[i], qy[i], qz[i], fine_rings, INFINITY, c, -1);
-    for (int j = 0; j < k; j++) { out_idx[i * k + j] = si[j * NN_THREADS]; out_d2[i * k + j] = sd[j * NN_THREADS]; }
+    c.finalize();
+    for (int j = 0; j < k; j++) { out_idx[i * k + j] = c.index(j); out_d2[i * k + j] = c.dist(j); }
   }
   return 0;
 }
