@@ -196,31 +196,41 @@ __device__ bool nn_query(const NNGridView& G, float qx, float qy, float qz, int 
   bool any_fine = true;
   for (int k = 0; k < 3; k++)
     if (fq[k] + NN_MAX_FINE_RINGS < 0 || fq[k] - NN_MAX_FINE_RINGS >= fdim[k]) any_fine = false;
-  const int last_ring = (ring_cap >= 0) ? min(ring_cap, NN_MAX_FINE_RINGS) : NN_MAX_FINE_RINGS;
+  fine_rings = min(max(fine_rings, 0), NN_MAX_FINE_RINGS);
+  const int last_ring = (ring_cap >= 0) ? max(fine_rings, min(ring_cap, NN_MAX_FINE_RINGS)) : NN_MAX_FINE_RINGS;
   if (ring_cap >= 0 && !any_fine) return false;
   if (any_fine) {
+    // Walked as x-ROWS of fine cells: consecutive fine cells of one coarse block are contiguous in the sorted arrays,
+    // so a row of 2r+1 cells is one or two ranges (one coarse-map load + two fine-table loads each) instead of
+    // 2r+1 dependent probes.  Shell by shell, NEAREST FIRST (full rows on the y/z faces, the two end cells of the
+    // inner rows): a list that fills with near candidates rejects most later ones in registers, and insertions are
+    // what a wave pays for most (scanning the whole block in raster order doubled this kernel's time).
     for (int r = 0; r <= last_ring; r++) {
+      const bool whole_block = false;
       for (int dz = -r; dz <= r; dz++) {
         const int z = fq[2] + dz;
         if (z < 0 || z >= fdim[2]) continue;
         for (int dy = -r; dy <= r; dy++) {
           const int y = fq[1] + dy;
           if (y < 0 || y >= fdim[1]) continue;
-          const bool shell_yz = (abs(dz) == r) || (abs(dy) == r);
-          const int step = shell_yz ? 1 : max(1, 2 * r);
-          for (int dx = -r; dx <= r; dx += step) {
-            const int x = fq[0] + dx;
-            if (x < 0 || x >= fdim[0]) continue;
-            const int blk = G.coarse_block[(x >> 3) + G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3))];
-            LSR_NN_COUNT(fine_probes, 1);
-            if (blk < 0) continue;
-            const int f = (x & 7) | ((y & 7) << 3) | ((z & 7) << 6);
-            const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + f;
-            scan_range(G, fs[0], fs[1], qx, qy, qz, c, self_skip);
+          const bool full_row = whole_block || (abs(dz) == r) || (abs(dy) == r);
+          const int cbase = G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3));
+          const int fyz = ((y & 7) << 3) | ((z & 7) << 6);
+          for (int part = 0; part < (full_row ? 1 : 2); part++) {
+            const int xs = full_row ? fq[0] - r : (part ? fq[0] + r : fq[0] - r);
+            const int x0 = max(xs, 0), x1 = min(full_row ? fq[0] + r : xs, fdim[0] - 1);
+            for (int cx = x0 >> 3; cx <= (x1 >> 3); cx++) {   // empty when x0 > x1
+              LSR_NN_COUNT(fine_probes, 1);
+              const int blk = G.coarse_block[cbase + cx];
+              if (blk < 0) continue;
+              const int xa = max(x0, cx * 8) & 7, xb = min(x1, cx * 8 + 7) & 7;
+              const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + fyz;
+              const int beg = fs[xa], end = fs[xb + 1];
+              if (beg < end) scan_range(G, beg, end, qx, qy, qz, c, self_skip);
+            }
           }
         }
       }
-      if (r < fine_rings) continue;
       float lo = INFINITY;
       for (int k = 0; k < 3; k++) {
         const float base = (float)(fq[k] + G.org[k]) * G.cell;
@@ -228,7 +238,7 @@ __device__ bool nn_query(const NNGridView& G, float qx, float qy, float qz, int 
       }
       lo = fmaxf(lo, 0.f);
       const float lo2 = lo * lo * 0.9999f;
-      if ((c.full() && c.worst() <= lo2) || lo2 > max_d2) return true;
+      if (r >= fine_rings && ((c.full() && c.worst() <= lo2) || lo2 > max_d2)) return true;
     }
   }
   if (ring_cap >= 0) return false;
