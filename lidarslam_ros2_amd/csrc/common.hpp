@@ -118,7 +118,8 @@ struct HashGridDev {
   DevBuf<int> coarse_block; // [cdim0*cdim1*cdim2] -> block id or -1
   DevBuf<int> block_off;    // [n_blocks + 1] start of each block in the sorted arrays
   DevBuf<int> fine_start;   // [n_blocks * 513] absolute start of each fine cell (+ end sentinel)
-  DeviceCloud sorted;       // points in (coarse, fine) cell order
+  DevBuf<float4> packed;    // points in (coarse, fine) cell order: {x, y, z, original index as int bits} — one 16-byte
+                            // load per candidate, no dependent index load
   DevBuf<int> order;        // sorted position -> original index
 };
 

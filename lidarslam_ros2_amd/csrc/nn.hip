@@ -40,11 +40,11 @@ __global__ __launch_bounds__(256) void nn_key_kernel(const float* __restrict__ x
 
 __global__ __launch_bounds__(256) void nn_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                         const float* __restrict__ z, const int* __restrict__ order, int n,
-                                                        float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz) {
+                                                        float4* __restrict__ packed) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int o = order[i];
-  sx[i] = x[o]; sy[i] = y[o]; sz[i] = z[o];
+  packed[i] = make_float4(x[o], y[o], z[o], __int_as_float(o));
 }
 
 __global__ __launch_bounds__(256) void nn_coarse_key_kernel(const unsigned int* __restrict__ key_sorted, int n, unsigned int sentinel,
@@ -207,7 +207,7 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
   int* run_off = run_cnt + n;
   int* d_nruns = run_off + n;
   if ((st = grid.order.reserve(n))) return st;
-  if ((st = grid.sorted.resize(n))) return st;
+  if ((st = grid.packed.reserve(n))) return st;
   if ((st = grid.coarse_block.reserve(ccells))) return st;
   LSR_HIP(hipMemsetAsync(grid.coarse_block.p, 0xFF, ccells * sizeof(int), stream));
   const int nb = (n + 255) / 256;
@@ -218,7 +218,7 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
   while (bits < 32 && (sentinel >> bits) != 0) bits++;  // only the bits the keys can use are sorted
   if ((st = sort_pairs_u32(key_in, key_out, val_in, grid.order.p, n, bits, sc.temp, stream))) return st;
   hipLaunchKernelGGL(nn_gather_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), grid.order.p, n,
-                     grid.sorted.x(), grid.sorted.y(), grid.sorted.z());
+                     grid.packed.p);
   hipLaunchKernelGGL(nn_coarse_key_kernel, dim3(nb), dim3(256), 0, stream, key_out, n, sentinel, ckey);
   if ((st = run_length_encode_u32(ckey, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
   int n_runs = 0;

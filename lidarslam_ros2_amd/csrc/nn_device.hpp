@@ -23,10 +23,7 @@ struct NNGridView {
   const int* coarse_block;
   const int* block_off;
   const int* fine_start;
-  const float* x;
-  const float* y;
-  const float* z;
-  const int* order;
+  const float4* p;   // cell-sorted points {x, y, z, original index as int bits}
 };
 
 __device__ __forceinline__ float dist2_rn(float qx, float qy, float qz, float px, float py, float pz) {
@@ -99,6 +96,7 @@ struct BestK {
   // One copy of this code per kernel (noinline): the candidate scan is instantiated at several call sites and an
   // inlined, unrolled rescan pushed nn_query past the instruction cache.
   __device__ LSR_NOINLINE void replace_worst(Key nk) {
+    LSR_NN_COUNT(offers_taken, 1);
     e[wslot * NN_THREADS] = nk;
     if (k == 20) {   // PCL's default k_correspondences
       rescan_fixed<20>();
@@ -147,29 +145,26 @@ struct BestK {
   }
 };
 
-// Candidates [beg, end) of the cell-sorted arrays.  Coordinates are fetched four at a time (independent loads in
-// flight: with one wave per SIMD nothing else hides the latency); the original index is only fetched for a
-// candidate that can enter the list (needed for the (distance, index) tie-break).
+// Candidates [beg, end) of the cell-sorted arrays.  A wave walks its 64 queries' ranges in lock step and every
+// batch of coordinate loads costs one full memory round trip (one wave per SIMD: nothing else hides it), so the
+// points are fetched NN_SCAN_BATCH at a time, one 16-byte load each ({x, y, z, original index}: no dependent index
+// load for the (distance, index) tie-break).
+constexpr int NN_SCAN_BATCH = 8;
 template <typename Coll>
 __device__ __forceinline__ void scan_range(const NNGridView& G, int beg, int end, float qx, float qy, float qz, Coll& c,
                                            int self_skip) {
   LSR_NN_COUNT(ranges, 1);
   LSR_NN_COUNT(candidates, end - beg);
-  for (int s = beg; s < end; s += 4) {
-    float X[4], Y[4], Z[4];
+  for (int s = beg; s < end; s += NN_SCAN_BATCH) {
+    float4 P[NN_SCAN_BATCH];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int su = min(s + u, end - 1);
-      X[u] = G.x[su]; Y[u] = G.y[su]; Z[u] = G.z[su];
-    }
+    for (int u = 0; u < NN_SCAN_BATCH; u++) P[u] = G.p[min(s + u, end - 1)];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < NN_SCAN_BATCH; u++) {
       if (s + u < end) {
-        const float d = dist2_rn(qx, qy, qz, X[u], Y[u], Z[u]);
-        if (!(d > c.worst())) {
-          const int oi = G.order[s + u];
-          if (oi != self_skip) c.offer(d, oi);
-        }
+        const float d = dist2_rn(qx, qy, qz, P[u].x, P[u].y, P[u].z);
+        const int oi = __float_as_int(P[u].w);
+        if (!(d > c.worst()) && oi != self_skip) c.offer(d, oi);
       }
     }
   }
@@ -366,8 +361,9 @@ __device__ __forceinline__ void coop_knn(const NNGridView& G, float qx, float qy
             const int s = s0 + lane;
             const bool valid = s < end;
             const int sl = valid ? s : end - 1;
-            const float d = dist2_rn(qx, qy, qz, G.x[sl], G.y[sl], G.z[sl]);
-            const int oi = G.order[sl];
+            const float4 pt = G.p[sl];
+            const float d = dist2_rn(qx, qy, qz, pt.x, pt.y, pt.z);
+            const int oi = __float_as_int(pt.w);
             bool qual = valid && (oi != self_skip) && (d < worst || (d == worst && oi < worst_i));
             unsigned long long mask = __ballot(qual);
             while (mask) {
@@ -413,8 +409,7 @@ inline NNGridView make_view(const HashGridDev& g) {
   v.coarse_block = g.coarse_block.p;
   v.block_off = g.block_off.p;
   v.fine_start = g.fine_start.p;
-  v.x = g.sorted.x(); v.y = g.sorted.y(); v.z = g.sorted.z();
-  v.order = g.order.p;
+  v.p = g.packed.p;
   return v;
 }
 

@@ -20,10 +20,11 @@ struct int2 { int x, y; };
 static inline int2 make_int2(int a, int b) { int2 r; r.x = a; r.y = b; return r; }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+struct float4 { float x, y, z, w; };
 // minimal stand-ins for what nn_device.hpp needs from common.hpp
 namespace lsr { template <typename T> struct DevBuf { T* p = nullptr; };
 struct DeviceCloud { float* x() const { return nullptr; } float* y() const { return nullptr; } float* z() const { return nullptr; } };
-struct HashGridDev { float cell; int org[3]; int cdim[3]; DevBuf<int> coarse_block, block_off, fine_start, order; DeviceCloud sorted; }; }
+struct HashGridDev { float cell; int org[3]; int cdim[3]; DevBuf<int> coarse_block, block_off, fine_start, order; DevBuf<float4> packed; }; }
 #define LSR_COMMON_HPP_STUB
 struct Counters { long ranges, candidates, fine_probes, phase2_queries, coarse_blocks, offers_taken, shifts; } g_cnt;
 #define LSR_NN_COUNT(what, n) (g_cnt.what += (n))
@@ -31,10 +32,12 @@ struct Counters { long ranges, candidates, fine_probes, phase2_queries, coarse_b
 using namespace lsr::nnd;
 extern "C" void get_counters(long* out) { memcpy(out, &g_cnt, sizeof(g_cnt)); memset(&g_cnt, 0, sizeof(g_cnt)); }
 extern "C" long run_knn(float cell, const int* org, const int* cdim, const int* coarse_block, const int* block_off, const int* fine_start,
-             const float* sx, const float* sy, const float* sz, const int* order, const float* qx, const float* qy, const float* qz, int nq, int k, int fine_rings, int* out_idx, float* out_d2) {
+             const float* sx, const float* sy, const float* sz, const int* order, int n_pts, const float* qx, const float* qy, const float* qz, int nq, int k, int fine_rings, int* out_idx, float* out_d2) {
   NNGridView G; G.cell = cell; G.inv_cell = 1.0f / cell;
   for (int a = 0; a < 3; a++) { G.org[a] = org[a]; G.cdim[a] = cdim[a]; }
-  G.coarse_block = coarse_block; G.block_off = block_off; G.fine_start = fine_start; G.x = sx; G.y = sy; G.z = sz; G.order = order;
+  G.coarse_block = coarse_block; G.block_off = block_off; G.fine_start = fine_start; float4* pk = (float4*)malloc(sizeof(float4) * (size_t)n_pts);
+  for (int t = 0; t < n_pts; t++) { pk[t].x = sx[t]; pk[t].y = sy[t]; pk[t].z = sz[t]; memcpy(&pk[t].w, &order[t], 4); }
+  G.p = pk;
   void* lds = malloc(BestK::lds_bytes(k));
   for (int i = 0; i < nq; i++) {
     BestK c; c.init(lds, 0, k);

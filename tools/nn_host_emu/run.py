@@ -30,7 +30,7 @@ def knn(g, q, k, fr):
     n = len(q); idx = np.zeros((n, k), np.int32); d2 = np.zeros((n, k), np.float32)
     qx, qy, qz = [np.ascontiguousarray(q[:, i]) for i in range(3)]
     lib.run_knn(C.c_float(g['cell']), P(g['org'], C.c_int), P(g['cdim'], C.c_int), P(g['coarse_block'], C.c_int), P(g['block_off'], C.c_int), P(g['fine_start'], C.c_int),
-                P(g['sx'], C.c_float), P(g['sy'], C.c_float), P(g['sz'], C.c_float), P(g['order'], C.c_int), P(qx, C.c_float), P(qy, C.c_float), P(qz, C.c_float), n, k, fr, P(idx, C.c_int), P(d2, C.c_float))
+                P(g['sx'], C.c_float), P(g['sy'], C.c_float), P(g['sz'], C.c_float), P(g['order'], C.c_int), len(g['order']), P(qx, C.c_float), P(qy, C.c_float), P(qz, C.c_float), n, k, fr, P(idx, C.c_int), P(d2, C.c_float))
     return idx, d2
 rng = np.random.default_rng(0)
 from lidarslam_ros2_amd import synth
