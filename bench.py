@@ -196,139 +196,142 @@ def main():
                            "note": "single 30k-pt scan = 118 workgroups on 256 CUs: latency-bound, voxel table is L2-resident; "
                                    "see batched.roofline for the bandwidth-relevant figure"}
 
-        # ---- batched leg: B registrations share every launch (loop-closure candidate set / N scans vs submap)
-        B = args.batch
-        regs = [ndt] + [make_ndt() for _ in range(B - 1)]
-        for r in regs[1:]:
-            r.shareTargetOf(ndt)
-        for r in regs:
-            r.setInputSource(src_dev)
-        guesses = [case.guess] * B
-        for _ in range(2):
-            align_batch(regs, guesses)
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        nb_steps = max(3, args.steps // 4)
-        for _ in range(nb_steps):
+        # The remaining legs (batched, GICP, loop gate, CPU baseline) are single-GPU reports: at N > 1 the other ranks
+        # would only wait for rank 0, and the CPU baseline is defined at N = 1.
+        if world == 1:
+            # ---- batched leg: B registrations share every launch (loop-closure candidate set / N scans vs submap)
+            B = args.batch
+            regs = [ndt] + [make_ndt() for _ in range(B - 1)]
+            for r in regs[1:]:
+                r.shareTargetOf(ndt)
             for r in regs:
                 r.setInputSource(src_dev)
-            finals, bres = align_batch(regs, guesses)
-        torch.cuda.synchronize()
-        tb = time.perf_counter() - tb
-        ndt.setProfiling(True)
-        ndt.getProfile(reset=True)
-        align_batch(regs, guesses)
-        bprof = ndt.getProfile(reset=True)
-        ndt.setProfiling(False)
-        b_us = 1e3 * bprof["deriv_ms_total"] / max(1, bprof["deriv_launches"])
-        b_bytes = B * (n_src * 12 + nblocks * 224) + bprof["deriv_pairs"] * 40
-        b_ach = b_bytes / (b_us * 1e-6) / 1e9
-        out["batched"] = {"batch": B, "value": B * nb_steps / tb, "unit": "registrations/s", "ms_per_batch": 1e3 * tb / nb_steps,
-                          "roofline": {"bound": "hbm", "achieved": b_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": b_ach / HBM_PEAK_GBS, "avg_launch_us": b_us,
-                                       "algorithmic_bytes_per_launch": b_bytes}}
-
-        # ---- GICP leg (BASELINE cfg 3): same scan, target re-filtered at 0.2, corr dist 5.0, eps 1e-8
-        try:
-            from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
-
-            gc = synth.cfg_gicp_30k(seed=rank)
-            gicp = GeneralizedIterativeClosestPoint(device=local_rank, stream=stream)
-            gicp.setMaxCorrespondenceDistance(5.0)
-            gicp.setTransformationEpsilon(1e-8)
-            g_tgt = torch.from_numpy(synth.as_pointxyzi(gc.target)).cuda()
-            g_src = torch.from_numpy(synth.as_pointxyzi(gc.source)).cuda()
-            tg = time.perf_counter()
-            gicp.setInputTarget(g_tgt)
-            gicp.setInputSource(g_src)
-            gicp.align(gc.guess)                       # first align also pays the target covariances (K5)
+            guesses = [case.guess] * B
+            for _ in range(2):
+                align_batch(regs, guesses)
             torch.cuda.synchronize()
-            t_first = time.perf_counter() - tg
-            tg = time.perf_counter()
-            ng = 5
-            for _ in range(ng):
-                gicp.setInputSource(g_src)             # source covariances are recomputed per scan, as in the reference
-                gicp.align(gc.guess)
+            tb = time.perf_counter()
+            nb_steps = max(3, args.steps // 4)
+            for _ in range(nb_steps):
+                for r in regs:
+                    r.setInputSource(src_dev)
+                finals, bres = align_batch(regs, guesses)
             torch.cuda.synchronize()
-            tg = time.perf_counter() - tg
-            gdt, gang = pose_delta(gicp.getFinalTransformation(), gc.truth)
-            out["gicp_cfg3"] = {"value": ng / tg, "unit": "registrations/s", "ms_per_registration": 1e3 * tg / ng,
-                                "first_registration_ms_incl_target_setup": 1e3 * t_first,
-                                "target_points": int(gc.target.shape[0]), "outer_iterations": gicp.last_result["iterations"],
-                                "gauss_newton_steps": gicp.last_result["n_evaluations"],
-                                "correspondences": gicp.last_result["n_correspondences"],
-                                "error_vs_truth": {"translation_m": gdt, "rotation_rad": gang}}
-        except Exception as e:  # the headline line must still be printed
-            out["gicp_cfg3"] = {"error": repr(e)}
+            tb = time.perf_counter() - tb
+            ndt.setProfiling(True)
+            ndt.getProfile(reset=True)
+            align_batch(regs, guesses)
+            bprof = ndt.getProfile(reset=True)
+            ndt.setProfiling(False)
+            b_us = 1e3 * bprof["deriv_ms_total"] / max(1, bprof["deriv_launches"])
+            b_bytes = B * (n_src * 12 + nblocks * 224) + bprof["deriv_pairs"] * 40
+            b_ach = b_bytes / (b_us * 1e-6) / 1e9
+            out["batched"] = {"batch": B, "value": B * nb_steps / tb, "unit": "registrations/s", "ms_per_batch": 1e3 * tb / nb_steps,
+                              "roofline": {"bound": "hbm", "achieved": b_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": b_ach / HBM_PEAK_GBS, "avg_launch_us": b_us,
+                                           "algorithmic_bytes_per_launch": b_bytes}}
 
-        # ---- loop-closure gate: searchLoop() compute on HBM-resident submaps
-        route = None
-        try:
-            from lidarslam_ros2_amd import LoopClosureParams, SubMap, search_loop
+            # ---- GICP leg (BASELINE cfg 3): same scan, target re-filtered at 0.2, corr dist 5.0, eps 1e-8
+            try:
+                from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
 
-            route = synth.make_loop_route()
-            sms = [SubMap(torch.from_numpy(synth.as_pointxyzi(s["cloud"])).cuda(), s["position"], s["orientation"], s["distance"])
-                   for s in route]
-            lp = dict(threshold_loop_closure_score=1.0, distance_loop_closure=20.0, range_of_searching_loop_closure=10.0,
-                      search_submap_num=2, voxel_leaf_size=0.2)
-            back = NormalDistributionsTransform(device=local_rank, stream=stream)   # graph_based_slam_component.cpp:64-72
-            back.setMaximumIterations(100)
-            back.setResolution(5.0)
-            back.setTransformationEpsilon(0.01)
-            edges = search_loop(back, sms, LoopClosureParams(**lp))
-            torch.cuda.synchronize()
-            tl = time.perf_counter()
-            nl = 10
-            for _ in range(nl):
+                gc = synth.cfg_gicp_30k(seed=rank)
+                gicp = GeneralizedIterativeClosestPoint(device=local_rank, stream=stream)
+                gicp.setMaxCorrespondenceDistance(5.0)
+                gicp.setTransformationEpsilon(1e-8)
+                g_tgt = torch.from_numpy(synth.as_pointxyzi(gc.target)).cuda()
+                g_src = torch.from_numpy(synth.as_pointxyzi(gc.source)).cuda()
+                tg = time.perf_counter()
+                gicp.setInputTarget(g_tgt)
+                gicp.setInputSource(g_src)
+                gicp.align(gc.guess)                       # first align also pays the target covariances (K5)
+                torch.cuda.synchronize()
+                t_first = time.perf_counter() - tg
+                tg = time.perf_counter()
+                ng = 5
+                for _ in range(ng):
+                    gicp.setInputSource(g_src)             # source covariances are recomputed per scan, as in the reference
+                    gicp.align(gc.guess)
+                torch.cuda.synchronize()
+                tg = time.perf_counter() - tg
+                gdt, gang = pose_delta(gicp.getFinalTransformation(), gc.truth)
+                out["gicp_cfg3"] = {"value": ng / tg, "unit": "registrations/s", "ms_per_registration": 1e3 * tg / ng,
+                                    "first_registration_ms_incl_target_setup": 1e3 * t_first,
+                                    "target_points": int(gc.target.shape[0]), "outer_iterations": gicp.last_result["iterations"],
+                                    "gauss_newton_steps": gicp.last_result["n_evaluations"],
+                                    "correspondences": gicp.last_result["n_correspondences"],
+                                    "error_vs_truth": {"translation_m": gdt, "rotation_rad": gang}}
+            except Exception as e:  # the headline line must still be printed
+                out["gicp_cfg3"] = {"error": repr(e)}
+
+            # ---- loop-closure gate: searchLoop() compute on HBM-resident submaps
+            route = None
+            try:
+                from lidarslam_ros2_amd import LoopClosureParams, SubMap, search_loop
+
+                route = synth.make_loop_route()
+                sms = [SubMap(torch.from_numpy(synth.as_pointxyzi(s["cloud"])).cuda(), s["position"], s["orientation"], s["distance"])
+                       for s in route]
+                lp = dict(threshold_loop_closure_score=1.0, distance_loop_closure=20.0, range_of_searching_loop_closure=10.0,
+                          search_submap_num=2, voxel_leaf_size=0.2)
+                back = NormalDistributionsTransform(device=local_rank, stream=stream)   # graph_based_slam_component.cpp:64-72
+                back.setMaximumIterations(100)
+                back.setResolution(5.0)
+                back.setTransformationEpsilon(0.01)
                 edges = search_loop(back, sms, LoopClosureParams(**lp))
-            torch.cuda.synchronize()
-            tl = (time.perf_counter() - tl) / nl
-            out["loop_gate"] = {"ms_per_search": 1e3 * tl, "submaps": len(route), "edge": list(edges[0].pair_id),
-                                "fitness_score": edges[0].fitness_score, "accepted": edges[0].accepted,
-                                "target_points": edges[0].n_target_points, "source_points": int(route[-1]["cloud"].shape[0]),
-                                "newton_iterations": edges[0].iterations,
-                                "what": "source transform + 5-submap window transform/concat + VoxelGrid(0.2) + "
-                                        "setInputTarget + align + getFitnessScore + gate, clouds resident in HBM"}
-        except Exception as e:
-            out["loop_gate"] = {"error": repr(e)}
+                torch.cuda.synchronize()
+                tl = time.perf_counter()
+                nl = 10
+                for _ in range(nl):
+                    edges = search_loop(back, sms, LoopClosureParams(**lp))
+                torch.cuda.synchronize()
+                tl = (time.perf_counter() - tl) / nl
+                out["loop_gate"] = {"ms_per_search": 1e3 * tl, "submaps": len(route), "edge": list(edges[0].pair_id),
+                                    "fitness_score": edges[0].fitness_score, "accepted": edges[0].accepted,
+                                    "target_points": edges[0].n_target_points, "source_points": int(route[-1]["cloud"].shape[0]),
+                                    "newton_iterations": edges[0].iterations,
+                                    "what": "source transform + 5-submap window transform/concat + VoxelGrid(0.2) + "
+                                            "setInputTarget + align + getFitnessScore + gate, clouds resident in HBM"}
+            except Exception as e:
+                out["loop_gate"] = {"error": repr(e)}
 
-        # ---- CPU baseline: the oracle (restatement of ndt_omp) on this box's host cores, bounded sample
-        if not args.no_cpu:
-            from oracle import oracle as O
+            # ---- CPU baseline: the oracle (restatement of ndt_omp) on this box's host cores, bounded sample
+            if not args.no_cpu:
+                from oracle import oracle as O
 
-            g = O.VoxelGridCovariance(case.target, res)
-            avail = min(len(os.sched_getaffinity(0)), O.max_threads())
-            p0 = O.matrix_to_pose(case.guess)
-            cores, best = 1, float("inf")
-            cands = [args.cpu_threads] if args.cpu_threads else [c for c in (1, 2, 4, 8, 16, 32, 64, 128) if c <= avail]
-            for c in cands:  # pick the thread count that is fastest on THIS box (oversubscribed hosts get slower with more)
-                O.ndt_derivatives(g, case.source, p0, resolution=res, num_threads=c)
-                tq = time.perf_counter()
-                for _ in range(2):
+                g = O.VoxelGridCovariance(case.target, res)
+                avail = min(len(os.sched_getaffinity(0)), O.max_threads())
+                p0 = O.matrix_to_pose(case.guess)
+                cores, best = 1, float("inf")
+                cands = [args.cpu_threads] if args.cpu_threads else [c for c in (1, 2, 4, 8, 16, 32, 64, 128) if c <= avail]
+                for c in cands:  # pick the thread count that is fastest on THIS box (oversubscribed hosts get slower with more)
                     O.ndt_derivatives(g, case.source, p0, resolution=res, num_threads=c)
-                tq = (time.perf_counter() - tq) / 2
-                if tq < best:
-                    cores, best = c, tq
-            tc = time.perf_counter()
-            ref = O.ndt_align(g, case.source, case.guess, resolution=res, trans_eps=0.0, max_iterations=max_iter,
-                              num_threads=cores)
-            tc = time.perf_counter() - tc
-            dt, ang = pose_delta(ndt.getFinalTransformation() if B == 1 else finals[0], ref["final"])
-            out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "registrations/s", "cores": cores, "kind": "port",
-                                   "sample": "1 registration of the same workload (30 Newton iterations, "
-                                             f"{ref['n_evals'] + ref['n_evals_grad'] + ref['n_hessian_recompute']} derivative passes)",
-                                   "seconds": tc, "newton_iterations": ref["iterations"], "host_threads_available": avail,
-                                   "ms_per_derivative_pass": 1e3 * best,
-                                   "note": "C++/OpenMP restatement of ndt_omp (oracle/), not ndt_omp itself"}
-            out["parity_vs_cpu"] = {"translation_m": dt, "rotation_rad": ang}
-            if route is not None and "error" not in out.get("loop_gate", {}):
-                tq = time.perf_counter()
-                ref_edges = O.search_loop(route, **lp, ndt_resolution=5.0, trans_eps=0.01, max_iterations=100, num_threads=cores)
-                tq = time.perf_counter() - tq
-                ldt, lang = pose_delta(edges[0].relative_pose, ref_edges[0]["relative_pose"])
-                out["loop_gate"]["cpu_port_ms_per_search"] = 1e3 * tq
-                out["loop_gate"]["parity_vs_cpu"] = {"same_edge": list(ref_edges[0]["pair_id"]) == list(edges[0].pair_id),
-                                                     "translation_m": ldt, "rotation_rad": lang}
+                    tq = time.perf_counter()
+                    for _ in range(2):
+                        O.ndt_derivatives(g, case.source, p0, resolution=res, num_threads=c)
+                    tq = (time.perf_counter() - tq) / 2
+                    if tq < best:
+                        cores, best = c, tq
+                tc = time.perf_counter()
+                ref = O.ndt_align(g, case.source, case.guess, resolution=res, trans_eps=0.0, max_iterations=max_iter,
+                                  num_threads=cores)
+                tc = time.perf_counter() - tc
+                dt, ang = pose_delta(ndt.getFinalTransformation() if B == 1 else finals[0], ref["final"])
+                out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "registrations/s", "cores": cores, "kind": "port",
+                                       "sample": "1 registration of the same workload (30 Newton iterations, "
+                                                 f"{ref['n_evals'] + ref['n_evals_grad'] + ref['n_hessian_recompute']} derivative passes)",
+                                       "seconds": tc, "newton_iterations": ref["iterations"], "host_threads_available": avail,
+                                       "ms_per_derivative_pass": 1e3 * best,
+                                       "note": "C++/OpenMP restatement of ndt_omp (oracle/), not ndt_omp itself"}
+                out["parity_vs_cpu"] = {"translation_m": dt, "rotation_rad": ang}
+                if route is not None and "error" not in out.get("loop_gate", {}):
+                    tq = time.perf_counter()
+                    ref_edges = O.search_loop(route, **lp, ndt_resolution=5.0, trans_eps=0.01, max_iterations=100, num_threads=cores)
+                    tq = time.perf_counter() - tq
+                    ldt, lang = pose_delta(edges[0].relative_pose, ref_edges[0]["relative_pose"])
+                    out["loop_gate"]["cpu_port_ms_per_search"] = 1e3 * tq
+                    out["loop_gate"]["parity_vs_cpu"] = {"same_edge": list(ref_edges[0]["pair_id"]) == list(edges[0].pair_id),
+                                                         "translation_m": ldt, "rotation_rad": lang}
         print(json.dumps(out), flush=True)
 
     if dist is not None:

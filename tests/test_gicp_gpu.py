@@ -118,3 +118,58 @@ def test_too_few_points_and_no_correspondences(O, case):
     g.align()                                   # < 4 correspondences: loop left, not converged, pose = guess
     assert not g.hasConverged()
     assert np.allclose(g.getFinalTransformation(), np.eye(4))
+
+
+def _assert_cov_close(cov, ref):
+    # same neighbours, eigenvectors of the same fp64 matrix by two Jacobi codes (see test_covariances_match_oracle)
+    err = np.abs(cov - ref).max(axis=(1, 2))
+    assert np.quantile(err, 0.99) < 1e-6
+    assert err.max() < 1e-2
+
+
+@pytest.mark.parametrize("k", [5, 10, 32])
+def test_covariances_other_k(O, k):
+    """k != 20 takes the generic list re-scan (k = 20, PCL's default, has an unrolled one); 32 is the largest k the
+    core accepts: all must give the oracle's neighbours and covariances."""
+    case = synth.small_case(n_source=3000, n_keyframes=2, seed=3)
+    src = case.source
+    from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
+
+    g = GeneralizedIterativeClosestPoint(0)
+    g.setCorrespondenceRandomness(k)
+    g.setInputTarget(case.target)
+    g.setInputSource(src)
+    cov = g.covariances("source")
+    ref = O.gicp_covariances(O.NearestNeighbour(src), src, k=k, num_threads=min(16, O.max_threads()))
+    _assert_cov_close(cov, ref)
+
+
+def test_k_correspondences_range():
+    from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
+    from lidarslam_ros2_amd._capi import RegistrationError
+
+    g = GeneralizedIterativeClosestPoint(0)
+    for bad in (2, 33):
+        with pytest.raises(RegistrationError):
+            g.setCorrespondenceRandomness(bad)
+
+
+def test_covariances_isolated_outliers_take_the_cooperative_path(O):
+    """A dense patch plus far, isolated points: the outliers' 20th neighbour lies tens of metres away, far beyond the
+    fine shells, so they are finished by the wave-per-point search — same covariances as the oracle."""
+    rng = np.random.default_rng(11)
+    dense = rng.uniform(-4, 4, (4000, 3)).astype(np.float32)
+    far = (rng.uniform(-1, 1, (40, 3)) * np.array([300.0, 300.0, 20.0])).astype(np.float32)
+    far = far[np.abs(far[:, :2]).max(axis=1) > 30.0]
+    pts = np.concatenate([dense, far]).astype(np.float32)
+    perm = rng.permutation(len(pts))
+    pts = pts[perm]
+    from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
+
+    g = GeneralizedIterativeClosestPoint(0)
+    g.setInputTarget(pts)
+    g.setInputSource(pts)
+    cov = g.covariances("source")
+    ref = O.gicp_covariances(O.NearestNeighbour(pts), pts, num_threads=min(16, O.max_threads()))
+    _assert_cov_close(cov, ref)
+    _assert_cov_close(g.covariances("target"), ref)
