@@ -270,6 +270,20 @@ def gicp_align(nn_tgt: NearestNeighbour, tgt: np.ndarray, tgt_cov: np.ndarray, s
                 n_correspondences=int(res.n_correspondences), final_cost=float(res.final_cost))
 
 
+def gicp_cost(src_xyz: np.ndarray, tgt_xyz: np.ndarray, M: np.ndarray, x, with_gradient: bool = True):
+    """f(x) = 1/m sum r^T M r over paired points (pair i = src[i], tgt[i]) and its gradient, as
+    OptimizationFunctorWithIndices::fdf evaluates them (SURVEY.md 9.7); x = (t, rx, ry, rz), R = Rz Ry Rx."""
+    s = np.ascontiguousarray(np.asarray(src_xyz, np.float32)[:, :3])
+    t = np.ascontiguousarray(np.asarray(tgt_xyz, np.float32)[:, :3])
+    Mc = np.ascontiguousarray(M, np.float64)
+    xv = np.ascontiguousarray(x, np.float64)
+    g = np.zeros(6)
+    fp = C.POINTER(C.c_float)
+    f = lib().orc_gicp_cost(s.ctypes.data_as(fp), t.ctypes.data_as(fp), _f64p(Mc), s.shape[0], _f64p(xv),
+                            _f64p(g) if with_gradient else None, None)
+    return float(f), g
+
+
 # ---- loop-closure gate (SURVEY.md 8f N3): GraphBasedSlamComponent::searchLoop -------------------
 def pose_msg_to_matrix(position, orientation) -> np.ndarray:
     """tf2::fromMsg(geometry_msgs::Pose) -> Eigen::Affine3d (graph_based_slam_component.cpp:171,219):
