@@ -174,7 +174,7 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (K3+K4 derivative pass), hipEvents around every launch
+        # ---- roofline of the dominant kernel (K3+K4 derivative pass), hipEvents around the launch chains
         ndt.setProfiling(True)
         ndt.getProfile(reset=True)
         for _ in range(3):
@@ -198,7 +198,9 @@ def main():
                            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_us,
                            "valid_pairs_per_point": pairs / n_src,
                            "compulsory_bytes_per_launch": n_src * 12 + grid["n_valid"] * 36,
-                           "note": "single 30k-pt scan = 118 workgroups on 256 CUs: latency-bound, voxel table is L2-resident; "
+                           "note": "avg_launch_us = hipEvents around the launch chains / derivative passes (launch to launch, "
+                                   "the ~2 us dependent-launch gap included; rocprofv3's kernel-only average is in profiles/). "
+                                   "A single 30k-pt scan is 118 workgroups on 256 CUs: latency-bound, voxel table cache-resident; "
                                    "see batched.roofline for the bandwidth-relevant figure"}
 
         # The remaining legs (batched, GICP, loop gate, CPU baseline) are single-GPU reports: at N > 1 the other ranks

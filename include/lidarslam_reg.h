@@ -68,7 +68,7 @@ typedef enum lsr_key {
   LSR_MAX_INNER_ITERATIONS = 36,      /* GICP max_inner_iterations_ (20) */
   LSR_RANSAC_ITERATIONS = 37,         /* setRANSACIterations (accepted, ignored) graph_based_slam_component.cpp:81 */
   LSR_HESSIAN_D1_SIGN = 38,           /* +1 = upstream "+sy" quirk in h_ang d1 (default), -1 = analytic */
-  LSR_PROFILE = 39                    /* 1 = bracket every derivative launch with hipEvents (lsr_get_profile) */
+  LSR_PROFILE = 39                    /* 1 = bracket the derivative launch chains with hipEvents (lsr_get_profile) */
 } lsr_key;
 
 typedef struct lsr_result {
@@ -81,8 +81,9 @@ typedef struct lsr_result {
 } lsr_result;
 
 typedef struct lsr_profile {
-  double deriv_ms_total;        /* summed hipEvent time of derivative-kernel launches since last reset */
-  int64_t deriv_launches;
+  double deriv_ms_total;        /* hipEvent time of the derivative-launch chains since last reset (events bracket every
+                                   chunk of launches as enqueued: launch-to-launch time, dependent-launch gap included) */
+  int64_t deriv_launches;       /* derivative passes that ran in those chains */
   int64_t deriv_points;         /* source points processed by those launches */
   int64_t deriv_pairs;          /* valid (point,voxel) pairs of the LAST launch (K-bar * N) */
 } lsr_profile;

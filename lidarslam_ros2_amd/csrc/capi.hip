@@ -2,6 +2,7 @@
 // device buffers, launch chains, result read-back.  No CPU fallback exists — every compute
 // entry point runs HIP kernels on a gfx950 device or returns an error status.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <mutex>
 #include <numeric>
@@ -90,7 +91,7 @@ void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_part
   P.pad = 0;
   P.st = d_state;
   P.partials = d_partials;
-  P.reserved = nullptr;
+  P.mailbox = nullptr;
 }
 
 int ensure_ndt_grid(lsr_handle h) {
@@ -113,47 +114,55 @@ int ensure_target_hash(lsr_handle h) {
   return LSR_OK;
 }
 
-// Chain of launches until every problem reports done.  Launch `seq` consumes the rows of launch seq-1
-// (ndt.hip), so an align of E derivative passes takes E+1 launches; states are double buffered by
-// launch parity: after L launches the current state of problem b is h_states[2*b + (L & 1)].
-int run_ndt_chain(lsr_handle lead, NdtProblem* d_probs, const NdtProblem* h_probs, int batch, int max_blocks, NdtState* d_states,
-                  NdtState* h_states, int neighborhood, bool dense, int min_evals, int hard_cap, bool profile, lsr_profile* prof,
-                  long points_per_launch, int* launches_out) {
-  int launched = 0;
-  int chunk = std::max(1, min_evals);
-  if (profile) chunk = 1;
-  while (launched < hard_cap) {
-    int c = std::min(chunk, hard_cap - launched);
-    if (profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
-    int st = ndt_launch_evals(d_probs, batch == 1 ? h_probs : nullptr, batch, max_blocks, neighborhood, dense, launched, c,
-                              lead->stream);
-    if (st) return st;
-    if (profile) LSR_HIP(hipEventRecord(lead->ev1, lead->stream));
-    launched += c;
-    LSR_HIP(hipMemcpyAsync(h_states, d_states, sizeof(NdtState) * 2 * batch, hipMemcpyDeviceToHost, lead->stream));
-    LSR_HIP(hipStreamSynchronize(lead->stream));
-    const int cur = launched & 1;
-    bool all_done = true;
-    for (int b = 0; b < batch; b++) all_done = all_done && (h_states[2 * b + cur].done != 0);
-    if (profile) {
-      float ms = 0.f;
-      LSR_HIP(hipEventElapsedTime(&ms, lead->ev0, lead->ev1));
-      if (!all_done) {  // the finalising launch (controller only, no derivative pass) is not a derivative launch
-        prof->deriv_ms_total += ms;
-        prof->deriv_launches += 1;
-        prof->deriv_points += points_per_launch;
+// The host feeds the launch chain and watches the mailboxes the chain writes into host memory (NdtMailbox, one per
+// registration of the batch): workgroup 0 of every launch reports its sequence number, the launch in which a
+// registration's controller finishes publishes its result and raises its `done`.  Launch `seq` consumes the rows of
+// launch seq-1 (ndt.hip), so an align of E derivative passes takes E+1 launches.  The host keeps a couple of launches
+// queued ahead of the device and never synchronises the stream or copies state back inside the chain; after the last
+// `done` at most LOW_WATER + REFILL queued launches remain, which exit at their head.
+int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_probs, int batch, int max_blocks, int neighborhood,
+                   bool dense, int first, int hard_cap, unsigned int token, int* launches_out) {
+  constexpr int LOW_WATER = 2, REFILL = 2;
+  const NdtMailbox* mb = h->mailbox.p;
+  const NdtProblem* h_single = (batch == 1) ? h_probs : nullptr;  // a single registration travels in the kernel arguments
+  int launched = std::max(1, std::min(first, hard_cap));
+  int st = ndt_launch_evals(d_probs, h_single, batch, max_blocks, neighborhood, dense, 0, launched, h->stream);
+  if (st) return st;
+  unsigned long long last_progress = 0;
+  auto t_progress = std::chrono::steady_clock::now();
+  int n_done = 0;  // mailboxes [0, n_done) have raised their flag
+  for (unsigned long long spins = 1;; spins++) {
+    while (n_done < batch && __atomic_load_n(&mb[n_done].done, __ATOMIC_ACQUIRE) == token) n_done++;
+    if (n_done == batch) break;
+    // every registration of a launch advances together: the first unfinished one tells how far the device is
+    const unsigned long long pr = __atomic_load_n(&mb[n_done].progress, __ATOMIC_RELAXED);
+    const int entered = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : -1;  // -1: nothing of this align yet
+    if (launched < hard_cap && launched - 1 - entered < LOW_WATER) {
+      const int c = std::min(REFILL, hard_cap - launched);
+      if ((st = ndt_launch_evals(d_probs, h_single, batch, max_blocks, neighborhood, dense, launched, c, h->stream))) return st;
+      launched += c;
+      continue;
+    }
+    if (launched >= hard_cap && entered >= hard_cap - 1) {  // the last permitted launch has started: let it finish
+      LSR_HIP(hipStreamSynchronize(h->stream));
+      while (n_done < batch && __atomic_load_n(&mb[n_done].done, __ATOMIC_ACQUIRE) == token) n_done++;
+      if (n_done == batch) break;
+      set_last_error("NDT controller did not finish within the launch cap");
+      return LSR_ERR_HIP;
+    }
+    if ((spins & 0x3FFF) == 0) {  // a device that stops making progress must not hang the caller forever
+      const auto now = std::chrono::steady_clock::now();
+      if (pr != last_progress) { last_progress = pr; t_progress = now; }
+      if (std::chrono::duration<double>(now - t_progress).count() > 30.0) {
+        const hipError_t e = hipStreamQuery(h->stream);
+        set_last_error(std::string("NDT launch chain made no progress for 30 s (stream: ") + hipGetErrorString(e) + ")");
+        return LSR_ERR_HIP;
       }
-      prof->deriv_pairs = 0;
-      for (int b = 0; b < batch; b++) prof->deriv_pairs += (int64_t)h_states[2 * b + cur].last_pairs;
     }
-    if (all_done) {
-      *launches_out = launched;
-      return LSR_OK;
-    }
-    if (!profile) chunk = 8;  // measured (tools/latency_probe.py): 8/8 .. 12/12 are equivalent, larger chunks only add idle launches
+    __builtin_ia32_pause();
   }
-  set_last_error("NDT controller did not finish within the launch cap");
-  return LSR_ERR_HIP;
+  *launches_out = launched;
+  return LSR_OK;
 }
 
 int ndt_hard_cap(const NdtParamsHost& p) {
@@ -206,32 +215,59 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     hard_cap = std::max(hard_cap, ndt_hard_cap(h->ndt));
     pts += (long)h->source.n;
   }
+  // host mailboxes, one per registration (pinned, host-coherent, mapped into the device)
+  if ((size_t)B > lead->mailbox.cap) {
+    LSR_HIP(hipStreamSynchronize(lead->stream));  // launches still queued from the previous align report into the old block
+    if ((st = lead->mailbox.reserve((size_t)B, hipHostMallocMapped | hipHostMallocCoherent))) return st;
+    std::memset(lead->mailbox.p, 0, sizeof(NdtMailbox) * lead->mailbox.cap);
+    LSR_HIP(hipHostGetDevicePointer((void**)&lead->d_mailbox, lead->mailbox.p, 0));
+  }
+  unsigned int token = ++lead->align_token;
+  if (token == 0) token = ++lead->align_token;  // 0 is the mailbox's idle value
+  for (int b = 0; b < B; b++) {
+    lead->h_prob.p[b].mailbox = lead->d_mailbox + b;
+    lead->h_state.p[2 * b].token = lead->h_state.p[2 * b + 1].token = (int)token;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
   if (B > 1)  // a single registration carries its NdtProblem in the kernel arguments
     LSR_HIP(hipMemcpyAsync(lead->d_prob.p, lead->h_prob.p, sizeof(NdtProblem) * B, hipMemcpyHostToDevice, lead->stream));
   LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
-  hipEvent_t e_start = lead->ev2, e_stop = lead->ev3;  // persistent per-handle events
-  LSR_HIP(hipEventRecord(e_start, lead->stream));
+  if (lead->profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   int launches = 0;
-  st = run_ndt_chain(lead, lead->d_prob.p, lead->h_prob.p, B, max_blocks, lead->d_state.p, lead->h_state.p, lead->ndt.neighborhood, dense, min_evals,
-                     hard_cap, lead->profile != 0, &lead->prof, pts, &launches);
+  st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, B, max_blocks, lead->ndt.neighborhood, dense, min_evals, hard_cap, token,
+                      &launches);
   if (st) return st;
-  LSR_HIP(hipEventRecord(e_stop, lead->stream));
-  LSR_HIP(hipEventSynchronize(e_stop));
-  float ms = 0.f;
-  LSR_HIP(hipEventElapsedTime(&ms, e_start, e_stop));
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  const NdtMailbox* M = lead->mailbox.p;
+  if (lead->profile) {
+    // hipEvents around the launch chain exactly as production runs it; the span also holds the finalising launch and
+    // the (at most four) queued launches that exit at their head, so the time per pass is slightly over-estimated
+    LSR_HIP(hipEventRecord(lead->ev1, lead->stream));
+    LSR_HIP(hipEventSynchronize(lead->ev1));
+    float ev_ms = 0.f;
+    LSR_HIP(hipEventElapsedTime(&ev_ms, lead->ev0, lead->ev1));
+    int passes = 0;
+    lead->prof.deriv_pairs = 0;
+    for (int b = 0; b < B; b++) {
+      passes = std::max(passes, M[b].n_evals);
+      lead->prof.deriv_pairs += (int64_t)M[b].last_pairs;
+    }
+    lead->prof.deriv_ms_total += ev_ms;
+    lead->prof.deriv_launches += passes;
+    lead->prof.deriv_points += (int64_t)passes * pts;
+  }
   for (int b = 0; b < B; b++) {
-    const NdtState& S = lead->h_state.p[2 * b + (launches & 1)];
     lsr_handle h = hs[b];
-    std::memcpy(h->final_T, S.final_T, sizeof(float) * 16);
-    h->converged = S.converged;
-    if (finals) std::memcpy(finals + 16 * b, S.final_T, sizeof(float) * 16);
+    std::memcpy(h->final_T, M[b].final_T, sizeof(float) * 16);
+    h->converged = M[b].converged;
+    if (finals) std::memcpy(finals + 16 * b, M[b].final_T, sizeof(float) * 16);
     if (results) {
-      results[b].converged = S.converged;
-      results[b].iterations = S.nr_iterations;
-      results[b].score = S.trans_probability;
-      results[b].n_evaluations = S.n_evals;
+      results[b].converged = M[b].converged;
+      results[b].iterations = M[b].nr_iterations;
+      results[b].score = M[b].trans_probability;
+      results[b].n_evaluations = M[b].n_evals;
       results[b].n_correspondences = 0;
-      results[b].gpu_ms = ms;
+      results[b].gpu_ms = ms;  // host clock from the state upload to the last raised flag (launches still queued are no-ops)
     }
   }
   return LSR_OK;

@@ -60,12 +60,12 @@ struct PinBuf {
   ~PinBuf() {
     if (p) (void)hipHostFree(p);
   }
-  int reserve(size_t n) {
+  int reserve(size_t n, unsigned int flags = hipHostMallocDefault) {
     if (n <= cap) return LSR_OK;
     if (p) LSR_HIP(hipHostFree(p));
     p = nullptr;
     cap = 0;
-    LSR_HIP(hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault));
+    LSR_HIP(hipHostMalloc((void**)&p, n * sizeof(T), flags));
     cap = n;
     return LSR_OK;
   }

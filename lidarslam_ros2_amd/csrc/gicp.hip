@@ -537,7 +537,7 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   std::memcpy(trans, I16, sizeof(I16));
   std::memcpy(prev, I16, sizeof(I16));
   const float thr2 = (float)(h->gicp.max_corr_dist * h->gicp.max_corr_dist);
-  int nr_iterations = 0, last_cnt = 0, gn_steps = 0;
+  int nr_iterations = 0, last_cnt = 0, gn_steps = 0, prev_inner = 4;
   bool converged = false;
   double last_cost = 0;
   GnState hs;
@@ -568,9 +568,12 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
                        t.cloud.y(), t.cloud.z(), d_pairs, d_count);
     std::memcpy(prev, trans, sizeof(prev));
     // inner Gauss-Newton chain: launches past convergence exit on the done flag
+    // The first outer iteration typically needs several steps, later ones one or two: enqueue one more than the previous
+    // outer iteration used (launches past convergence are no-ops, but each still costs ~5 us of stream time).
     int launched = 0;
+    const int want = (nr_iterations == 0) ? 4 : std::max(2, std::min(4, prev_inner + 1));
     while (true) {
-      const int chunk = std::min(4, h->gicp.max_inner + 1 - launched);
+      const int chunk = std::max(1, std::min(want, h->gicp.max_inner + 1 - launched));
       for (int it = 0; it < chunk; it++) {
         hipLaunchKernelGGL(gicp_gn_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, ws.out.x(), ws.out.y(), ws.out.z(), n, d_pairs,
                            &d_blk->st, d_partials);
@@ -585,6 +588,7 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
     last_cnt = hs.m;
     if (hs.m < 4) break;  // reference: NotEnoughPointsException is caught, loop left unconverged
     gn_steps += hs.inner_iter;
+    prev_inner = hs.inner_iter + 1;  // evaluations = steps + the converged one
     last_cost = hs.f;
     if (!(hs.gnorm == hs.gnorm)) break;  // NaN: the reference's solver exception path
     // transformation_ = applyState(identity, x)

@@ -42,6 +42,9 @@ struct lsr_handle_s {
   DevBuf<NdtProblem> d_prob;
   PinBuf<NdtState> h_state;
   PinBuf<NdtProblem> h_prob;
+  PinBuf<lsr::NdtMailbox> mailbox;        // host-coherent, mapped: progress + result of a single registration
+  lsr::NdtMailbox* d_mailbox = nullptr;   // device view of mailbox.p
+  unsigned int align_token = 0;
   DevBuf<float> d_T16;
   DevBuf<float> d_poses;  // N2: keyframe poses
 

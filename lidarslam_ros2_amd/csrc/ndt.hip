@@ -622,6 +622,9 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   __syncthreads();
   LdsState* L = (LdsState*)s_state;
   LSR_STAMP(1)
+  if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0)  // progress report for the host's launch feeder (relaxed)
+    __hip_atomic_store(&P.mailbox->progress, ((unsigned long long)(unsigned int)L->token << 32) | (unsigned int)seq,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (uniform_i(L->done)) {  // finished earlier: keep both state buffers identical so later launches see it too
     if (blockIdx.x == 0 && seq > 0) {
       unsigned int* gdw = reinterpret_cast<unsigned int*>(Sout);
@@ -651,7 +654,22 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
     if (tid < STATE_DW) gdw[tid] = s_state[tid];
     if (tid + NDT_THREADS < STATE_DW) gdw[tid + NDT_THREADS] = s_state[tid + NDT_THREADS];
   }
-  if (uniform_i(L->done)) return;
+  if (uniform_i(L->done)) {
+    // the controller has just finished this align(): publish the result into the host mailbox, flag last
+    if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0) {
+      NdtMailbox* mb = P.mailbox;
+#pragma unroll
+      for (int k = 0; k < 16; k++) mb->final_T[k] = L->final_T[k];
+      mb->converged = L->converged;
+      mb->nr_iterations = L->nr_iterations;
+      mb->n_evals = L->n_evals;
+      mb->trans_probability = L->trans_probability;
+      mb->last_pairs = L->last_pairs;
+      __threadfence_system();
+      __hip_atomic_store(&mb->done, (unsigned int)L->token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   LSR_STAMP(7)
 
   // ---- this launch's request, straight from the LDS image

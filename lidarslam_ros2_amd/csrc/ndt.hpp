@@ -45,12 +45,24 @@ struct NdtState {
   int nr_iterations, converged;
   // ---- More-Thuente state
   double phi_0, d_phi_0, a_l, f_l, g_l, a_u, f_u, g_u, a_t;
-  int open_interval, interval_converged, step_iterations, pad0;
+  int open_interval, interval_converged, step_iterations;
+  int token;          // identifies this align() in the host mailbox (NdtMailbox)
   // ---- results
   float final_T[16];  // column-major 4x4
   double trans_probability;
   double last_pairs;
   int n_evals, pad1;
+};
+
+// Host mailbox of a single registration (pinned, host-coherent memory mapped into the device): the chain reports its
+// progress and its result straight into host memory, so the host feeds launches and detects the end of an align()
+// by polling two words — no device-to-host copy and no stream synchronisation inside the chain.
+struct NdtMailbox {
+  unsigned long long progress;  // (token << 32) | seq of the launch workgroup 0 has entered most recently
+  unsigned int done;            // = token once the controller has finished; written last (release, system scope)
+  int converged, nr_iterations, n_evals;
+  double trans_probability, last_pairs;
+  float final_T[16];            // column-major 4x4
 };
 
 // One registration problem as the kernels see it (array of these for batched launches).
@@ -69,7 +81,7 @@ struct NdtProblem {
   int pad;
   NdtState* st;             // [2] double buffered by launch parity
   double* partials;         // [2][nblocks][NDT_NRED]
-  void* reserved;
+  NdtMailbox* mailbox;      // device view of the host mailbox (single registrations fed by polling) or nullptr
 };
 
 struct NdtParamsHost {
