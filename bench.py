@@ -36,7 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 780.1 + 8.44) * 1024)  # single 30k-pt pass, see roofline.traffic_source
+PMC_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 785.1 + 8.47) * 1024)  # single 30k-pt pass, see roofline.traffic_source
 
 
 def main():
@@ -191,7 +191,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "ndt_eval_kernel<7> (derivative pass + fused Newton/More-Thuente controller)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            # HBM bytes per launch from rocprofv3 PMC passes of this kernel on this workload
-                           # (profiles/r01_pmc_ndt_eval_final.md): FETCH_SIZE 780 KB x2 (gfx950 reports half of wide
+                           # (profiles/r01_pmc_ndt_eval_final.md): FETCH_SIZE 785 KB x2 (gfx950 reports half of wide
                            # coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE 8 KB.  bench.py cannot collect
                            # PMCs itself; re-measure with tools/pmc_run.sh when the kernel changes.
                            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "profiles/r01_pmc_ndt_eval_final.md",
