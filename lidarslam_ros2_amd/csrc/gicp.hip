@@ -8,6 +8,8 @@
 // The reference minimises the same cost with BFGS; north_star asks for Gauss-Newton accumulation, so
 // the inner solver here is GN with the reference's stopping rule (|grad| < 1e-2 or max_inner
 // iterations).  Same cost and correspondences => same minimiser; the oracle carries both solvers.
+#include <chrono>
+
 #include "handle.hpp"
 #include "nn_device.hpp"
 
@@ -367,8 +369,13 @@ __device__ void solve6_gn(const double* H, const double* b, double* x) {
 }
 
 __global__ __launch_bounds__(256) void gicp_update_kernel(GnState* __restrict__ S, const double* __restrict__ partials, int nblocks,
-                                                          const int* __restrict__ count) {
-  if (S->inner_done) return;
+                                                          const int* __restrict__ count, GicpMailbox* mb, unsigned int token,
+                                                          int launch_index) {
+  const unsigned long long progress = ((unsigned long long)token << 32) | (unsigned int)launch_index;
+  if (S->inner_done) {
+    if (threadIdx.x == 0) __hip_atomic_store(&mb->progress, progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   __shared__ double s_grp[8][32];
   __shared__ double s_sum[32];
   const int t = threadIdx.x;
@@ -387,37 +394,49 @@ __global__ __launch_bounds__(256) void gicp_update_kernel(GnState* __restrict__ 
   }
   __syncthreads();
   if (t != 0) return;
+  bool finished = false;
   if (S->inner_iter == 0 && S->m == 0) {  // first step of this outer iteration: adopt K6's pair count
     S->m = *count;
-    if (S->m < 4) {  // the reference's NotEnoughPointsException: leave x alone, the host ends the outer loop
-      S->inner_done = 1;
-      return;
+    if (S->m < 4) finished = true;  // the reference's NotEnoughPointsException: leave x alone, the host ends the outer loop
+  }
+  if (!finished) {
+    const double m = (double)S->m;
+    double g[6], H[36];
+    S->f = s_sum[0] / m;
+    for (int k = 0; k < 6; k++) g[k] = 2.0 * s_sum[1 + k] / m;
+    int idx = 7;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) {
+        H[i * 6 + j] = H[j * 6 + i] = 2.0 * s_sum[idx] / m;
+        idx++;
+      }
+    double gn = 0;
+    for (int k = 0; k < 6; k++) gn += g[k] * g[k];
+    gn = sqrt(gn);
+    S->gnorm = gn;
+    if (gn < 1e-2 || S->inner_iter >= S->max_inner || !(gn == gn)) {  // BFGS testGradient(1e-2) / max_inner_iterations_
+      finished = true;
+    } else {
+      double neg[6], dx[6];
+      for (int k = 0; k < 6; k++) neg[k] = -g[k];
+      solve6_gn(H, neg, dx);
+      for (int k = 0; k < 6; k++) S->x[k] += dx[k];
+      S->inner_iter++;
+      gn_apply_state(*S);
     }
   }
-  const double m = (double)S->m;
-  double g[6], H[36];
-  S->f = s_sum[0] / m;
-  for (int k = 0; k < 6; k++) g[k] = 2.0 * s_sum[1 + k] / m;
-  int idx = 7;
-  for (int i = 0; i < 6; i++)
-    for (int j = i; j < 6; j++) {
-      H[i * 6 + j] = H[j * 6 + i] = 2.0 * s_sum[idx] / m;
-      idx++;
-    }
-  double gn = 0;
-  for (int k = 0; k < 6; k++) gn += g[k] * g[k];
-  gn = sqrt(gn);
-  S->gnorm = gn;
-  if (gn < 1e-2 || S->inner_iter >= S->max_inner || !(gn == gn)) {  // BFGS testGradient(1e-2) / max_inner_iterations_
+  if (finished) {
     S->inner_done = 1;
-    return;
+    // the inner loop of this outer iteration has ended: publish what the host's outer bookkeeping needs, flag last
+    for (int k = 0; k < 6; k++) mb->x[k] = S->x[k];
+    mb->f = S->f;
+    mb->gnorm = S->gnorm;
+    mb->m = S->m;
+    mb->inner_iter = S->inner_iter;
+    __threadfence_system();
+    __hip_atomic_store(&mb->done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  double neg[6], dx[6];
-  for (int k = 0; k < 6; k++) neg[k] = -g[k];
-  solve6_gn(H, neg, dx);
-  for (int k = 0; k < 6; k++) S->x[k] += dx[k];
-  S->inner_iter++;
-  gn_apply_state(*S);
+  __hip_atomic_store(&mb->progress, progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 void mat4_mul_f(const float* A, const float* B, float* C) {  // column-major fp32 product
@@ -527,8 +546,13 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   float* d_G16 = reinterpret_cast<float*>(ws.state.p + sizeof(IterBlock) + 64);
   PairRec* d_pairs = reinterpret_cast<PairRec*>(ws.pairs.p);
 
-  hipEvent_t e0 = h->ev2, e1 = h->ev3;  // persistent per-handle events
-  LSR_HIP(hipEventRecord(e0, s));
+  if (!ws.d_mailbox) {
+    if ((st = ws.mailbox.reserve(1, hipHostMallocMapped | hipHostMallocCoherent))) return st;
+    std::memset(ws.mailbox.p, 0, sizeof(GicpMailbox));
+    LSR_HIP(hipHostGetDevicePointer((void**)&ws.d_mailbox, ws.mailbox.p, 0));
+  }
+  const GicpMailbox* mb = ws.mailbox.p;
+  const auto t_begin = std::chrono::steady_clock::now();
   LSR_HIP(hipMemcpyAsync(d_G16, G, 16 * sizeof(float), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(gicp_apply_guess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->source.x(), h->source.y(), h->source.z(),
                      n, d_G16, ws.out.x(), ws.out.y(), ws.out.z());
@@ -567,24 +591,57 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
                        ws.out.x(), ws.out.y(), ws.out.z(), n, d_blk->T16, d_blk->Rm, thr2, h->source_cov.p, t.cov.p, t.cloud.x(),
                        t.cloud.y(), t.cloud.z(), d_pairs, d_count);
     std::memcpy(prev, trans, sizeof(prev));
-    // inner Gauss-Newton chain: launches past convergence exit on the done flag
+    // Inner Gauss-Newton chain, fed by polling the host mailbox (GicpMailbox): gicp_update_kernel reports every step that
+    // has run and publishes {x, f, |g|, m, steps} when the inner loop ends — no copy back, no stream synchronisation.
     // The first outer iteration typically needs several steps, later ones one or two: enqueue one more than the previous
-    // outer iteration used (launches past convergence are no-ops, but each still costs ~5 us of stream time).
+    // outer iteration used and top up only if the device runs dry (steps past convergence exit at their head).
+    unsigned int token = ++ws.token;
+    if (token == 0) token = ++ws.token;  // 0 is the mailbox's idle value
+    const int cap = h->gicp.max_inner + 1;
     int launched = 0;
-    const int want = (nr_iterations == 0) ? 4 : std::max(2, std::min(4, prev_inner + 1));
-    while (true) {
-      const int chunk = std::max(1, std::min(want, h->gicp.max_inner + 1 - launched));
-      for (int it = 0; it < chunk; it++) {
+    auto enqueue_steps = [&](int c) {
+      for (int it = 0; it < c; it++) {
         hipLaunchKernelGGL(gicp_gn_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, ws.out.x(), ws.out.y(), ws.out.z(), n, d_pairs,
                            &d_blk->st, d_partials);
-        hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(256), 0, s, &d_blk->st, d_partials, nblocks, d_count);
+        hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(256), 0, s, &d_blk->st, d_partials, nblocks, d_count, ws.d_mailbox,
+                           token, launched + it + 1);
       }
-      launched += chunk;
-      LSR_HIP(hipMemcpyAsync(&hb->st, &d_blk->st, sizeof(GnState), hipMemcpyDeviceToHost, s));
-      LSR_HIP(hipStreamSynchronize(s));
-      hs = hb->st;
-      if (hs.inner_done || launched >= h->gicp.max_inner + 1) break;
+      launched += c;
+    };
+    enqueue_steps(std::max(1, std::min((nr_iterations == 0) ? 4 : std::max(2, std::min(4, prev_inner + 1)), cap)));
+    LSR_HIP(hipGetLastError());
+    {
+      unsigned long long last_progress = 0;
+      auto t_progress = std::chrono::steady_clock::now();
+      for (unsigned long long spins = 1;; spins++) {
+        if (__atomic_load_n(&mb->done, __ATOMIC_ACQUIRE) == token) break;
+        const unsigned long long pr = __atomic_load_n(&mb->progress, __ATOMIC_RELAXED);
+        const int ran = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : 0;
+        if (ran >= launched) {  // everything enqueued has run and the loop is not over
+          if (launched >= cap) {  // cannot happen: the step with inner_iter == max_inner ends the loop
+            set_last_error("GICP inner loop did not finish within max_inner_iterations + 1 steps");
+            return LSR_ERR_HIP;
+          }
+          enqueue_steps(std::min(2, cap - launched));
+          LSR_HIP(hipGetLastError());
+          continue;
+        }
+        if ((spins & 0x3FFF) == 0) {  // a device that stops making progress must not hang the caller forever
+          const auto now = std::chrono::steady_clock::now();
+          if (pr != last_progress) { last_progress = pr; t_progress = now; }
+          if (std::chrono::duration<double>(now - t_progress).count() > 30.0) {
+            set_last_error(std::string("GICP launch chain made no progress for 30 s (stream: ") + hipGetErrorString(hipStreamQuery(s)) + ")");
+            return LSR_ERR_HIP;
+          }
+        }
+        __builtin_ia32_pause();
+      }
     }
+    hs.m = mb->m;
+    hs.inner_iter = mb->inner_iter;
+    hs.f = mb->f;
+    hs.gnorm = mb->gnorm;
+    for (int k = 0; k < 6; k++) hs.x[k] = mb->x[k];
     last_cnt = hs.m;
     if (hs.m < 4) break;  // reference: NotEnoughPointsException is caught, loop left unconverged
     gn_steps += hs.inner_iter;
@@ -613,10 +670,8 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
       std::memcpy(prev, trans, sizeof(prev));
     }
   }
-  LSR_HIP(hipEventRecord(e1, s));
-  LSR_HIP(hipEventSynchronize(e1));
-  float ms = 0.f;
-  LSR_HIP(hipEventElapsedTime(&ms, e0, e1));
+  // host clock from the first enqueue to the last raised flag (the steps still queued exit at their head)
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   mat4_mul_f(prev, G, h->final_T);  // final_transformation_ = previous_transformation_ * guess
   h->converged = converged ? 1 : 0;
   if (final_T) std::memcpy(final_T, h->final_T, sizeof(float) * 16);

@@ -17,6 +17,16 @@ struct GicpParamsHost {
   int k = 20;
 };
 
+// Host mailbox of the inner Gauss-Newton loop (pinned, host-coherent, mapped into the device): gicp_update_kernel reports
+// how many of the enqueued steps have run and, when the inner loop of an outer iteration ends, the state the host needs
+// for the outer bookkeeping — no device-to-host copy, no stream synchronisation per outer iteration.
+struct GicpMailbox {
+  unsigned long long progress;   // (token << 32) | update launches of this outer iteration that have run
+  unsigned int done;             // = token once the inner loop has ended; written last (release, system scope)
+  int m, inner_iter, pad;
+  double x[6], f, gnorm;
+};
+
 struct GicpWorkspace {
   DeviceCloud out;               // guess * source ("output" of the reference's align)
   DevBuf<unsigned char> pairs;   // PairRec[n]
@@ -24,6 +34,9 @@ struct GicpWorkspace {
   DevBuf<unsigned char> state;   // per-iteration block {GnState, T16, Rm} + counters
   PinBuf<unsigned char> pin;     // pinned host mirror of the per-iteration block
   DevBuf<int> work;              // K5: count + indices of the points deferred to the wave-cooperative search
+  PinBuf<GicpMailbox> mailbox;
+  GicpMailbox* d_mailbox = nullptr;
+  unsigned int token = 0;        // one per outer iteration
 };
 
 int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res);

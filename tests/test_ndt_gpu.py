@@ -139,3 +139,48 @@ def test_batch_equals_single(O, case):
     # and a batch is reproducible run to run (fixed-order reductions, no float atomics)
     finals2, _ = align_batch(regs, guesses)
     assert np.array_equal(finals, finals2)
+
+
+def test_back_to_back_aligns_of_different_lengths_do_not_interfere(case):
+    """The launch chain of an align() is fed by polling a host mailbox and may leave a few queued launches that
+    exit at their head.  A mixed sequence of long, short and zero-iteration aligns — single and
+    batched, growing and shrinking the batch — on ONE handle must give exactly what fresh handles give."""
+    from lidarslam_ros2_amd import align_batch
+
+    res = 5.0
+    tgt = synth.as_pointxyzi(case.target)
+    src = synth.as_pointxyzi(case.source)
+    schedule = [(0.01, 35), (0.0, 5), (0.01, 0), (0.0, 12), (1e-6, 35), (0.01, 1), (0.0, 0), (0.01, 35)]
+
+    def run(ndt, eps, mi, guess):
+        ndt.setTransformationEpsilon(eps)
+        ndt.setMaximumIterations(mi)
+        ndt.setInputSource(src)
+        ndt.align(guess)
+        r = ndt.last_result
+        return ndt.getFinalTransformation().copy(), r["iterations"], r["n_evaluations"], bool(ndt.hasConverged())
+
+    fresh = []
+    for eps, mi in schedule:
+        n = make_ndt(res)
+        n.setInputTarget(tgt)
+        fresh.append(run(n, eps, mi, case.guess))
+    one = make_ndt(res)
+    one.setInputTarget(tgt)
+    peers = [make_ndt(res) for _ in range(4)]
+    for p in peers:
+        p.shareTargetOf(one)
+        p.setInputSource(src)
+    for rep in range(3):
+        for k, (eps, mi) in enumerate(schedule):
+            got = run(one, eps, mi, case.guess)
+            assert np.array_equal(got[0], fresh[k][0]) and got[1:] == fresh[k][1:], (rep, k)
+            if k % 3 == rep % 3:   # interleave batches of changing size on the same lead handle / stream
+                B = 2 + (k + rep) % 4
+                regs = [one] + peers[:B - 1]
+                for r in regs:
+                    r.setTransformationEpsilon(0.01)
+                    r.setMaximumIterations(35)
+                finals, results = align_batch(regs, [case.guess] * B)
+                for b in range(1, B):
+                    assert np.array_equal(finals[b], finals[1]) and results[b]["iterations"] == results[1]["iterations"]
