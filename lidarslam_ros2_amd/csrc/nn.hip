@@ -230,7 +230,7 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
   hipLaunchKernelGGL(nn_fine_table_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream, key_out, run_key, run_off, run_cnt,
                      n_runs, grid.coarse_block.p, grid.block_off.p, grid.fine_start.p);
   LSR_HIP(hipGetLastError());
-  LSR_HIP(hipStreamSynchronize(stream));
+  // no synchronisation here: every consumer of the grid (and of the scratch buffers) is ordered on the same stream
   grid.n_blocks = n_runs;  // a trailing run of non-finite points (if any) is never referenced by coarse_block
   return LSR_OK;
 }
