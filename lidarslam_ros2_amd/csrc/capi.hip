@@ -329,12 +329,18 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   if (stream) {
     h->stream = (hipStream_t)stream;
   } else {
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return LSR_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+      set_last_error("hipStreamCreateWithFlags failed");
+      delete h;
+      return LSR_ERR_HIP;
+    }
     h->own_stream = true;
   }
-  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->ev2) != hipSuccess ||
-      hipEventCreate(&h->ev3) != hipSuccess) { delete h; return LSR_ERR_HIP; }
-  if (h->d_T16.reserve(16)) { delete h; return LSR_ERR_HIP; }
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || h->d_T16.reserve(16) != LSR_OK) {
+    set_last_error("handle resources could not be created");
+    (void)lsr_destroy(h);  // releases whatever was created so far
+    return LSR_ERR_HIP;
+  }
   *out = h;
   return LSR_OK;
 }
@@ -345,8 +351,6 @@ int lsr_destroy(lsr_handle h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
-  if (h->ev2) (void)hipEventDestroy(h->ev2);
-  if (h->ev3) (void)hipEventDestroy(h->ev3);
   h->target.reset();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;

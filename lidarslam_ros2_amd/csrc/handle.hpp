@@ -15,12 +15,10 @@ struct lsr_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // profiling brackets (LSR_PROFILE)
 
   NdtParamsHost ndt;
   GicpParamsHost gicp;
-  bool trans_eps_set = false;
-  bool max_iter_set = false;
   double euclidean_fitness_eps = -1.7976931348623157e308;
   int num_threads = 0, ransac_iterations = 0;
   int profile = 0;
