@@ -142,7 +142,9 @@ int lsr_share_target(lsr_handle h, lsr_handle owner);
 /* registration_->align(output, guess)    scanmatcher_component.cpp:353; graph_based_slam_component.cpp:230
  * guess: col-major 4x4 or NULL (= identity, the backend's align(output)).  final_transformation: out, 16 floats.
  * output_pts (nullable): host buffer of n_source records of out_stride_bytes; xyz of the source
- * transformed by the final transformation are written at offset 0 of every record. */
+ * transformed by the final transformation are written at offset 0 of every record, the remaining bytes of
+ * each record are zeroed (PCL keeps the source's other fields there; both reference callers discard
+ * `output`, scanmatcher_component.cpp:350-353, graph_based_slam_component.cpp:229-230 — pass NULL to skip it). */
 int lsr_align(lsr_handle h, const float* guess, float* final_transformation, lsr_result* result,
               void* output_pts, size_t out_stride_bytes);
 /* B independent registrations advanced together in shared launches (loop-closure candidate set /
