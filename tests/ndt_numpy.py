@@ -26,14 +26,19 @@ def jang_rows(p):
 
 
 class NumpyNdt:
-    def __init__(self, dump, min_b, max_b, leaf, d1, d2):
+    def __init__(self, dump, min_b, max_b, leaf, d1, d2, search=7):
         self.leaf, self.d1, self.d2 = float(leaf), d1, d2
         self.min_b, self.max_b = np.asarray(min_b, np.int64), np.asarray(max_b, np.int64)
         div = self.max_b - self.min_b + 1
         self.mul = np.array([1, div[0], div[0] * div[1]], np.int64)
         ok = dump["n"] >= 6
         self.table = {int(k): (m, c) for k, m, c in zip(dump["idx"][ok], dump["mean"][ok], dump["icov"][ok])}
-        self.off = np.array([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.int64)
+        if search == 1:      # DIRECT1: the cell of the transformed point only
+            self.off = np.zeros((1, 3), np.int64)
+        elif search == 26:   # DIRECT26: the full 3x3x3 block, centre included (27 cells)
+            self.off = np.array([[a, b, c] for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)], np.int64)
+        else:                # DIRECT7: centre + the six face neighbours
+            self.off = np.array([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.int64)
 
     def score_grad(self, src, p):
         """fp64 score and gradient; cell lookup uses the same fp32 floor(x'/leaf) as the reference so the

@@ -139,6 +139,20 @@ def test_hessian_matches_finite_differences_and_d1_quirk(small):
     assert np.abs(H64 - H_up).max() <= 1e-4 * scale
 
 
+@pytest.mark.parametrize("search", [1, 26])
+def test_direct1_and_direct26_match_fp64_numpy(small, search):
+    """The other two pclomp neighbourhoods (DIRECT1: own cell; DIRECT26: the whole 3x3x3 block) against the fp64
+    numpy restatement: same voxel sets, same score and gradient."""
+    case, res, grid, _ = small
+    d1, d2, _ = O.gauss_constants(res)
+    ref = NumpyNdt(grid.dump(), grid.min_b, grid.max_b, res, d1, d2, search=search)
+    p = O.matrix_to_pose(case.guess) + np.array([-0.06, 0.09, 0.02, -0.003, 0.005, 0.008])
+    s, g, _ = O.ndt_derivatives(grid, case.source, p, resolution=res, search=search)
+    s64, g64 = ref.score_grad(case.source, p)
+    assert abs(s - s64) <= 2e-5 * abs(s64)
+    assert np.abs(g - g64).max() <= 1e-4 * np.abs(g64).max()
+
+
 def test_direct7_boundary_cases(small):
     case, res, grid, ref = small
     far = (case.source + np.float32(1e4)).astype(np.float32)     # outside the bbox: zero neighbours
