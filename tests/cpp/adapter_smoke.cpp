@@ -1,6 +1,7 @@
 // Compiles the pcl::Registration-shaped adapter without PCL (stand-in point/cloud types with PCL's
 // layout) and exercises the exact call sequence of ScanMatcherComponent
 // (scanmatcher/src/scanmatcher_component.cpp:105-113,275,329,353,356,375).
+#include <cmath>
 #include <cstdio>
 #include <memory>
 #include <vector>
@@ -37,7 +38,7 @@ int main() {
     float u = (i % 64) * 0.3f, v = (i / 64) * 0.3f;
     tgt->points.push_back({u, v, 0.02f * ((i * 7) % 5), 1.f, 0, 0, 0, 0});
     tgt->points.push_back({u, 0.05f * ((i * 3) % 7), v, 1.f, 0, 0, 0, 0});
-    if (i % 3 == 0) src->points.push_back({u + 0.2f, v - 0.1f, 0.02f * ((i * 7) % 5), 1.f, 0, 0, 0, 0});
+    if (i % 3 == 0) src->points.push_back({u + 0.2f, v - 0.1f, 0.02f * ((i * 7) % 5), 1.f, (float)i, 0, 0, 0});
   }
   registration_->setInputTarget(tgt);
   registration_->setInputSource(src);
@@ -46,6 +47,19 @@ int main() {
   auto T = registration_->getFinalTransformation();
   std::printf("OK converged=%d iters=%d t=(%.3f %.3f %.3f) fitness=%.4f out=%zu\n", (int)registration_->hasConverged(),
               registration_->getFinalNumIteration(), T(0, 3), T(1, 3), T(2, 3), registration_->getFitnessScore(), output.points.size());
+
+  // `output` = the source with xyz moved by the final transformation, every other field kept (what PCL's align leaves)
+  int fields_ok = 1;
+  for (size_t i = 0; i < output.points.size(); i++) {
+    const PointXYZI& a = src->points[i];
+    const PointXYZI& b = output.points[i];
+    const float ex = T(0, 0) * a.x + T(0, 1) * a.y + T(0, 2) * a.z + T(0, 3);
+    const float ey = T(1, 0) * a.x + T(1, 1) * a.y + T(1, 2) * a.z + T(1, 3);
+    const float ez = T(2, 0) * a.x + T(2, 1) * a.y + T(2, 2) * a.z + T(2, 3);
+    const float err = std::fabs(b.x - ex) + std::fabs(b.y - ey) + std::fabs(b.z - ez);
+    if (!(err < 1e-3f) || b.intensity != a.intensity || b.pad != a.pad) fields_ok = 0;
+  }
+  std::printf("OUTPUT fields_ok=%d\n", fields_ok);
 
   // searchLoop() through the C ABI: four "submaps" sharing the target cloud; the last one has
   // travelled far enough and sits next to the first, so exactly one candidate (id 0) is registered.
