@@ -242,6 +242,36 @@ def main():
             except Exception as e:  # the headline line must still be printed
                 out["batched"] = {"error": repr(e)}
 
+            # ---- frontend leg (BASELINE cfg 1): the reference's own settings (transformation_epsilon 0.01, default
+            #      iteration cap) — what ScanMatcherComponent runs per scan; same scan, same resident submap
+            try:
+                front = make_ndt()
+                front.shareTargetOf(ndt)
+                front.setTransformationEpsilon(0.01)
+                front.setMaximumIterations(35)
+
+                def front_step():
+                    _capi.check(lib.lsr_set_input_source_device(front._h, src_ptr, 32, n_src_pts), "lsr_set_input_source_device")
+                    _capi.check(lib.lsr_align(front._h, g16.ctypes.data_as(fptr), fin16.ctypes.data_as(fptr), C.byref(front._last),
+                                              None, 0), "lsr_align")
+
+                for _ in range(5):
+                    front_step()
+                torch.cuda.synchronize()
+                tf = time.perf_counter()
+                nf = 50
+                for _ in range(nf):
+                    front_step()
+                torch.cuda.synchronize()
+                tf = (time.perf_counter() - tf) / nf
+                out["frontend_cfg1"] = {"value": 1.0 / tf, "unit": "registrations/s", "ms_per_registration": 1e3 * tf,
+                                        "newton_iterations": int(front._last.iterations),
+                                        "derivative_passes": int(front._last.n_evaluations),
+                                        "converged": bool(front._last.converged),
+                                        "what": "setInputSource (HBM-resident scan) + align with transformation_epsilon 0.01"}
+            except Exception as e:
+                out["frontend_cfg1"] = {"error": repr(e)}
+
             # ---- GICP leg (BASELINE cfg 3): same scan, target re-filtered at 0.2, corr dist 5.0, eps 1e-8
             try:
                 from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
