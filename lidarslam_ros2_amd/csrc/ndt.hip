@@ -9,9 +9,11 @@
 //  * the voxel table is a dense int32 cell->slot map plus compact 64-B leaf records
 //    {mean.xyz, icov upper triangle} read as three 16-B loads; at the reference resolutions the
 //    whole table (<= a few MB) is L2/Infinity-Cache resident, HBM only streams the source planes;
-//  * the 29 sums of a pass travel: registers -> wave butterfly -> LDS -> one 256-B partial row per
-//    workgroup (write-through) -> last-arriving workgroup sums rows in fixed order (deterministic,
-//    no floating-point atomics).
+//  * the 29 sums of a pass travel: registers -> quad sum (DPP) -> LDS transpose -> one 256-B partial row per
+//    workgroup (plain stores) -> EVERY workgroup of the next launch sums the rows in the same fixed order at its
+//    head (deterministic, no floating-point atomics, no inter-workgroup synchronisation inside a launch);
+//  * progress and the final result go straight into a pinned host mailbox (NdtMailbox, ndt.hpp): the host feeds
+//    the launch chain by polling it, nothing is copied back.
 #include "ndt.hpp"
 
 #include <cmath>
@@ -286,7 +288,7 @@ __device__ __forceinline__ void request_eval(LdsState* S, int want_hessian, bool
   S->pad1 = refresh_hang ? 3 : 1;  // bit0: build T/jang for x_t, bit1: also hang
 }
 
-// Executed by ALL threads of the last workgroup (uniform control flow, two barriers).
+// Executed by ALL threads of the workgroup (uniform control flow, two barriers).
 // lanes 0-2: fp64 sin/cos of the three angles (with the reference's 1e-4 snap), lanes 3-5: fp32 sin/cos
 // (the reference composes the point transform from float-cast angles); then four lanes fill
 // jang / hang(lo) / hang(hi) / T + final_T.
@@ -357,7 +359,8 @@ __device__ void build_request(NdtState* S, double* cs_d /*6*/, float* cs_f /*6*/
 }
 
 // K4: consume the sums of the pass that just finished and decide what happens next.
-// Runs on one lane of the last-arriving workgroup.  sums: [0]=score [1..6]=grad [7]=pairs [8..28]=H upper.
+// Runs on one lane of EVERY workgroup (redundantly, same inputs, same result).  sums: [0]=score [1..6]=grad
+// [7]=pairs [8..28]=H upper.
 __device__ __attribute__((noinline)) void ndt_controller(LdsState* S, const LdsDouble* sums) {
   const double mu = 1.e-4, nu = 0.9;
   const int max_step_iterations = 10;
