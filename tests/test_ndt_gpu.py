@@ -184,3 +184,34 @@ def test_back_to_back_aligns_of_different_lengths_do_not_interfere(case):
                 finals, results = align_batch(regs, [case.guess] * B)
                 for b in range(1, B):
                     assert np.array_equal(finals[b], finals[1]) and results[b]["iterations"] == results[1]["iterations"]
+
+
+def test_gpu_matches_the_committed_golden_fixture():
+    """tests/golden/ndt_small_golden.npz (written by tests/golden/make_golden.py from the oracle, committed): the HIP
+    path against the fixture itself, independent of the oracle library being rebuilt identically on this box."""
+    import os
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ndt_small_golden.npz"))
+    case = synth.small_case(n_source=int(gold["n_source"]), n_keyframes=int(gold["n_keyframes"]))
+    assert case.target.shape[0] == int(gold["n_target"]) and np.array_equal(case.source, gold["source"])
+    res = float(gold["res"])
+    ndt = make_ndt(res)
+    ndt.setInputTarget(synth.as_pointxyzi(case.target))
+    ndt.setInputSource(synth.as_pointxyzi(case.source))
+    info, d = ndt.gridInfo(), ndt.gridDump()
+    # voxel set and membership counts: bit-exact
+    assert np.array_equal(info["min_b"], gold["min_b"]) and np.array_equal(info["max_b"], gold["max_b"])
+    assert np.array_equal(d["idx"], gold["leaf_idx"]) and np.array_equal(d["n"], gold["leaf_n"])
+    # one derivative pass at the fixture's pose
+    s, g, H = ndt.derivatives(gold["p"], compute_hessian=True)
+    assert abs(s - float(gold["score"])) <= 1e-5 * abs(float(gold["score"]))
+    assert np.abs(g - gold["grad"]).max() <= 2e-5 * np.abs(gold["grad"]).max()
+    assert np.abs(H - gold["hess"]).max() <= 2e-5 * np.abs(gold["hess"]).max()
+    # align(): the reference's schedule and the tight one
+    for eps, mi, key in ((0.01, 35, "eps001"), (1e-6, 30, "tight")):
+        ndt.setTransformationEpsilon(eps)
+        ndt.setMaximumIterations(mi)
+        ndt.align(gold["guess"])
+        dt, ang = pose_delta(ndt.getFinalTransformation(), gold["final_" + key])
+        assert dt <= POSE_T_TOL and ang <= POSE_R_TOL, (key, dt, ang)
+        assert ndt.getFinalNumIteration() == int(gold["iters_" + key])
