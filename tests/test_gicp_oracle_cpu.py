@@ -172,3 +172,30 @@ def test_fitness_score_vs_bruteforce_and_max_range():
     keep = d2 <= mr
     assert keep.any() and not keep.all()
     assert nn.fitness_score(src, T, max_range=mr) == pytest.approx(d2[keep].mean(), rel=1e-6)
+
+
+def test_oracle_reproduces_the_gicp_golden_fixture():
+    """tests/golden/gicp_small_golden.npz was written by tests/golden/make_golden_gicp.py from this oracle: any drift of
+    the restatement (k-NN order, covariance recipe, either inner solver, the fitness sum, the voxel filter) shows here.
+    Integer work bit-exact; floating point to the last few ulps (thread count and summation order are fixed)."""
+    import os
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "gicp_small_golden.npz"))
+    case = synth.small_case(n_source=int(gold["n_source"]), n_keyframes=int(gold["n_keyframes"]))
+    assert case.target.shape[0] == int(gold["n_target_raw"]) and np.array_equal(case.source, gold["source"])
+    tgt = O.voxel_grid_filter(case.target, float(gold["leaf"]))
+    assert tgt.shape[0] == int(gold["n_target"]) and np.array_equal(tgt[:64], gold["target_head"])
+    nn_t, nn_s = O.NearestNeighbour(tgt), O.NearestNeighbour(case.source)
+    idx, d2 = nn_t.search(case.source, gold["guess"], num_threads=1)
+    assert np.array_equal(idx, gold["nn_idx"]) and np.array_equal(d2, gold["nn_d2"])
+    ct, cs = O.gicp_covariances(nn_t, tgt, num_threads=1), O.gicp_covariances(nn_s, case.source, num_threads=1)
+    assert np.allclose(cs[:200], gold["cov_src_head"], rtol=0, atol=1e-13)
+    assert np.allclose(ct[:200], gold["cov_tgt_head"], rtol=0, atol=1e-13)
+    for solver, key in ((0, "bfgs"), (1, "gn")):
+        r = O.gicp_align(nn_t, tgt, ct, case.source, cs, gold["guess"], solver=solver, num_threads=1)
+        assert r["iterations"] == int(gold["iters_" + key])
+        assert np.allclose(r["final"], gold["final_" + key], rtol=0, atol=1e-6)
+        if solver == 1:
+            assert r["n_correspondences"] == int(gold["n_corr"])
+            fit = nn_t.fitness_score(case.source, r["final"], num_threads=1)
+            assert fit == pytest.approx(float(gold["fitness"]), rel=1e-9)
