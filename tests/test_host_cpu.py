@@ -193,3 +193,40 @@ def test_cpp_adapter_runs_the_frontend_call_sequence(tmp_path):
     assert out.startswith("OK converged=1"), out
     assert "OUTPUT fields_ok=1" in out, out      # align(output): xyz transformed, intensity etc. kept (PCL semantics)
     assert "LOOP st=0 n=1 from=0 to=3 accepted=1" in out, out
+
+
+def test_c_abi_argument_validation_needs_no_device():
+    """Error conventions of the boundary: status codes, never an exception or a crash — checked on
+    the paths that do not need a device (null handles, invalid method, status strings)."""
+    from lidarslam_ros2_amd import _capi
+
+    lib = _capi.load()
+    lib.lsr_status_string.restype = C.c_char_p
+    lib.lsr_last_error.restype = C.c_char_p
+    names = {0: b"ok", -1: b"invalid argument", -3: b"HIP runtime error", -4: b"input target not set",
+             -5: b"input source not set", -6: b"not implemented", -7: b"voxel index overflow", -8: b"too few points",
+             -99: b"unknown status"}
+    for code, text in names.items():
+        assert lib.lsr_status_string(code) == text
+    null = C.c_void_p(None)
+    out16 = (C.c_float * 16)()
+    dbl, i32 = C.c_double(), C.c_int()
+    assert lib.lsr_destroy(null) == 0                                   # destroying nothing is fine
+    assert lib.lsr_set_f64(null, _capi.RESOLUTION, C.c_double(1.0)) == -1
+    assert b"null handle" in lib.lsr_last_error()
+    assert lib.lsr_set_i32(null, _capi.MAX_ITERATIONS, 3) == -1
+    assert lib.lsr_get_f64(null, _capi.RESOLUTION, C.byref(dbl)) == -1
+    assert lib.lsr_get_i32(null, _capi.MAX_ITERATIONS, C.byref(i32)) == -1
+    assert lib.lsr_set_input_target(null, None, 32, 0) == -1
+    assert lib.lsr_set_input_source(null, None, 32, 0) == -1
+    assert lib.lsr_align(null, None, out16, None, None, 0) == -1
+    assert lib.lsr_get_final_transformation(null, out16) == -1
+    assert lib.lsr_has_converged(null, C.byref(i32)) == -1
+    assert lib.lsr_get_fitness_score(null, C.c_double(1.0), C.byref(dbl)) == -1
+    assert lib.lsr_align_batch(None, 0, None, None, None) == -1
+    h = C.c_void_p()
+    assert lib.lsr_create(7, 0, None, C.byref(h)) == -1 and not h.value  # registration_method neither NDT nor GICP
+    assert lib.lsr_create(_capi.METHOD_NDT, 0, None, None) == -1
+    n = C.c_int(-5)
+    st = lib.lsr_device_count(C.byref(n))
+    assert (st == 0 and n.value >= 0) or (st == -2 and n.value == 0)
