@@ -68,7 +68,17 @@ typedef enum lsr_key {
   LSR_MAX_INNER_ITERATIONS = 36,      /* GICP max_inner_iterations_ (20) */
   LSR_RANSAC_ITERATIONS = 37,         /* setRANSACIterations (accepted, ignored) graph_based_slam_component.cpp:81 */
   LSR_HESSIAN_D1_SIGN = 38,           /* +1 = upstream "+sy" quirk in h_ang d1 (default), -1 = analytic */
-  LSR_PROFILE = 39                    /* 1 = bracket the derivative launch chains with hipEvents (lsr_get_profile) */
+  LSR_PROFILE = 39,                   /* 1 = bracket the derivative launch chains with hipEvents (lsr_get_profile) */
+  /* tuning (no effect on results beyond fp64 summation order): */
+  LSR_NDT_WORKGROUP = 40,             /* threads per workgroup of the NDT derivative pass: 0 = automatic, 128, 256 */
+  LSR_NDT_TABLE_MODE = 41,            /* where the pass reads leaf records: -1 = automatic, 0 = dense global table,
+                                         1 = compact global table, 2 = whole table staged in LDS (when it fits) */
+  LSR_GRID_BUILDER = 42,              /* 0 = automatic (counting sort for <= 16383 grid cells, radix sort beyond), 1 = always
+                                         the radix-sort builder */
+  LSR_WAIT_MODE = 43                  /* how the calling thread waits for the device inside align() / setInputTarget():
+                                         0 = spin (lowest latency, pins one core per running call), 1 = sched_yield between
+                                         polls, 2 = sleep 20 us between polls (a ROS2 MultiThreadedExecutor runs two
+                                         registration objects side by side, lidarslam/src/lidarslam.cpp:12-17) */
 } lsr_key;
 
 typedef struct lsr_result {
@@ -215,6 +225,9 @@ int lsr_gicp_covariances(lsr_handle h, int which, double* cov);
 /* 1-NN of the source transformed by T16 (nullable = identity) in the target: idx[n], d2[n]. */
 int lsr_nearest_neighbors(lsr_handle h, const float* T16, int32_t* idx, float* d2);
 int lsr_get_profile(lsr_handle h, lsr_profile* out, int reset);
+/* Host-only self check (needs no device): the angular coefficient tables of NDT eq. 6.19 / 6.21 at pose p6 by the scalar
+ * formulas (jang_ref[24], hang_ref[48]) and by the 72-entry table the device evaluates one entry per lane (jang_tab, hang_tab). */
+int lsr_debug_angle_tables(const double* p6, int d1_sign, float* jang_ref, float* hang_ref, float* jang_tab, float* hang_tab);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
 (RESOLUTION, TRANSFORMATION_EPSILON, STEP_SIZE, OUTLIER_RATIO, MAX_CORRESPONDENCE_DISTANCE, ROTATION_EPSILON,
  EUCLIDEAN_FITNESS_EPSILON, GICP_EPSILON) = range(8)
 (MAX_ITERATIONS, NEIGHBORHOOD, NUM_THREADS, K_CORRESPONDENCES, MAX_INNER_ITERATIONS, RANSAC_ITERATIONS,
- HESSIAN_D1_SIGN, PROFILE) = range(32, 40)
+ HESSIAN_D1_SIGN, PROFILE, NDT_WORKGROUP, NDT_TABLE_MODE, GRID_BUILDER, WAIT_MODE) = range(32, 44)
 
 EXPORTED_SYMBOLS = [
     "lsr_version", "lsr_status_string", "lsr_last_error", "lsr_device_count", "lsr_create", "lsr_destroy",
@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "lsr_share_target", "lsr_align", "lsr_align_batch",
     "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_search_loop", "lsr_ndt_grid_info",
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
+    "lsr_debug_angle_tables",
 ]
 
 
@@ -115,6 +116,7 @@ def load() -> C.CDLL:
     L.lsr_gicp_covariances.argtypes = [vp, C.c_int, dp]
     L.lsr_nearest_neighbors.argtypes = [vp, fp, ip, fp]
     L.lsr_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
+    L.lsr_debug_angle_tables.argtypes = [dp, C.c_int, fp, fp, fp, fp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int or name not in ("lsr_version", "lsr_status_string", "lsr_last_error"):

@@ -4,8 +4,10 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <numeric>
+#include <thread>
 
 #include "handle.hpp"
 
@@ -67,8 +69,8 @@ int upload_cloud(lsr_handle h, const void* pts, size_t stride, size_t n, bool on
 // Workgroups per registration.  A single registration spreads one point per thread over as many CUs as
 // it can (latency); a batch wants ~4 resident workgroups per CU in total and lets every thread stride
 // over several points, which amortises the reduction and the partial-row traffic (throughput).
-int ndt_nblocks(size_t n, int batch = 1) {
-  int nb = (int)((n + NDT_THREADS - 1) / NDT_THREADS);
+int ndt_nblocks(size_t n, int batch = 1, int threads = NDT_THREADS) {
+  int nb = (int)((n + threads - 1) / threads);
   nb = std::max(1, std::min(nb, NDT_MAX_BLOCKS));
   if (batch > 1) {
     int per = std::max(4, (4 * 256 + batch - 1) / batch);  // the batch kernel runs 4 workgroups per CU
@@ -77,11 +79,14 @@ int ndt_nblocks(size_t n, int batch = 1) {
   return nb;
 }
 
-void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_partials, int batch = 1) {
+void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_partials, int batch = 1, int threads = NDT_THREADS) {
   const VoxelGridDev& g = h->target->grid;
   P.sx = h->source.x(); P.sy = h->source.y(); P.sz = h->source.z();
   P.n = (int)h->source.n;
-  P.nblocks = ndt_nblocks(h->source.n, batch);
+  P.nblocks = ndt_nblocks(h->source.n, batch, threads);
+  P.lds_image = g.lds_image.p;
+  P.lds_map_bytes = g.lds_map_bytes;
+  P.lds_bytes = g.lds_bytes;
   P.cell_slot = g.cell_slot.p;
   P.rec = g.rec.p;
   for (int k = 0; k < 3; k++) { P.min_b[k] = g.min_b[k]; P.max_b[k] = g.max_b[k]; }
@@ -120,13 +125,17 @@ int ensure_target_hash(lsr_handle h) {
 // launch seq-1 (ndt.hip), so an align of E derivative passes takes E+1 launches.  The host keeps a couple of launches
 // queued ahead of the device and never synchronises the stream or copies state back inside the chain; after the last
 // `done` at most LOW_WATER + REFILL queued launches remain, which exit at their head.
-int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_probs, int batch, int max_blocks, int neighborhood,
-                   bool dense, int first, int hard_cap, unsigned int token, int* launches_out) {
-  constexpr int LOW_WATER = 2, REFILL = 2;
+int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_probs, const NdtLaunchCfg& cfg, int first, int hard_cap,
+                   unsigned int token, int* launches_out) {
+  // spin: two launches queued ahead are enough; yield / sleep give the core away between polls, so more launches are
+  // kept queued to ride out the scheduler's latency (surplus launches exit at their head, ~2 us each)
+  const int wait_mode = h->scratch.wait_mode;
+  const int LOW_WATER = (wait_mode == WAIT_SPIN) ? 2 : (wait_mode == WAIT_YIELD ? 4 : 16), REFILL = (wait_mode == WAIT_SLEEP) ? 8 : 2;
+  const int batch = cfg.batch;
   const NdtMailbox* mb = h->mailbox.p;
   const NdtProblem* h_single = (batch == 1) ? h_probs : nullptr;  // a single registration travels in the kernel arguments
   int launched = std::max(1, std::min(first, hard_cap));
-  int st = ndt_launch_evals(d_probs, h_single, batch, max_blocks, neighborhood, dense, 0, launched, h->stream);
+  int st = ndt_launch_evals(d_probs, h_single, cfg, 0, launched, h->stream);
   if (st) return st;
   unsigned long long last_progress = 0;
   auto t_progress = std::chrono::steady_clock::now();
@@ -139,7 +148,7 @@ int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_
     const int entered = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : -1;  // -1: nothing of this align yet
     if (launched < hard_cap && launched - 1 - entered < LOW_WATER) {
       const int c = std::min(REFILL, hard_cap - launched);
-      if ((st = ndt_launch_evals(d_probs, h_single, batch, max_blocks, neighborhood, dense, launched, c, h->stream))) return st;
+      if ((st = ndt_launch_evals(d_probs, h_single, cfg, launched, c, h->stream))) return st;
       launched += c;
       continue;
     }
@@ -150,7 +159,7 @@ int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_
       set_last_error("NDT controller did not finish within the launch cap");
       return LSR_ERR_HIP;
     }
-    if ((spins & 0x3FFF) == 0) {  // a device that stops making progress must not hang the caller forever
+    if ((spins & 0x3FFF) == 0 || wait_mode == WAIT_SLEEP) {  // a device that stops making progress must not hang the caller forever
       const auto now = std::chrono::steady_clock::now();
       if (pr != last_progress) { last_progress = pr; t_progress = now; }
       if (std::chrono::duration<double>(now - t_progress).count() > 30.0) {
@@ -159,7 +168,9 @@ int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_
         return LSR_ERR_HIP;
       }
     }
-    __builtin_ia32_pause();
+    if (wait_mode == WAIT_YIELD) std::this_thread::yield();
+    else if (wait_mode == WAIT_SLEEP) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    else __builtin_ia32_pause();
   }
   *launches_out = launched;
   return LSR_OK;
@@ -192,22 +203,41 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   if ((st = lead->h_state.reserve(2 * (size_t)B))) return st;
   if ((st = lead->d_prob.reserve(B))) return st;
   if ((st = lead->h_prob.reserve(B))) return st;
+  // launch geometry: where the leaf records are read from, workgroup size (lead handle's tuning keys, 0 / -1 = automatic)
+  NdtLaunchCfg cfg;
+  cfg.batch = B;
+  cfg.neighborhood = lead->ndt.neighborhood;
+  cfg.threads = (lead->ndt_threads == 128 || lead->ndt_threads == 256) ? lead->ndt_threads : NDT_THREADS;
+  {
+    bool all_lds = true, all_dense = true;
+    int lds_max = 0;
+    for (int b = 0; b < B; b++) {
+      const VoxelGridDev& g = hs[b]->target->grid;
+      all_lds = all_lds && g.lds_bytes > 0;
+      all_dense = all_dense && g.dense;
+      lds_max = std::max(lds_max, g.lds_bytes);
+    }
+    int tab = all_lds ? NDT_TAB_LDS : (all_dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT);
+    if (lead->ndt_table_mode == NDT_TAB_DENSE && all_dense) tab = NDT_TAB_DENSE;   // tuning override (only where valid)
+    if (lead->ndt_table_mode == NDT_TAB_COMPACT) tab = NDT_TAB_COMPACT;
+    cfg.tab = tab;
+    cfg.lds_bytes = (tab == NDT_TAB_LDS) ? lds_max : 0;
+  }
   size_t tot_blocks = 0;
   int max_blocks = 1;
   for (int b = 0; b < B; b++) {
-    int nb = ndt_nblocks(hs[b]->source.n, B);
+    int nb = ndt_nblocks(hs[b]->source.n, B, cfg.threads);
     tot_blocks += nb;
     max_blocks = std::max(max_blocks, nb);
   }
+  cfg.max_blocks = max_blocks;
   if ((st = lead->d_partials.reserve(2 * tot_blocks * NDT_NRED))) return st;
   size_t blk_off = 0;
   int min_evals = 1, hard_cap = 1;
-  bool dense = true;
-  for (int b = 0; b < B; b++) dense = dense && hs[b]->target->grid.dense;
   long pts = 0;
   for (int b = 0; b < B; b++) {
     lsr_handle h = hs[b];
-    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_partials.p + 2 * blk_off * NDT_NRED, B);
+    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_partials.p + 2 * blk_off * NDT_NRED, B, cfg.threads);
     blk_off += lead->h_prob.p[b].nblocks;
     ndt_fill_initial_state(lead->h_state.p[2 * b], guesses ? guesses + 16 * b : nullptr, h->ndt, (int)h->source.n);
     lead->h_state.p[2 * b + 1] = lead->h_state.p[2 * b];
@@ -234,8 +264,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
   if (lead->profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   int launches = 0;
-  st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, B, max_blocks, lead->ndt.neighborhood, dense, min_evals, hard_cap, token,
-                      &launches);
+  st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, cfg, min_evals, hard_cap, token, &launches);
   if (st) return st;
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   const NdtMailbox* M = lead->mailbox.p;
@@ -326,6 +355,11 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   // pclomp ctor defaults
   h->ndt.resolution = 1.0; h->ndt.step_size = 0.1; h->ndt.outlier_ratio = 0.55; h->ndt.trans_eps = 0.1;
   h->ndt.max_iterations = 35; h->ndt.neighborhood = LSR_DIRECT7; h->ndt.d1_sign = 1;
+  // tuning defaults may be preset from the environment (A/B runs without touching the caller)
+  if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 128 || v == 256) h->ndt_threads = v; }
+  if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 2) h->ndt_table_mode = v; }
+  if (const char* e = std::getenv("LSR_WAIT_MODE")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->scratch.wait_mode = v; }
+  if (const char* e = std::getenv("LSR_GRID_BUILDER")) { h->scratch.force_sort_path = (std::atoi(e) == 1); }
   if (stream) {
     h->stream = (hipStream_t)stream;
   } else {
@@ -409,6 +443,20 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
     case LSR_RANSAC_ITERATIONS: h->ransac_iterations = v; return LSR_OK;  // no effect on NDT/GICP maths
     case LSR_HESSIAN_D1_SIGN: h->ndt.d1_sign = (v >= 0) ? 1 : -1; return LSR_OK;
     case LSR_PROFILE: h->profile = v ? 1 : 0; return LSR_OK;
+    case LSR_NDT_WORKGROUP:
+      if (v != 0 && v != 128 && v != 256) { set_last_error("NDT workgroup size must be 0 (auto), 128 or 256"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->ndt_threads = v; return LSR_OK;
+    case LSR_NDT_TABLE_MODE:
+      if (v < -1 || v > 2) { set_last_error("NDT table mode must be -1 (auto), 0 dense, 1 compact, 2 LDS"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->ndt_table_mode = v; return LSR_OK;
+    case LSR_GRID_BUILDER:
+      if (v < 0 || v > 1) { set_last_error("grid builder must be 0 (auto) or 1 (radix-sort builder)"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->scratch.force_sort_path = (v == 1);
+      if (h->target) h->target->has_grid = false;
+      return LSR_OK;
+    case LSR_WAIT_MODE:
+      if (v < 0 || v > 2) { set_last_error("wait mode must be 0 (spin), 1 (yield) or 2 (sleep)"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->scratch.wait_mode = v; return LSR_OK;
     default: set_last_error("unknown i32 key"); return LSR_ERR_INVALID_ARGUMENT;
   }
 }
@@ -425,6 +473,10 @@ int lsr_get_i32(lsr_handle h, int key, int* v) {
     case LSR_RANSAC_ITERATIONS: *v = h->ransac_iterations; return LSR_OK;
     case LSR_HESSIAN_D1_SIGN: *v = h->ndt.d1_sign; return LSR_OK;
     case LSR_PROFILE: *v = h->profile; return LSR_OK;
+    case LSR_NDT_WORKGROUP: *v = h->ndt_threads; return LSR_OK;
+    case LSR_NDT_TABLE_MODE: *v = h->ndt_table_mode; return LSR_OK;
+    case LSR_GRID_BUILDER: *v = h->scratch.force_sort_path ? 1 : 0; return LSR_OK;
+    case LSR_WAIT_MODE: *v = h->scratch.wait_mode; return LSR_OK;
     default: set_last_error("unknown i32 key"); return LSR_ERR_INVALID_ARGUMENT;
   }
 }
@@ -861,15 +913,26 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
   if ((st = h->h_state.reserve(2))) return st;
   if ((st = h->d_prob.reserve(1))) return st;
   if ((st = h->h_prob.reserve(1))) return st;
-  int nb = ndt_nblocks(h->source.n);
+  NdtLaunchCfg cfg;
+  cfg.neighborhood = h->ndt.neighborhood;
+  cfg.threads = (h->ndt_threads == 128 || h->ndt_threads == 256) ? h->ndt_threads : NDT_THREADS;
+  {
+    const VoxelGridDev& g = h->target->grid;
+    cfg.tab = g.lds_bytes > 0 ? NDT_TAB_LDS : (g.dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT);
+    if (h->ndt_table_mode == NDT_TAB_DENSE && g.dense) cfg.tab = NDT_TAB_DENSE;
+    if (h->ndt_table_mode == NDT_TAB_COMPACT) cfg.tab = NDT_TAB_COMPACT;
+    cfg.lds_bytes = (cfg.tab == NDT_TAB_LDS) ? g.lds_bytes : 0;
+  }
+  int nb = ndt_nblocks(h->source.n, 1, cfg.threads);
+  cfg.max_blocks = nb;
   if ((st = h->d_partials.reserve(2 * (size_t)nb * NDT_NRED))) return st;
-  fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p);
+  fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p, 1, cfg.threads);
   ndt_fill_diag_state(h->h_state.p[0], p6, T16, compute_hessian, h->ndt, (int)h->source.n);
   h->h_state.p[1] = h->h_state.p[0];
   LSR_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, sizeof(NdtProblem), hipMemcpyHostToDevice, h->stream));
   LSR_HIP(hipMemcpyAsync(h->d_state.p, h->h_state.p, 2 * sizeof(NdtState), hipMemcpyHostToDevice, h->stream));
   // launch 0 evaluates, launch 1 sums the rows into the state (PH_DIAG) -> state buffer (2 & 1) = 0
-  if ((st = ndt_launch_evals(h->d_prob.p, h->h_prob.p, 1, nb, h->ndt.neighborhood, h->target->grid.dense, 0, 2, h->stream))) return st;
+  if ((st = ndt_launch_evals(h->d_prob.p, h->h_prob.p, cfg, 0, 2, h->stream))) return st;
   LSR_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, sizeof(NdtState), hipMemcpyDeviceToHost, h->stream));
   LSR_HIP(hipStreamSynchronize(h->stream));
   const NdtState& S = h->h_state.p[0];

@@ -101,6 +101,10 @@ struct VoxelGridDev {
   bool dense = false;      // rec[] indexed by cell (dense) or by leaf slot (compact)
   DevBuf<int> cell_slot;   // dense [ncells] -> record slot or -1
   DevBuf<float4> rec;      // [n_leaves * 4]
+  // LDS image of the valid-voxel table (ndt_pack_lds_table): uint16 cell->slot map (0xFFFF = none) followed by 48-byte
+  // records of the usable leaves; lds_bytes == 0 when the table is too large to stage
+  DevBuf<uint4> lds_image;
+  int lds_map_bytes = 0, lds_bytes = 0;
   // fp64 copies for inspection/parity (mean 3, icov 9 row-major) + key + count per leaf
   DevBuf<double> mean64, icov64;
   DevBuf<int> leaf_key, leaf_n;
@@ -123,12 +127,40 @@ struct HashGridDev {
   DevBuf<int> order;        // sorted position -> original index
 };
 
+// Host mailbox of the target-side builders (pinned, host-coherent memory mapped into the device): the kernels publish
+// the few scalars the host needs (bounding box, leaf counts) straight into host memory and the host polls a token —
+// no device-to-host copy and no stream synchronisation inside a grid build.
+struct BuildMailbox {
+  unsigned int bbox[8];       // order-preserving uint encoding of min xyz, max xyz; [6] = #finite points
+  unsigned int bbox_token;    // release-stored after bbox[]
+  int n_valid, n_occupied;    // leaves usable by lookups / leaves holding at least one point
+  int lds_bytes, lds_map_bytes;
+  unsigned int done_token;    // release-stored after the counts
+  unsigned int pad[2];
+};
+
+// How a host thread waits on a mailbox word (lsr_set_i32(LSR_WAIT_MODE)): a ROS2 MultiThreadedExecutor runs two
+// registration objects side by side (lidarslam/src/lidarslam.cpp:12-17), and a spinning wait pins one core per align.
+enum WaitMode : int { WAIT_SPIN = 0, WAIT_YIELD = 1, WAIT_SLEEP = 2 };
+
 // Per-handle scratch for the target-side builders.
 struct BuildScratch {
   DevBuf<char> temp;
   DevBuf<unsigned int> words;
   DevBuf<double> sums;
+  DevBuf<float> sorted;            // dense-grid counting sort: cell-sorted x | y | z planes
+  DevBuf<unsigned int> bbox_acc;   // bbox_kernel accumulators (self-resetting)
+  bool force_sort_path = false;    // tests: build dense key spaces with the general (radix sort) builder too
+  PinBuf<BuildMailbox> mb;         // host view
+  BuildMailbox* d_mb = nullptr;    // device view of mb.p
+  unsigned int token = 0;
+  int wait_mode = WAIT_SPIN;
+  int ensure_mailbox();
 };
+
+// Poll *word until it equals token (acquire).  Returns LSR_ERR_HIP if the stream reports an error or nothing happens
+// for 30 s.  Defined in grid_dense.hip.
+int wait_mailbox_word(const volatile unsigned int* word, unsigned int token, hipStream_t stream, int wait_mode, const char* what);
 
 struct TargetData {
   DeviceCloud cloud;

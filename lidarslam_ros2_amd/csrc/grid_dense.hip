@@ -1,0 +1,323 @@
+// K1/K2 for DENSE key spaces (<= VG_DENSE_MAX_CELLS grid cells: every reference configuration at ndt_resolution 5.0):
+// the voxel-covariance grid of pclomp::VoxelGridCovariance::filter (scanmatcher_component.cpp:275,307;
+// graph_based_slam_component.cpp:227) built with a hand-written LDS-histogram counting sort instead of
+// a general radix sort:
+//
+//   bbox (publishes into the host mailbox)                                        1 launch, host polls one word
+//   vg_hist_kernel     key per point (uint16) + per-block LDS histogram           reads 12 B/pt, writes 2 B/pt
+//   vg_scan_kernel     per cell: exclusive scan over the blocks                   nblk x C words
+//   vg_cellscan_kernel one workgroup: exclusive scan over the cells -> start[]
+//   vg_scatter_kernel  STABLE scatter of x,y,z into cell order                    reads 14 B/pt, writes 12 B/pt
+//   vg_leaf_kernel     one workgroup per cell: fp64 sums in a fixed order + leaf finalisation (K2)   reads 12 B/pt
+//   lds_pack_kernel    LDS image of the usable leaves, counts into the host mailbox
+//
+// = 7 launches, no device-to-host copy, two host polls (bbox, done) — against ~35 launches and three stream
+// synchronisations of the sort-based builder (which remains for larger key spaces, ndt.hip).
+// Determinism: integer histograms; the scatter ranks equal keys by point index (wave ballots, waves ordered through
+// packed 16-bit per-wave counters); the sums of a leaf are formed in an order that depends on its point count only.
+#include <chrono>
+#include <thread>
+
+#include "grid_device.hpp"
+#include "ndt.hpp"
+
+namespace lsr {
+
+int BuildScratch::ensure_mailbox() {
+  if (mb.p) return LSR_OK;
+  int st = mb.reserve(1, hipHostMallocMapped | hipHostMallocCoherent);
+  if (st) return st;
+  std::memset(mb.p, 0, sizeof(BuildMailbox));
+  LSR_HIP(hipHostGetDevicePointer((void**)&d_mb, mb.p, 0));
+  return LSR_OK;
+}
+
+int wait_mailbox_word(const volatile unsigned int* word, unsigned int token, hipStream_t stream, int wait_mode, const char* what) {
+  auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long long spins = 1;; spins++) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == token) return LSR_OK;
+    if (wait_mode == WAIT_YIELD) std::this_thread::yield();
+    else if (wait_mode == WAIT_SLEEP) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    else __builtin_ia32_pause();
+    if ((spins & 0x3FFF) == 0 || wait_mode == WAIT_SLEEP) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+        const hipError_t e = hipStreamQuery(stream);
+        set_last_error(std::string(what) + ": no answer from the device for 30 s (stream: " + hipGetErrorString(e) + ")");
+        return LSR_ERR_HIP;
+      }
+    }
+  }
+}
+
+namespace {
+
+constexpr int VG_CHUNK = 4096;  // points per workgroup: 4 waves x 16 steps x 64 lanes
+constexpr int VG_STEPS = 16;
+
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// key = linear leaf index exactly as VoxelGridCovariance computes it; non-finite points get the
+// sentinel bin `ncells` (sorted last, never a leaf)
+__global__ __launch_bounds__(256) void vg_hist_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                      int n, float inv_leaf, int mb0, int mb1, int mb2, int mul1, int mul2, int ncells,
+                                                      unsigned short* __restrict__ keys, unsigned short* __restrict__ hist) {
+  extern __shared__ unsigned int s_hist[];  // [ncells + 1]
+  const int C = ncells + 1, tid = threadIdx.x;
+  for (int k = tid; k < C; k += 256) s_hist[k] = 0u;
+  __syncthreads();
+  const int base = blockIdx.x * VG_CHUNK;
+#pragma unroll 4
+  for (int j = 0; j < VG_CHUNK / 256; j++) {
+    const int i = base + j * 256 + tid;
+    if (i < n) {
+      const float px = x[i], py = y[i], pz = z[i];
+      unsigned int k = (unsigned int)ncells;
+      if (isfinite(px) && isfinite(py) && isfinite(pz)) {
+        const int i0 = (int)(floorf(px * inv_leaf) - (float)mb0);
+        const int i1 = (int)(floorf(py * inv_leaf) - (float)mb1);
+        const int i2 = (int)(floorf(pz * inv_leaf) - (float)mb2);
+        k = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
+        if (k >= (unsigned int)ncells) k = (unsigned int)ncells;  // cannot happen for a bbox built from the same floats
+      }
+      keys[i] = (unsigned short)k;
+      atomicAdd(&s_hist[k], 1u);
+    }
+  }
+  __syncthreads();
+  unsigned short* row = hist + (size_t)blockIdx.x * C;
+  for (int k = tid; k < C; k += 256) row[k] = (unsigned short)s_hist[k];  // <= VG_CHUNK = 4096
+}
+
+// per cell: exclusive scan of the block histograms (offset of this block's points inside the cell) + cell total
+__global__ __launch_bounds__(256) void vg_scan_kernel(const unsigned short* __restrict__ hist, int nblk, int C,
+                                                      unsigned int* __restrict__ blkoff, unsigned int* __restrict__ total) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= C) return;
+  unsigned int run = 0u;
+  int b = 0;
+  for (; b + 8 <= nblk; b += 8) {
+    unsigned int c[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) c[u] = hist[(size_t)(b + u) * C + k];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { blkoff[(size_t)(b + u) * C + k] = run; run += c[u]; }
+  }
+  for (; b < nblk; b++) { const unsigned int c = hist[(size_t)b * C + k]; blkoff[(size_t)b * C + k] = run; run += c; }
+  total[k] = run;
+}
+
+// one workgroup: exclusive scan over the cells -> start[0..C] (start[C] = n)
+__global__ __launch_bounds__(1024) void vg_cellscan_kernel(const unsigned int* __restrict__ total, int C, unsigned int* __restrict__ start) {
+  __shared__ unsigned int s_s[1024];
+  const int tid = threadIdx.x;
+  const int per = (C + 1023) / 1024;
+  const int c0 = tid * per, c1 = min(C, c0 + per);
+  unsigned int cnt = 0u;
+  for (int c = c0; c < c1; c++) cnt += total[c];
+  s_s[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const unsigned int v = (tid >= off) ? s_s[tid - off] : 0u;
+    __syncthreads();
+    s_s[tid] += v;
+    __syncthreads();
+  }
+  unsigned int run = s_s[tid] - cnt;
+  for (int c = c0; c < c1; c++) { start[c] = run; run += total[c]; }
+  if (tid == 1023) start[C] = s_s[1023];
+}
+
+// Stable scatter into cell order.  Wave w of block b owns points [b*4096 + w*1024, +1024) and walks them in 16 steps of
+// 64 consecutive points.  s_c[k] packs four 16-bit counters (one per wave): first the per-wave counts of key k, then
+// their exclusive prefix over the waves, then — advanced by ds_add_rtn_u64 — the running offset of each wave.  Inside a
+// step, lanes with equal keys are ranked by a ballot (lower lane = lower point index first).
+__global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                         int n, const unsigned short* __restrict__ keys, const unsigned int* __restrict__ blkoff,
+                                                         const unsigned int* __restrict__ start, int C, float* __restrict__ ox,
+                                                         float* __restrict__ oy, float* __restrict__ oz) {
+  extern __shared__ unsigned long long s_c[];  // [C]
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  for (int k = tid; k < C; k += 256) s_c[k] = 0ull;
+  const int base_i = blockIdx.x * VG_CHUNK + w * (VG_CHUNK / 4) + lane;
+  unsigned int key[VG_STEPS];
+  float px[VG_STEPS], py[VG_STEPS], pz[VG_STEPS];
+#pragma unroll
+  for (int j = 0; j < VG_STEPS; j++) {
+    const int i = base_i + j * 64;
+    const bool in = i < n;
+    key[j] = in ? (unsigned int)keys[i] : 0xFFFFu;
+    px[j] = in ? x[i] : 0.f; py[j] = in ? y[i] : 0.f; pz[j] = in ? z[i] : 0.f;
+  }
+  __syncthreads();
+  const int sh = 16 * w;
+#pragma unroll
+  for (int j = 0; j < VG_STEPS; j++)
+    if (key[j] != 0xFFFFu) atomicAdd(&s_c[key[j]], 1ull << sh);
+  __syncthreads();
+  for (int k = tid; k < C; k += 256) {
+    const unsigned long long v = s_c[k];
+    const unsigned long long c0 = v & 0xFFFFull, c1 = (v >> 16) & 0xFFFFull, c2 = (v >> 32) & 0xFFFFull;
+    s_c[k] = (c0 << 16) | ((c0 + c1) << 32) | ((c0 + c1 + c2) << 48);
+  }
+  // absolute position of this block's first point of every key this lane holds (one round trip for all 16 steps)
+  unsigned int absb[VG_STEPS];
+  const unsigned int* boff = blkoff + (size_t)blockIdx.x * C;
+#pragma unroll
+  for (int j = 0; j < VG_STEPS; j++) absb[j] = (key[j] != 0xFFFFu) ? (start[key[j]] + boff[key[j]]) : 0u;
+  __syncthreads();
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int j = 0; j < VG_STEPS; j++) {
+    const unsigned int k = key[j];
+    const bool active = k != 0xFFFFu;
+    unsigned int rank = 0u, rel = 0u;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const unsigned int kk = (unsigned int)__shfl((int)k, leader, 64);
+      const bool mine = active && (k == kk);
+      const unsigned long long m = __ballot(mine);
+      unsigned long long old = 0ull;
+      if (lane == leader) old = atomicAdd(&s_c[kk], (unsigned long long)__popcll(m) << sh);
+      const unsigned int old_lo = (unsigned int)__shfl((int)(unsigned int)old, leader, 64);
+      const unsigned int old_hi = (unsigned int)__shfl((int)(unsigned int)(old >> 32), leader, 64);
+      if (mine) {
+        const unsigned long long o = ((unsigned long long)old_hi << 32) | old_lo;
+        rel = (unsigned int)(o >> sh) & 0xFFFFu;
+        rank = (unsigned int)__popcll(m & lt_mask);
+      }
+      todo &= ~m;
+    }
+    if (active) {
+      const unsigned int pos = absb[j] + rel + rank;
+      ox[pos] = px[j]; oy[pos] = py[j]; oz[pos] = pz[j];
+    }
+  }
+}
+
+// K1 + K2, one workgroup (8 waves) per grid cell: wave v sums the cell's points v*64 + lane + 512*t (cell order = point
+// order), waves are combined in wave order, thread 0 finalises the leaf (leaf_finalize_dev).  Dense record layout
+// (record of cell c at rec[4c]); empty cells are written as zero records.
+constexpr int VG_LEAF_THREADS = 512;
+__global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                                  const float* __restrict__ sz, const unsigned int* __restrict__ start,
+                                                                  int ncells, int min_points, double eig_mult, float4* __restrict__ rec,
+                                                                  double* __restrict__ mean64, double* __restrict__ icov64,
+                                                                  int* __restrict__ leaf_key, int* __restrict__ leaf_n,
+                                                                  int* __restrict__ cell_slot) {
+  const int cell = blockIdx.x, tid = threadIdx.x;
+  const unsigned int off = start[cell];
+  const int cnt = (int)(start[cell + 1] - off);
+  if (cnt == 0) {
+    if (tid < 4) rec[(size_t)cell * 4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid == 0) { leaf_key[cell] = -1; leaf_n[cell] = 0; cell_slot[cell] = -1; }
+    return;
+  }
+  __shared__ double s_w[VG_LEAF_THREADS / 64][9];
+  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const float* bx = sx + off; const float* by = sy + off; const float* bz = sz + off;
+  int j = tid;
+  for (; j + 7 * VG_LEAF_THREADS < cnt; j += 8 * VG_LEAF_THREADS) {  // eight independent loads per plane in flight
+    float fx[8], fy[8], fz[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { fx[u] = bx[j + u * VG_LEAF_THREADS]; fy[u] = by[j + u * VG_LEAF_THREADS]; fz[u] = bz[j + u * VG_LEAF_THREADS]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const double px = (double)fx[u], py = (double)fy[u], pz = (double)fz[u];
+      s[0] += px; s[1] += py; s[2] += pz;
+      s[3] += px * px; s[4] += px * py; s[5] += px * pz;
+      s[6] += py * py; s[7] += py * pz; s[8] += pz * pz;
+    }
+  }
+  for (; j < cnt; j += VG_LEAF_THREADS) {
+    const double px = (double)bx[j], py = (double)by[j], pz = (double)bz[j];
+    s[0] += px; s[1] += py; s[2] += pz;
+    s[3] += px * px; s[4] += px * py; s[5] += px * pz;
+    s[6] += py * py; s[7] += py * pz; s[8] += pz * pz;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) s[k] = wave_sum64(s[k]);
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) s_w[tid >> 6][k] = s[k];
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  double tot[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    double t = s_w[0][k];
+#pragma unroll
+    for (int v = 1; v < VG_LEAF_THREADS / 64; v++) t += s_w[v][k];
+    tot[k] = t;
+  }
+  double mean[3], icov[9];
+  bool valid;
+  const int n = leaf_finalize_dev(tot, cnt, min_points, eig_mult, mean, icov, &valid);
+  leaf_key[cell] = cell;
+  leaf_n[cell] = n;
+  for (int k = 0; k < 3; k++) mean64[(size_t)cell * 3 + k] = mean[k];
+  for (int k = 0; k < 9; k++) icov64[(size_t)cell * 9 + k] = icov[k];
+  rec[(size_t)cell * 4 + 0] = make_float4((float)mean[0], (float)mean[1], (float)mean[2], (float)icov[0]);
+  rec[(size_t)cell * 4 + 1] = make_float4((float)icov[1], (float)icov[2], (float)icov[4], (float)icov[5]);
+  rec[(size_t)cell * 4 + 2] = make_float4((float)icov[8], (float)n, 0.f, 0.f);
+  rec[(size_t)cell * 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  cell_slot[cell] = valid ? cell : -1;
+}
+
+}  // namespace
+
+// Everything after the bounding box for a dense key space.  grid.min_b / max_b / div_b / ncells are set by the caller.
+int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  const int n = (int)cloud.n;
+  const int ncells = (int)grid.ncells, C = ncells + 1;
+  const int nblk = (n + VG_CHUNK - 1) / VG_CHUNK;
+  const float inv_leaf = 1.0f / leaf;
+  int st;
+  // scratch words: total[C] | start[C+1] | blkoff[nblk*C] | hist(u16)[nblk*C] | keys(u16)[n]
+  const size_t w_total = (size_t)C, w_start = (size_t)C + 1, w_blkoff = (size_t)nblk * C, w_hist = ((size_t)nblk * C + 1) / 2,
+               w_keys = ((size_t)n + 1) / 2;
+  if ((st = sc.words.reserve(16 + w_total + w_start + w_blkoff + w_hist + w_keys + 16))) return st;
+  unsigned int* total = sc.words.p + 16;
+  unsigned int* start = total + w_total;
+  unsigned int* blkoff = start + w_start;
+  unsigned short* hist = reinterpret_cast<unsigned short*>(blkoff + w_blkoff);
+  unsigned short* keys = reinterpret_cast<unsigned short*>(blkoff + w_blkoff + w_hist);
+  const size_t pitch = ((size_t)n + 63) & ~(size_t)63;
+  if ((st = sc.sorted.reserve(3 * pitch))) return st;
+  float* sx = sc.sorted.p; float* sy = sx + pitch; float* sz = sy + pitch;
+  if ((st = grid.cell_slot.reserve(grid.ncells))) return st;
+  if ((st = grid.rec.reserve(grid.ncells * 4))) return st;
+  if ((st = grid.mean64.reserve(grid.ncells * 3))) return st;
+  if ((st = grid.icov64.reserve(grid.ncells * 9))) return st;
+  if ((st = grid.leaf_key.reserve(grid.ncells))) return st;
+  if ((st = grid.leaf_n.reserve(grid.ncells))) return st;
+  grid.dense = true;
+
+  static bool attr_done[64] = {};
+  int dev = 0;
+  LSR_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    LSR_HIP(hipFuncSetAttribute((const void*)vg_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VG_DENSE_MAX_CELLS * 4 + 4));
+    LSR_HIP(hipFuncSetAttribute((const void*)vg_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VG_DENSE_MAX_CELLS * 8 + 8));
+    attr_done[dev] = true;
+  }
+  const int mul1 = grid.div_b[0], mul2 = grid.div_b[0] * grid.div_b[1];
+  hipLaunchKernelGGL(vg_hist_kernel, dim3(nblk), dim3(256), (size_t)C * 4, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
+                     grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, ncells, keys, hist);
+  hipLaunchKernelGGL(vg_scan_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, hist, nblk, C, blkoff, total);
+  hipLaunchKernelGGL(vg_cellscan_kernel, dim3(1), dim3(1024), 0, stream, total, C, start);
+  hipLaunchKernelGGL(vg_scatter_kernel, dim3(nblk), dim3(256), (size_t)C * 8, stream, cloud.x(), cloud.y(), cloud.z(), n, keys, blkoff,
+                     start, C, sx, sy, sz);
+  hipLaunchKernelGGL(vg_leaf_kernel, dim3(ncells), dim3(VG_LEAF_THREADS), 0, stream, sx, sy, sz, start, ncells, 6, 0.01, grid.rec.p,
+                     grid.mean64.p, grid.icov64.p, grid.leaf_key.p, grid.leaf_n.p, grid.cell_slot.p);
+  LSR_HIP(hipGetLastError());
+  grid.n_leaves = ncells;  // leaf arrays are indexed by cell; empty cells carry leaf_key = -1
+  return LSR_OK;
+}
+
+}  // namespace lsr

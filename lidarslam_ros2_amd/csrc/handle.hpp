@@ -22,6 +22,8 @@ struct lsr_handle_s {
   double euclidean_fitness_eps = -1.7976931348623157e308;
   int num_threads = 0, ransac_iterations = 0;
   int profile = 0;
+  int ndt_threads = 0;       // LSR_NDT_WORKGROUP: 0 = automatic, 128 / 256
+  int ndt_table_mode = -1;   // LSR_NDT_TABLE_MODE: -1 = automatic, else lsr::NdtTableMode
 
   std::shared_ptr<TargetData> target;
   DeviceCloud source;

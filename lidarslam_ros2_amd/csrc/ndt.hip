@@ -18,6 +18,7 @@
 
 #include <cmath>
 
+#include "grid_device.hpp"
 #include "sort.hpp"
 
 namespace lsr {
@@ -281,18 +282,100 @@ __device__ __forceinline__ void solve6(const LdsDouble* H, const double* __restr
 }
 
 // Mark the next evaluation request for pose x_t; the transform / angle tables themselves are built
-// by build_request() right after the controller returns, spread over several lanes.
+// by build_request() right after the controller returns, spread over the lanes of the workgroup.
 __device__ __forceinline__ void request_eval(LdsState* S, int want_hessian, bool refresh_hang, int phase) {
   S->want_hessian = want_hessian;
   S->phase = phase;
   S->pad1 = refresh_hang ? 3 : 1;  // bit0: build T/jang for x_t, bit1: also hang
 }
 
+// The angular coefficient tables of eq. 6.19 (jang, 24 entries) and eq. 6.21 (hang, 48 entries) as DATA: every entry is
+//   s1 * (f[u1] * f[u2]) + s2 * ((f[v1] * f[v2]) * f[v3]),   f = {1, cx, cy, cz, sx, sy, sz, 0},  s in {0, +1, -1}
+// so 72 lanes evaluate the 72 entries with one uniform instruction sequence (eight different formulas on one lane
+// cost the sum of all of them; eight formulas on eight lanes of one wave cost the same: divergence serialises).
+// The products are formed in the same association as the scalar code in angle_tables() ((a*b)*c).
+namespace angtab {
+enum { ONE = 0, CX = 1, CY = 2, CZ = 3, SX = 4, SY = 5, SZ = 6, NIL = 7, P = 1, M = 2, Z = 0 };
+constexpr unsigned int e(int s1, int u1, int u2, int s2, int v1, int v2, int v3) {
+  return (unsigned)u1 | ((unsigned)u2 << 3) | ((unsigned)v1 << 6) | ((unsigned)v2 << 9) | ((unsigned)v3 << 12) | ((unsigned)s1 << 15) |
+         ((unsigned)s2 << 17);
+}
+constexpr unsigned int two(int s1, int u1, int u2) { return e(s1, u1, u2, Z, ONE, ONE, ONE); }
+constexpr unsigned int three(int s2, int v1, int v2, int v3) { return e(Z, ONE, ONE, s2, v1, v2, v3); }
+constexpr unsigned int zero() { return e(Z, ONE, ONE, Z, ONE, ONE, ONE); }
+}  // namespace angtab
+
+#define LSR_ANGLE_ENTRIES \
+    angtab::e(angtab::M, angtab::SX, angtab::SZ, angtab::P, angtab::CX, angtab::SY, angtab::CZ), \
+    angtab::e(angtab::M, angtab::SX, angtab::CZ, angtab::M, angtab::CX, angtab::SY, angtab::SZ), \
+    angtab::two(angtab::M, angtab::CX, angtab::CY), \
+    angtab::e(angtab::P, angtab::CX, angtab::SZ, angtab::P, angtab::SX, angtab::SY, angtab::CZ), \
+    angtab::e(angtab::P, angtab::CX, angtab::CZ, angtab::M, angtab::SX, angtab::SY, angtab::SZ), \
+    angtab::two(angtab::M, angtab::SX, angtab::CY), \
+    angtab::two(angtab::M, angtab::SY, angtab::CZ), angtab::two(angtab::P, angtab::SY, angtab::SZ), angtab::two(angtab::P, angtab::CY, angtab::ONE), \
+    angtab::three(angtab::P, angtab::SX, angtab::CY, angtab::CZ), angtab::three(angtab::M, angtab::SX, angtab::CY, angtab::SZ), \
+    angtab::two(angtab::P, angtab::SX, angtab::SY), \
+    angtab::three(angtab::M, angtab::CX, angtab::CY, angtab::CZ), angtab::three(angtab::P, angtab::CX, angtab::CY, angtab::SZ), \
+    angtab::two(angtab::M, angtab::CX, angtab::SY), \
+    angtab::two(angtab::M, angtab::CY, angtab::SZ), angtab::two(angtab::M, angtab::CY, angtab::CZ), angtab::zero(), \
+    angtab::e(angtab::P, angtab::CX, angtab::CZ, angtab::M, angtab::SX, angtab::SY, angtab::SZ), \
+    angtab::e(angtab::M, angtab::CX, angtab::SZ, angtab::M, angtab::SX, angtab::SY, angtab::CZ), angtab::zero(), \
+    angtab::e(angtab::P, angtab::SX, angtab::CZ, angtab::P, angtab::CX, angtab::SY, angtab::SZ), \
+    angtab::e(angtab::M, angtab::SX, angtab::SZ, angtab::P, angtab::CX, angtab::SY, angtab::CZ), angtab::zero(), \
+    angtab::e(angtab::M, angtab::CX, angtab::SZ, angtab::M, angtab::SX, angtab::SY, angtab::CZ), \
+    angtab::e(angtab::M, angtab::CX, angtab::CZ, angtab::P, angtab::SX, angtab::SY, angtab::SZ), angtab::two(angtab::P, angtab::SX, angtab::CY), \
+    angtab::e(angtab::M, angtab::SX, angtab::SZ, angtab::P, angtab::CX, angtab::SY, angtab::CZ), \
+    angtab::e(angtab::M, angtab::SX, angtab::CZ, angtab::M, angtab::CX, angtab::SY, angtab::SZ), angtab::two(angtab::M, angtab::CX, angtab::CY), \
+    angtab::three(angtab::P, angtab::CX, angtab::CY, angtab::CZ), angtab::three(angtab::M, angtab::CX, angtab::CY, angtab::SZ), \
+    angtab::two(angtab::P, angtab::CX, angtab::SY), \
+    angtab::three(angtab::P, angtab::SX, angtab::CY, angtab::CZ), angtab::three(angtab::M, angtab::SX, angtab::CY, angtab::SZ), \
+    angtab::two(angtab::P, angtab::SX, angtab::SY), \
+    angtab::e(angtab::M, angtab::SX, angtab::CZ, angtab::M, angtab::CX, angtab::SY, angtab::SZ), \
+    angtab::e(angtab::P, angtab::SX, angtab::SZ, angtab::M, angtab::CX, angtab::SY, angtab::CZ), angtab::zero(), \
+    angtab::e(angtab::P, angtab::CX, angtab::CZ, angtab::M, angtab::SX, angtab::SY, angtab::SZ), \
+    angtab::e(angtab::M, angtab::CX, angtab::SZ, angtab::M, angtab::SX, angtab::SY, angtab::CZ), angtab::zero(), \
+    angtab::two(angtab::M, angtab::CY, angtab::CZ), angtab::two(angtab::P, angtab::CY, angtab::SZ), \
+    angtab::two(angtab::P, angtab::SY, angtab::ONE), \
+    angtab::three(angtab::M, angtab::SX, angtab::SY, angtab::CZ), angtab::three(angtab::P, angtab::SX, angtab::SY, angtab::SZ), \
+    angtab::two(angtab::P, angtab::SX, angtab::CY), \
+    angtab::three(angtab::P, angtab::CX, angtab::SY, angtab::CZ), angtab::three(angtab::M, angtab::CX, angtab::SY, angtab::SZ), \
+    angtab::two(angtab::M, angtab::CX, angtab::CY), \
+    angtab::two(angtab::P, angtab::SY, angtab::SZ), angtab::two(angtab::P, angtab::SY, angtab::CZ), angtab::zero(), \
+    angtab::three(angtab::M, angtab::SX, angtab::CY, angtab::SZ), angtab::three(angtab::M, angtab::SX, angtab::CY, angtab::CZ), angtab::zero(), \
+    angtab::three(angtab::P, angtab::CX, angtab::CY, angtab::SZ), angtab::three(angtab::P, angtab::CX, angtab::CY, angtab::CZ), angtab::zero(), \
+    angtab::two(angtab::M, angtab::CY, angtab::CZ), angtab::two(angtab::P, angtab::CY, angtab::SZ), angtab::zero(), \
+    angtab::e(angtab::M, angtab::CX, angtab::SZ, angtab::M, angtab::SX, angtab::SY, angtab::CZ), \
+    angtab::e(angtab::M, angtab::CX, angtab::CZ, angtab::P, angtab::SX, angtab::SY, angtab::SZ), angtab::zero(), \
+    angtab::e(angtab::M, angtab::SX, angtab::SZ, angtab::P, angtab::CX, angtab::SY, angtab::CZ), \
+    angtab::e(angtab::M, angtab::SX, angtab::CZ, angtab::M, angtab::CX, angtab::SY, angtab::SZ), angtab::zero(), \
+    angtab::zero(), angtab::zero(), angtab::zero()
+
+__device__ __constant__ unsigned int k_angle_entries[72] = {LSR_ANGLE_ENTRIES};
+static const unsigned int k_angle_entries_host[72] = {LSR_ANGLE_ENTRIES};
+
+
+__host__ __device__ inline double angle_entry_value(unsigned int ent, const double* f) {
+  const double t1 = f[ent & 7u] * f[(ent >> 3) & 7u];
+  const double t2 = (f[(ent >> 6) & 7u] * f[(ent >> 9) & 7u]) * f[(ent >> 12) & 7u];
+  const unsigned int s1 = (ent >> 15) & 3u, s2 = (ent >> 17) & 3u;
+  const double a = (s1 == 0u) ? 0.0 : ((s1 == 1u) ? t1 : -t1);
+  const double b = (s2 == 0u) ? 0.0 : ((s2 == 1u) ? t2 : -t2);
+  return a + b;
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() makes hipcc drain vmcnt too, which
+// would stall every wave on the voxel-table DMA (global_load_lds) long before its data is needed; the head's
+// intermediate barriers only order LDS accesses, the DMA is drained once, by the last __syncthreads() before the points
+// are evaluated.
+__device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Executed by ALL threads of the workgroup (uniform control flow, two barriers).
-// lanes 0-2: fp64 sin/cos of the three angles (with the reference's 1e-4 snap), lanes 3-5: fp32 sin/cos
-// (the reference composes the point transform from float-cast angles); then four lanes fill
-// jang / hang(lo) / hang(hi) / T + final_T.
-__device__ void build_request(NdtState* S, double* cs_d /*6*/, float* cs_f /*6*/) {
+// lanes 0-2: fp64 sin/cos of the three angles (with the reference's 1e-4 snap), lanes 3-5: fp32 sin/cos (the
+// reference composes the point transform from float-cast angles); then lanes 0..23 (0..71 when the Hessian tables
+// are refreshed) evaluate one table entry each and the last lane of the workgroup builds T + final_T.
+// `ent` = k_angle_entries[tid], fetched with the head loads of the kernel (off the critical path).
+template <int THREADS>
+__device__ __forceinline__ void build_request(NdtState* S, double* f /*8*/, float* cs_f /*6*/, const unsigned int ent) {
   const int tid = threadIdx.x;
   const int mode = S->pad1;
   if (mode == 0) return;  // uniform: every thread reads the same LDS word
@@ -300,49 +383,26 @@ __device__ void build_request(NdtState* S, double* cs_d /*6*/, float* cs_f /*6*/
     const double a = S->x_t[3 + tid];
     double sn, cn;
     if (fabs(a) < 10e-5) { cn = 1.0; sn = 0.0; } else { sincos(a, &sn, &cn); }
-    cs_d[tid] = cn;
-    cs_d[3 + tid] = sn;
+    f[1 + tid] = cn;
+    f[4 + tid] = sn;
   } else if (tid < 6) {
     const float a = (float)S->x_t[tid];
     float sn, cn;
     sincosf(a, &sn, &cn);
     cs_f[tid - 3] = cn;
     cs_f[tid] = sn;
+  } else if (tid == 6) {
+    f[0] = 1.0;
+    f[7] = 0.0;
   }
-  __syncthreads();
-  const double cx = cs_d[0], cy = cs_d[1], cz = cs_d[2], sx = cs_d[3], sy = cs_d[4], sz = cs_d[5];
-  if (tid == 0) {
-    float* jang = S->jang;
-    jang[0] = (float)(-sx * sz + cx * sy * cz); jang[1] = (float)(-sx * cz - cx * sy * sz); jang[2] = (float)(-cx * cy);
-    jang[3] = (float)(cx * sz + sx * sy * cz);  jang[4] = (float)(cx * cz - sx * sy * sz);  jang[5] = (float)(-sx * cy);
-    jang[6] = (float)(-sy * cz);                jang[7] = (float)(sy * sz);                 jang[8] = (float)(cy);
-    jang[9] = (float)(sx * cy * cz);            jang[10] = (float)(-sx * cy * sz);          jang[11] = (float)(sx * sy);
-    jang[12] = (float)(-cx * cy * cz);          jang[13] = (float)(cx * cy * sz);           jang[14] = (float)(-cx * sy);
-    jang[15] = (float)(-cy * sz);               jang[16] = (float)(-cy * cz);               jang[17] = 0.f;
-    jang[18] = (float)(cx * cz - sx * sy * sz); jang[19] = (float)(-cx * sz - sx * sy * cz); jang[20] = 0.f;
-    jang[21] = (float)(sx * cz + cx * sy * sz); jang[22] = (float)(cx * sy * cz - sx * sz);  jang[23] = 0.f;
-    S->pad1 = 0;
-  } else if (tid == 64 && (mode & 2)) {
-    float* hang = S->hang;
-    hang[0] = (float)(-cx * sz - sx * sy * cz); hang[1] = (float)(-cx * cz + sx * sy * sz); hang[2] = (float)(sx * cy);
-    hang[3] = (float)(-sx * sz + cx * sy * cz); hang[4] = (float)(-cx * sy * sz - sx * cz); hang[5] = (float)(-cx * cy);
-    hang[6] = (float)(cx * cy * cz);            hang[7] = (float)(-cx * cy * sz);           hang[8] = (float)(cx * sy);
-    hang[9] = (float)(sx * cy * cz);            hang[10] = (float)(-sx * cy * sz);          hang[11] = (float)(sx * sy);
-    hang[12] = (float)(-sx * cz - cx * sy * sz); hang[13] = (float)(sx * sz - cx * sy * cz); hang[14] = 0.f;
-    hang[15] = (float)(cx * cz - sx * sy * sz); hang[16] = (float)(-sx * sy * cz - cx * sz); hang[17] = 0.f;
-    hang[18] = (float)(-cy * cz);               hang[19] = (float)(cy * sz);                hang[20] = (float)(S->d1_sign >= 0 ? sy : -sy);
-    hang[21] = (float)(-sx * sy * cz);          hang[22] = (float)(sx * sy * sz);           hang[23] = (float)(sx * cy);
-  } else if (tid == 128 && (mode & 2)) {
-    float* hang = S->hang;
-    hang[24] = (float)(cx * sy * cz);           hang[25] = (float)(-cx * sy * sz);          hang[26] = (float)(-cx * cy);
-    hang[27] = (float)(sy * sz);                hang[28] = (float)(sy * cz);                hang[29] = 0.f;
-    hang[30] = (float)(-sx * cy * sz);          hang[31] = (float)(-sx * cy * cz);          hang[32] = 0.f;
-    hang[33] = (float)(cx * cy * sz);           hang[34] = (float)(cx * cy * cz);           hang[35] = 0.f;
-    hang[36] = (float)(-cy * cz);               hang[37] = (float)(cy * sz);                hang[38] = 0.f;
-    hang[39] = (float)(-cx * sz - sx * sy * cz); hang[40] = (float)(-cx * cz + sx * sy * sz); hang[41] = 0.f;
-    hang[42] = (float)(-sx * sz + cx * sy * cz); hang[43] = (float)(-cx * sy * sz - sx * cz); hang[44] = 0.f;
-    hang[45] = hang[46] = hang[47] = 0.f;
-  } else if (tid == 192) {
+  barrier_lds_only();
+  const int nent = (mode & 2) ? 72 : 24;
+  if (tid < nent) {
+    double val = angle_entry_value(ent, f);
+    if (tid == 24 + 20 && S->d1_sign < 0) val = -val;
+    if (tid < 24) S->jang[tid] = (float)val; else S->hang[tid - 24] = (float)val;
+    if (tid == 0) S->pad1 = 0;
+  } else if (tid == THREADS - 1) {
     // fp32 (Translation * Rx * Ry * Rz), as pose_to_T12
     const float fcx = cs_f[0], fcy = cs_f[1], fcz = cs_f[2], fsx = cs_f[3], fsy = cs_f[4], fsz = cs_f[5];
     const float a00 = fcy, a02 = fsy;
@@ -355,7 +415,7 @@ __device__ void build_request(NdtState* S, double* cs_d /*6*/, float* cs_f /*6*/
     T[3] = (float)S->x_t[0]; T[7] = (float)S->x_t[1]; T[11] = (float)S->x_t[2];
     T12_to_colmajor16(T, S->final_T);  // final_transformation_ is assigned before every MT pass
   }
-  __syncthreads();
+  barrier_lds_only();
 }
 
 // K4: consume the sums of the pass that just finished and decide what happens next.
@@ -568,59 +628,69 @@ struct Offsets<27> {
 // value produced by its own launch.
 //  BYVAL: a single-registration launch carries its NdtProblem in the kernel arguments, which removes
 //         one dependent memory round trip from the latency chain of every pass.
-//  DENSE: leaf records are stored per grid cell (no cell->slot indirection): one dependent gather
-//         less per point; chosen when the dense table is small enough (ndt_build_grid).
-template <int NOFF, bool BYVAL, bool DENSE>
-__global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq) {
+//  TAB:   where the leaf records live (NdtTableMode).  NDT_TAB_LDS stages the whole valid-voxel table
+//         (uint16 cell->slot map + 48-byte records, <= NDT_LDS_TABLE_MAX) into LDS with wave-wide 16-byte
+//         global->LDS DMA issued right after the state has landed: the copy flies while one lane runs the
+//         controller, and the 7 x 3 dependent gathers of a point become ds_read_b128 (no L2 round trip).
+//  THREADS: workgroup size (256: fewer partial rows for every head to read; 128: every CU gets a workgroup
+//         for a 30k-point scan and the LDS gathers of a CU halve).
+template <int NOFF, bool BYVAL, int TAB, int THREADS>
+__global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq) {
   const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
   if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x;
   LSR_STAMP(0)
   LSR_SPAN_BEGIN(seq)
 
-  // LDS: [value][64 quad sums] transpose buffer (pitch 72: conflict free ds_*_b64) — also the row-sum
-  // scratch of the head —, the state image, the 32 totals.
-  __shared__ double s_raw[29 * NDT_RED_PITCH];
+  constexpr int NQ = THREADS / 4;    // quad sums per value
+  constexpr int PITCH = NQ + 8;      // doubles per row of the transpose buffer (conflict free ds_*_b64)
+  constexpr int NGRP = THREADS / 16; // row groups of the head: 16 lanes x 16 bytes cover one 256-byte partial row
+  constexpr int SEGS = THREADS / 32; // interleaved segments per value in the final row sum
+  // LDS: [value][quad sums] transpose buffer — also the row-sum scratch of the head —, the state image, the totals.
+  __shared__ double s_raw[29 * PITCH];
   __shared__ double s_sum[NDT_NRED];
-  __shared__ double s_lu[8][8];
-  constexpr int STATE_DW = (int)(sizeof(NdtState) / 4);
-  static_assert(sizeof(NdtState) % 8 == 0 && STATE_DW <= 2 * NDT_THREADS, "NdtState copy assumes <= 512 dwords");
-  __shared__ double s_state_d[STATE_DW / 2];
-  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_state_d);
-  double(*s_part)[NDT_RED_PITCH] = reinterpret_cast<double(*)[NDT_RED_PITCH]>(s_raw);
-  double(*s_grp)[NDT_NRED] = reinterpret_cast<double(*)[NDT_NRED]>(s_raw);  // [8][32] doubles, head only
+  __shared__ double s_lu[8][2];
+  constexpr int STATE_Q = (int)(sizeof(NdtState) / 16);
+  static_assert(sizeof(NdtState) % 16 == 0 && STATE_Q <= THREADS, "NdtState copy assumes <= THREADS uint4");
+  static_assert(NGRP * NDT_NRED <= 29 * PITCH, "head scratch aliases the transpose buffer");
+  __shared__ uint4 s_state_q[STATE_Q];
+  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_state_q);
+  double(*s_part)[PITCH] = reinterpret_cast<double(*)[PITCH]>(s_raw);
+  double(*s_grp)[NDT_NRED] = reinterpret_cast<double(*)[NDT_NRED]>(s_raw);  // [NGRP][32] doubles, head only
+  extern __shared__ uint4 s_table[];  // NDT_TAB_LDS: [uint16 cell->slot map | 48-byte records]
 
   const NdtState* __restrict__ Sin = P.st + (seq & 1);
   NdtState* __restrict__ Sout = P.st + ((seq + 1) & 1);
 
   // ---- head: issue everything this workgroup needs from HBM/L2 at once
-  const int stride = P.nblocks * NDT_THREADS;
-  int i = blockIdx.x * NDT_THREADS + tid;
+  const int stride = P.nblocks * THREADS;
+  int i = blockIdx.x * THREADS + tid;
   float x = 0.f, y = 0.f, z = 0.f;
   if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
+  const unsigned int ang_entry = (tid < 72) ? k_angle_entries[tid] : 0u;  // consumed by build_request (off the critical path)
   {
-    const unsigned int* gdw = reinterpret_cast<const unsigned int*>(Sin);
-    const unsigned int st0 = (tid < STATE_DW) ? gdw[tid] : 0u;
-    const unsigned int st1 = (tid + NDT_THREADS < STATE_DW) ? gdw[tid + NDT_THREADS] : 0u;
-    // rows of the previous launch: 8 groups x 32 values; group g owns rows g, g+8, ...; 16 loads in flight
-    const int v = tid & 31, grp = tid >> 5;
-    double sum = 0.0;
+    const uint4* gq = reinterpret_cast<const uint4*>(Sin);
+    const uint4 stq = (tid < STATE_Q) ? gq[tid] : make_uint4(0u, 0u, 0u, 0u);
+    // rows of the previous launch, 16 bytes per lane: lane pair-index v2 = values {2 v2, 2 v2 + 1}; group g owns rows
+    // g, g + NGRP, ...; 8 loads in flight per lane
+    const int v2 = tid & 15, grp = tid >> 4;
+    double2 sum = make_double2(0.0, 0.0);
     if (seq > 0) {
-      const double* base = P.partials + (size_t)((seq + 1) & 1) * P.nblocks * NDT_NRED + v;
-      for (int b0 = grp; b0 < P.nblocks; b0 += 128) {
-        double r[16];
+      const double2* base = reinterpret_cast<const double2*>(P.partials + (size_t)((seq + 1) & 1) * P.nblocks * NDT_NRED) + v2;
+      for (int b0 = grp; b0 < P.nblocks; b0 += 8 * NGRP) {
+        double2 r[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-          const int b = b0 + 8 * k;
-          r[k] = (b < P.nblocks) ? base[(size_t)b * NDT_NRED] : 0.0;
+        for (int k = 0; k < 8; k++) {
+          const int b = b0 + NGRP * k;
+          r[k] = (b < P.nblocks) ? base[(size_t)b * (NDT_NRED / 2)] : make_double2(0.0, 0.0);
         }
-        sum += (((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))) +
-               (((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15])));
+        sum.x += ((r[0].x + r[1].x) + (r[2].x + r[3].x)) + ((r[4].x + r[5].x) + (r[6].x + r[7].x));
+        sum.y += ((r[0].y + r[1].y) + (r[2].y + r[3].y)) + ((r[4].y + r[5].y) + (r[6].y + r[7].y));
       }
     }
-    s_grp[grp][v] = sum;
-    if (tid < STATE_DW) s_state[tid] = st0;
-    if (tid + NDT_THREADS < STATE_DW) s_state[tid + NDT_THREADS] = st1;
+    s_grp[grp][2 * v2] = sum.x;
+    s_grp[grp][2 * v2 + 1] = sum.y;
+    if (tid < STATE_Q) s_state_q[tid] = stq;
   }
   __syncthreads();
   LdsState* L = (LdsState*)s_state;
@@ -630,32 +700,47 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (uniform_i(L->done)) {  // finished earlier: keep both state buffers identical so later launches see it too
     if (blockIdx.x == 0 && seq > 0) {
-      unsigned int* gdw = reinterpret_cast<unsigned int*>(Sout);
-      if (tid < STATE_DW) gdw[tid] = s_state[tid];
-      if (tid + NDT_THREADS < STATE_DW) gdw[tid + NDT_THREADS] = s_state[tid + NDT_THREADS];
+      uint4* gq = reinterpret_cast<uint4*>(Sout);
+      if (tid < STATE_Q) gq[tid] = s_state_q[tid];
     }
     return;
+  }
+  if (TAB == NDT_TAB_LDS) {
+    // voxel table -> LDS by DMA (no VGPR staging): one wave-wide instruction moves 64 x 16 B = 1 KiB to a wave-uniform
+    // LDS base; pose independent, so it is issued BEFORE the controller runs and lands in its shadow
+    // Wave 0 issues none: it calls the controller, and a device function starts with s_waitcnt vmcnt(0) by ABI.
+    const int nchunks = P.lds_bytes >> 10;
+    const unsigned char* img = reinterpret_cast<const unsigned char*>(P.lds_image) + (size_t)(tid & 63) * 16;
+    unsigned char* dst = reinterpret_cast<unsigned char*>(s_table);
+    if (tid >= 64)
+      for (int c = (tid >> 6) - 1; c < nchunks; c += THREADS / 64 - 1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + (size_t)c * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + (size_t)c * 1024), 16, 0, 0);
   }
   if (seq > 0) {
     // rows hold what the request in the state asked for: 29 sums with Hessian, 8 without
     const int nprev = (uniform_i(L->want_hessian) != 0) ? 29 : NDT_NRED_GRAD;
     if (tid < NDT_NRED) {
       double t = 0.0;
-      if (tid < nprev)
-        for (int g2 = 0; g2 < NDT_THREADS / 32; g2++) t += s_grp[g2][tid];
+      if (tid < nprev) {
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int g2 = 0; g2 < NGRP; g2 += 2) { t0 += s_grp[g2][tid]; t1 += s_grp[g2 + 1][tid]; }
+        t = t0 + t1;
+      }
       s_sum[tid] = t;
     }
-    __syncthreads();
+    barrier_lds_only();
     LSR_STAMP(6)
     if (tid == 0) ndt_controller(L, (const LdsDouble*)s_sum);
-    __syncthreads();
-    build_request(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[1][0]));
+    barrier_lds_only();
+    LSR_STAMP(5)
+    build_request<THREADS>(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[4][0]), ang_entry);
     LSR_STAMP(4)
   }
   if (blockIdx.x == 0) {
-    unsigned int* gdw = reinterpret_cast<unsigned int*>(Sout);
-    if (tid < STATE_DW) gdw[tid] = s_state[tid];
-    if (tid + NDT_THREADS < STATE_DW) gdw[tid + NDT_THREADS] = s_state[tid + NDT_THREADS];
+    uint4* gq = reinterpret_cast<uint4*>(Sout);
+    if (tid < STATE_Q) gq[tid] = s_state_q[tid];
   }
   if (uniform_i(L->done)) {
     // the controller has just finished this align(): publish the result into the host mailbox, flag last
@@ -683,7 +768,10 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
 #pragma unroll
   for (int k = 0; k < 12; k++) T[k] = uniform_f(L->T[k]);
   const float leaf = P.leaf;
-  __syncthreads();  // s_grp (aliases the transpose buffer) is dead from here on
+  __syncthreads();  // s_grp (aliases the transpose buffer) is dead from here on; the table DMA has landed (vmcnt(0))
+
+  const unsigned short* s_map = reinterpret_cast<const unsigned short*>(s_table);
+  const float4* s_rec = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(s_table) + P.lds_map_bytes);
 
   double acc[29];
 #pragma unroll
@@ -700,9 +788,9 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
     const int ci = finite_ok ? (int)fx : INT_MIN / 2, cj = finite_ok ? (int)fy : INT_MIN / 2, ck = finite_ok ? (int)fz : INT_MIN / 2;
 
     // Branch-free neighbourhood: every record load is issued up front (out-of-range neighbours read
-    // cell 0 and are masked), so a point costs ONE gather round trip instead of one per neighbour.
+    // cell 0 / slot 0 and are masked), so a point costs ONE gather round trip instead of one per neighbour.
     bool valid[NOFF];
-    size_t ridx[NOFF];
+    int cellv[NOFF];
 #pragma unroll
     for (int o = 0; o < NOFF; o++) {
       int dx, dy, dz;
@@ -710,22 +798,45 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
       const int a = ci + dx, b = cj + dy, c = ck + dz;
       const bool in = (a >= P.min_b[0]) & (a <= P.max_b[0]) & (b >= P.min_b[1]) & (b <= P.max_b[1]) &
                       (c >= P.min_b[2]) & (c <= P.max_b[2]);
-      const int cell = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
-      if (DENSE) {
-        valid[o] = in;
-        ridx[o] = (size_t)cell;
-      } else {
-        const int sl = P.cell_slot[cell];
-        valid[o] = in & (sl >= 0);
-        ridx[o] = (size_t)(sl >= 0 ? sl : 0);
-      }
+      valid[o] = in;
+      cellv[o] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
     }
-    float4 r0[NOFF], r1[NOFF], r2[NOFF];
+    float4 r0[NOFF], r1[NOFF];
+    float c22v[NOFF];
+    if (TAB == NDT_TAB_LDS) {
+      int slot[NOFF];
 #pragma unroll
-    for (int o = 0; o < NOFF; o++) {
-      r0[o] = P.rec[ridx[o] * 4 + 0];
-      r1[o] = P.rec[ridx[o] * 4 + 1];
-      r2[o] = P.rec[ridx[o] * 4 + 2];
+      for (int o = 0; o < NOFF; o++) {
+        const int sl = (int)s_map[cellv[o]];
+        valid[o] = valid[o] & (sl != 0xFFFF);  // the LDS table only holds usable leaves (n >= 6, valid covariance)
+        slot[o] = valid[o] ? sl : 0;
+      }
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) {
+        r0[o] = s_rec[slot[o] * 3 + 0];
+        r1[o] = s_rec[slot[o] * 3 + 1];
+        c22v[o] = reinterpret_cast<const float*>(s_rec + slot[o] * 3 + 2)[0];
+      }
+    } else {
+      size_t ridx[NOFF];
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) {
+        if (TAB == NDT_TAB_DENSE) {
+          ridx[o] = (size_t)cellv[o];
+        } else {
+          const int sl = P.cell_slot[cellv[o]];
+          valid[o] = valid[o] & (sl >= 0);
+          ridx[o] = (size_t)(sl >= 0 ? sl : 0);
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) {
+        r0[o] = P.rec[ridx[o] * 4 + 0];
+        r1[o] = P.rec[ridx[o] * 4 + 1];
+        const float4 r2 = P.rec[ridx[o] * 4 + 2];
+        c22v[o] = r2.x;
+        valid[o] = valid[o] & (r2.y >= 6.f);  // empty / under-populated / invalidated cells carry n < 6
+      }
     }
 
     float score = 0.f, npairs = 0.f;
@@ -733,9 +844,9 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
     float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;  // sum w * (C - d2 Cq Cq^T)
 #pragma unroll
     for (int o = 0; o < NOFF; o++) {
-      const bool leaf_ok = valid[o] & (r2[o].y >= 6.f);  // empty / under-populated / invalidated cells carry n < 6
+      const bool leaf_ok = valid[o];
       const float q0 = tx - r0[o].x, q1 = ty - r0[o].y, q2 = tz - r0[o].z;
-      const float c00 = r0[o].w, c01 = r1[o].x, c02 = r1[o].y, c11 = r1[o].z, c12 = r1[o].w, c22 = r2[o].x;
+      const float c00 = r0[o].w, c01 = r1[o].x, c02 = r1[o].y, c11 = r1[o].z, c12 = r1[o].w, c22 = c22v[o];
       const float Cq0 = fmaf(c00, q0, fmaf(c01, q1, c02 * q2));
       const float Cq1 = fmaf(c01, q0, fmaf(c11, q1, c12 * q2));
       const float Cq2 = fmaf(c02, q0, fmaf(c12, q1, c22 * q2));
@@ -817,8 +928,8 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   }
 
   LSR_STAMP(2)
-  // ---- workgroup reduction: quad sum in registers (DPP) -> LDS transpose [value][64 quads] ->
-  //      8 interleaved segment sums per value -> one partial row
+  // ---- workgroup reduction: quad sum in registers (DPP) -> LDS transpose [value][quad sums] ->
+  //      SEGS interleaved segment sums per value -> one partial row
   const int nred = hess ? 29 : NDT_NRED_GRAD;
   if (hess) {
 #pragma unroll
@@ -840,15 +951,14 @@ __global__ __launch_bounds__(NDT_THREADS) void ndt_eval_kernel(const NdtProblem 
   __syncthreads();
   double* prow = P.partials + ((size_t)(seq & 1) * P.nblocks + blockIdx.x) * NDT_NRED;
   {
-    const int v = tid >> 3, seg = tid & 7;  // 32 values x 8 interleaved segments of the 64 quad sums
+    const int v = tid / SEGS, seg = tid % SEGS;  // 32 values x SEGS interleaved segments of the NQ quad sums
     double t = 0.0;
     if (v < nred) {
 #pragma unroll
-      for (int k = 0; k < NDT_THREADS / 32; k++) t += s_part[v][seg + 8 * k];
+      for (int k = 0; k < NQ / SEGS; k++) t += s_part[v][seg + SEGS * k];
     }
-    t += __shfl_xor(t, 1, 64);
-    t += __shfl_xor(t, 2, 64);
-    t += __shfl_xor(t, 4, 64);
+#pragma unroll
+    for (int m = 1; m < SEGS; m <<= 1) t += __shfl_xor(t, m, 64);
     if (seg == 0 && v < nred) prow[v] = t;  // consumed by EVERY workgroup at the head of the next launch
   }
   LSR_STAMP(3)
@@ -872,31 +982,80 @@ namespace {
 
 }  // namespace
 
+}  // namespace lsr
+// Host-side self check of the table-driven angle coefficients (no device needed): the scalar formulas of
+// angle_tables() next to the 72 table entries evaluated exactly as build_request() does on the device.
+extern "C" int lsr_debug_angle_tables(const double* p6, int d1_sign, float* jang_ref, float* hang_ref, float* jang_tab, float* hang_tab) {
+  if (!p6 || !jang_ref || !hang_ref || !jang_tab || !hang_tab) return LSR_ERR_INVALID_ARGUMENT;
+  lsr::angle_tables(p6, true, d1_sign, jang_ref, hang_ref);
+  double f[8];
+  f[0] = 1.0; f[7] = 0.0;
+  for (int k = 0; k < 3; k++) {
+    const double a = p6[3 + k];
+    if (std::fabs(a) < 10e-5) { f[1 + k] = 1.0; f[4 + k] = 0.0; } else { f[1 + k] = std::cos(a); f[4 + k] = std::sin(a); }
+  }
+  for (int t = 0; t < 72; t++) {
+    double v = lsr::angle_entry_value(lsr::k_angle_entries_host[t], f);
+    if (t == 24 + 20 && d1_sign < 0) v = -v;
+    if (t < 24) jang_tab[t] = (float)v; else hang_tab[t - 24] = (float)v;
+  }
+  return LSR_OK;
+}
+namespace lsr {
+
+template <int NOFF, int TAB, int THREADS>
+static int launch_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs,
+                          int seq) {
+  // dynamic LDS beyond the 64 KiB default needs the attribute once per kernel instantiation
+  static bool allowed[2][64] = {};  // [byval][device]
+  if (dyn_lds > 48 * 1024) {
+    int dev = 0;
+    LSR_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !allowed[byval ? 1 : 0][dev]) {
+      const void* fn = byval ? (const void*)ndt_eval_kernel<NOFF, true, TAB, THREADS> : (const void*)ndt_eval_kernel<NOFF, false, TAB, THREADS>;
+      LSR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NDT_LDS_TABLE_MAX));
+      allowed[byval ? 1 : 0][dev] = true;
+    }
+  }
+  if (byval) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, TAB, THREADS>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq);
+  else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, TAB, THREADS>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq);
+  return LSR_OK;
+}
+
 template <int NOFF>
-static void launch_one(bool byval, bool dense, dim3 grid, dim3 block, hipStream_t stream, const NdtProblem& pv,
-                       const NdtProblem* d_probs, int seq) {
-  if (byval) {
-    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, true>), grid, block, 0, stream, pv, d_probs, seq);
-    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, false>), grid, block, 0, stream, pv, d_probs, seq);
-  } else {
-    if (dense) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, true>), grid, block, 0, stream, pv, d_probs, seq);
-    else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, false>), grid, block, 0, stream, pv, d_probs, seq);
+static int launch_one(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_t stream, const NdtProblem& pv,
+                      const NdtProblem* d_probs, int seq) {
+  const size_t dyn = (cfg.tab == NDT_TAB_LDS) ? (size_t)cfg.lds_bytes : 0;
+  if (cfg.threads == 128) {
+    switch (cfg.tab) {
+      case NDT_TAB_LDS: return launch_variant<NOFF, NDT_TAB_LDS, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
+      case NDT_TAB_COMPACT: return launch_variant<NOFF, NDT_TAB_COMPACT, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
+      default: return launch_variant<NOFF, NDT_TAB_DENSE, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
+    }
+  }
+  switch (cfg.tab) {
+    case NDT_TAB_LDS: return launch_variant<NOFF, NDT_TAB_LDS, 256>(byval, grid, dyn, stream, pv, d_probs, seq);
+    case NDT_TAB_COMPACT: return launch_variant<NOFF, NDT_TAB_COMPACT, 256>(byval, grid, dyn, stream, pv, d_probs, seq);
+    default: return launch_variant<NOFF, NDT_TAB_DENSE, 256>(byval, grid, dyn, stream, pv, d_probs, seq);
   }
 }
 
 // Launches seq0 .. seq0+count-1 of the chain (launch seq consumes the rows of launch seq-1).
-int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, int batch, int max_blocks, int neighborhood,
-                     bool dense, int seq0, int count, hipStream_t stream) {
-  dim3 grid(max_blocks, batch), block(NDT_THREADS);
-  const bool byval = (batch == 1 && h_single != nullptr);
+int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, const NdtLaunchCfg& cfg, int seq0, int count,
+                     hipStream_t stream) {
+  if (cfg.threads != 128 && cfg.threads != 256) { set_last_error("NDT workgroup size must be 128 or 256"); return LSR_ERR_INVALID_ARGUMENT; }
+  dim3 grid(cfg.max_blocks, cfg.batch);
+  const bool byval = (cfg.batch == 1 && h_single != nullptr);
   NdtProblem pv;
   if (byval) pv = *h_single; else std::memset(&pv, 0, sizeof(pv));
   for (int i = 0; i < count; i++) {
-    switch (neighborhood) {
-      case LSR_DIRECT1: launch_one<1>(byval, dense, grid, block, stream, pv, d_probs, seq0 + i); break;
-      case LSR_DIRECT26: launch_one<27>(byval, dense, grid, block, stream, pv, d_probs, seq0 + i); break;
-      default: launch_one<7>(byval, dense, grid, block, stream, pv, d_probs, seq0 + i); break;
+    int st;
+    switch (cfg.neighborhood) {
+      case LSR_DIRECT1: st = launch_one<1>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+      case LSR_DIRECT26: st = launch_one<27>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+      default: st = launch_one<7>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
     }
+    if (st) return st;
   }
   LSR_HIP(hipGetLastError());
   return LSR_OK;
@@ -918,9 +1077,13 @@ inline float ord2f(unsigned int u) {
   return f;
 }
 
-// bbox over finite points: ord[0..2] = min, ord[3..5] = max (order-preserving uint encoding), ord[6] = #finite
+// bbox over finite points.  acc[0..2] = max of ~ord(min) (so that an all-zero buffer is the neutral element of every
+// slot), acc[3..5] = max of ord(max), acc[6] = #finite, acc[7] = arrival ticket.  The last workgroup to arrive publishes
+// the result into the host mailbox (order-preserving uint encoding: bbox[0..2] = min, [3..5] = max, [6] = #finite),
+// raises the token, and leaves acc[] zeroed for the next call: no init copy, no read-back copy, no stream sync.
 __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                   const float* __restrict__ z, int n, unsigned int* __restrict__ ord) {
+                                                   const float* __restrict__ z, int n, unsigned int* __restrict__ acc,
+                                                   BuildMailbox* __restrict__ mb, unsigned int token) {
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   unsigned int cnt = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -956,10 +1119,20 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ x, 
       for (int k = 0; k < 3; k++) {
         float a = fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k]));
         float b = fmaxf(fmaxf(s_mx[0][k], s_mx[1][k]), fmaxf(s_mx[2][k], s_mx[3][k]));
-        atomicMin(&ord[k], f2ord(a));
-        atomicMax(&ord[3 + k], f2ord(b));
+        atomicMax(&acc[k], ~f2ord(a));
+        atomicMax(&acc[3 + k], f2ord(b));
       }
-      atomicAdd(&ord[6], c);
+      atomicAdd(&acc[6], c);
+    }
+    __threadfence();
+    if (atomicAdd(&acc[7], 1u) == gridDim.x - 1) {  // every other workgroup's atomics are complete
+      unsigned int v[7];
+      for (int k = 0; k < 7; k++) v[k] = __hip_atomic_load(&acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < 8; k++) __hip_atomic_store(&acc[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < 3; k++) { mb->bbox[k] = ~v[k]; mb->bbox[3 + k] = v[3 + k]; }
+      mb->bbox[6] = v[6];
+      __threadfence_system();
+      __hip_atomic_store(&mb->bbox_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -1011,66 +1184,7 @@ __global__ __launch_bounds__(256) void leaf_sum_kernel(const float* __restrict__
   }
 }
 
-// Symmetric 3x3 eigen-decomposition (cyclic Jacobi), eigenvalues ascending, eigenvectors in columns.
-__device__ void sym3_eigen_dev(const double* Ain, double* w, double* V) {
-  double a00 = Ain[0], a01 = Ain[1], a02 = Ain[2], a11 = Ain[4], a12 = Ain[5], a22 = Ain[8];
-  double q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  for (int sweep = 0; sweep < 32; sweep++) {
-    double off = a01 * a01 + a02 * a02 + a12 * a12;
-    double diag = a00 * a00 + a11 * a11 + a22 * a22;
-    if (off <= 1e-300 || off <= 1e-34 * diag) break;
-#define LSR_JACOBI(app, aqq, apq, arp, arq, cp, cq)                                   \
-  if (apq != 0.0) {                                                                   \
-    double theta = (aqq - app) / (2.0 * apq);                                         \
-    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
-    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;                                    \
-    double npp = app - t * apq, nqq = aqq + t * apq;                                  \
-    double nrp = c * arp - s * arq, nrq = s * arp + c * arq;                          \
-    app = npp; aqq = nqq; apq = 0.0; arp = nrp; arq = nrq;                            \
-    for (int k = 0; k < 3; k++) {                                                     \
-      double qp = q[k * 3 + cp], qq = q[k * 3 + cq];                                  \
-      q[k * 3 + cp] = c * qp - s * qq;                                                \
-      q[k * 3 + cq] = s * qp + c * qq;                                                \
-    }                                                                                 \
-  }
-    LSR_JACOBI(a00, a11, a01, a02, a12, 0, 1)
-    LSR_JACOBI(a00, a22, a02, a01, a12, 0, 2)
-    LSR_JACOBI(a11, a22, a12, a01, a02, 1, 2)
-#undef LSR_JACOBI
-  }
-  double d[3] = {a00, a11, a22};
-  int i0 = 0, i1 = 1, i2 = 2;
-  if (d[i0] > d[i1]) { int t = i0; i0 = i1; i1 = t; }
-  if (d[i1] > d[i2]) { int t = i1; i1 = i2; i2 = t; }
-  if (d[i0] > d[i1]) { int t = i0; i0 = i1; i1 = t; }
-  int idx[3] = {i0, i1, i2};
-  for (int k = 0; k < 3; k++) {
-    w[k] = d[idx[k]];
-    for (int i = 0; i < 3; i++) V[i * 3 + k] = q[i * 3 + idx[k]];
-  }
-}
-
-__device__ bool sym3_inverse_dev(const double* A, double* Ai) {
-  double c00 = A[4] * A[8] - A[5] * A[7];
-  double c01 = A[5] * A[6] - A[3] * A[8];
-  double c02 = A[3] * A[7] - A[4] * A[6];
-  double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
-  double id = 1.0 / det;
-  Ai[0] = c00 * id;
-  Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id;
-  Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
-  Ai[3] = c01 * id;
-  Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id;
-  Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
-  Ai[6] = c02 * id;
-  Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id;
-  Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
-  bool ok = true;
-  for (int k = 0; k < 9; k++) ok = ok && isfinite(Ai[k]);
-  return ok;
-}
-
-// K2: one thread per leaf: mean, single-pass covariance, (n-1)/n, eigenvalue clamp, inverse.
+// K2: one thread per leaf: mean, single-pass covariance, (n-1)/n, eigenvalue clamp, inverse (leaf_finalize_dev).
 __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __restrict__ sums, const unsigned int* __restrict__ run_key,
                                                             const int* __restrict__ run_cnt, int n_runs, int min_points,
                                                             double eig_mult, float4* __restrict__ rec,
@@ -1081,48 +1195,18 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __rest
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_runs) return;
   const unsigned int key = run_key[r];
-  int n = run_cnt[r];
   if (key == sentinel) {  // the run of non-finite points: not a leaf
     leaf_key[r] = -1;
     leaf_n[r] = 0;
     return;
   }
-  const double* s = sums + (size_t)r * 9;
-  const double nn = (double)n;
-  double mean[3] = {s[0] / nn, s[1] / nn, s[2] / nn};
-  double icov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  bool valid = false;
-  if (n >= min_points) {
-    const double sq[9] = {s[3], s[4], s[5], s[4], s[6], s[7], s[5], s[7], s[8]};
-    double cov[9];
-    const double f = (nn - 1.0) / nn;
-    for (int a = 0; a < 3; a++)
-      for (int b = 0; b <= a; b++) {
-        double v = ((sq[a * 3 + b] - 2.0 * (s[a] * mean[b])) / nn + mean[a] * mean[b]) * f;
-        cov[a * 3 + b] = v;
-        cov[b * 3 + a] = v;
-      }
-    double w[3], V[9];
-    sym3_eigen_dev(cov, w, V);
-    if (!(w[0] < 0 || w[1] < 0 || w[2] <= 0)) {
-      const double lmin = eig_mult * w[2];
-      if (w[0] < lmin) {
-        w[0] = lmin;
-        if (w[1] < lmin) w[1] = lmin;
-        // cov = V diag(w) V^T  (V orthonormal: V^-1 = V^T)
-        for (int a = 0; a < 3; a++)
-          for (int b = 0; b < 3; b++)
-            cov[a * 3 + b] = V[a * 3 + 0] * w[0] * V[b * 3 + 0] + V[a * 3 + 1] * w[1] * V[b * 3 + 1] +
-                             V[a * 3 + 2] * w[2] * V[b * 3 + 2];
-      }
-      valid = sym3_inverse_dev(cov, icov);
-    }
-    if (!valid) n = -1;
-  }
+  double mean[3], icov[9];
+  bool valid;
+  const int n = leaf_finalize_dev(sums + (size_t)r * 9, run_cnt[r], min_points, eig_mult, mean, icov, &valid);
   leaf_key[r] = (int)key;
   leaf_n[r] = n;
   for (int k = 0; k < 3; k++) mean64[(size_t)r * 3 + k] = mean[k];
-  for (int k = 0; k < 9; k++) icov64[(size_t)r * 9 + k] = valid ? icov[k] : 0.0;
+  for (int k = 0; k < 9; k++) icov64[(size_t)r * 9 + k] = icov[k];
   const size_t ri = dense ? (size_t)key : (size_t)r;  // dense: record lives at its cell index
   rec[ri * 4 + 0] = make_float4((float)mean[0], (float)mean[1], (float)mean[2], (float)icov[0]);
   rec[ri * 4 + 1] = make_float4((float)icov[1], (float)icov[2], (float)icov[4], (float)icov[5]);
@@ -1172,23 +1256,28 @@ int transform_to_strided(const DeviceCloud& src, const float* d_T16, void* d_out
   return LSR_OK;
 }
 
-// Bounding box over the finite points of a cloud (synchronises the stream).
+// Bounding box over the finite points of a cloud: one launch, the result arrives in the host mailbox (the host polls
+// one word; no copy, no stream synchronisation).
 int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_finite, BuildScratch& sc, hipStream_t stream) {
   const int n = (int)cloud.n;
-  int st = sc.words.reserve(16);
+  *n_finite = 0;
+  for (int k = 0; k < 3; k++) { mn[k] = 0.f; mx[k] = 0.f; }
+  if (n <= 0) return LSR_OK;
+  int st = sc.ensure_mailbox();
   if (st) return st;
-  unsigned int* ord = sc.words.p;
-  unsigned int ord_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
-  LSR_HIP(hipMemcpyAsync(ord, ord_init, sizeof(ord_init), hipMemcpyHostToDevice, stream));
-  if (n > 0) {
-    int nb = std::min((n + 255) / 256, 96);  // one atomic set per workgroup: keep the contention low
-    hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, ord);
+  if (sc.bbox_acc.p == nullptr) {
+    if ((st = sc.bbox_acc.reserve(16))) return st;
+    LSR_HIP(hipMemsetAsync(sc.bbox_acc.p, 0, 16 * sizeof(unsigned int), stream));
   }
-  unsigned int ord_h[8];
-  LSR_HIP(hipMemcpyAsync(ord_h, ord, sizeof(ord_h), hipMemcpyDeviceToHost, stream));
-  LSR_HIP(hipStreamSynchronize(stream));
-  *n_finite = ord_h[6];
-  for (int k = 0; k < 3; k++) { mn[k] = ord2f(ord_h[k]); mx[k] = ord2f(ord_h[3 + k]); }
+  unsigned int token = ++sc.token;
+  if (token == 0) token = ++sc.token;
+  int nb = std::min((n + 255) / 256, 96);  // one atomic set per workgroup: keep the contention low
+  hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, sc.bbox_acc.p, sc.d_mb, token);
+  LSR_HIP(hipGetLastError());
+  if ((st = wait_mailbox_word(&sc.mb.p->bbox_token, token, stream, sc.wait_mode, "bounding box"))) return st;
+  const BuildMailbox& M = *sc.mb.p;
+  *n_finite = M.bbox[6];
+  if (M.bbox[6]) for (int k = 0; k < 3; k++) { mn[k] = ord2f(M.bbox[k]); mx[k] = ord2f(M.bbox[3 + k]); }
   return LSR_OK;
 }
 
@@ -1314,6 +1403,94 @@ int interleave(const DeviceCloud& in, void* d_out, size_t stride_bytes, hipStrea
   return LSR_OK;
 }
 
+// ---- LDS image of the valid-voxel table (NDT_TAB_LDS) ----------------------------------------------------------
+// One workgroup: ordered compaction of the usable leaves (cell order => deterministic slot numbers), uint16 cell->slot
+// map (0xFFFF = no usable leaf) followed by 48-byte records {mean.xyz, c00 | c01 c02 c11 c12 | c22, 0, 0, 0}.  The image is
+// only written when it fits image_cap bytes.  The counts go to the host mailbox (n_valid, n_occupied, lds bytes), then
+// the done token: the host learns the outcome of the whole grid build by polling one word.
+namespace {
+__global__ __launch_bounds__(1024) void lds_pack_kernel(const int* __restrict__ cell_slot, const float4* __restrict__ rec,
+                                                        const int* __restrict__ leaf_n /*nullable: per cell*/, int ncells, int map_bytes,
+                                                        int image_cap, unsigned char* __restrict__ image, BuildMailbox* __restrict__ mb,
+                                                        unsigned int token) {
+  __shared__ int s_cnt[1024];
+  __shared__ int s_occ[16];
+  const int tid = threadIdx.x;
+  const int per = (ncells + 1023) / 1024;
+  const int c0 = min(ncells, tid * per), c1 = min(ncells, c0 + per);
+  int cnt = 0, occ = 0;
+  for (int c = c0; c < c1; c++) {
+    cnt += (cell_slot[c] >= 0);
+    if (leaf_n) occ += (leaf_n[c] != 0);
+  }
+  s_cnt[tid] = cnt;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) occ += __shfl_xor(occ, m, 64);
+  if ((tid & 63) == 0) s_occ[tid >> 6] = occ;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = (tid >= off) ? s_cnt[tid - off] : 0;
+    __syncthreads();
+    s_cnt[tid] += v;
+    __syncthreads();
+  }
+  const int n_valid = s_cnt[1023];
+  const long long want = (((long long)map_bytes + (long long)max(n_valid, 1) * NDT_LDS_REC_BYTES) + 1023) & ~1023ll;
+  const bool fits = image != nullptr && want <= (long long)image_cap && n_valid <= 65534;
+  if (fits) {
+    int slot = s_cnt[tid] - cnt;
+    unsigned short* map = reinterpret_cast<unsigned short*>(image);
+    float4* out = reinterpret_cast<float4*>(image + map_bytes);
+    for (int c = c0; c < c1; c++) {
+      const int ri = cell_slot[c];
+      if (ri >= 0) {
+        const float4 a = rec[(size_t)ri * 4 + 0], b = rec[(size_t)ri * 4 + 1], d = rec[(size_t)ri * 4 + 2];
+        out[(size_t)slot * 3 + 0] = a;
+        out[(size_t)slot * 3 + 1] = b;
+        out[(size_t)slot * 3 + 2] = make_float4(d.x, 0.f, 0.f, 0.f);
+        map[c] = (unsigned short)slot;
+        slot++;
+      } else {
+        map[c] = 0xFFFFu;
+      }
+    }
+    // tail of the image (padding of the map to 16 bytes, of the records to 1 KiB, record 0 of an empty table): zero
+    unsigned int* words = reinterpret_cast<unsigned int*>(image);
+    const int w0 = (ncells * 2 + 3) / 4, w1 = map_bytes / 4;
+    for (int k = w0 + tid; k < w1; k += 1024) words[k] = 0u;
+    if (tid == 0 && (ncells & 1)) map[ncells] = 0u;
+    const int r0 = (map_bytes + n_valid * NDT_LDS_REC_BYTES) / 4, r1 = (int)(want / 4);
+    for (int k = r0 + tid; k < r1; k += 1024) words[k] = 0u;
+  }
+  __syncthreads();
+  if (tid == 0 && mb != nullptr) {
+    int o = 0;
+    for (int k = 0; k < 16; k++) o += s_occ[k];
+    mb->n_valid = n_valid;
+    mb->n_occupied = o;
+    mb->lds_bytes = fits ? (int)want : 0;
+    mb->lds_map_bytes = fits ? map_bytes : 0;
+    __threadfence_system();
+    __hip_atomic_store(&mb->done_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+}  // namespace
+
+// Enqueue the pack; the outcome is read from the host mailbox by ndt_finish_grid().
+int ndt_pack_lds_table(VoxelGridDev& grid, BuildScratch& sc, bool per_cell_leaf_n, unsigned int token, hipStream_t stream) {
+  grid.lds_bytes = grid.lds_map_bytes = 0;
+  int st = sc.ensure_mailbox();
+  if (st) return st;
+  const bool may_fit = grid.ncells > 0 && grid.ncells * 2 + 16 + NDT_LDS_REC_BYTES <= (size_t)NDT_LDS_TABLE_MAX;
+  const int map_bytes = (int)((grid.ncells * 2 + 15) & ~(size_t)15);
+  if (may_fit && (st = grid.lds_image.reserve(NDT_LDS_TABLE_MAX / 16))) return st;
+  hipLaunchKernelGGL(lds_pack_kernel, dim3(1), dim3(1024), 0, stream, grid.cell_slot.p, grid.rec.p,
+                     per_cell_leaf_n ? grid.leaf_n.p : (const int*)nullptr, (int)grid.ncells, map_bytes, (int)NDT_LDS_TABLE_MAX,
+                     may_fit ? reinterpret_cast<unsigned char*>(grid.lds_image.p) : (unsigned char*)nullptr, sc.d_mb, token);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
 int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
   DevBuf<char>& temp = sc.temp;
   DevBuf<unsigned int>& scratch = sc.words;
@@ -1322,35 +1499,16 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
   grid.leaf = leaf;
   grid.n_leaves = grid.n_valid = 0;
   grid.ncells = 0;
+  grid.lds_bytes = grid.lds_map_bytes = 0;
   for (int k = 0; k < 3; k++) { grid.min_b[k] = 0; grid.max_b[k] = -1; grid.div_b[k] = 0; }
   if (n == 0) return LSR_OK;
   const float inv_leaf = 1.0f / leaf;
 
-  // scratch carved from one allocation: ord[8] | key_in[n] | key_out[n] | val_in[n] | val_out[n] | run_key[n] | run_cnt[n] | run_off[n] | nruns | nvalid
-  size_t words = 16 + 7 * (size_t)n + 16;
-  int st = scratch.reserve(words);
-  if (st) return st;
-  unsigned int* ord = scratch.p;
-  unsigned int* key_in = ord + 16;
-  unsigned int* key_out = key_in + n;
-  int* val_in = (int*)(key_out + n);
-  int* val_out = val_in + n;
-  unsigned int* run_key = (unsigned int*)(val_out + n);
-  int* run_cnt = (int*)(run_key + n);
-  int* run_off = run_cnt + n;
-  int* d_nruns = run_off + n;
-  int* d_nvalid = d_nruns + 1;
-
-  unsigned int ord_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
-  LSR_HIP(hipMemcpyAsync(ord, ord_init, sizeof(ord_init), hipMemcpyHostToDevice, stream));
-  int nb = std::min((n + 255) / 256, 96);
-  hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, ord);
-  unsigned int ord_h[8];
-  LSR_HIP(hipMemcpyAsync(ord_h, ord, sizeof(ord_h), hipMemcpyDeviceToHost, stream));
-  LSR_HIP(hipStreamSynchronize(stream));
-  if (ord_h[6] == 0) return LSR_OK;  // no finite point: empty grid
   float mn[3], mx[3];
-  for (int k = 0; k < 3; k++) { mn[k] = ord2f(ord_h[k]); mx[k] = ord2f(ord_h[3 + k]); }
+  unsigned int n_finite = 0;
+  int st = cloud_bbox(cloud, mn, mx, &n_finite, sc, stream);   // host poll #1
+  if (st) return st;
+  if (n_finite == 0) return LSR_OK;  // no finite point: empty grid
   int64_t d[3];
   for (int k = 0; k < 3; k++) d[k] = (int64_t)((mx[k] - mn[k]) * inv_leaf) + 1;
   if (d[0] * d[1] * d[2] > (int64_t)INT32_MAX) {
@@ -1364,14 +1522,41 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
   }
   const int mul1 = grid.div_b[0], mul2 = grid.div_b[0] * grid.div_b[1];
   grid.ncells = (size_t)grid.div_b[0] * grid.div_b[1] * grid.div_b[2];
+  unsigned int token = ++sc.token;
+  if (token == 0) token = ++sc.token;
+
+  if (grid.ncells <= (size_t)VG_DENSE_MAX_CELLS && !sc.force_sort_path) {
+    // dense key space: hand-written counting sort, no further host round trip until the final poll (grid_dense.hip)
+    if ((st = ndt_build_grid_dense(cloud, leaf, grid, sc, stream))) return st;
+    if ((st = ndt_pack_lds_table(grid, sc, true, token, stream))) return st;
+    if ((st = wait_mailbox_word(&sc.mb.p->done_token, token, stream, sc.wait_mode, "voxel grid build"))) return st;  // host poll #2
+    grid.n_valid = sc.mb.p->n_valid;
+    grid.lds_bytes = sc.mb.p->lds_bytes;
+    grid.lds_map_bytes = sc.mb.p->lds_map_bytes;
+    return LSR_OK;
+  }
+
+  // ---- general key space: stable radix sort (rocPRIM) + run-length encoding
   st = grid.cell_slot.reserve(grid.ncells);
   if (st) return st;
   LSR_HIP(hipMemsetAsync(grid.cell_slot.p, 0xFF, grid.ncells * sizeof(int), stream));
   const unsigned int sentinel = (unsigned int)grid.ncells;  // non-finite points: one past the last leaf index
+  // scratch carved from one allocation: pad[16] | key_in[n] | key_out[n] | val_in[n] | val_out[n] | run_key[n] | run_cnt[n] | run_off[n] | nruns | nvalid
+  size_t words = 16 + 7 * (size_t)n + 16;
+  if ((st = scratch.reserve(words))) return st;
+  unsigned int* key_in = scratch.p + 16;
+  unsigned int* key_out = key_in + n;
+  int* val_in = (int*)(key_out + n);
+  int* val_out = val_in + n;
+  unsigned int* run_key = (unsigned int*)(val_out + n);
+  int* run_cnt = (int*)(run_key + n);
+  int* run_off = run_cnt + n;
+  int* d_nruns = run_off + n;
+  int* d_nvalid = d_nruns + 1;
 
   hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n,
                      inv_leaf, grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, sentinel, key_in, val_in);
-  // keys live in [0, ncells]: only that many radix bits are sorted (12 at res 5.0 instead of 32)
+  // keys live in [0, ncells]: only that many radix bits are sorted
   st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), temp, stream);
   if (st) return st;
   st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, temp, stream);
@@ -1403,11 +1588,12 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
                      6, 0.01, grid.rec.p, grid.mean64.p, grid.icov64.p, grid.leaf_key.p, grid.leaf_n.p, grid.cell_slot.p,
                      d_nvalid, grid.dense ? 1 : 0, sentinel);
   LSR_HIP(hipGetLastError());
-  int n_valid = 0;
-  LSR_HIP(hipMemcpyAsync(&n_valid, d_nvalid, sizeof(int), hipMemcpyDeviceToHost, stream));
-  LSR_HIP(hipStreamSynchronize(stream));
   grid.n_leaves = n_runs;  // includes the sentinel run if non-finite points exist (leaf_key = -1)
-  grid.n_valid = n_valid;
+  if ((st = ndt_pack_lds_table(grid, sc, false, token, stream))) return st;
+  if ((st = wait_mailbox_word(&sc.mb.p->done_token, token, stream, sc.wait_mode, "voxel grid build"))) return st;
+  grid.n_valid = sc.mb.p->n_valid;
+  grid.lds_bytes = sc.mb.p->lds_bytes;
+  grid.lds_map_bytes = sc.mb.p->lds_map_bytes;
   return LSR_OK;
 }
 

@@ -22,9 +22,18 @@ enum NdtPhase : int {
 
 constexpr int NDT_NRED = 32;       // doubles per partial row: [0]=score [1..6]=grad [7]=#pairs [8..28]=Hessian upper triangle
 constexpr int NDT_NRED_GRAD = 8;   // entries reduced on gradient-only passes
-constexpr int NDT_THREADS = 256;
+constexpr int NDT_THREADS = 256;       // default workgroup size of the derivative pass (128 is the other instantiation)
 constexpr int NDT_MAX_BLOCKS = 1024;
-constexpr int NDT_RED_PITCH = 72;   // doubles per row of the LDS transpose buffer (64 quad sums + pad)
+constexpr int NDT_LDS_REC_BYTES = 48;  // LDS-resident leaf record: {mean.xyz, c00 | c01 c02 c11 c12 | c22, -, -, -}
+constexpr int NDT_LDS_TABLE_MAX = 128 * 1024;  // largest voxel-table image staged into LDS (160 KiB per CU on gfx950)
+
+// Where the derivative pass finds the leaf records (chosen per launch by the host):
+enum NdtTableMode : int {
+  NDT_TAB_DENSE = 0,    // 64-byte records per grid cell in global memory (no cell->slot indirection)
+  NDT_TAB_COMPACT = 1,  // cell_slot[] -> compact 64-byte records in global memory (huge grids)
+  NDT_TAB_LDS = 2       // the whole valid-voxel table (uint16 cell->slot map + 48-byte records) staged into LDS at the
+                        // head of every launch, in the shadow of the controller: gathers become ds_read_b128
+};
 
 struct NdtState {
   // ---- evaluation request, read by every workgroup of the next launch
@@ -78,6 +87,9 @@ struct NdtProblem {
   int max_b[3];
   int mul1, mul2;
   float leaf;
+  int lds_map_bytes;        // NDT_TAB_LDS: bytes of the uint16 cell->slot map at the start of lds_image (multiple of 16)
+  const uint4* lds_image;   // NDT_TAB_LDS: [map | records], padded to a multiple of 1 KiB (one wave-wide 16-byte DMA)
+  int lds_bytes;
   int pad;
   NdtState* st;             // [2] double buffered by launch parity
   double* partials;         // [2][nblocks][NDT_NRED]
@@ -95,13 +107,29 @@ void ndt_gauss_constants(double resolution, double outlier_ratio, double* d1, do
 
 int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_finite, BuildScratch& sc, hipStream_t stream);
 
-// K1/K2: build grid from the SoA cloud. Synchronises the stream (host needs the bbox + leaf count).
+// K1/K2: build grid from the SoA cloud.  Returns once the grid is complete (host polls the build mailbox twice).
 int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
 
-// Launch `count` chained derivative+controller passes for `batch` problems.
+// Geometry of a launch chain (fixed for the whole align()).
+struct NdtLaunchCfg {
+  int batch = 1;
+  int max_blocks = 1;      // grid.x (largest nblocks of the batch)
+  int neighborhood = LSR_DIRECT7;
+  int tab = NDT_TAB_DENSE; // NdtTableMode
+  int threads = NDT_THREADS;
+  int lds_bytes = 0;       // dynamic LDS (largest lds_bytes of the batch) when tab == NDT_TAB_LDS
+};
+// Launch `count` chained derivative+controller passes.
 // h_single (nullable): host copy of the problem, passed by value when batch == 1.
-int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, int batch, int max_blocks, int neighborhood,
-                     bool dense, int seq0, int count, hipStream_t stream);
+int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, const NdtLaunchCfg& cfg, int seq0, int count,
+                     hipStream_t stream);
+// Enqueue the LDS image of the valid-voxel table (grid.lds_image) after the leaf records exist; the kernel publishes
+// n_valid / lds_bytes (0 when the table does not fit NDT_LDS_TABLE_MAX) and the `token` into the host mailbox.
+int ndt_pack_lds_table(VoxelGridDev& grid, BuildScratch& sc, bool per_cell_leaf_n, unsigned int token, hipStream_t stream);
+// K1/K2 for dense key spaces (grid_dense.hip): counting sort + per-cell sums + finalisation, everything enqueued, no host
+// round trip.  grid.min_b / div_b / ncells must be set.
+constexpr int VG_DENSE_MAX_CELLS = 16383;
+int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
 // Host: controller state at the entry of computeTransformation (guess nullable = identity).
 void ndt_fill_initial_state(NdtState& st, const float* guess16, const NdtParamsHost& prm, int n_points);
 // Fill a diagnostic request on the host (lsr_ndt_derivatives).
