@@ -96,6 +96,7 @@ void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_part
   P.pad = 0;
   P.st = d_state;
   P.partials = d_partials;
+  P.bins = h->d_bins.p;
   P.mailbox = nullptr;
 }
 
@@ -208,6 +209,9 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   cfg.batch = B;
   cfg.neighborhood = lead->ndt.neighborhood;
   cfg.threads = (lead->ndt_threads == 128 || lead->ndt_threads == 256) ? lead->ndt_threads : NDT_THREADS;
+  // single registrations run four lanes per point on every CU (quad kernel) unless the tuning key says otherwise
+  cfg.quad = (B == 1 && lead->ndt_quad != 0) ? 1 : 0;
+  if (cfg.quad) cfg.threads = NDT_QUAD_POINTS;  // points per workgroup pass: sizes nblocks
   {
     bool all_lds = true, all_dense = true;
     int lds_max = 0;
@@ -220,8 +224,13 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     int tab = all_lds ? NDT_TAB_LDS : (all_dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT);
     if (lead->ndt_table_mode == NDT_TAB_DENSE && all_dense) tab = NDT_TAB_DENSE;   // tuning override (only where valid)
     if (lead->ndt_table_mode == NDT_TAB_COMPACT) tab = NDT_TAB_COMPACT;
+    if (cfg.quad && tab == NDT_TAB_LDS && lds_max > NDT_LDS_TABLE_MAX_QUAD) tab = all_dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT;
     cfg.tab = tab;
     cfg.lds_bytes = (tab == NDT_TAB_LDS) ? lds_max : 0;
+  }
+  if (cfg.quad) {
+    if ((st = lead->d_bins.reserve((size_t)NDT_NBANKS * NDT_BANK_WORDS))) return st;
+    LSR_HIP(hipMemsetAsync(lead->d_bins.p, 0, sizeof(long long) * NDT_NBANKS * NDT_BANK_WORDS, lead->stream));
   }
   size_t tot_blocks = 0;
   int max_blocks = 1;
@@ -358,6 +367,7 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   // tuning defaults may be preset from the environment (A/B runs without touching the caller)
   if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 128 || v == 256) h->ndt_threads = v; }
   if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 2) h->ndt_table_mode = v; }
+  if (const char* e = std::getenv("LSR_NDT_QUAD")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_quad = v; }
   if (const char* e = std::getenv("LSR_WAIT_MODE")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->scratch.wait_mode = v; }
   if (const char* e = std::getenv("LSR_GRID_BUILDER")) { h->scratch.force_sort_path = (std::atoi(e) == 1); }
   if (stream) {
@@ -449,6 +459,9 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
     case LSR_NDT_TABLE_MODE:
       if (v < -1 || v > 2) { set_last_error("NDT table mode must be -1 (auto), 0 dense, 1 compact, 2 LDS"); return LSR_ERR_INVALID_ARGUMENT; }
       h->ndt_table_mode = v; return LSR_OK;
+    case LSR_NDT_QUAD:
+      if (v < -1 || v > 1) { set_last_error("NDT quad mode must be -1 (auto), 0 or 1"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->ndt_quad = v; return LSR_OK;
     case LSR_GRID_BUILDER:
       if (v < 0 || v > 1) { set_last_error("grid builder must be 0 (auto) or 1 (radix-sort builder)"); return LSR_ERR_INVALID_ARGUMENT; }
       h->scratch.force_sort_path = (v == 1);
@@ -475,6 +488,7 @@ int lsr_get_i32(lsr_handle h, int key, int* v) {
     case LSR_PROFILE: *v = h->profile; return LSR_OK;
     case LSR_NDT_WORKGROUP: *v = h->ndt_threads; return LSR_OK;
     case LSR_NDT_TABLE_MODE: *v = h->ndt_table_mode; return LSR_OK;
+    case LSR_NDT_QUAD: *v = h->ndt_quad; return LSR_OK;
     case LSR_GRID_BUILDER: *v = h->scratch.force_sort_path ? 1 : 0; return LSR_OK;
     case LSR_WAIT_MODE: *v = h->scratch.wait_mode; return LSR_OK;
     default: set_last_error("unknown i32 key"); return LSR_ERR_INVALID_ARGUMENT;
@@ -922,6 +936,16 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
     if (h->ndt_table_mode == NDT_TAB_DENSE && g.dense) cfg.tab = NDT_TAB_DENSE;
     if (h->ndt_table_mode == NDT_TAB_COMPACT) cfg.tab = NDT_TAB_COMPACT;
     cfg.lds_bytes = (cfg.tab == NDT_TAB_LDS) ? g.lds_bytes : 0;
+  }
+  cfg.quad = (h->ndt_quad != 0) ? 1 : 0;
+  if (cfg.quad) {
+    cfg.threads = NDT_QUAD_POINTS;
+    if (cfg.tab == NDT_TAB_LDS && cfg.lds_bytes > NDT_LDS_TABLE_MAX_QUAD) {
+      cfg.tab = h->target->grid.dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT;
+      cfg.lds_bytes = 0;
+    }
+    if ((st = h->d_bins.reserve((size_t)NDT_NBANKS * NDT_BANK_WORDS))) return st;
+    LSR_HIP(hipMemsetAsync(h->d_bins.p, 0, sizeof(long long) * NDT_NBANKS * NDT_BANK_WORDS, h->stream));
   }
   int nb = ndt_nblocks(h->source.n, 1, cfg.threads);
   cfg.max_blocks = nb;

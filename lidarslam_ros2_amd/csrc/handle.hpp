@@ -24,6 +24,7 @@ struct lsr_handle_s {
   int profile = 0;
   int ndt_threads = 0;       // LSR_NDT_WORKGROUP: 0 = automatic, 128 / 256
   int ndt_table_mode = -1;   // LSR_NDT_TABLE_MODE: -1 = automatic, else lsr::NdtTableMode
+  int ndt_quad = -1;         // LSR_NDT_QUAD: -1 = automatic (single registrations), 0 = one lane per point, 1 = four
 
   std::shared_ptr<TargetData> target;
   DeviceCloud source;
@@ -39,6 +40,7 @@ struct lsr_handle_s {
   // NDT run-time buffers (batch-capable: the leader of a batch owns arrays for all members)
   DevBuf<NdtState> d_state;
   DevBuf<double> d_partials;
+  DevBuf<long long> d_bins;   // quad kernel: NDT_NBANKS banks of int64 accumulators
   DevBuf<NdtProblem> d_prob;
   PinBuf<NdtState> h_state;
   PinBuf<NdtProblem> h_prob;

@@ -178,35 +178,56 @@ __device__ __forceinline__ double wave_sum(double v) {
 typedef __attribute__((address_space(3))) NdtState LdsState;
 typedef __attribute__((address_space(3))) double LdsDouble;
 
+// fp64 division / square root for the More-Thuente interpolation formulas, on ONE lane with the rest of the chip
+// waiting: hardware seed (v_rcp_f64 / v_rsq_f64) + two Newton steps + one residual correction = ~10 dependent
+// instructions instead of the ~35 of the IEEE sequences (div_scale / div_fmas / div_fixup).  Results are within 1 ulp
+// of the correctly rounded ones; badly scaled operands take the IEEE path.
+__device__ __forceinline__ double mt_div(double a, double b) {
+  if (!(fabs(b) > 1e-290 && fabs(b) < 1e290)) return a / b;  // zero / denormal / huge / NaN divisor: the IEEE sequence
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double mt_sqrt(double x) {
+  if (!(x > 1e-290 && x < 1e290)) return sqrt(x);  // zero / negative / denormal / huge / NaN: the IEEE sequence
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  const double s = x * y;
+  return fma(fma(-s, s, x), 0.5 * y, s);
+}
+
 // ---- More-Thuente helpers ----
 __device__ __forceinline__ double mt_trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t,
                                  double f_t, double g_t) {
   if (f_t > f_l) {
-    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
-    double w = sqrt(z * z - g_t * g_l);
-    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
-    double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    double z = mt_div(3 * (f_t - f_l), a_t - a_l) - g_t - g_l;
+    double w = mt_sqrt(z * z - g_t * g_l);
+    double a_c = a_l + mt_div((a_t - a_l) * (w - g_l - z), g_t - g_l + 2 * w);
+    double a_q = a_l - mt_div(0.5 * (a_l - a_t) * g_l, g_l - mt_div(f_l - f_t, a_l - a_t));
     if (fabs(a_c - a_l) < fabs(a_q - a_l)) return a_c;
     return 0.5 * (a_q + a_c);
   } else if (g_t * g_l < 0) {
-    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
-    double w = sqrt(z * z - g_t * g_l);
-    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
-    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    double z = mt_div(3 * (f_t - f_l), a_t - a_l) - g_t - g_l;
+    double w = mt_sqrt(z * z - g_t * g_l);
+    double a_c = a_l + mt_div((a_t - a_l) * (w - g_l - z), g_t - g_l + 2 * w);
+    double a_s = a_l - mt_div(a_l - a_t, g_l - g_t) * g_l;
     if (fabs(a_c - a_t) >= fabs(a_s - a_t)) return a_c;
     return a_s;
   } else if (fabs(g_t) <= fabs(g_l)) {
-    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
-    double w = sqrt(z * z - g_t * g_l);
-    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
-    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    double z = mt_div(3 * (f_t - f_l), a_t - a_l) - g_t - g_l;
+    double w = mt_sqrt(z * z - g_t * g_l);
+    double a_c = a_l + mt_div((a_t - a_l) * (w - g_l - z), g_t - g_l + 2 * w);
+    double a_s = a_l - mt_div(a_l - a_t, g_l - g_t) * g_l;
     double a_n = (fabs(a_c - a_t) < fabs(a_s - a_t)) ? a_c : a_s;
     if (a_t > a_l) return fmin(a_t + 0.66 * (a_u - a_t), a_n);
     return fmax(a_t + 0.66 * (a_u - a_t), a_n);
   } else {
-    double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
-    double w = sqrt(z * z - g_t * g_u);
-    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+    double z = mt_div(3 * (f_t - f_u), a_t - a_u) - g_t - g_u;
+    double w = mt_sqrt(z * z - g_t * g_u);
+    return a_u + mt_div((a_t - a_u) * (w - g_u - z), g_t - g_u + 2 * w);
   }
 }
 
@@ -615,6 +636,97 @@ struct Offsets<27> {
   }
 };
 
+// One (point, voxel) pair of eq. 6.9-6.13 in the factorised form: the point Jacobian and second derivatives
+// do not depend on the voxel, so a pair only adds to A = sum w C q and E = sum w (C - d2 Cq Cq^T); fp32 per pair with
+// ndt_omp's precision recipe: the weight is scaled by the DOUBLE gauss_d1 and rounded back to float.
+__device__ __forceinline__ void pair_terms(const bool leaf_ok, const bool hess, const float tx, const float ty, const float tz,
+                                           const float4 r0, const float4 r1, const float c22, const float d2, const double d1d,
+                                           float& score, float& npairs, float& A0, float& A1, float& A2, float& E00, float& E01,
+                                           float& E02, float& E11, float& E12, float& E22) {
+  const float q0 = tx - r0.x, q1 = ty - r0.y, q2 = tz - r0.z;
+  const float c00 = r0.w, c01 = r1.x, c02 = r1.y, c11 = r1.z, c12 = r1.w;
+  const float Cq0 = fmaf(c00, q0, fmaf(c01, q1, c02 * q2));
+  const float Cq1 = fmaf(c01, q0, fmaf(c11, q1, c12 * q2));
+  const float Cq2 = fmaf(c02, q0, fmaf(c12, q1, c22 * q2));
+  const float qCq = fmaf(q0, Cq0, fmaf(q1, Cq1, q2 * Cq2));
+  const float e = expf(-d2 * qCq * 0.5f);
+  const float w0 = d2 * e;
+  // ndt_omp drops the whole pair (score included) when d2*e is outside [0,1] or NaN
+  const bool ok = leaf_ok & (w0 <= 1.f) & (w0 >= 0.f);
+  score += ok ? (float)(-d1d * (double)e) : 0.f;
+  npairs += ok ? 1.f : 0.f;
+  const float w = (float)((double)w0 * d1d);
+  A0 = ok ? fmaf(w, Cq0, A0) : A0;
+  A1 = ok ? fmaf(w, Cq1, A1) : A1;
+  A2 = ok ? fmaf(w, Cq2, A2) : A2;
+  if (hess) {
+    const float wd = -w * d2;
+    E00 = ok ? E00 + fmaf(wd * Cq0, Cq0, w * c00) : E00;
+    E01 = ok ? E01 + fmaf(wd * Cq0, Cq1, w * c01) : E01;
+    E02 = ok ? E02 + fmaf(wd * Cq0, Cq2, w * c02) : E02;
+    E11 = ok ? E11 + fmaf(wd * Cq1, Cq1, w * c11) : E11;
+    E12 = ok ? E12 + fmaf(wd * Cq1, Cq2, w * c12) : E12;
+    E22 = ok ? E22 + fmaf(wd * Cq2, Cq2, w * c22) : E22;
+  }
+}
+
+// The 29 per-point terms (score, 3 + 3 gradient, #pairs, 21 Hessian upper triangle) from the point's A / E sums, the point
+// Jacobian J = [I | J3 J4 J5] (eq. 6.18/6.19) and the second-derivative vectors (eq. 6.20/6.21) of the UNTRANSFORMED point.
+// o[8..28] are only written when hess.
+__device__ __forceinline__ void point_terms(const bool hess, const float px, const float py, const float pz, const float score,
+                                            const float npairs, const float A0, const float A1, const float A2, const float E00,
+                                            const float E01, const float E02, const float E11, const float E12, const float E22,
+                                            const LdsState* L, float* __restrict__ o) {
+  const __attribute__((address_space(3))) float* ja = L->jang;
+  const float j_a = fmaf(ja[0], px, fmaf(ja[1], py, ja[2] * pz));
+  const float j_b = fmaf(ja[3], px, fmaf(ja[4], py, ja[5] * pz));
+  const float j_c = fmaf(ja[6], px, fmaf(ja[7], py, ja[8] * pz));
+  const float j_d = fmaf(ja[9], px, fmaf(ja[10], py, ja[11] * pz));
+  const float j_e = fmaf(ja[12], px, fmaf(ja[13], py, ja[14] * pz));
+  const float j_f = fmaf(ja[15], px, ja[16] * py);
+  const float j_g = fmaf(ja[18], px, ja[19] * py);
+  const float j_h = fmaf(ja[21], px, ja[22] * py);
+  // J3 = (0, a, b), J4 = (c, d, e), J5 = (f, g, h)
+  o[0] = score;
+  o[1] = A0;
+  o[2] = A1;
+  o[3] = A2;
+  o[4] = fmaf(A1, j_a, A2 * j_b);
+  o[5] = fmaf(A0, j_c, fmaf(A1, j_d, A2 * j_e));
+  o[6] = fmaf(A0, j_f, fmaf(A1, j_g, A2 * j_h));
+  o[7] = npairs;
+  if (hess) {
+    // E J_k for k = 3,4,5
+    const float e3x = fmaf(E01, j_a, E02 * j_b), e3y = fmaf(E11, j_a, E12 * j_b), e3z = fmaf(E12, j_a, E22 * j_b);
+    const float e4x = fmaf(E00, j_c, fmaf(E01, j_d, E02 * j_e)), e4y = fmaf(E01, j_c, fmaf(E11, j_d, E12 * j_e)),
+                e4z = fmaf(E02, j_c, fmaf(E12, j_d, E22 * j_e));
+    const float e5x = fmaf(E00, j_f, fmaf(E01, j_g, E02 * j_h)), e5y = fmaf(E01, j_f, fmaf(E11, j_g, E12 * j_h)),
+                e5z = fmaf(E02, j_f, fmaf(E12, j_g, E22 * j_h));
+    const __attribute__((address_space(3))) float* ha = L->hang;
+    // second-derivative vectors (eq. 6.20/6.21) dotted with A = sum w C q
+    const float ha2 = fmaf(ha[0], px, fmaf(ha[1], py, ha[2] * pz)), ha3 = fmaf(ha[3], px, fmaf(ha[4], py, ha[5] * pz));
+    const float hb2 = fmaf(ha[6], px, fmaf(ha[7], py, ha[8] * pz)), hb3 = fmaf(ha[9], px, fmaf(ha[10], py, ha[11] * pz));
+    const float hc2 = fmaf(ha[12], px, ha[13] * py), hc3 = fmaf(ha[15], px, ha[16] * py);
+    const float hd1 = fmaf(ha[18], px, fmaf(ha[19], py, ha[20] * pz)), hd2 = fmaf(ha[21], px, fmaf(ha[22], py, ha[23] * pz)),
+                hd3 = fmaf(ha[24], px, fmaf(ha[25], py, ha[26] * pz));
+    const float he1 = fmaf(ha[27], px, ha[28] * py), he2 = fmaf(ha[30], px, ha[31] * py), he3 = fmaf(ha[33], px, ha[34] * py);
+    const float hf1 = fmaf(ha[36], px, ha[37] * py), hf2 = fmaf(ha[39], px, ha[40] * py), hf3 = fmaf(ha[42], px, ha[43] * py);
+    // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+    o[8] = E00;  o[9] = E01;  o[10] = E02;
+    o[11] = e3x; o[12] = e4x; o[13] = e5x;
+    o[14] = E11; o[15] = E12;
+    o[16] = e3y; o[17] = e4y; o[18] = e5y;
+    o[19] = E22;
+    o[20] = e3z; o[21] = e4z; o[22] = e5z;
+    o[23] = fmaf(j_a, e3y, j_b * e3z) + fmaf(A1, ha2, A2 * ha3);                       // (3,3)
+    o[24] = fmaf(j_a, e4y, j_b * e4z) + fmaf(A1, hb2, A2 * hb3);                       // (3,4)
+    o[25] = fmaf(j_a, e5y, j_b * e5z) + fmaf(A1, hc2, A2 * hc3);                       // (3,5)
+    o[26] = fmaf(j_c, e4x, fmaf(j_d, e4y, j_e * e4z)) + fmaf(A0, hd1, fmaf(A1, hd2, A2 * hd3));  // (4,4)
+    o[27] = fmaf(j_c, e5x, fmaf(j_d, e5y, j_e * e5z)) + fmaf(A0, he1, fmaf(A1, he2, A2 * he3));  // (4,5)
+    o[28] = fmaf(j_f, e5x, fmaf(j_g, e5y, j_h * e5z)) + fmaf(A0, hf1, fmaf(A1, hf2, A2 * hf3));  // (5,5)
+  }
+}
+
 // One derivative pass (K3) preceded by the controller step (K4) that consumes the PREVIOUS pass.
 //
 // "Pull" structure: launch number `seq` starts — in EVERY workgroup, redundantly and deterministically
@@ -843,87 +955,20 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
     float A0 = 0.f, A1 = 0.f, A2 = 0.f;                                      // sum w * C q
     float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;  // sum w * (C - d2 Cq Cq^T)
 #pragma unroll
-    for (int o = 0; o < NOFF; o++) {
-      const bool leaf_ok = valid[o];
-      const float q0 = tx - r0[o].x, q1 = ty - r0[o].y, q2 = tz - r0[o].z;
-      const float c00 = r0[o].w, c01 = r1[o].x, c02 = r1[o].y, c11 = r1[o].z, c12 = r1[o].w, c22 = c22v[o];
-      const float Cq0 = fmaf(c00, q0, fmaf(c01, q1, c02 * q2));
-      const float Cq1 = fmaf(c01, q0, fmaf(c11, q1, c12 * q2));
-      const float Cq2 = fmaf(c02, q0, fmaf(c12, q1, c22 * q2));
-      const float qCq = fmaf(q0, Cq0, fmaf(q1, Cq1, q2 * Cq2));
-      const float e = expf(-d2 * qCq * 0.5f);
-      const float w0 = d2 * e;
-      // ndt_omp drops the whole pair (score included) when d2*e is outside [0,1] or NaN
-      const bool ok = leaf_ok & (w0 <= 1.f) & (w0 >= 0.f);
-      score += ok ? (float)(-d1d * (double)e) : 0.f;
-      npairs += ok ? 1.f : 0.f;
-      const float w = (float)((double)w0 * d1d);
-      A0 = ok ? fmaf(w, Cq0, A0) : A0;
-      A1 = ok ? fmaf(w, Cq1, A1) : A1;
-      A2 = ok ? fmaf(w, Cq2, A2) : A2;
-      if (hess) {
-        const float wd = -w * d2;
-        E00 = ok ? E00 + fmaf(wd * Cq0, Cq0, w * c00) : E00;
-        E01 = ok ? E01 + fmaf(wd * Cq0, Cq1, w * c01) : E01;
-        E02 = ok ? E02 + fmaf(wd * Cq0, Cq2, w * c02) : E02;
-        E11 = ok ? E11 + fmaf(wd * Cq1, Cq1, w * c11) : E11;
-        E12 = ok ? E12 + fmaf(wd * Cq1, Cq2, w * c12) : E12;
-        E22 = ok ? E22 + fmaf(wd * Cq2, Cq2, w * c22) : E22;
-      }
-    }
+    for (int o = 0; o < NOFF; o++)
+      pair_terms(valid[o], hess, tx, ty, tz, r0[o], r1[o], c22v[o], d2, d1d, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22);
     const float px = x, py = y, pz = z;
     i += stride;
     if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }   // next point's loads fly under the maths below
     if (npairs == 0.f) continue;
-
-    // Point Jacobian J = [I | J3 J4 J5] from the UNTRANSFORMED point (eq. 6.18/6.19)
-    const __attribute__((address_space(3))) float* ja = L->jang;
-    const float j_a = fmaf(ja[0], px, fmaf(ja[1], py, ja[2] * pz));
-    const float j_b = fmaf(ja[3], px, fmaf(ja[4], py, ja[5] * pz));
-    const float j_c = fmaf(ja[6], px, fmaf(ja[7], py, ja[8] * pz));
-    const float j_d = fmaf(ja[9], px, fmaf(ja[10], py, ja[11] * pz));
-    const float j_e = fmaf(ja[12], px, fmaf(ja[13], py, ja[14] * pz));
-    const float j_f = fmaf(ja[15], px, ja[16] * py);
-    const float j_g = fmaf(ja[18], px, ja[19] * py);
-    const float j_h = fmaf(ja[21], px, ja[22] * py);
-    // J3 = (0, a, b), J4 = (c, d, e), J5 = (f, g, h)
-    acc[0] += (double)score;
-    acc[1] += (double)A0;
-    acc[2] += (double)A1;
-    acc[3] += (double)A2;
-    acc[4] += (double)fmaf(A1, j_a, A2 * j_b);
-    acc[5] += (double)fmaf(A0, j_c, fmaf(A1, j_d, A2 * j_e));
-    acc[6] += (double)fmaf(A0, j_f, fmaf(A1, j_g, A2 * j_h));
-    acc[7] += (double)npairs;
+    float ot[29];
+    point_terms(hess, px, py, pz, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22, L, ot);
     if (hess) {
-      // E J_k for k = 3,4,5
-      const float e3x = fmaf(E01, j_a, E02 * j_b), e3y = fmaf(E11, j_a, E12 * j_b), e3z = fmaf(E12, j_a, E22 * j_b);
-      const float e4x = fmaf(E00, j_c, fmaf(E01, j_d, E02 * j_e)), e4y = fmaf(E01, j_c, fmaf(E11, j_d, E12 * j_e)),
-                  e4z = fmaf(E02, j_c, fmaf(E12, j_d, E22 * j_e));
-      const float e5x = fmaf(E00, j_f, fmaf(E01, j_g, E02 * j_h)), e5y = fmaf(E01, j_f, fmaf(E11, j_g, E12 * j_h)),
-                  e5z = fmaf(E02, j_f, fmaf(E12, j_g, E22 * j_h));
-      const __attribute__((address_space(3))) float* ha = L->hang;
-      // second-derivative vectors (eq. 6.20/6.21) dotted with A = sum w C q
-      const float ha2 = fmaf(ha[0], px, fmaf(ha[1], py, ha[2] * pz)), ha3 = fmaf(ha[3], px, fmaf(ha[4], py, ha[5] * pz));
-      const float hb2 = fmaf(ha[6], px, fmaf(ha[7], py, ha[8] * pz)), hb3 = fmaf(ha[9], px, fmaf(ha[10], py, ha[11] * pz));
-      const float hc2 = fmaf(ha[12], px, ha[13] * py), hc3 = fmaf(ha[15], px, ha[16] * py);
-      const float hd1 = fmaf(ha[18], px, fmaf(ha[19], py, ha[20] * pz)), hd2 = fmaf(ha[21], px, fmaf(ha[22], py, ha[23] * pz)),
-                  hd3 = fmaf(ha[24], px, fmaf(ha[25], py, ha[26] * pz));
-      const float he1 = fmaf(ha[27], px, ha[28] * py), he2 = fmaf(ha[30], px, ha[31] * py), he3 = fmaf(ha[33], px, ha[34] * py);
-      const float hf1 = fmaf(ha[36], px, ha[37] * py), hf2 = fmaf(ha[39], px, ha[40] * py), hf3 = fmaf(ha[42], px, ha[43] * py);
-      // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
-      acc[8] += (double)E00;  acc[9] += (double)E01;  acc[10] += (double)E02;
-      acc[11] += (double)e3x; acc[12] += (double)e4x; acc[13] += (double)e5x;
-      acc[14] += (double)E11; acc[15] += (double)E12;
-      acc[16] += (double)e3y; acc[17] += (double)e4y; acc[18] += (double)e5y;
-      acc[19] += (double)E22;
-      acc[20] += (double)e3z; acc[21] += (double)e4z; acc[22] += (double)e5z;
-      acc[23] += (double)(fmaf(j_a, e3y, j_b * e3z) + fmaf(A1, ha2, A2 * ha3));                       // (3,3)
-      acc[24] += (double)(fmaf(j_a, e4y, j_b * e4z) + fmaf(A1, hb2, A2 * hb3));                       // (3,4)
-      acc[25] += (double)(fmaf(j_a, e5y, j_b * e5z) + fmaf(A1, hc2, A2 * hc3));                       // (3,5)
-      acc[26] += (double)(fmaf(j_c, e4x, fmaf(j_d, e4y, j_e * e4z)) + fmaf(A0, hd1, fmaf(A1, hd2, A2 * hd3)));  // (4,4)
-      acc[27] += (double)(fmaf(j_c, e5x, fmaf(j_d, e5y, j_e * e5z)) + fmaf(A0, he1, fmaf(A1, he2, A2 * he3)));  // (4,5)
-      acc[28] += (double)(fmaf(j_f, e5x, fmaf(j_g, e5y, j_h * e5z)) + fmaf(A0, hf1, fmaf(A1, hf2, A2 * hf3)));  // (5,5)
+#pragma unroll
+      for (int k = 0; k < 29; k++) acc[k] += (double)ot[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDT_NRED_GRAD; k++) acc[k] += (double)ot[k];
     }
   }
 
@@ -960,6 +1005,288 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
 #pragma unroll
     for (int m = 1; m < SEGS; m <<= 1) t += __shfl_xor(t, m, 64);
     if (seg == 0 && v < nred) prow[v] = t;  // consumed by EVERY workgroup at the head of the next launch
+  }
+  LSR_STAMP(3)
+  LSR_SPAN_END(seq)
+}
+
+// ===========================================================================================
+// K3 + K4, "quad" variant for single registrations: FOUR lanes per source point
+// ===========================================================================================
+// A 30k-point scan is 469 waves of one-lane-per-point work on a chip with 1024 SIMDs, and the time of a pass is the
+// dependent-instruction latency of ONE wave (~1000 instructions).  Here a quad of lanes shares a point: lane l takes
+// neighbours l and l + 4 of the DIRECT7 neighbourhood (l, l+4, l+8, ... for DIRECT26), the per-point sums A = sum w C q and
+// E = sum w (C - d2 Cq Cq^T) are combined inside the quad with DPP adds, and the (angle dependent) Jacobian / Hessian terms
+// of the point are then formed by all four lanes (identical values; lane 0 of the quad hands them to the reduction, so the
+// quad-sum step of the one-lane kernel disappears).  512-thread workgroups of 128 points put two waves on every SIMD of
+// every CU.
+// With 235 workgroups the partial-ROW scheme would make every head read twice as many rows; this kernel accumulates the
+// workgroup partials into int64 bins instead (NDT_NBINS chunks of 31 bits against fixed quanta, integer atomics, one row
+// per shard): exact, order independent => bit-reproducible, and the head reads 10 KiB whatever the number of workgroups.
+// Launch seq adds to bank seq % 3, reads bank (seq-1) % 3 and clears bank (seq+1) % 3.
+__device__ __forceinline__ float dpp_quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
+
+template <int NOFF, int TAB>
+__global__ __launch_bounds__(NDT_QUAD_THREADS) void ndt_eval_quad_kernel(const NdtProblem P, const int seq) {
+  constexpr int THREADS = NDT_QUAD_THREADS, PTS = NDT_QUAD_POINTS;
+  constexpr int PITCH = PTS + 8;
+  constexpr int SEGS = THREADS / 32;       // 16 interleaved segments per value in the workgroup sum
+  constexpr int NT = (NOFF + 3) / 4;       // neighbours per lane
+  if ((int)blockIdx.x >= P.nblocks) return;
+  const int tid = threadIdx.x, ql = tid & 3, pq = tid >> 2;
+  LSR_STAMP(0)
+  LSR_SPAN_BEGIN(seq)
+
+  __shared__ double s_part[29][PITCH];
+  __shared__ double s_bin[NDT_NBINS][32];
+  __shared__ double s_sum[NDT_NRED];
+  __shared__ double s_lu[8][2];
+  constexpr int STATE_Q = (int)(sizeof(NdtState) / 16);
+  __shared__ uint4 s_state_q[STATE_Q];
+  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_state_q);
+  extern __shared__ uint4 s_table[];
+
+  const NdtState* __restrict__ Sin = P.st + (seq & 1);
+  NdtState* __restrict__ Sout = P.st + ((seq + 1) & 1);
+
+  // ---- head: everything this workgroup needs from memory in one round trip
+  const int stride = P.nblocks * PTS;
+  int i = blockIdx.x * PTS + pq;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
+  const unsigned int ang_entry = (tid < 72) ? k_angle_entries[tid] : 0u;
+  {
+    const uint4* gq = reinterpret_cast<const uint4*>(Sin);
+    const uint4 stq = (tid < STATE_Q) ? gq[tid] : make_uint4(0u, 0u, 0u, 0u);
+    // bins of the previous launch: thread (k, v) folds the NDT_NSHARDS shards of bin k of value v (exact int64 adds)
+    long long msum = 0;
+    if (seq > 0 && tid < NDT_NBINS * 32) {
+      const long long* b = P.bins + (size_t)((seq + 2) % NDT_NBANKS) * NDT_BANK_WORDS + tid;
+      long long m[NDT_NSHARDS];
+#pragma unroll
+      for (int sh = 0; sh < NDT_NSHARDS; sh++) m[sh] = b[sh * (NDT_NBINS * 32)];
+      msum = ((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7]));
+    }
+    if (tid < NDT_NBINS * 32) {
+      const int k = tid >> 5;
+      // quantum of bin k: 2^(62 - 31 (k + 1)); an int64 below 2^53 converts exactly
+      const double q = __hiloint2double((1023 + 62 - 31 * (k + 1)) << 20, 0);
+      s_bin[k][tid & 31] = (double)msum * q;
+    }
+    if (tid < STATE_Q) s_state_q[tid] = stq;
+  }
+  __syncthreads();
+  LdsState* L = (LdsState*)s_state;
+  LSR_STAMP(1)
+  if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0)  // progress report for the host's launch feeder (relaxed)
+    __hip_atomic_store(&P.mailbox->progress, ((unsigned long long)(unsigned int)L->token << 32) | (unsigned int)seq,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (uniform_i(L->done)) {  // finished earlier: keep both state buffers identical so later launches see it too
+    if (blockIdx.x == 0 && seq > 0) {
+      uint4* gq = reinterpret_cast<uint4*>(Sout);
+      if (tid < STATE_Q) gq[tid] = s_state_q[tid];
+    }
+    return;
+  }
+  if (TAB == NDT_TAB_LDS) {
+    // voxel table -> LDS by DMA, issued by waves 1..7 (wave 0 calls the controller: device functions start with
+    // s_waitcnt vmcnt(0)); lands in the shadow of the controller
+    const int nchunks = P.lds_bytes >> 10;
+    const unsigned char* img = reinterpret_cast<const unsigned char*>(P.lds_image) + (size_t)(tid & 63) * 16;
+    unsigned char* dst = reinterpret_cast<unsigned char*>(s_table);
+    if (tid >= 64)
+      for (int c = (tid >> 6) - 1; c < nchunks; c += THREADS / 64 - 1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + (size_t)c * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + (size_t)c * 1024), 16, 0, 0);
+  }
+  if (seq > 0) {
+    if (tid < NDT_NRED) {
+      // fold the bins smallest quantum first (fixed order); a raised poison slot (overflow / NaN partial) poisons all sums
+      double t = (((s_bin[4][tid] + s_bin[3][tid]) + s_bin[2][tid]) + s_bin[1][tid]) + s_bin[0][tid];
+      if (s_bin[0][31] != 0.0 || s_bin[1][31] != 0.0) t = __longlong_as_double(0x7FF8000000000000ll);
+      s_sum[tid] = t;
+    }
+    barrier_lds_only();
+    LSR_STAMP(6)
+    if (tid == 0) ndt_controller(L, (const LdsDouble*)s_sum);
+    barrier_lds_only();
+    LSR_STAMP(5)
+    build_request<THREADS>(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[4][0]), ang_entry);
+    LSR_STAMP(4)
+  }
+  if (blockIdx.x == 0) {
+    uint4* gq = reinterpret_cast<uint4*>(Sout);
+    if (tid < STATE_Q) gq[tid] = s_state_q[tid];
+  }
+  if (uniform_i(L->done)) {
+    // the controller has just finished this align(): publish the result into the host mailbox, flag last
+    if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0) {
+      NdtMailbox* mb = P.mailbox;
+#pragma unroll
+      for (int k = 0; k < 16; k++) mb->final_T[k] = L->final_T[k];
+      mb->converged = L->converged;
+      mb->nr_iterations = L->nr_iterations;
+      mb->n_evals = L->n_evals;
+      mb->trans_probability = L->trans_probability;
+      mb->last_pairs = L->last_pairs;
+      __threadfence_system();
+      __hip_atomic_store(&mb->done, (unsigned int)L->token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  if (blockIdx.x == 0) {  // clear the bank launch seq + 1 will add to (read last by launch seq - 1, which is complete)
+    uint4* zb = reinterpret_cast<uint4*>(P.bins + (size_t)((seq + 1) % NDT_NBANKS) * NDT_BANK_WORDS);
+    for (int k = tid; k < NDT_BANK_WORDS / 2; k += THREADS) zb[k] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  LSR_STAMP(7)
+
+  // ---- this launch's request, straight from the LDS image
+  const bool hess = uniform_i(L->want_hessian) != 0;
+  const double d1d = uniform_d(L->d1);
+  const float d2 = uniform_f((float)L->d2);
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = uniform_f(L->T[k]);
+  const float leaf = P.leaf;
+  __syncthreads();  // the table DMA has landed (vmcnt(0) + barrier)
+
+  const unsigned short* s_map = reinterpret_cast<const unsigned short*>(s_table);
+  const float4* s_rec = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(s_table) + P.lds_map_bytes);
+
+  double acc[29];
+#pragma unroll
+  for (int k = 0; k < 29; k++) acc[k] = 0.0;
+
+  while (i < P.n) {  // uniform across the quad
+    const float tx = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
+    const float ty = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
+    const float tz = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
+    const float fx = floorf(tx / leaf), fy = floorf(ty / leaf), fz = floorf(tz / leaf);
+    const bool finite_ok = (fabsf(fx) < 1.0e9f) && (fabsf(fy) < 1.0e9f) && (fabsf(fz) < 1.0e9f);
+    const int ci = finite_ok ? (int)fx : INT_MIN / 2, cj = finite_ok ? (int)fy : INT_MIN / 2, ck = finite_ok ? (int)fz : INT_MIN / 2;
+
+    bool valid[NT];
+    int cellv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int o = ql + 4 * t;  // this lane's t-th neighbour
+      int dx, dy, dz;
+      Offsets<NOFF>::get(o, dx, dy, dz);
+      const int a = ci + dx, b = cj + dy, c = ck + dz;
+      const bool in = (o < NOFF) & (a >= P.min_b[0]) & (a <= P.max_b[0]) & (b >= P.min_b[1]) & (b <= P.max_b[1]) &
+                      (c >= P.min_b[2]) & (c <= P.max_b[2]);
+      valid[t] = in;
+      cellv[t] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
+    }
+    float4 r0[NT], r1[NT];
+    float c22v[NT];
+    if (TAB == NDT_TAB_LDS) {
+      int slot[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const int sl = (int)s_map[cellv[t]];
+        valid[t] = valid[t] & (sl != 0xFFFF);
+        slot[t] = valid[t] ? sl : 0;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        r0[t] = s_rec[slot[t] * 3 + 0];
+        r1[t] = s_rec[slot[t] * 3 + 1];
+        c22v[t] = reinterpret_cast<const float*>(s_rec + slot[t] * 3 + 2)[0];
+      }
+    } else {
+      size_t ridx[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        if (TAB == NDT_TAB_DENSE) {
+          ridx[t] = (size_t)cellv[t];
+        } else {
+          const int sl = P.cell_slot[cellv[t]];
+          valid[t] = valid[t] & (sl >= 0);
+          ridx[t] = (size_t)(sl >= 0 ? sl : 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        r0[t] = P.rec[ridx[t] * 4 + 0];
+        r1[t] = P.rec[ridx[t] * 4 + 1];
+        const float4 r2 = P.rec[ridx[t] * 4 + 2];
+        c22v[t] = r2.x;
+        valid[t] = valid[t] & (r2.y >= 6.f);
+      }
+    }
+
+    float score = 0.f, npairs = 0.f;
+    float A0 = 0.f, A1 = 0.f, A2 = 0.f;
+    float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+      pair_terms(valid[t], hess, tx, ty, tz, r0[t], r1[t], c22v[t], d2, d1d, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22);
+    // the quad's four partial sums -> every lane of the quad (fp32, as the reference sums a point's voxels in float)
+    score = dpp_quad_sum(score); npairs = dpp_quad_sum(npairs);
+    A0 = dpp_quad_sum(A0); A1 = dpp_quad_sum(A1); A2 = dpp_quad_sum(A2);
+    if (hess) {
+      E00 = dpp_quad_sum(E00); E01 = dpp_quad_sum(E01); E02 = dpp_quad_sum(E02);
+      E11 = dpp_quad_sum(E11); E12 = dpp_quad_sum(E12); E22 = dpp_quad_sum(E22);
+    }
+    const float px = x, py = y, pz = z;
+    i += stride;
+    if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
+    if (npairs == 0.f) continue;
+    float o[29];
+    point_terms(hess, px, py, pz, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22, L, o);
+    if (hess) {
+#pragma unroll
+      for (int k = 0; k < 29; k++) acc[k] += (double)o[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDT_NRED_GRAD; k++) acc[k] += (double)o[k];
+    }
+  }
+
+  LSR_STAMP(2)
+  // ---- workgroup sum: lane 0 of every quad hands over its point(s) -> [value][128 quads] -> 16 interleaved segment sums
+  const int nred = hess ? 29 : NDT_NRED_GRAD;
+  if (ql == 0) {
+    if (hess) {
+#pragma unroll
+      for (int k = 0; k < 29; k++) s_part[k][pq] = acc[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDT_NRED_GRAD; k++) s_part[k][pq] = acc[k];
+    }
+  }
+  __syncthreads();
+  {
+    const int v = tid / SEGS, seg = tid % SEGS;
+    double t = 0.0;
+    if (v < nred) {
+#pragma unroll
+      for (int k = 0; k < PTS / SEGS; k++) t += s_part[v][seg + SEGS * k];
+    }
+#pragma unroll
+    for (int m = 1; m < SEGS; m <<= 1) t += __shfl_xor(t, m, 64);
+    if (seg == 0 && v < nred) {
+      // exact split of the partial into 31-bit chunks, one integer atomic per non-zero chunk
+      long long* bank = P.bins + (size_t)(seq % NDT_NBANKS) * NDT_BANK_WORDS + (size_t)(blockIdx.x & (NDT_NSHARDS - 1)) * (NDT_NBINS * 32);
+      double r = t;
+      if (!(fabs(r) < 4611686018427387904.0)) {  // 2^62: overflow or NaN
+        atomicAdd(reinterpret_cast<unsigned long long*>(bank + 31), 1ull);
+        r = 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < NDT_NBINS; k++) {
+        const double q = __hiloint2double((1023 + 62 - 31 * (k + 1)) << 20, 0);
+        const double iq = __hiloint2double((1023 - 62 + 31 * (k + 1)) << 20, 0);
+        const int m = (int)(r * iq);  // truncation: |r| < 2^31 q
+        r = fma(-(double)m, q, r);    // exact remainder
+        if (m != 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + k * 32 + v), (unsigned long long)(long long)m);
+      }
+    }
   }
   LSR_STAMP(3)
   LSR_SPAN_END(seq)
@@ -1040,9 +1367,50 @@ static int launch_one(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_
   }
 }
 
+template <int NOFF, int TAB>
+static int launch_quad_variant(dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, int seq) {
+  static bool allowed[64] = {};
+  if (dyn_lds > 32 * 1024) {
+    int dev = 0;
+    LSR_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !allowed[dev]) {
+      LSR_HIP(hipFuncSetAttribute((const void*)ndt_eval_quad_kernel<NOFF, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)NDT_LDS_TABLE_MAX_QUAD));
+      allowed[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB>), grid, dim3(NDT_QUAD_THREADS), dyn_lds, stream, pv, seq);
+  return LSR_OK;
+}
+
+template <int NOFF>
+static int launch_quad(const NdtLaunchCfg& cfg, dim3 grid, hipStream_t stream, const NdtProblem& pv, int seq) {
+  const size_t dyn = (cfg.tab == NDT_TAB_LDS) ? (size_t)cfg.lds_bytes : 0;
+  switch (cfg.tab) {
+    case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS>(grid, dyn, stream, pv, seq);
+    case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT>(grid, dyn, stream, pv, seq);
+    default: return launch_quad_variant<NOFF, NDT_TAB_DENSE>(grid, dyn, stream, pv, seq);
+  }
+}
+
 // Launches seq0 .. seq0+count-1 of the chain (launch seq consumes the rows of launch seq-1).
 int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, const NdtLaunchCfg& cfg, int seq0, int count,
                      hipStream_t stream) {
+  if (cfg.quad) {
+    if (cfg.batch != 1 || !h_single || !h_single->bins) { set_last_error("the quad kernel runs single registrations"); return LSR_ERR_INVALID_ARGUMENT; }
+    dim3 qgrid(cfg.max_blocks, 1);
+    for (int i = 0; i < count; i++) {
+      int st;
+      switch (cfg.neighborhood) {
+        case LSR_DIRECT1: st = launch_quad<1>(cfg, qgrid, stream, *h_single, seq0 + i); break;
+        case LSR_DIRECT26: st = launch_quad<27>(cfg, qgrid, stream, *h_single, seq0 + i); break;
+        default: st = launch_quad<7>(cfg, qgrid, stream, *h_single, seq0 + i); break;
+      }
+      if (st) return st;
+    }
+    LSR_HIP(hipGetLastError());
+    return LSR_OK;
+  }
   if (cfg.threads != 128 && cfg.threads != 256) { set_last_error("NDT workgroup size must be 128 or 256"); return LSR_ERR_INVALID_ARGUMENT; }
   dim3 grid(cfg.max_blocks, cfg.batch);
   const bool byval = (cfg.batch == 1 && h_single != nullptr);

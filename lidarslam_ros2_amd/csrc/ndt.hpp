@@ -26,8 +26,19 @@ constexpr int NDT_THREADS = 256;       // default workgroup size of the derivati
 constexpr int NDT_MAX_BLOCKS = 1024;
 constexpr int NDT_LDS_REC_BYTES = 48;  // LDS-resident leaf record: {mean.xyz, c00 | c01 c02 c11 c12 | c22, -, -, -}
 constexpr int NDT_LDS_TABLE_MAX = 128 * 1024;  // largest voxel-table image staged into LDS (160 KiB per CU on gfx950)
+constexpr int NDT_LDS_TABLE_MAX_QUAD = 120 * 1024;  // the quad kernel keeps a 31 KiB reduction buffer next to it
 
 // Where the derivative pass finds the leaf records (chosen per launch by the host):
+// Exact, order-independent accumulation of the per-workgroup partial sums (quad kernel): every fp64 partial is split
+// into NDT_NBINS signed 31-bit chunks against fixed binary quanta q_k = 2^(62 - 31 (k + 1)) and added to int64 bins with
+// integer atomics — integer addition is associative, so the totals are bit-reproducible whatever order the workgroups
+// finish in, and exact (no rounding until the bins are folded back into one double).  Partials must stay below 2^62 in
+// magnitude; anything else (overflow, NaN) raises the poison slot and the controller sees NaN.
+constexpr int NDT_NBINS = 5;
+constexpr int NDT_NSHARDS = 8;                                   // one accumulator row per XCD-ish shard (blockIdx & 7)
+constexpr int NDT_BANK_WORDS = NDT_NSHARDS * NDT_NBINS * 32;     // int64 words per bank (32 value slots, 29 used, 31 = poison)
+constexpr int NDT_NBANKS = 3;                                    // launch seq adds to bank seq%3, reads (seq-1)%3, clears (seq+1)%3
+
 enum NdtTableMode : int {
   NDT_TAB_DENSE = 0,    // 64-byte records per grid cell in global memory (no cell->slot indirection)
   NDT_TAB_COMPACT = 1,  // cell_slot[] -> compact 64-byte records in global memory (huge grids)
@@ -91,6 +102,7 @@ struct NdtProblem {
   const uint4* lds_image;   // NDT_TAB_LDS: [map | records], padded to a multiple of 1 KiB (one wave-wide 16-byte DMA)
   int lds_bytes;
   int pad;
+  long long* bins;          // quad kernel: [NDT_NBANKS][NDT_NSHARDS][NDT_NBINS][32] int64 accumulators (zeroed by the host before launch 0)
   NdtState* st;             // [2] double buffered by launch parity
   double* partials;         // [2][nblocks][NDT_NRED]
   NdtMailbox* mailbox;      // device view of the host mailbox (single registrations fed by polling) or nullptr
@@ -118,7 +130,11 @@ struct NdtLaunchCfg {
   int tab = NDT_TAB_DENSE; // NdtTableMode
   int threads = NDT_THREADS;
   int lds_bytes = 0;       // dynamic LDS (largest lds_bytes of the batch) when tab == NDT_TAB_LDS
+  int quad = 0;            // 1: four lanes per source point, 512-thread workgroups, binned integer accumulation (single
+                           // registrations: spreads a 30k-point scan over every CU); 0: one lane per point, partial rows
 };
+constexpr int NDT_QUAD_THREADS = 512;
+constexpr int NDT_QUAD_POINTS = NDT_QUAD_THREADS / 4;  // source points per workgroup pass
 // Launch `count` chained derivative+controller passes.
 // h_single (nullable): host copy of the problem, passed by value when batch == 1.
 int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, const NdtLaunchCfg& cfg, int seq0, int count,

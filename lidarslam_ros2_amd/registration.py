@@ -239,6 +239,22 @@ class Registration:
                                                    d2.ctypes.data_as(C.POINTER(C.c_float))), "nearestNeighbors")
         return idx, d2
 
+    def setTuning(self, workgroup: Optional[int] = None, table_mode: Optional[int] = None, grid_builder: Optional[int] = None,
+                  wait_mode: Optional[int] = None, quad: Optional[int] = None):
+        """Tuning keys of the core (no effect on results beyond fp64 summation order): NDT workgroup size (0 auto, 128,
+        256), where the derivative pass reads the voxel table (-1 auto, 0 dense global, 1 compact global, 2 LDS), the
+        grid builder (0 auto, 1 radix sort), how the calling thread waits (0 spin, 1 yield, 2 sleep)."""
+        if workgroup is not None:
+            self._seti(capi.NDT_WORKGROUP, workgroup, "setTuning(workgroup)")
+        if table_mode is not None:
+            self._seti(capi.NDT_TABLE_MODE, table_mode, "setTuning(table_mode)")
+        if grid_builder is not None:
+            self._seti(capi.GRID_BUILDER, grid_builder, "setTuning(grid_builder)")
+        if wait_mode is not None:
+            self._seti(capi.WAIT_MODE, wait_mode, "setTuning(wait_mode)")
+        if quad is not None:
+            self._seti(capi.NDT_QUAD, quad, "setTuning(quad)")
+
     def setProfiling(self, on: bool):
         self._seti(capi.PROFILE, 1 if on else 0, "setProfiling")
 

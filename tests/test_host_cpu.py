@@ -28,6 +28,34 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.lsr_status_string(-2) == b"no usable gfx950 device"
 
 
+def test_table_driven_angle_coefficients_equal_the_scalar_formulas():
+    """The device builds j_ang / h_ang (NDT eq. 6.19 / 6.21) one table entry per lane; the host-side self check evaluates
+    the same 72 entries next to the scalar formulas — including the 1e-4 small-angle snap and both
+    settings of the h_ang d1 sign quirk.  No device needed."""
+    from lidarslam_ros2_amd import _capi
+
+    lib = _capi.load()
+    fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    rng = np.random.default_rng(5)
+    for t in range(600):
+        ang = rng.uniform(-3.2, 3.2, 3) if t % 3 else rng.uniform(-2e-4, 2e-4, 3)
+        p = np.concatenate([rng.normal(size=3), ang])
+        for sign in (1, -1):
+            jr, hr, jt, ht = (np.zeros(24, np.float32), np.zeros(48, np.float32), np.zeros(24, np.float32), np.zeros(48, np.float32))
+            assert lib.lsr_debug_angle_tables(p.ctypes.data_as(dp), sign, jr.ctypes.data_as(fp), hr.ctypes.data_as(fp),
+                                              jt.ctypes.data_as(fp), ht.ctypes.data_as(fp)) == 0
+            assert np.array_equal(jr, jt), (t, sign)
+            assert np.array_equal(hr, ht), (t, sign)
+    # cross-check one entry against the closed form: j_ang row c = (-sy cz, sy sz, cy)
+    p = np.array([0, 0, 0, 0.3, -0.4, 0.5])
+    jr, hr, jt, ht = (np.zeros(24, np.float32), np.zeros(48, np.float32), np.zeros(24, np.float32), np.zeros(48, np.float32))
+    lib.lsr_debug_angle_tables(p.ctypes.data_as(dp), 1, jr.ctypes.data_as(fp), hr.ctypes.data_as(fp), jt.ctypes.data_as(fp),
+                               ht.ctypes.data_as(fp))
+    sy, cy, sz, cz = np.sin(-0.4), np.cos(-0.4), np.sin(0.5), np.cos(0.5)
+    assert np.allclose(jt[6:9], [-sy * cz, sy * sz, cy], atol=1e-7)
+    assert ht[20] == np.float32(sy)
+
+
 def test_no_cpu_fallback_without_a_device():
     """Without a GPU lsr_create must fail loudly (LSR_ERR_NO_DEVICE) — there is no CPU path."""
     import torch

@@ -215,3 +215,103 @@ def test_gpu_matches_the_committed_golden_fixture():
         dt, ang = pose_delta(ndt.getFinalTransformation(), gold["final_" + key])
         assert dt <= POSE_T_TOL and ang <= POSE_R_TOL, (key, dt, ang)
         assert ndt.getFinalNumIteration() == int(gold["iters_" + key])
+
+
+# ---- launch variants of the derivative pass and the two grid builders -----------------------------------------------
+# (quad: four lanes per point + integer-binned accumulation, workgroup of the one-lane kernel, table mode: 0 dense global,
+#  1 compact global, 2 LDS)
+VARIANTS = [(1, 0, 2), (1, 0, 0), (1, 0, 1), (0, 256, 0), (0, 256, 1), (0, 256, 2), (0, 128, 0), (0, 128, 2)]
+
+
+@pytest.mark.parametrize("quad,workgroup,table_mode", VARIANTS)
+def test_every_launch_variant_matches_the_oracle(O, case, quad, workgroup, table_mode):
+    """The same derivative pass and the same align through every kernel instantiation (workgroup size x where the leaf
+    records are read from): oracle tolerances for one pass, north_star bar and equal iteration counts for align."""
+    res = 5.0
+    ndt = make_ndt(res)
+    ndt.setTuning(workgroup=workgroup, table_mode=table_mode, quad=quad)
+    ndt.setInputTarget(synth.as_pointxyzi(case.target))
+    ndt.setInputSource(synth.as_pointxyzi(case.source))
+    ref = O.VoxelGridCovariance(case.target, res)
+    rng = np.random.default_rng(11)
+    for hess in (True, False):
+        p = O.matrix_to_pose(case.guess) + np.r_[rng.uniform(-0.3, 0.3, 3), rng.uniform(-0.02, 0.02, 3)]
+        s, g, H = ndt.derivatives(p, compute_hessian=hess)
+        rs, rg, rH = O.ndt_derivatives(ref, case.source, p, compute_hessian=hess, resolution=res)
+        assert abs(s - rs) <= 1e-5 * abs(rs)
+        assert np.abs(g - rg).max() <= 2e-5 * np.abs(rg).max()
+        if hess:
+            assert np.abs(H - rH).max() <= 2e-5 * np.abs(rH).max()
+    for eps, max_iter in ((0.01, 35), (1e-6, 30)):
+        ndt.setTransformationEpsilon(eps)
+        ndt.setMaximumIterations(max_iter)
+        ndt.align(case.guess)
+        r = O.ndt_align(ref, case.source, case.guess, resolution=res, trans_eps=eps, max_iterations=max_iter)
+        dt, ang = pose_delta(ndt.getFinalTransformation(), r["final"])
+        assert dt <= POSE_T_TOL and ang <= POSE_R_TOL
+        assert ndt.getFinalNumIteration() == r["iterations"]
+
+
+def test_launch_variants_agree_with_each_other(case):
+    """Same points, same voxels, same fp32 per-pair arithmetic.  One-lane variants differ only in the fp64 summation tree
+    (~1e-12 relative); the quad variants sum a point's voxels in a different fp32 order (fp32 ulps of the per-point terms)
+    and agree among themselves to the last bit (exact integer accumulation: the table mode cannot matter)."""
+    res = 5.0
+    out = {}
+    p = np.r_[0.3, -0.2, 0.05, 0.01, -0.015, 0.02]
+    for v in VARIANTS:
+        quad, workgroup, table_mode = v
+        ndt = make_ndt(res)
+        ndt.setTuning(workgroup=workgroup, table_mode=table_mode, quad=quad)
+        ndt.setInputTarget(synth.as_pointxyzi(case.target))
+        ndt.setInputSource(synth.as_pointxyzi(case.source))
+        out[v] = ndt.derivatives(p, compute_hessian=True)
+        assert np.array_equal(out[v][2], ndt.derivatives(p, compute_hessian=True)[2])   # bit-reproducible
+    s0, g0, H0 = out[(0, 256, 0)]
+    for v, (s, g, H) in out.items():
+        tol = 2e-6 if v[0] else 1e-11
+        assert abs(s - s0) <= tol * abs(s0), v
+        assert np.abs(g - g0).max() <= tol * np.abs(g0).max(), v
+        assert np.abs(H - H0).max() <= tol * np.abs(H0).max(), v
+    sq, gq, Hq = out[(1, 0, 2)]
+    for v in ((1, 0, 0), (1, 0, 1)):
+        assert out[v][0] == sq and np.array_equal(out[v][1], gq) and np.array_equal(out[v][2], Hq), v
+
+
+@pytest.mark.parametrize("res", [5.0, 3.0])
+def test_counting_sort_builder_equals_radix_sort_builder(case, res):
+    """K1/K2 by the counting-sort builder (dense key spaces) and by the radix-sort builder: identical voxel set, counts and
+    bbox; means / inverse covariances differ only by the fp64 summation order."""
+    tgt = synth.as_pointxyzi(case.target)
+    tgt[7::97, 0] = np.nan     # a few non-finite points: dropped by both builders
+    a, b = make_ndt(res), make_ndt(res)
+    b.setTuning(grid_builder=1)
+    a.setInputTarget(tgt)
+    b.setInputTarget(tgt)
+    ia, ib = a.gridInfo(), b.gridInfo()
+    assert np.array_equal(ia["min_b"], ib["min_b"]) and np.array_equal(ia["max_b"], ib["max_b"])
+    assert ia["n_leaves"] == ib["n_leaves"] and ia["n_valid"] == ib["n_valid"]
+    da, db = a.gridDump(), b.gridDump()
+    assert np.array_equal(da["idx"], db["idx"]) and np.array_equal(da["n"], db["n"])
+    assert np.abs(da["mean"] - db["mean"]).max() < 1e-11
+    valid = da["n"] >= 6
+    num = np.abs(da["icov"][valid] - db["icov"][valid]).max(axis=(1, 2))
+    den = np.abs(db["icov"][valid]).max(axis=(1, 2))
+    assert (num / den).max() < 1e-8
+    # rebuilding gives bit-identical results (deterministic summation order)
+    a.setInputTarget(tgt)
+    da2 = a.gridDump()
+    assert np.array_equal(da["mean"], da2["mean"]) and np.array_equal(da["icov"], da2["icov"])
+
+
+@pytest.mark.parametrize("wait_mode", [1, 2])
+def test_wait_modes_give_the_same_result(O, case, wait_mode):
+    res = 5.0
+    a, b = make_ndt(res), make_ndt(res)
+    b.setTuning(wait_mode=wait_mode)
+    for r in (a, b):
+        r.setInputTarget(synth.as_pointxyzi(case.target))
+        r.setInputSource(synth.as_pointxyzi(case.source))
+        r.align(case.guess)
+    assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())
+    assert a.getFinalNumIteration() == b.getFinalNumIteration()
