@@ -70,7 +70,8 @@ typedef enum lsr_key {
   LSR_HESSIAN_D1_SIGN = 38,           /* +1 = upstream "+sy" quirk in h_ang d1 (default), -1 = analytic */
   LSR_PROFILE = 39,                   /* 1 = bracket the derivative launch chains with hipEvents (lsr_get_profile) */
   /* tuning (no effect on results beyond fp64 summation order): */
-  LSR_NDT_WORKGROUP = 40,             /* threads per workgroup of the NDT derivative pass: 0 = automatic, 128, 256 */
+  LSR_NDT_WORKGROUP = 40,             /* one-lane kernel: threads per workgroup (128, 256); quad kernel: source points per
+                                         workgroup (64, 128; four lanes each); 0 = automatic */
   LSR_NDT_TABLE_MODE = 41,            /* where the pass reads leaf records: -1 = automatic, 0 = dense global table,
                                          1 = compact global table, 2 = whole table staged in LDS (when it fits) */
   LSR_GRID_BUILDER = 42,              /* 0 = automatic (counting sort for <= 16383 grid cells, radix sort beyond), 1 = always

@@ -211,7 +211,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   cfg.threads = (lead->ndt_threads == 128 || lead->ndt_threads == 256) ? lead->ndt_threads : NDT_THREADS;
   // single registrations run four lanes per point on every CU (quad kernel) unless the tuning key says otherwise
   cfg.quad = (B == 1 && lead->ndt_quad != 0) ? 1 : 0;
-  if (cfg.quad) cfg.threads = NDT_QUAD_POINTS;  // points per workgroup pass: sizes nblocks
+  if (cfg.quad) cfg.threads = (lead->ndt_threads == 64 || lead->ndt_threads == 128) ? lead->ndt_threads : NDT_QUAD_POINTS;  // POINTS per workgroup
   {
     bool all_lds = true, all_dense = true;
     int lds_max = 0;
@@ -365,7 +365,7 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   h->ndt.resolution = 1.0; h->ndt.step_size = 0.1; h->ndt.outlier_ratio = 0.55; h->ndt.trans_eps = 0.1;
   h->ndt.max_iterations = 35; h->ndt.neighborhood = LSR_DIRECT7; h->ndt.d1_sign = 1;
   // tuning defaults may be preset from the environment (A/B runs without touching the caller)
-  if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 128 || v == 256) h->ndt_threads = v; }
+  if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) h->ndt_threads = v; }
   if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 2) h->ndt_table_mode = v; }
   if (const char* e = std::getenv("LSR_NDT_QUAD")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_quad = v; }
   if (const char* e = std::getenv("LSR_WAIT_MODE")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->scratch.wait_mode = v; }
@@ -454,7 +454,7 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
     case LSR_HESSIAN_D1_SIGN: h->ndt.d1_sign = (v >= 0) ? 1 : -1; return LSR_OK;
     case LSR_PROFILE: h->profile = v ? 1 : 0; return LSR_OK;
     case LSR_NDT_WORKGROUP:
-      if (v != 0 && v != 128 && v != 256) { set_last_error("NDT workgroup size must be 0 (auto), 128 or 256"); return LSR_ERR_INVALID_ARGUMENT; }
+      if (v != 0 && v != 64 && v != 128 && v != 256) { set_last_error("NDT workgroup key must be 0 (auto), 64, 128 or 256"); return LSR_ERR_INVALID_ARGUMENT; }
       h->ndt_threads = v; return LSR_OK;
     case LSR_NDT_TABLE_MODE:
       if (v < -1 || v > 2) { set_last_error("NDT table mode must be -1 (auto), 0 dense, 1 compact, 2 LDS"); return LSR_ERR_INVALID_ARGUMENT; }
@@ -939,7 +939,7 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
   }
   cfg.quad = (h->ndt_quad != 0) ? 1 : 0;
   if (cfg.quad) {
-    cfg.threads = NDT_QUAD_POINTS;
+    cfg.threads = (h->ndt_threads == 64 || h->ndt_threads == 128) ? h->ndt_threads : NDT_QUAD_POINTS;
     if (cfg.tab == NDT_TAB_LDS && cfg.lds_bytes > NDT_LDS_TABLE_MAX_QUAD) {
       cfg.tab = h->target->grid.dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT;
       cfg.lds_bytes = 0;

@@ -231,16 +231,17 @@ __device__ __forceinline__ double mt_trial_value(double a_l, double f_l, double 
   }
 }
 
-__device__ __forceinline__ bool mt_update_interval(LdsState* S, double a_t, double f_t, double g_t) {
-  if (f_t > S->f_l) {
-    S->a_u = a_t; S->f_u = f_t; S->g_u = g_t;
+struct MtInterval { double a_l, f_l, g_l, a_u, f_u, g_u; };
+__device__ __forceinline__ bool mt_update_interval(MtInterval& I, double a_t, double f_t, double g_t) {
+  if (f_t > I.f_l) {
+    I.a_u = a_t; I.f_u = f_t; I.g_u = g_t;
     return false;
-  } else if (g_t * (S->a_l - a_t) > 0) {
-    S->a_l = a_t; S->f_l = f_t; S->g_l = g_t;
+  } else if (g_t * (I.a_l - a_t) > 0) {
+    I.a_l = a_t; I.f_l = f_t; I.g_l = g_t;
     return false;
-  } else if (g_t * (S->a_l - a_t) < 0) {
-    S->a_u = S->a_l; S->f_u = S->f_l; S->g_u = S->g_l;
-    S->a_l = a_t; S->f_l = f_t; S->g_l = g_t;
+  } else if (g_t * (I.a_l - a_t) < 0) {
+    I.a_u = I.a_l; I.f_u = I.f_l; I.g_u = I.g_l;
+    I.a_l = a_t; I.f_l = f_t; I.g_l = g_t;
     return false;
   }
   return true;
@@ -251,17 +252,23 @@ __device__ __forceinline__ bool mt_update_interval(LdsState* S, double a_t, doub
 // both give H^{-1} b.  A column whose pivot vanishes is dropped = its unknown set to 0, which is the
 // SVD's minimum-norm answer for the degenerate all-zero Hessian of a scan that overlaps no voxel.
 // (A wave-parallel Gauss-Jordan on an LDS matrix was measured slower: +0.9 us per pass on average.)
-__device__ __forceinline__ void solve6(const LdsDouble* H, const double* __restrict__ b, double* __restrict__ x) {
+// Hu: the 21 values of the upper triangle, row-major (0,0..5) (1,1..5) ... (5,5), in registers.
+__device__ __forceinline__ void solve6(const double* __restrict__ Hu, const double* __restrict__ b, double* __restrict__ x) {
   double A[6][7];
   double scale = 0;
+  {
+    int k = 0;
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 6; i++) {
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-      A[i][j] = H[i * 6 + j];
-      scale = fmax(scale, fabs(A[i][j]));
+      for (int j = i; j < 6; j++) {
+        A[i][j] = Hu[k];
+        A[j][i] = Hu[k];
+        scale = fmax(scale, fabs(Hu[k]));
+        k++;
+      }
+      A[i][6] = b[i];
     }
-    A[i][6] = b[i];
   }
   unsigned int dropped = 0u;
 #pragma unroll
@@ -300,14 +307,6 @@ __device__ __forceinline__ void solve6(const LdsDouble* H, const double* __restr
     for (int j = k + 1; j < 6; j++) sacc -= A[k][j] * x[j];
     x[k] = (dropped & (1u << k)) ? 0.0 : sacc / A[k][k];
   }
-}
-
-// Mark the next evaluation request for pose x_t; the transform / angle tables themselves are built
-// by build_request() right after the controller returns, spread over the lanes of the workgroup.
-__device__ __forceinline__ void request_eval(LdsState* S, int want_hessian, bool refresh_hang, int phase) {
-  S->want_hessian = want_hessian;
-  S->phase = phase;
-  S->pad1 = refresh_hang ? 3 : 1;  // bit0: build T/jang for x_t, bit1: also hang
 }
 
 // The angular coefficient tables of eq. 6.19 (jang, 24 entries) and eq. 6.21 (hang, 48 entries) as DATA: every entry is
@@ -442,138 +441,195 @@ __device__ __forceinline__ void build_request(NdtState* S, double* f /*8*/, floa
 // K4: consume the sums of the pass that just finished and decide what happens next.
 // Runs on one lane of EVERY workgroup (redundantly, same inputs, same result).  sums: [0]=score [1..6]=grad
 // [7]=pairs [8..28]=H upper.
+// One lane against LDS is a latency machine: a ds_read costs ~100 cycles before its value can be used, and the compiler
+// must keep reads and writes through the two LDS pointers in program order.  So the function reads everything it may
+// need in ONE batch of independent loads up front, runs the Newton / More-Thuente state machine in
+// registers, and writes the state back in one batch of stores at the end (first version: field-by-field LDS access,
+// 28 serialised read->wait->write round trips for the copy of the sums alone, 1.9 us for the shortest path).
 __device__ __attribute__((noinline)) void ndt_controller(LdsState* S, const LdsDouble* sums) {
   const double mu = 1.e-4, nu = 0.9;
   const int max_step_iterations = 10;
-  S->n_evals++;
-  S->last_pairs = sums[7];
-  const int phase = S->phase;
+  // ---- one batch of loads
+  double sv[29];
+#pragma unroll
+  for (int k = 0; k < 29; k++) sv[k] = sums[k];
+  int phase = S->phase;
   const bool had_hessian = S->want_hessian != 0;
+  const int n_evals = S->n_evals + 1;
+  int nr_iterations = S->nr_iterations, converged = S->converged;
+  int open_interval = S->open_interval, interval_converged = S->interval_converged, step_iterations = S->step_iterations;
+  const int max_iter = S->max_iter, n_points = S->n_points;
+  const double step_max = S->step_max, step_min = S->step_min, eps = S->eps;
+  double p[6], dir[6], g[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { p[i] = S->p[i]; dir[i] = S->dir[i]; g[i] = S->g[i]; }
+  double score = S->score;
+  double phi_0 = S->phi_0, d_phi_0 = S->d_phi_0, a_t = S->a_t;
+  MtInterval I = {S->a_l, S->f_l, S->g_l, S->a_u, S->f_u, S->g_u};
+
   if (phase != PH_MT_HESS) {
-    S->score = sums[0];
-    for (int i = 0; i < 6; i++) S->g[i] = sums[1 + i];
+    score = sv[0];
+#pragma unroll
+    for (int i = 0; i < 6; i++) g[i] = sv[1 + i];
   }
-  if (had_hessian) {
-    int k = 8;
-    for (int i = 0; i < 6; i++)
-      for (int j = i; j < 6; j++) {
-        S->H[i * 6 + j] = sums[k];
-        S->H[j * 6 + i] = sums[k];
-        k++;
-      }
-  }
-  if (phase == PH_DIAG) {
+  S->n_evals = n_evals;
+  S->last_pairs = sv[7];
+  S->score = score;
+#pragma unroll
+  for (int i = 0; i < 6; i++) S->g[i] = g[i];
+  if (phase == PH_DIAG) {  // lsr_ndt_derivatives: the sums are the result
+    if (had_hessian) {
+      int k = 8;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) {
+          S->H[i * 6 + j] = sv[k];
+          S->H[j * 6 + i] = sv[k];
+          k++;
+        }
+    }
     S->done = 1;
     return;
   }
 
   enum { ST_NEWTON_BEGIN, ST_MT_CHECK, ST_NEWTON_END, ST_FINISH } stage;
   double phi_t = 0, d_phi_t = 0, psi_t = 0, d_psi_t = 0;
+  // outcome of this call
+  int want_hessian = had_hessian ? 1 : 0, request = 0 /* S->pad1: bit0 build T/jang for x_t, bit1 also hang */, done = 0;
+  bool new_x_t = false;
+  double x_t[6] = {0, 0, 0, 0, 0, 0};
+  double trans_probability = 0;
+
   if (phase == PH_INIT) {
     stage = ST_NEWTON_BEGIN;
   } else if (phase == PH_MT_HESS) {
     stage = ST_NEWTON_END;
   } else {
-    phi_t = -S->score;
+    phi_t = -score;
     double dot = 0;
-    for (int i = 0; i < 6; i++) dot += S->g[i] * S->dir[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) dot += g[i] * dir[i];
     d_phi_t = -dot;
-    psi_t = phi_t - S->phi_0 - mu * S->d_phi_0 * S->a_t;
-    d_psi_t = d_phi_t - mu * S->d_phi_0;
+    psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t;
+    d_psi_t = d_phi_t - mu * d_phi_0;
     if (phase == PH_MT_TRIAL) {
-      if (S->open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
-        S->open_interval = 0;
-        S->f_l = S->f_l + S->phi_0 - mu * S->d_phi_0 * S->a_l;
-        S->g_l = S->g_l + mu * S->d_phi_0;
-        S->f_u = S->f_u + S->phi_0 - mu * S->d_phi_0 * S->a_u;
-        S->g_u = S->g_u + mu * S->d_phi_0;
+      if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+        open_interval = 0;
+        I.f_l = I.f_l + phi_0 - mu * d_phi_0 * I.a_l;
+        I.g_l = I.g_l + mu * d_phi_0;
+        I.f_u = I.f_u + phi_0 - mu * d_phi_0 * I.a_u;
+        I.g_u = I.g_u + mu * d_phi_0;
       }
-      if (S->open_interval)
-        S->interval_converged = mt_update_interval(S, S->a_t, psi_t, d_psi_t) ? 1 : 0;
+      if (open_interval)
+        interval_converged = mt_update_interval(I, a_t, psi_t, d_psi_t) ? 1 : 0;
       else
-        S->interval_converged = mt_update_interval(S, S->a_t, phi_t, d_phi_t) ? 1 : 0;
-      S->step_iterations++;
+        interval_converged = mt_update_interval(I, a_t, phi_t, d_phi_t) ? 1 : 0;
+      step_iterations++;
     }
     stage = ST_MT_CHECK;
   }
 
-  for (int guard = 0; guard < 8; guard++) {
+  for (int guard = 0; guard < 8 && !done && !request && !(phase == PH_MT_HESS && stage == ST_MT_CHECK); guard++) {
     if (stage == ST_NEWTON_BEGIN) {
       double neg_g[6], delta[6];
-      for (int i = 0; i < 6; i++) neg_g[i] = -S->g[i];
-      solve6(S->H, neg_g, delta);
+#pragma unroll
+      for (int i = 0; i < 6; i++) neg_g[i] = -g[i];
+      solve6(sv + 8, neg_g, delta);  // the Hessian in use is always the one of the pass that just finished
       double nrm = 0;
+#pragma unroll
       for (int i = 0; i < 6; i++) nrm += delta[i] * delta[i];
       nrm = sqrt(nrm);
       if (nrm == 0 || nrm != nrm) {
-        S->converged = (nrm == nrm) ? 1 : 0;
+        converged = (nrm == nrm) ? 1 : 0;
         stage = ST_FINISH;
         continue;
       }
-      for (int i = 0; i < 6; i++) S->dir[i] = delta[i] / nrm;
+#pragma unroll
+      for (int i = 0; i < 6; i++) dir[i] = delta[i] / nrm;
       // ---- computeStepLengthMT prologue
-      S->phi_0 = -S->score;
+      phi_0 = -score;
       double dot = 0;
-      for (int i = 0; i < 6; i++) dot += S->g[i] * S->dir[i];
-      S->d_phi_0 = -dot;
-      if (S->d_phi_0 >= 0) {
-        if (S->d_phi_0 == 0) {
-          S->a_t = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) dot += g[i] * dir[i];
+      d_phi_0 = -dot;
+      if (d_phi_0 >= 0) {
+        if (d_phi_0 == 0) {
+          a_t = 0;
           stage = ST_NEWTON_END;
           continue;
         }
-        S->d_phi_0 = -S->d_phi_0;
-        for (int i = 0; i < 6; i++) S->dir[i] = -S->dir[i];
+        d_phi_0 = -d_phi_0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) dir[i] = -dir[i];
       }
-      S->a_l = 0; S->a_u = 0;
-      S->f_l = 0; S->f_u = 0;  // psi(0) = phi_0 - phi_0 - mu*d_phi_0*0
-      S->g_l = S->d_phi_0 - mu * S->d_phi_0;
-      S->g_u = S->g_l;
-      S->interval_converged = (S->step_max - S->step_min) < 0 ? 1 : 0;
-      S->open_interval = 1;
-      S->step_iterations = 0;
-      double a_t = fmin(nrm, S->step_max);
-      a_t = fmax(a_t, S->step_min);
-      S->a_t = a_t;
-      for (int i = 0; i < 6; i++) S->x_t[i] = S->p[i] + S->dir[i] * a_t;
-      request_eval(S, 1, true, PH_MT_FIRST);
-      return;
+      I.a_l = 0; I.a_u = 0;
+      I.f_l = 0; I.f_u = 0;  // psi(0) = phi_0 - phi_0 - mu*d_phi_0*0
+      I.g_l = d_phi_0 - mu * d_phi_0;
+      I.g_u = I.g_l;
+      interval_converged = (step_max - step_min) < 0 ? 1 : 0;
+      open_interval = 1;
+      step_iterations = 0;
+      a_t = fmax(fmin(nrm, step_max), step_min);
+#pragma unroll
+      for (int i = 0; i < 6; i++) x_t[i] = p[i] + dir[i] * a_t;
+      new_x_t = true;
+      want_hessian = 1; phase = PH_MT_FIRST; request = 3;
     } else if (stage == ST_MT_CHECK) {
-      if (!S->interval_converged && S->step_iterations < max_step_iterations &&
-          !(psi_t <= 0 && d_phi_t <= -nu * S->d_phi_0)) {
-        double a_t;
-        if (S->open_interval)
-          a_t = mt_trial_value(S->a_l, S->f_l, S->g_l, S->a_u, S->f_u, S->g_u, S->a_t, psi_t, d_psi_t);
+      if (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+        if (open_interval)
+          a_t = mt_trial_value(I.a_l, I.f_l, I.g_l, I.a_u, I.f_u, I.g_u, a_t, psi_t, d_psi_t);
         else
-          a_t = mt_trial_value(S->a_l, S->f_l, S->g_l, S->a_u, S->f_u, S->g_u, S->a_t, phi_t, d_phi_t);
-        a_t = fmin(a_t, S->step_max);
-        a_t = fmax(a_t, S->step_min);
-        S->a_t = a_t;
-        for (int i = 0; i < 6; i++) S->x_t[i] = S->p[i] + S->dir[i] * a_t;
-        request_eval(S, 0, false, PH_MT_TRIAL);
-        return;
+          a_t = mt_trial_value(I.a_l, I.f_l, I.g_l, I.a_u, I.f_u, I.g_u, a_t, phi_t, d_phi_t);
+        a_t = fmax(fmin(a_t, step_max), step_min);
+#pragma unroll
+        for (int i = 0; i < 6; i++) x_t[i] = p[i] + dir[i] * a_t;
+        new_x_t = true;
+        want_hessian = 0; phase = PH_MT_TRIAL; request = 1;
+      } else if (step_iterations) {
+        // computeHessian at x_t: current j_ang, h_ang left over from the last with-Hessian pass; same pose, no request
+        want_hessian = 1;
+        phase = PH_MT_HESS;
+        stage = ST_MT_CHECK;  // leaves the loop (see its condition)
+      } else {
+        stage = ST_NEWTON_END;
       }
-      if (S->step_iterations) {
-        // computeHessian at x_t: current j_ang, h_ang left over from the last with-Hessian pass.
-        S->want_hessian = 1;
-        S->phase = PH_MT_HESS;
-        return;
-      }
-      stage = ST_NEWTON_END;
     } else if (stage == ST_NEWTON_END) {
-      for (int i = 0; i < 6; i++) S->p[i] += S->dir[i] * S->a_t;
-      if (S->nr_iterations > S->max_iter || (S->nr_iterations && (fabs(S->a_t) < S->eps))) S->converged = 1;
-      S->nr_iterations++;
-      stage = S->converged ? ST_FINISH : ST_NEWTON_BEGIN;
+#pragma unroll
+      for (int i = 0; i < 6; i++) p[i] += dir[i] * a_t;
+      if (nr_iterations > max_iter || (nr_iterations && (fabs(a_t) < eps))) converged = 1;
+      nr_iterations++;
+      stage = converged ? ST_FINISH : ST_NEWTON_BEGIN;
+      phase = PH_INIT;  // (only a marker for the loop condition: the Hessian recomputation has been consumed)
     } else {  // ST_FINISH
-      S->trans_probability = S->score / (double)S->n_points;
-      S->done = 1;
-      return;
+      trans_probability = score / (double)n_points;
+      done = 1;
     }
   }
-  // unreachable in practice (the a_t == 0 path converges after two rounds)
-  S->trans_probability = S->score / (double)S->n_points;
-  S->done = 1;
+  if (!done && !request && phase != PH_MT_HESS) {  // unreachable in practice (the a_t == 0 path converges after two rounds)
+    trans_probability = score / (double)n_points;
+    done = 1;
+  }
+
+  // ---- one batch of stores
+  S->want_hessian = want_hessian;
+  S->phase = phase;
+  S->pad1 = request;
+  S->done = done;
+  S->nr_iterations = nr_iterations;
+  S->converged = converged;
+  S->open_interval = open_interval;
+  S->interval_converged = interval_converged;
+  S->step_iterations = step_iterations;
+  S->phi_0 = phi_0; S->d_phi_0 = d_phi_0; S->a_t = a_t;
+  S->a_l = I.a_l; S->f_l = I.f_l; S->g_l = I.g_l; S->a_u = I.a_u; S->f_u = I.f_u; S->g_u = I.g_u;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { S->p[i] = p[i]; S->dir[i] = dir[i]; }
+  if (new_x_t) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) S->x_t[i] = x_t[i];
+  }
+  if (done) S->trans_probability = trans_probability;
 }
 
 #ifdef LSR_TIMING
@@ -589,10 +645,23 @@ __device__ long long* g_lsr_timing = nullptr;  // [blocks][16] {wall, shader} pa
 #define LSR_SPAN_END(seq)                                                                                     \
   if (threadIdx.x == 0 && g_lsr_timing && blockIdx.y == 0)                                                     \
     atomicMax((unsigned long long*)&g_lsr_timing[(512 + ((seq) & 255)) * 32 + 1], (unsigned long long)wall_clock64());
+// controller time by the phase it consumed: rows 800 + phase hold {sum of ticks, count, sum of request-build ticks}
+#define LSR_CTL_BEGIN(L)                                                              \
+  long long _ctl_t0 = 0; int _ctl_ph = 0;                                              \
+  if (threadIdx.x == 0 && g_lsr_timing && blockIdx.x == 0 && blockIdx.y == 0) { _ctl_t0 = (long long)wall_clock64(); _ctl_ph = (L)->phase; }
+#define LSR_CTL_END(col)                                                              \
+  if (threadIdx.x == 0 && g_lsr_timing && blockIdx.x == 0 && blockIdx.y == 0) {          \
+    const long long _t = (long long)wall_clock64();                                     \
+    atomicAdd((unsigned long long*)&g_lsr_timing[(800 + _ctl_ph) * 32 + (col)], (unsigned long long)(_t - _ctl_t0)); \
+    if ((col) == 0) atomicAdd((unsigned long long*)&g_lsr_timing[(800 + _ctl_ph) * 32 + 1], 1ull);                     \
+    _ctl_t0 = _t;                                                                       \
+  }
 #else
 #define LSR_STAMP(k)
 #define LSR_SPAN_BEGIN(seq)
 #define LSR_SPAN_END(seq)
+#define LSR_CTL_BEGIN(L)
+#define LSR_CTL_END(col)
 #endif
 
 // Values read from the LDS state image are wave-uniform; telling the compiler (v_readfirstlane -> SGPR)
@@ -844,10 +913,13 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
     }
     barrier_lds_only();
     LSR_STAMP(6)
+    LSR_CTL_BEGIN(L)
     if (tid == 0) ndt_controller(L, (const LdsDouble*)s_sum);
     barrier_lds_only();
+    LSR_CTL_END(0)
     LSR_STAMP(5)
     build_request<THREADS>(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[4][0]), ang_entry);
+    LSR_CTL_END(2)
     LSR_STAMP(4)
   }
   if (blockIdx.x == 0) {
@@ -1030,18 +1102,19 @@ __device__ __forceinline__ float dpp_quad_sum(float v) {
   return v;
 }
 
-template <int NOFF, int TAB>
-__global__ __launch_bounds__(NDT_QUAD_THREADS) void ndt_eval_quad_kernel(const NdtProblem P, const int seq) {
-  constexpr int THREADS = NDT_QUAD_THREADS, PTS = NDT_QUAD_POINTS;
-  constexpr int PITCH = PTS + 8;
-  constexpr int SEGS = THREADS / 32;       // 16 interleaved segments per value in the workgroup sum
+template <int NOFF, int TAB, int PTS>
+__global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem P, const int seq) {
+  constexpr int THREADS = 4 * PTS;
+  constexpr int PITCH = PTS + 4;           // floats per row of the per-point buffers
+  constexpr int SEGS = THREADS / 32;       // interleaved segments per value in the workgroup sum
   constexpr int NT = (NOFF + 3) / 4;       // neighbours per lane
   if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x, ql = tid & 3, pq = tid >> 2;
   LSR_STAMP(0)
   LSR_SPAN_BEGIN(seq)
 
-  __shared__ double s_part[29][PITCH];
+  __shared__ float s_pt[14][PITCH];   // phase A -> B: per point {score, #pairs, A (3), E (6), x, y, z}
+  __shared__ float s_o[29][PITCH];    // phase B -> C: the 29 per-point terms
   __shared__ double s_bin[NDT_NBINS][32];
   __shared__ double s_sum[NDT_NRED];
   __shared__ double s_lu[8][2];
@@ -1112,10 +1185,13 @@ __global__ __launch_bounds__(NDT_QUAD_THREADS) void ndt_eval_quad_kernel(const N
     }
     barrier_lds_only();
     LSR_STAMP(6)
+    LSR_CTL_BEGIN(L)
     if (tid == 0) ndt_controller(L, (const LdsDouble*)s_sum);
     barrier_lds_only();
+    LSR_CTL_END(0)
     LSR_STAMP(5)
     build_request<THREADS>(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[4][0]), ang_entry);
+    LSR_CTL_END(2)
     LSR_STAMP(4)
   }
   if (blockIdx.x == 0) {
@@ -1157,120 +1233,135 @@ __global__ __launch_bounds__(NDT_QUAD_THREADS) void ndt_eval_quad_kernel(const N
   const unsigned short* s_map = reinterpret_cast<const unsigned short*>(s_table);
   const float4* s_rec = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(s_table) + P.lds_map_bytes);
 
-  double acc[29];
-#pragma unroll
-  for (int k = 0; k < 29; k++) acc[k] = 0.0;
+  // Three phases per batch of PTS points, so that no instruction is issued for more lanes than it has work for:
+  //  A (all 4 PTS lanes, four per point): transform, neighbourhood, pair terms, quad combine -> 14 floats per point in LDS
+  //  B (PTS lanes, one per point): the 29 Jacobian / Hessian terms of the point -> LDS
+  //  C (all lanes): fp64 sum over the points, SEGS segments per value
+  const int nred = hess ? 29 : NDT_NRED_GRAD;
+  const int cv = tid / SEGS, cseg = tid % SEGS;
+  double csum = 0.0;
+  for (int base = blockIdx.x * PTS; base < P.n; base += stride) {  // uniform across the workgroup
+    // ---- phase A
+    {
+      const float tx = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
+      const float ty = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
+      const float tz = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
+      const float fx = floorf(tx / leaf), fy = floorf(ty / leaf), fz = floorf(tz / leaf);
+      const bool finite_ok = (i < P.n) && (fabsf(fx) < 1.0e9f) && (fabsf(fy) < 1.0e9f) && (fabsf(fz) < 1.0e9f);
+      const int ci = finite_ok ? (int)fx : INT_MIN / 2, cj = finite_ok ? (int)fy : INT_MIN / 2, ck = finite_ok ? (int)fz : INT_MIN / 2;
 
-  while (i < P.n) {  // uniform across the quad
-    const float tx = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
-    const float ty = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
-    const float tz = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
-    const float fx = floorf(tx / leaf), fy = floorf(ty / leaf), fz = floorf(tz / leaf);
-    const bool finite_ok = (fabsf(fx) < 1.0e9f) && (fabsf(fy) < 1.0e9f) && (fabsf(fz) < 1.0e9f);
-    const int ci = finite_ok ? (int)fx : INT_MIN / 2, cj = finite_ok ? (int)fy : INT_MIN / 2, ck = finite_ok ? (int)fz : INT_MIN / 2;
-
-    bool valid[NT];
-    int cellv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      const int o = ql + 4 * t;  // this lane's t-th neighbour
-      int dx, dy, dz;
-      Offsets<NOFF>::get(o, dx, dy, dz);
-      const int a = ci + dx, b = cj + dy, c = ck + dz;
-      const bool in = (o < NOFF) & (a >= P.min_b[0]) & (a <= P.max_b[0]) & (b >= P.min_b[1]) & (b <= P.max_b[1]) &
-                      (c >= P.min_b[2]) & (c <= P.max_b[2]);
-      valid[t] = in;
-      cellv[t] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
-    }
-    float4 r0[NT], r1[NT];
-    float c22v[NT];
-    if (TAB == NDT_TAB_LDS) {
-      int slot[NT];
+      bool valid[NT];
+      int cellv[NT];
 #pragma unroll
       for (int t = 0; t < NT; t++) {
-        const int sl = (int)s_map[cellv[t]];
-        valid[t] = valid[t] & (sl != 0xFFFF);
-        slot[t] = valid[t] ? sl : 0;
+        const int o = ql + 4 * t;  // this lane's t-th neighbour
+        int dx, dy, dz;
+        Offsets<NOFF>::get(o, dx, dy, dz);
+        const int a = ci + dx, b = cj + dy, c = ck + dz;
+        const bool in = (o < NOFF) & (a >= P.min_b[0]) & (a <= P.max_b[0]) & (b >= P.min_b[1]) & (b <= P.max_b[1]) &
+                        (c >= P.min_b[2]) & (c <= P.max_b[2]);
+        valid[t] = in;
+        cellv[t] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
       }
+      float4 r0[NT], r1[NT];
+      float c22v[NT];
+      if (TAB == NDT_TAB_LDS) {
+        int slot[NT];
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        r0[t] = s_rec[slot[t] * 3 + 0];
-        r1[t] = s_rec[slot[t] * 3 + 1];
-        c22v[t] = reinterpret_cast<const float*>(s_rec + slot[t] * 3 + 2)[0];
-      }
-    } else {
-      size_t ridx[NT];
+        for (int t = 0; t < NT; t++) {
+          const int sl = (int)s_map[cellv[t]];
+          valid[t] = valid[t] & (sl != 0xFFFF);
+          slot[t] = valid[t] ? sl : 0;
+        }
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        if (TAB == NDT_TAB_DENSE) {
-          ridx[t] = (size_t)cellv[t];
-        } else {
-          const int sl = P.cell_slot[cellv[t]];
-          valid[t] = valid[t] & (sl >= 0);
-          ridx[t] = (size_t)(sl >= 0 ? sl : 0);
+        for (int t = 0; t < NT; t++) {
+          r0[t] = s_rec[slot[t] * 3 + 0];
+          r1[t] = s_rec[slot[t] * 3 + 1];
+          c22v[t] = reinterpret_cast<const float*>(s_rec + slot[t] * 3 + 2)[0];
+        }
+      } else {
+        size_t ridx[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          if (TAB == NDT_TAB_DENSE) {
+            ridx[t] = (size_t)cellv[t];
+          } else {
+            const int sl = P.cell_slot[cellv[t]];
+            valid[t] = valid[t] & (sl >= 0);
+            ridx[t] = (size_t)(sl >= 0 ? sl : 0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          r0[t] = P.rec[ridx[t] * 4 + 0];
+          r1[t] = P.rec[ridx[t] * 4 + 1];
+          const float4 r2 = P.rec[ridx[t] * 4 + 2];
+          c22v[t] = r2.x;
+          valid[t] = valid[t] & (r2.y >= 6.f);
         }
       }
+
+      float score = 0.f, npairs = 0.f;
+      float A0 = 0.f, A1 = 0.f, A2 = 0.f;
+      float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        r0[t] = P.rec[ridx[t] * 4 + 0];
-        r1[t] = P.rec[ridx[t] * 4 + 1];
-        const float4 r2 = P.rec[ridx[t] * 4 + 2];
-        c22v[t] = r2.x;
-        valid[t] = valid[t] & (r2.y >= 6.f);
+      for (int t = 0; t < NT; t++)
+        pair_terms(valid[t], hess, tx, ty, tz, r0[t], r1[t], c22v[t], d2, d1d, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22);
+      // the quad's four partial sums -> every lane of the quad (fp32, as the reference sums a point's voxels in float)
+      score = dpp_quad_sum(score); npairs = dpp_quad_sum(npairs);
+      A0 = dpp_quad_sum(A0); A1 = dpp_quad_sum(A1); A2 = dpp_quad_sum(A2);
+      if (hess) {
+        E00 = dpp_quad_sum(E00); E01 = dpp_quad_sum(E01); E02 = dpp_quad_sum(E02);
+        E11 = dpp_quad_sum(E11); E12 = dpp_quad_sum(E12); E22 = dpp_quad_sum(E22);
+      }
+      // lane l of the quad stores rows l, l + 4, l + 8, (l + 12) of the point's record: one to four stores per lane
+      const float row0 = (ql == 0) ? score : (ql == 1) ? npairs : (ql == 2) ? A0 : A1;
+      const float row1 = (ql == 0) ? A2 : (ql == 1) ? E00 : (ql == 2) ? E01 : E02;
+      const float row2 = (ql == 0) ? E11 : (ql == 1) ? E12 : (ql == 2) ? E22 : x;
+      s_pt[ql][pq] = row0;
+      s_pt[4 + ql][pq] = row1;
+      s_pt[8 + ql][pq] = row2;
+      if (ql < 2) s_pt[12 + ql][pq] = (ql == 0) ? y : z;
+      i += stride;
+      x = 0.f; y = 0.f; z = 0.f;
+      if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }   // next batch's loads fly under phases B and C
+    }
+    barrier_lds_only();
+    // ---- phase B
+    if (tid < PTS) {
+      const float npairs = s_pt[1][tid];
+      float o[29];
+      if (npairs != 0.f) {
+        point_terms(hess, s_pt[11][tid], s_pt[12][tid], s_pt[13][tid], s_pt[0][tid], npairs, s_pt[2][tid], s_pt[3][tid], s_pt[4][tid],
+                    s_pt[5][tid], s_pt[6][tid], s_pt[7][tid], s_pt[8][tid], s_pt[9][tid], s_pt[10][tid], L, o);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 29; k++) o[k] = 0.f;
+      }
+      if (hess) {
+#pragma unroll
+        for (int k = 0; k < 29; k++) s_o[k][tid] = o[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < NDT_NRED_GRAD; k++) s_o[k][tid] = o[k];
       }
     }
-
-    float score = 0.f, npairs = 0.f;
-    float A0 = 0.f, A1 = 0.f, A2 = 0.f;
-    float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;
+    barrier_lds_only();
+    // ---- phase C: the float terms of the reference's per-point sums, accumulated in double
+    if (cv < nred) {
 #pragma unroll
-    for (int t = 0; t < NT; t++)
-      pair_terms(valid[t], hess, tx, ty, tz, r0[t], r1[t], c22v[t], d2, d1d, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22);
-    // the quad's four partial sums -> every lane of the quad (fp32, as the reference sums a point's voxels in float)
-    score = dpp_quad_sum(score); npairs = dpp_quad_sum(npairs);
-    A0 = dpp_quad_sum(A0); A1 = dpp_quad_sum(A1); A2 = dpp_quad_sum(A2);
-    if (hess) {
-      E00 = dpp_quad_sum(E00); E01 = dpp_quad_sum(E01); E02 = dpp_quad_sum(E02);
-      E11 = dpp_quad_sum(E11); E12 = dpp_quad_sum(E12); E22 = dpp_quad_sum(E22);
+      for (int k = 0; k < PTS / SEGS; k++) csum += (double)s_o[cv][cseg + SEGS * k];
     }
-    const float px = x, py = y, pz = z;
-    i += stride;
-    if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
-    if (npairs == 0.f) continue;
-    float o[29];
-    point_terms(hess, px, py, pz, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22, L, o);
-    if (hess) {
-#pragma unroll
-      for (int k = 0; k < 29; k++) acc[k] += (double)o[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < NDT_NRED_GRAD; k++) acc[k] += (double)o[k];
-    }
+    // (the next batch overwrites s_pt only: phase C of this batch reads s_o, phase B of the next one is behind a barrier)
   }
 
   LSR_STAMP(2)
-  // ---- workgroup sum: lane 0 of every quad hands over its point(s) -> [value][128 quads] -> 16 interleaved segment sums
-  const int nred = hess ? 29 : NDT_NRED_GRAD;
-  if (ql == 0) {
-    if (hess) {
-#pragma unroll
-      for (int k = 0; k < 29; k++) s_part[k][pq] = acc[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < NDT_NRED_GRAD; k++) s_part[k][pq] = acc[k];
-    }
-  }
-  __syncthreads();
   {
-    const int v = tid / SEGS, seg = tid % SEGS;
-    double t = 0.0;
-    if (v < nred) {
-#pragma unroll
-      for (int k = 0; k < PTS / SEGS; k++) t += s_part[v][seg + SEGS * k];
-    }
+    const int v = cv;
+    double t = csum;
 #pragma unroll
     for (int m = 1; m < SEGS; m <<= 1) t += __shfl_xor(t, m, 64);
-    if (seg == 0 && v < nred) {
+    if (cseg == 0 && v < nred) {
       // exact split of the partial into 31-bit chunks, one integer atomic per non-zero chunk
       long long* bank = P.bins + (size_t)(seq % NDT_NBANKS) * NDT_BANK_WORDS + (size_t)(blockIdx.x & (NDT_NSHARDS - 1)) * (NDT_NBINS * 32);
       double r = t;
@@ -1367,29 +1458,36 @@ static int launch_one(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_
   }
 }
 
-template <int NOFF, int TAB>
+template <int NOFF, int TAB, int PTS>
 static int launch_quad_variant(dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, int seq) {
   static bool allowed[64] = {};
   if (dyn_lds > 32 * 1024) {
     int dev = 0;
     LSR_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !allowed[dev]) {
-      LSR_HIP(hipFuncSetAttribute((const void*)ndt_eval_quad_kernel<NOFF, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      LSR_HIP(hipFuncSetAttribute((const void*)ndt_eval_quad_kernel<NOFF, TAB, PTS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)NDT_LDS_TABLE_MAX_QUAD));
       allowed[dev] = true;
     }
   }
-  hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB>), grid, dim3(NDT_QUAD_THREADS), dyn_lds, stream, pv, seq);
+  hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB, PTS>), grid, dim3(4 * PTS), dyn_lds, stream, pv, seq);
   return LSR_OK;
 }
 
 template <int NOFF>
 static int launch_quad(const NdtLaunchCfg& cfg, dim3 grid, hipStream_t stream, const NdtProblem& pv, int seq) {
   const size_t dyn = (cfg.tab == NDT_TAB_LDS) ? (size_t)cfg.lds_bytes : 0;
+  if (cfg.threads == 64) {  // points per workgroup
+    switch (cfg.tab) {
+      case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 64>(grid, dyn, stream, pv, seq);
+      case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 64>(grid, dyn, stream, pv, seq);
+      default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 64>(grid, dyn, stream, pv, seq);
+    }
+  }
   switch (cfg.tab) {
-    case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS>(grid, dyn, stream, pv, seq);
-    case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT>(grid, dyn, stream, pv, seq);
-    default: return launch_quad_variant<NOFF, NDT_TAB_DENSE>(grid, dyn, stream, pv, seq);
+    case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 128>(grid, dyn, stream, pv, seq);
+    case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 128>(grid, dyn, stream, pv, seq);
+    default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 128>(grid, dyn, stream, pv, seq);
   }
 }
 

@@ -220,7 +220,7 @@ def test_gpu_matches_the_committed_golden_fixture():
 # ---- launch variants of the derivative pass and the two grid builders -----------------------------------------------
 # (quad: four lanes per point + integer-binned accumulation, workgroup of the one-lane kernel, table mode: 0 dense global,
 #  1 compact global, 2 LDS)
-VARIANTS = [(1, 0, 2), (1, 0, 0), (1, 0, 1), (0, 256, 0), (0, 256, 1), (0, 256, 2), (0, 128, 0), (0, 128, 2)]
+VARIANTS = [(1, 0, 2), (1, 0, 0), (1, 0, 1), (1, 64, 2), (0, 256, 0), (0, 256, 1), (0, 256, 2), (0, 128, 0), (0, 128, 2)]
 
 
 @pytest.mark.parametrize("quad,workgroup,table_mode", VARIANTS)

@@ -16,7 +16,7 @@ for builder in (0, 1):
     for _ in range(20):
         t0 = time.perf_counter(); ndt.setInputTarget(tgt); ts.append(time.perf_counter() - t0)
     print(f"setInputTarget builder {builder}: median {1e3 * np.median(ts):.3f} ms min {1e3 * np.min(ts):.3f} ms", ndt.gridInfo(), flush=True)
-for quad, wg, tab in ((1, 0, 2), (1, 0, 0), (0, 256, 2), (0, 256, 0)):
+for quad, wg, tab in ((1, 128, 2), (1, 64, 2), (1, 128, 0), (0, 256, 2), (0, 256, 0)):
     for eps, mi, name, reps in ((0.0, 30, "cfg2", 10), (0.01, 35, "cfg1", 40)):
         ndt = NormalDistributionsTransform(0); ndt.setResolution(5.0); ndt.setTransformationEpsilon(eps); ndt.setMaximumIterations(mi)
         ndt.setTuning(workgroup=wg, table_mode=tab, quad=quad)

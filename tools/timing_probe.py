@@ -14,12 +14,15 @@ assert lib.lsr_debug_timing_buffer(C.byref(buf)) == 0
 case = synth.cfg_ndt_30k()
 hip = C.CDLL("libamdhip64.so")
 host = np.zeros((1024, 32), np.int64)
-for quad, wg, tab in ((1, 128, 2), (1, 128, 0), (0, 256, 2), (0, 256, 0)):
+PHASES = ["INIT", "MT_FIRST", "MT_TRIAL", "MT_HESS", "DIAG"]
+for quad, wg, tab in ((1, 128, 2), (1, 64, 2), (0, 256, 2)):
     ndt = NormalDistributionsTransform(0); ndt.setResolution(5.0); ndt.setTransformationEpsilon(0.0); ndt.setMaximumIterations(30)
-    ndt.setTuning(workgroup=0 if quad else wg, table_mode=tab, quad=quad)
+    ndt.setTuning(workgroup=wg, table_mode=tab, quad=quad)
     ndt.setInputTarget(case.target); ndt.setInputSource(case.source)
     nb = (case.source.shape[0] + wg - 1) // wg
     for rep in range(3):
+        if rep == 2:
+            hip.hipMemset(C.c_void_p(buf.value + 800 * 32 * 8), 0, 8 * 32 * 8)
         ndt.align(case.guess)
         hip.hipDeviceSynchronize(); hip.hipMemcpy(C.c_void_p(host.ctypes.data), buf, host.nbytes, 2)
         w = host[:nb, 0::2].astype(np.float64) * 10.0   # ns
@@ -28,4 +31,8 @@ for quad, wg, tab in ((1, 128, 2), (1, 128, 0), (0, 256, 2), (0, 256, 0)):
         h = lambda a, b: np.median(w[:, a] - w[:, b])
         print(f"quad {quad} wg {wg} tab {tab}: HEAD state+rows in LDS +{h(1, 0):.0f} ns | totals +{h(6, 1):.0f} | controller +{h(5, 6):.0f} | "
               f"request +{h(4, 5):.0f} || MAIN (from main start 7): points done +{h(2, 7):.0f} | row written +{h(3, 2):.0f} "
-              f"| entry->main start (last pass, other launch) n/a | last result {ndt.last_result['iterations']} it {ndt.last_result['n_evaluations']} passes", flush=True)
+              f"| {ndt.last_result['iterations']} it {ndt.last_result['n_evaluations']} passes", flush=True)
+        for ph, name in enumerate(PHASES):
+            tot, cnt, req = host[800 + ph, 0], host[800 + ph, 1], host[800 + ph, 2]
+            if cnt:
+                print(f"      controller after {name:8s}: {cnt:4d} calls, mean {10.0 * tot / cnt:.0f} ns; request build mean {10.0 * req / cnt:.0f} ns", flush=True)
