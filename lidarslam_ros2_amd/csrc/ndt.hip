@@ -252,8 +252,15 @@ __device__ __forceinline__ bool mt_update_interval(MtInterval& I, double a_t, do
 // both give H^{-1} b.  A column whose pivot vanishes is dropped = its unknown set to 0, which is the
 // SVD's minimum-norm answer for the degenerate all-zero Hessian of a scan that overlaps no voxel.
 // (A wave-parallel Gauss-Jordan on an LDS matrix was measured slower: +0.9 us per pass on average.)
-// Hu: the 21 values of the upper triangle, row-major (0,0..5) (1,1..5) ... (5,5), in registers.
-__device__ __forceinline__ void solve6(const double* __restrict__ Hu, const double* __restrict__ b, double* __restrict__ x) {
+// Hu: the 21 values of the upper triangle, row-major (0,0..5) (1,1..5) ... (5,5), read straight from the LDS totals
+// (21 independent ds_reads, one wait).
+// Its own (not inlined) function: with the 6x7 working matrix in registers it needs ~140 VGPRs, which still fits the
+// caller-saved half of the register file — inlined into the Newton half the two together spill to scratch.
+// g: the gradient (the right-hand side is -g); out[0..5] receives delta.
+__device__ __attribute__((noinline)) void solve6(const LdsDouble* Hu, const LdsDouble* g, LdsDouble* out) {
+  double b[6], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) b[i] = -g[i];
   double A[6][7];
   double scale = 0;
   {
@@ -307,6 +314,8 @@ __device__ __forceinline__ void solve6(const double* __restrict__ Hu, const doub
     for (int j = k + 1; j < 6; j++) sacc -= A[k][j] * x[j];
     x[k] = (dropped & (1u << k)) ? 0.0 : sacc / A[k][k];
   }
+#pragma unroll
+  for (int i = 0; i < 6; i++) out[i] = x[i];
 }
 
 // The angular coefficient tables of eq. 6.19 (jang, 24 entries) and eq. 6.21 (hang, 48 entries) as DATA: every entry is
@@ -442,194 +451,217 @@ __device__ __forceinline__ void build_request(NdtState* S, double* f /*8*/, floa
 // Runs on one lane of EVERY workgroup (redundantly, same inputs, same result).  sums: [0]=score [1..6]=grad
 // [7]=pairs [8..28]=H upper.
 // One lane against LDS is a latency machine: a ds_read costs ~100 cycles before its value can be used, and the compiler
-// must keep reads and writes through the two LDS pointers in program order.  So the function reads everything it may
-// need in ONE batch of independent loads up front, runs the Newton / More-Thuente state machine in
-// registers, and writes the state back in one batch of stores at the end (first version: field-by-field LDS access,
-// 28 serialised read->wait->write round trips for the copy of the sums alone, 1.9 us for the shortest path).
-__device__ __attribute__((noinline)) void ndt_controller(LdsState* S, const LdsDouble* sums) {
+// keeps reads and writes through the two LDS pointers in program order.  So each function reads what it needs in batches
+// of independent loads, works in registers, and stores at the end (first version: field-by-field LDS access, 28
+// serialised read->wait->write round trips for the copy of the sums alone, 1.9 us for the shortest path).
+// The line search (9 of 10 passes at cfg 2) and the 6x6 solve are functions of their own (called, not inlined: 50 kernel
+// instantiations share them), each small enough to live in the caller-saved half of the register file: the AMDGPU
+// calling convention makes a callee spill every callee-saved VGPR it touches to scratch, and one function holding the
+// whole state machine plus the register-resident elimination needed 250 of them (3.3 us instead of 1.9).
+enum CtlNext : int { CTL_DONE = 0, CTL_NEWTON_BEGIN = 1, CTL_NEWTON_END = 2 };
+
+// Line-search half (computeStepLengthMT): bookkeeping of every pass + the More-Thuente decision after a
+// line-search pass.  Returns what the Newton half has to do, CTL_DONE if the next request is already in the state.
+__device__ __attribute__((noinline)) int ndt_controller_mt(LdsState* S, const LdsDouble* sums) {
   const double mu = 1.e-4, nu = 0.9;
   const int max_step_iterations = 10;
-  // ---- one batch of loads
-  double sv[29];
+  double sv[8];  // score, gradient, #pairs; the Hessian sums stay in LDS until the Newton solve loads them
 #pragma unroll
-  for (int k = 0; k < 29; k++) sv[k] = sums[k];
-  int phase = S->phase;
+  for (int k = 0; k < 8; k++) sv[k] = sums[k];
+  const int phase = S->phase;
   const bool had_hessian = S->want_hessian != 0;
   const int n_evals = S->n_evals + 1;
-  int nr_iterations = S->nr_iterations, converged = S->converged;
-  int open_interval = S->open_interval, interval_converged = S->interval_converged, step_iterations = S->step_iterations;
-  const int max_iter = S->max_iter, n_points = S->n_points;
-  const double step_max = S->step_max, step_min = S->step_min, eps = S->eps;
-  double p[6], dir[6], g[6];
+  if (phase == PH_INIT || phase == PH_MT_HESS || phase == PH_DIAG) {
+    S->n_evals = n_evals;
+    S->last_pairs = sv[7];
+    if (phase != PH_MT_HESS) {  // the Hessian recomputation leaves score and gradient of the last trial in place
+      S->score = sv[0];
 #pragma unroll
-  for (int i = 0; i < 6; i++) { p[i] = S->p[i]; dir[i] = S->dir[i]; g[i] = S->g[i]; }
-  double score = S->score;
-  double phi_0 = S->phi_0, d_phi_0 = S->d_phi_0, a_t = S->a_t;
+      for (int i = 0; i < 6; i++) S->g[i] = sv[1 + i];
+    }
+    if (phase == PH_DIAG) {  // lsr_ndt_derivatives: the sums are the result
+      if (had_hessian) {
+        double hu[21];
+#pragma unroll
+        for (int k = 0; k < 21; k++) hu[k] = sums[8 + k];
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = i; j < 6; j++) {
+            S->H[i * 6 + j] = hu[k];
+            S->H[j * 6 + i] = hu[k];
+            k++;
+          }
+      }
+      S->done = 1;
+      return CTL_DONE;
+    }
+    return phase == PH_INIT ? CTL_NEWTON_BEGIN : CTL_NEWTON_END;
+  }
+  // ---- PH_MT_FIRST / PH_MT_TRIAL: one batch of loads
+  int open_interval = S->open_interval, interval_converged = S->interval_converged, step_iterations = S->step_iterations;
+  const double step_max = S->step_max, step_min = S->step_min;
+  double p[6], dir[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { p[i] = S->p[i]; dir[i] = S->dir[i]; }
+  const double phi_0 = S->phi_0, d_phi_0 = S->d_phi_0;
+  double a_t = S->a_t;
   MtInterval I = {S->a_l, S->f_l, S->g_l, S->a_u, S->f_u, S->g_u};
 
-  if (phase != PH_MT_HESS) {
-    score = sv[0];
+  const double score = sv[0];
+  const double phi_t = -score;
+  double dot = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) g[i] = sv[1 + i];
+  for (int i = 0; i < 6; i++) dot += sv[1 + i] * dir[i];
+  const double d_phi_t = -dot;
+  const double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t;
+  const double d_psi_t = d_phi_t - mu * d_phi_0;
+  if (phase == PH_MT_TRIAL) {
+    if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+      open_interval = 0;
+      I.f_l = I.f_l + phi_0 - mu * d_phi_0 * I.a_l;
+      I.g_l = I.g_l + mu * d_phi_0;
+      I.f_u = I.f_u + phi_0 - mu * d_phi_0 * I.a_u;
+      I.g_u = I.g_u + mu * d_phi_0;
+    }
+    if (open_interval)
+      interval_converged = mt_update_interval(I, a_t, psi_t, d_psi_t) ? 1 : 0;
+    else
+      interval_converged = mt_update_interval(I, a_t, phi_t, d_phi_t) ? 1 : 0;
+    step_iterations++;
   }
+  int next = CTL_DONE;
+  if (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+    if (open_interval)
+      a_t = mt_trial_value(I.a_l, I.f_l, I.g_l, I.a_u, I.f_u, I.g_u, a_t, psi_t, d_psi_t);
+    else
+      a_t = mt_trial_value(I.a_l, I.f_l, I.g_l, I.a_u, I.f_u, I.g_u, a_t, phi_t, d_phi_t);
+    a_t = fmax(fmin(a_t, step_max), step_min);
+#pragma unroll
+    for (int i = 0; i < 6; i++) S->x_t[i] = p[i] + dir[i] * a_t;
+    S->a_t = a_t;
+    S->want_hessian = 0;
+    S->phase = PH_MT_TRIAL;
+    S->pad1 = 1;  // build T / jang for x_t
+  } else if (step_iterations) {
+    // computeHessian at x_t: current j_ang, h_ang left over from the last with-Hessian pass; same pose, no new request
+    S->want_hessian = 1;
+    S->phase = PH_MT_HESS;
+  } else {
+    next = CTL_NEWTON_END;
+  }
+  // ---- one batch of stores
   S->n_evals = n_evals;
   S->last_pairs = sv[7];
   S->score = score;
 #pragma unroll
-  for (int i = 0; i < 6; i++) S->g[i] = g[i];
-  if (phase == PH_DIAG) {  // lsr_ndt_derivatives: the sums are the result
-    if (had_hessian) {
-      int k = 8;
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = i; j < 6; j++) {
-          S->H[i * 6 + j] = sv[k];
-          S->H[j * 6 + i] = sv[k];
-          k++;
-        }
-    }
-    S->done = 1;
-    return;
-  }
-
-  enum { ST_NEWTON_BEGIN, ST_MT_CHECK, ST_NEWTON_END, ST_FINISH } stage;
-  double phi_t = 0, d_phi_t = 0, psi_t = 0, d_psi_t = 0;
-  // outcome of this call
-  int want_hessian = had_hessian ? 1 : 0, request = 0 /* S->pad1: bit0 build T/jang for x_t, bit1 also hang */, done = 0;
-  bool new_x_t = false;
-  double x_t[6] = {0, 0, 0, 0, 0, 0};
-  double trans_probability = 0;
-
-  if (phase == PH_INIT) {
-    stage = ST_NEWTON_BEGIN;
-  } else if (phase == PH_MT_HESS) {
-    stage = ST_NEWTON_END;
-  } else {
-    phi_t = -score;
-    double dot = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) dot += g[i] * dir[i];
-    d_phi_t = -dot;
-    psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t;
-    d_psi_t = d_phi_t - mu * d_phi_0;
-    if (phase == PH_MT_TRIAL) {
-      if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
-        open_interval = 0;
-        I.f_l = I.f_l + phi_0 - mu * d_phi_0 * I.a_l;
-        I.g_l = I.g_l + mu * d_phi_0;
-        I.f_u = I.f_u + phi_0 - mu * d_phi_0 * I.a_u;
-        I.g_u = I.g_u + mu * d_phi_0;
-      }
-      if (open_interval)
-        interval_converged = mt_update_interval(I, a_t, psi_t, d_psi_t) ? 1 : 0;
-      else
-        interval_converged = mt_update_interval(I, a_t, phi_t, d_phi_t) ? 1 : 0;
-      step_iterations++;
-    }
-    stage = ST_MT_CHECK;
-  }
-
-  for (int guard = 0; guard < 8 && !done && !request && !(phase == PH_MT_HESS && stage == ST_MT_CHECK); guard++) {
-    if (stage == ST_NEWTON_BEGIN) {
-      double neg_g[6], delta[6];
-#pragma unroll
-      for (int i = 0; i < 6; i++) neg_g[i] = -g[i];
-      solve6(sv + 8, neg_g, delta);  // the Hessian in use is always the one of the pass that just finished
-      double nrm = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++) nrm += delta[i] * delta[i];
-      nrm = sqrt(nrm);
-      if (nrm == 0 || nrm != nrm) {
-        converged = (nrm == nrm) ? 1 : 0;
-        stage = ST_FINISH;
-        continue;
-      }
-#pragma unroll
-      for (int i = 0; i < 6; i++) dir[i] = delta[i] / nrm;
-      // ---- computeStepLengthMT prologue
-      phi_0 = -score;
-      double dot = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++) dot += g[i] * dir[i];
-      d_phi_0 = -dot;
-      if (d_phi_0 >= 0) {
-        if (d_phi_0 == 0) {
-          a_t = 0;
-          stage = ST_NEWTON_END;
-          continue;
-        }
-        d_phi_0 = -d_phi_0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) dir[i] = -dir[i];
-      }
-      I.a_l = 0; I.a_u = 0;
-      I.f_l = 0; I.f_u = 0;  // psi(0) = phi_0 - phi_0 - mu*d_phi_0*0
-      I.g_l = d_phi_0 - mu * d_phi_0;
-      I.g_u = I.g_l;
-      interval_converged = (step_max - step_min) < 0 ? 1 : 0;
-      open_interval = 1;
-      step_iterations = 0;
-      a_t = fmax(fmin(nrm, step_max), step_min);
-#pragma unroll
-      for (int i = 0; i < 6; i++) x_t[i] = p[i] + dir[i] * a_t;
-      new_x_t = true;
-      want_hessian = 1; phase = PH_MT_FIRST; request = 3;
-    } else if (stage == ST_MT_CHECK) {
-      if (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
-        if (open_interval)
-          a_t = mt_trial_value(I.a_l, I.f_l, I.g_l, I.a_u, I.f_u, I.g_u, a_t, psi_t, d_psi_t);
-        else
-          a_t = mt_trial_value(I.a_l, I.f_l, I.g_l, I.a_u, I.f_u, I.g_u, a_t, phi_t, d_phi_t);
-        a_t = fmax(fmin(a_t, step_max), step_min);
-#pragma unroll
-        for (int i = 0; i < 6; i++) x_t[i] = p[i] + dir[i] * a_t;
-        new_x_t = true;
-        want_hessian = 0; phase = PH_MT_TRIAL; request = 1;
-      } else if (step_iterations) {
-        // computeHessian at x_t: current j_ang, h_ang left over from the last with-Hessian pass; same pose, no request
-        want_hessian = 1;
-        phase = PH_MT_HESS;
-        stage = ST_MT_CHECK;  // leaves the loop (see its condition)
-      } else {
-        stage = ST_NEWTON_END;
-      }
-    } else if (stage == ST_NEWTON_END) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) p[i] += dir[i] * a_t;
-      if (nr_iterations > max_iter || (nr_iterations && (fabs(a_t) < eps))) converged = 1;
-      nr_iterations++;
-      stage = converged ? ST_FINISH : ST_NEWTON_BEGIN;
-      phase = PH_INIT;  // (only a marker for the loop condition: the Hessian recomputation has been consumed)
-    } else {  // ST_FINISH
-      trans_probability = score / (double)n_points;
-      done = 1;
-    }
-  }
-  if (!done && !request && phase != PH_MT_HESS) {  // unreachable in practice (the a_t == 0 path converges after two rounds)
-    trans_probability = score / (double)n_points;
-    done = 1;
-  }
-
-  // ---- one batch of stores
-  S->want_hessian = want_hessian;
-  S->phase = phase;
-  S->pad1 = request;
-  S->done = done;
-  S->nr_iterations = nr_iterations;
-  S->converged = converged;
+  for (int i = 0; i < 6; i++) S->g[i] = sv[1 + i];
   S->open_interval = open_interval;
   S->interval_converged = interval_converged;
   S->step_iterations = step_iterations;
-  S->phi_0 = phi_0; S->d_phi_0 = d_phi_0; S->a_t = a_t;
   S->a_l = I.a_l; S->f_l = I.f_l; S->g_l = I.g_l; S->a_u = I.a_u; S->f_u = I.f_u; S->g_u = I.g_u;
+  return next;
+}
+
+// Newton half (computeTransformation), in two small pieces around the call of solve6 so that nothing but
+// the two LDS pointers is live across a call (a callee-saved register costs its user a scratch spill).
+// End of a Newton iteration: pose update, convergence test.  Returns CTL_NEWTON_BEGIN, or CTL_DONE after finishing.
+__device__ __forceinline__ int ndt_newton_end(LdsState* S) {
+  const int nr_iterations = S->nr_iterations, max_iter = S->max_iter;
+  const double a_t = S->a_t, eps = S->eps;
+  double p[6], dir[6];
 #pragma unroll
-  for (int i = 0; i < 6; i++) { S->p[i] = p[i]; S->dir[i] = dir[i]; }
-  if (new_x_t) {
+  for (int i = 0; i < 6; i++) { p[i] = S->p[i]; dir[i] = S->dir[i]; }
+  const double score = S->score;
+  const int n_points = S->n_points;
+  int converged = S->converged;
+  if (nr_iterations > max_iter || (nr_iterations && (fabs(a_t) < eps))) converged = 1;
 #pragma unroll
-    for (int i = 0; i < 6; i++) S->x_t[i] = x_t[i];
+  for (int i = 0; i < 6; i++) S->p[i] = p[i] + dir[i] * a_t;
+  S->nr_iterations = nr_iterations + 1;
+  S->converged = converged;
+  if (converged) {
+    S->trans_probability = score / (double)n_points;
+    S->done = 1;
+    return CTL_DONE;
   }
-  if (done) S->trans_probability = trans_probability;
+  return CTL_NEWTON_BEGIN;
+}
+
+// Start of a Newton iteration, after solve6 left delta = -H^{-1} g in `delta`: direction, computeStepLengthMT prologue,
+// first step of the line search.  Returns CTL_DONE (request written or align finished) or CTL_NEWTON_END (zero slope).
+__device__ __forceinline__ int ndt_newton_begin(LdsState* S, const LdsDouble* delta_lds) {
+  const double mu = 1.e-4;
+  double delta[6], g[6], p[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { delta[i] = delta_lds[i]; g[i] = S->g[i]; p[i] = S->p[i]; }
+  const double score = S->score, step_max = S->step_max, step_min = S->step_min;
+  const int n_points = S->n_points;
+  double nrm = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) nrm += delta[i] * delta[i];
+  nrm = sqrt(nrm);
+  if (nrm == 0 || nrm != nrm) {
+    S->converged = (nrm == nrm) ? 1 : 0;
+    S->trans_probability = score / (double)n_points;
+    S->done = 1;
+    return CTL_DONE;
+  }
+  double dir[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) dir[i] = delta[i] / nrm;
+  const double phi_0 = -score;
+  double dot = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) dot += g[i] * dir[i];
+  double d_phi_0 = -dot;
+  S->phi_0 = phi_0;
+  if (d_phi_0 >= 0) {
+    if (d_phi_0 == 0) {
+      S->d_phi_0 = d_phi_0;
+      S->a_t = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) S->dir[i] = dir[i];
+      return CTL_NEWTON_END;
+    }
+    d_phi_0 = -d_phi_0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) dir[i] = -dir[i];
+  }
+  const double a_t = fmax(fmin(nrm, step_max), step_min);
+  S->d_phi_0 = d_phi_0;
+  S->a_l = 0; S->a_u = 0;
+  S->f_l = 0; S->f_u = 0;  // psi(0) = phi_0 - phi_0 - mu*d_phi_0*0
+  S->g_l = d_phi_0 - mu * d_phi_0;
+  S->g_u = d_phi_0 - mu * d_phi_0;
+  S->interval_converged = (step_max - step_min) < 0 ? 1 : 0;
+  S->open_interval = 1;
+  S->step_iterations = 0;
+  S->a_t = a_t;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { S->dir[i] = dir[i]; S->x_t[i] = p[i] + dir[i] * a_t; }
+  S->want_hessian = 1;
+  S->phase = PH_MT_FIRST;
+  S->pad1 = 3;  // build T / jang / hang for x_t
+  return CTL_DONE;
+}
+
+__device__ __forceinline__ void ndt_controller(LdsState* S, const LdsDouble* sums) {
+  int next = ndt_controller_mt(S, sums);
+  LdsDouble* scratch = const_cast<LdsDouble*>(sums);  // sums[0..7] are consumed by now: delta lands in sums[0..5]
+  for (int guard = 0; guard < 8 && next != CTL_DONE; guard++) {
+    if (next == CTL_NEWTON_END) {
+      next = ndt_newton_end(S);
+    } else {
+      solve6(sums + 8, S->g, scratch);  // the Hessian in use is always the one of the pass that just finished
+      next = ndt_newton_begin(S, scratch);
+    }
+  }
+  if (next != CTL_DONE) {  // unreachable in practice (the a_t == 0 path converges after two rounds)
+    S->trans_probability = S->score / (double)S->n_points;
+    S->done = 1;
+  }
 }
 
 #ifdef LSR_TIMING
@@ -656,12 +688,30 @@ __device__ long long* g_lsr_timing = nullptr;  // [blocks][16] {wall, shader} pa
     if ((col) == 0) atomicAdd((unsigned long long*)&g_lsr_timing[(800 + _ctl_ph) * 32 + 1], 1ull);                     \
     _ctl_t0 = _t;                                                                       \
   }
+// per-pass phase durations of workgroup 0 by pass type: rows 810 (gradient-only pass) / 811 (with Hessian) hold
+// {count, head ticks (entry -> state in LDS), main ticks (request read -> points done), tail ticks, shader cycles entry -> exit,
+//  wall ticks entry -> exit}
+#define LSR_PASS_BEGIN()                                                               \
+  long long _p_t0 = 0, _p_c0 = 0, _p_t1 = 0, _p_t7 = 0, _p_t2 = 0;                         \
+  const bool _p_on = (threadIdx.x == 0 && g_lsr_timing && blockIdx.x == 0 && blockIdx.y == 0); \
+  if (_p_on) { _p_t0 = (long long)wall_clock64(); _p_c0 = (long long)clock64(); }
+#define LSR_PASS_MARK(var) if (_p_on) { var = (long long)wall_clock64(); }
+#define LSR_PASS_END(hess)                                                             \
+  if (_p_on) {                                                                          \
+    const long long _t3 = (long long)wall_clock64(), _c3 = (long long)clock64();         \
+    unsigned long long* _r = (unsigned long long*)&g_lsr_timing[(810 + ((hess) ? 1 : 0)) * 32]; \
+    atomicAdd(&_r[0], 1ull); atomicAdd(&_r[1], (unsigned long long)(_p_t1 - _p_t0)); atomicAdd(&_r[2], (unsigned long long)(_p_t2 - _p_t7)); \
+    atomicAdd(&_r[3], (unsigned long long)(_t3 - _p_t2)); atomicAdd(&_r[4], (unsigned long long)(_c3 - _p_c0)); atomicAdd(&_r[5], (unsigned long long)(_t3 - _p_t0)); \
+  }
 #else
 #define LSR_STAMP(k)
 #define LSR_SPAN_BEGIN(seq)
 #define LSR_SPAN_END(seq)
 #define LSR_CTL_BEGIN(L)
 #define LSR_CTL_END(col)
+#define LSR_PASS_BEGIN()
+#define LSR_PASS_MARK(var)
+#define LSR_PASS_END(hess)
 #endif
 
 // Values read from the LDS state image are wave-uniform; telling the compiler (v_readfirstlane -> SGPR)
@@ -821,6 +871,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
   if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x;
   LSR_STAMP(0)
+  LSR_PASS_BEGIN()
   LSR_SPAN_BEGIN(seq)
 
   constexpr int NQ = THREADS / 4;    // quad sums per value
@@ -876,6 +927,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
   __syncthreads();
   LdsState* L = (LdsState*)s_state;
   LSR_STAMP(1)
+  LSR_PASS_MARK(_p_t1)
   if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0)  // progress report for the host's launch feeder (relaxed)
     __hip_atomic_store(&P.mailbox->progress, ((unsigned long long)(unsigned int)L->token << 32) | (unsigned int)seq,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -943,6 +995,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
     return;
   }
   LSR_STAMP(7)
+  LSR_PASS_MARK(_p_t7)
 
   // ---- this launch's request, straight from the LDS image
   const bool hess = uniform_i(L->want_hessian) != 0;
@@ -1045,6 +1098,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
   }
 
   LSR_STAMP(2)
+  LSR_PASS_MARK(_p_t2)
   // ---- workgroup reduction: quad sum in registers (DPP) -> LDS transpose [value][quad sums] ->
   //      SEGS interleaved segment sums per value -> one partial row
   const int nred = hess ? 29 : NDT_NRED_GRAD;
@@ -1079,6 +1133,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
     if (seg == 0 && v < nred) prow[v] = t;  // consumed by EVERY workgroup at the head of the next launch
   }
   LSR_STAMP(3)
+  LSR_PASS_END(hess)
   LSR_SPAN_END(seq)
 }
 
@@ -1111,6 +1166,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x, ql = tid & 3, pq = tid >> 2;
   LSR_STAMP(0)
+  LSR_PASS_BEGIN()
   LSR_SPAN_BEGIN(seq)
 
   __shared__ float s_pt[14][PITCH];   // phase A -> B: per point {score, #pairs, A (3), E (6), x, y, z}
@@ -1155,6 +1211,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   __syncthreads();
   LdsState* L = (LdsState*)s_state;
   LSR_STAMP(1)
+  LSR_PASS_MARK(_p_t1)
   if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0)  // progress report for the host's launch feeder (relaxed)
     __hip_atomic_store(&P.mailbox->progress, ((unsigned long long)(unsigned int)L->token << 32) | (unsigned int)seq,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1219,6 +1276,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
     for (int k = tid; k < NDT_BANK_WORDS / 2; k += THREADS) zb[k] = make_uint4(0u, 0u, 0u, 0u);
   }
   LSR_STAMP(7)
+  LSR_PASS_MARK(_p_t7)
 
   // ---- this launch's request, straight from the LDS image
   const bool hess = uniform_i(L->want_hessian) != 0;
@@ -1356,6 +1414,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   }
 
   LSR_STAMP(2)
+  LSR_PASS_MARK(_p_t2)
   {
     const int v = cv;
     double t = csum;
@@ -1380,6 +1439,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
     }
   }
   LSR_STAMP(3)
+  LSR_PASS_END(hess)
   LSR_SPAN_END(seq)
 }
 

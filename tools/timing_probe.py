@@ -22,7 +22,7 @@ for quad, wg, tab in ((1, 128, 2), (1, 64, 2), (0, 256, 2)):
     nb = (case.source.shape[0] + wg - 1) // wg
     for rep in range(3):
         if rep == 2:
-            hip.hipMemset(C.c_void_p(buf.value + 800 * 32 * 8), 0, 8 * 32 * 8)
+            hip.hipMemset(C.c_void_p(buf.value + 800 * 32 * 8), 0, 16 * 32 * 8)
         ndt.align(case.guess)
         hip.hipDeviceSynchronize(); hip.hipMemcpy(C.c_void_p(host.ctypes.data), buf, host.nbytes, 2)
         w = host[:nb, 0::2].astype(np.float64) * 10.0   # ns
@@ -32,6 +32,11 @@ for quad, wg, tab in ((1, 128, 2), (1, 64, 2), (0, 256, 2)):
         print(f"quad {quad} wg {wg} tab {tab}: HEAD state+rows in LDS +{h(1, 0):.0f} ns | totals +{h(6, 1):.0f} | controller +{h(5, 6):.0f} | "
               f"request +{h(4, 5):.0f} || MAIN (from main start 7): points done +{h(2, 7):.0f} | row written +{h(3, 2):.0f} "
               f"| {ndt.last_result['iterations']} it {ndt.last_result['n_evaluations']} passes", flush=True)
+        for hs, name in ((0, "gradient-only"), (1, "with Hessian")):
+            r = host[810 + hs].astype(np.float64)
+            if r[0]:
+                print(f"      {name:13s} passes: {int(r[0]):4d}; workgroup 0 means: head {10 * r[1] / r[0]:.0f} ns, main {10 * r[2] / r[0]:.0f} ns, tail {10 * r[3] / r[0]:.0f} ns, "
+                      f"entry->exit {10 * r[5] / r[0]:.0f} ns at {r[4] / (10 * r[5]) :.3f} GHz shader clock", flush=True)
         for ph, name in enumerate(PHASES):
             tot, cnt, req = host[800 + ph, 0], host[800 + ph, 1], host[800 + ph, 2]
             if cnt:
