@@ -257,10 +257,64 @@ __device__ __forceinline__ bool mt_update_interval(MtInterval& I, double a_t, do
 // Its own (not inlined) function: with the 6x7 working matrix in registers it needs ~140 VGPRs, which still fits the
 // caller-saved half of the register file — inlined into the Newton half the two together spill to scratch.
 // g: the gradient (the right-hand side is -g); out[0..5] receives delta.
+// Fast path first: near the optimum the Hessian is definite, and an unpivoted LDL^T of the upper triangle (~100 fp64 FMAs
+// and 6 reciprocals on the one lane everybody waits for) is as stable as pivoted elimination there.  It is accepted only
+// when every pivot has the sign of the first one and none is tiny against the matrix scale; anything else (indefinite
+// far from the optimum, rank deficient) takes the pivoted elimination below.
 __device__ __attribute__((noinline)) void solve6(const LdsDouble* Hu, const LdsDouble* g, LdsDouble* out) {
   double b[6], x[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) b[i] = -g[i];
+  {
+    double a[6][6];  // upper triangle in a[i][j], i <= j
+    double scale = 0;
+    {
+      int k = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) { a[i][j] = Hu[k]; scale = fmax(scale, fabs(a[i][j])); k++; }
+    }
+    // a[i][j] (i < j) becomes L[j][i] * d[i] during the sweep, then L[j][i]; d[j] replaces a[j][j]
+    double d[6], rd[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double dj = a[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) dj = fma(-a[k][j] * a[k][j], d[k], dj);  // a[k][j] holds L[j][k]
+      d[j] = dj;
+      ok = ok && (dj * d[0] > 0.0) && (fabs(dj) > 1e-13 * scale);
+      rd[j] = mt_div(1.0, dj);
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) {
+        double v = a[j][i];
+#pragma unroll
+        for (int k = 0; k < j; k++) v = fma(-a[k][i] * a[k][j], d[k], v);
+        a[j][i] = v * rd[j];  // L[i][j]
+      }
+    }
+    if (ok) {
+      double y[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) {  // L y = b
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v = fma(-a[k][i], y[k], v);
+        y[i] = v;
+      }
+#pragma unroll
+      for (int i = 5; i >= 0; i--) {  // L^T x = D^-1 y
+        double v = y[i] * rd[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) v = fma(-a[i][k], x[k], v);
+        x[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 6; i++) out[i] = x[i];
+      return;
+    }
+  }
   double A[6][7];
   double scale = 0;
   {
@@ -462,7 +516,7 @@ enum CtlNext : int { CTL_DONE = 0, CTL_NEWTON_BEGIN = 1, CTL_NEWTON_END = 2 };
 
 // Line-search half (computeStepLengthMT): bookkeeping of every pass + the More-Thuente decision after a
 // line-search pass.  Returns what the Newton half has to do, CTL_DONE if the next request is already in the state.
-__device__ __attribute__((noinline)) int ndt_controller_mt(LdsState* S, const LdsDouble* sums) {
+__device__ __forceinline__ int ndt_controller_mt(LdsState* S, const LdsDouble* sums) {
   const double mu = 1.e-4, nu = 0.9;
   const int max_step_iterations = 10;
   double sv[8];  // score, gradient, #pairs; the Hessian sums stay in LDS until the Newton solve loads them
@@ -671,6 +725,10 @@ __device__ long long* g_lsr_timing = nullptr;  // [blocks][16] {wall, shader} pa
     g_lsr_timing[blockIdx.x * 32 + 2 * (k)] = (long long)wall_clock64();                \
     g_lsr_timing[blockIdx.x * 32 + 2 * (k) + 1] = (long long)clock64();                 \
   }
+#define LSR_STAMP_T(k, t)                                                              \
+  if ((int)threadIdx.x == (t) && g_lsr_timing && blockIdx.y == 0) {                       \
+    g_lsr_timing[blockIdx.x * 32 + 2 * (k)] = (long long)wall_clock64();                \
+  }
 #define LSR_SPAN_BEGIN(seq)                                                                                   \
   if (threadIdx.x == 0 && g_lsr_timing && blockIdx.y == 0)                                                     \
     atomicMin((unsigned long long*)&g_lsr_timing[(512 + ((seq) & 255)) * 32 + 0], (unsigned long long)wall_clock64());
@@ -705,6 +763,7 @@ __device__ long long* g_lsr_timing = nullptr;  // [blocks][16] {wall, shader} pa
   }
 #else
 #define LSR_STAMP(k)
+#define LSR_STAMP_T(k, t)
 #define LSR_SPAN_BEGIN(seq)
 #define LSR_SPAN_END(seq)
 #define LSR_CTL_BEGIN(L)
@@ -871,6 +930,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
   if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x;
   LSR_STAMP(0)
+  LSR_STAMP_T(9, THREADS - 64)
   LSR_PASS_BEGIN()
   LSR_SPAN_BEGIN(seq)
 
@@ -898,8 +958,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
   const int stride = P.nblocks * THREADS;
   int i = blockIdx.x * THREADS + tid;
   float x = 0.f, y = 0.f, z = 0.f;
-  if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
-  const unsigned int ang_entry = (tid < 72) ? k_angle_entries[tid] : 0u;  // consumed by build_request (off the critical path)
+  unsigned int ang_entry = 0u;
   {
     const uint4* gq = reinterpret_cast<const uint4*>(Sin);
     const uint4 stq = (tid < STATE_Q) ? gq[tid] : make_uint4(0u, 0u, 0u, 0u);
@@ -923,8 +982,15 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
     s_grp[grp][2 * v2] = sum.x;
     s_grp[grp][2 * v2 + 1] = sum.y;
     if (tid < STATE_Q) s_state_q[tid] = stq;
+    // Issued AFTER the shared (hot) lines have landed, on purpose: vmcnt retires in order, so loads issued earlier would
+    // make the head wait for this workgroup's own points (first touch of their lines).  They are needed after the
+    // controller and fly across the barriers of the head (which wait for LDS traffic only).
+    if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
+    if (tid < 72) ang_entry = k_angle_entries[tid];  // consumed by build_request
   }
-  __syncthreads();
+  LSR_STAMP_T(8, 0)
+  LSR_STAMP_T(10, THREADS - 64)
+  barrier_lds_only();  // not __syncthreads(): the point loads stay in flight
   LdsState* L = (LdsState*)s_state;
   LSR_STAMP(1)
   LSR_PASS_MARK(_p_t1)
@@ -1166,6 +1232,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x, ql = tid & 3, pq = tid >> 2;
   LSR_STAMP(0)
+  LSR_STAMP_T(9, THREADS - 64)
   LSR_PASS_BEGIN()
   LSR_SPAN_BEGIN(seq)
 
@@ -1186,8 +1253,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   const int stride = P.nblocks * PTS;
   int i = blockIdx.x * PTS + pq;
   float x = 0.f, y = 0.f, z = 0.f;
-  if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
-  const unsigned int ang_entry = (tid < 72) ? k_angle_entries[tid] : 0u;
+  unsigned int ang_entry = 0u;
   {
     const uint4* gq = reinterpret_cast<const uint4*>(Sin);
     const uint4 stq = (tid < STATE_Q) ? gq[tid] : make_uint4(0u, 0u, 0u, 0u);
@@ -1207,8 +1273,13 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
       s_bin[k][tid & 31] = (double)msum * q;
     }
     if (tid < STATE_Q) s_state_q[tid] = stq;
+    // issued after the shared lines have landed, on purpose (see the one-lane kernel): these fly across the head's barriers
+    if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
+    if (tid < 72) ang_entry = k_angle_entries[tid];
   }
-  __syncthreads();
+  LSR_STAMP_T(8, 0)
+  LSR_STAMP_T(10, THREADS - 64)
+  barrier_lds_only();  // not __syncthreads(): the point loads stay in flight
   LdsState* L = (LdsState*)s_state;
   LSR_STAMP(1)
   LSR_PASS_MARK(_p_t1)

@@ -32,6 +32,8 @@ for quad, wg, tab in ((1, 128, 2), (1, 64, 2), (0, 256, 2)):
         print(f"quad {quad} wg {wg} tab {tab}: HEAD state+rows in LDS +{h(1, 0):.0f} ns | totals +{h(6, 1):.0f} | controller +{h(5, 6):.0f} | "
               f"request +{h(4, 5):.0f} || MAIN (from main start 7): points done +{h(2, 7):.0f} | row written +{h(3, 2):.0f} "
               f"| {ndt.last_result['iterations']} it {ndt.last_result['n_evaluations']} passes", flush=True)
+        print(f"      head detail (medians over workgroups, last launch): wave 0 entry -> its loads landed +{h(8, 0):.0f} ns -> barrier passed +{h(1, 8):.0f} ns | "
+              f"last wave entry {h(9, 0):+.0f} ns after wave 0, its loads landed +{h(10, 9):.0f} ns", flush=True)
         for hs, name in ((0, "gradient-only"), (1, "with Hessian")):
             r = host[810 + hs].astype(np.float64)
             if r[0]:
