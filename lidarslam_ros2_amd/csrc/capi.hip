@@ -228,10 +228,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     cfg.tab = tab;
     cfg.lds_bytes = (tab == NDT_TAB_LDS) ? lds_max : 0;
   }
-  if (cfg.quad) {
-    if ((st = lead->d_bins.reserve((size_t)NDT_NBANKS * NDT_BANK_WORDS))) return st;
-    LSR_HIP(hipMemsetAsync(lead->d_bins.p, 0, sizeof(long long) * NDT_NBANKS * NDT_BANK_WORDS, lead->stream));
-  }
+  if (cfg.quad && (st = lead->d_bins.reserve((size_t)NDT_NBANKS * NDT_BANK_WORDS))) return st;  // cleared by ndt_init_single
   size_t tot_blocks = 0;
   int max_blocks = 1;
   for (int b = 0; b < B; b++) {
@@ -270,7 +267,11 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   const auto t0 = std::chrono::steady_clock::now();
   if (B > 1)  // a single registration carries its NdtProblem in the kernel arguments
     LSR_HIP(hipMemcpyAsync(lead->d_prob.p, lead->h_prob.p, sizeof(NdtProblem) * B, hipMemcpyHostToDevice, lead->stream));
-  LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
+  if (B == 1) {  // state in the kernel arguments of one small launch (no SDMA copy, no memset)
+    if ((st = ndt_init_single(lead->h_state.p[0], lead->d_state.p, cfg.quad ? lead->d_bins.p : nullptr, lead->stream))) return st;
+  } else {
+    LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
+  }
   if (lead->profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   int launches = 0;
   st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, cfg, min_evals, hard_cap, token, &launches);

@@ -729,12 +729,17 @@ __device__ long long* g_lsr_timing = nullptr;  // [blocks][16] {wall, shader} pa
   if ((int)threadIdx.x == (t) && g_lsr_timing && blockIdx.y == 0) {                       \
     g_lsr_timing[blockIdx.x * 32 + 2 * (k)] = (long long)wall_clock64();                \
   }
+#ifdef LSR_TIMING_SPAN  // contended atomics in front of the head's loads: distorts the head by microseconds, off by default
 #define LSR_SPAN_BEGIN(seq)                                                                                   \
   if (threadIdx.x == 0 && g_lsr_timing && blockIdx.y == 0)                                                     \
     atomicMin((unsigned long long*)&g_lsr_timing[(512 + ((seq) & 255)) * 32 + 0], (unsigned long long)wall_clock64());
 #define LSR_SPAN_END(seq)                                                                                     \
   if (threadIdx.x == 0 && g_lsr_timing && blockIdx.y == 0)                                                     \
     atomicMax((unsigned long long*)&g_lsr_timing[(512 + ((seq) & 255)) * 32 + 1], (unsigned long long)wall_clock64());
+#else
+#define LSR_SPAN_BEGIN(seq)
+#define LSR_SPAN_END(seq)
+#endif
 // controller time by the phase it consumed: rows 800 + phase hold {sum of ticks, count, sum of request-build ticks}
 #define LSR_CTL_BEGIN(L)                                                              \
   long long _ctl_t0 = 0; int _ctl_ph = 0;                                              \
@@ -1358,6 +1363,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   for (int k = 0; k < 12; k++) T[k] = uniform_f(L->T[k]);
   const float leaf = P.leaf;
   __syncthreads();  // the table DMA has landed (vmcnt(0) + barrier)
+  LSR_STAMP(11)
 
   const unsigned short* s_map = reinterpret_cast<const unsigned short*>(s_table);
   const float4* s_rec = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(s_table) + P.lds_map_bytes);
@@ -1455,6 +1461,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
       x = 0.f; y = 0.f; z = 0.f;
       if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }   // next batch's loads fly under phases B and C
     }
+    LSR_STAMP(12)
     barrier_lds_only();
     // ---- phase B
     if (tid < PTS) {
@@ -1475,7 +1482,9 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
         for (int k = 0; k < NDT_NRED_GRAD; k++) s_o[k][tid] = o[k];
       }
     }
+    LSR_STAMP(13)
     barrier_lds_only();
+    LSR_STAMP(14)
     // ---- phase C: the float terms of the reference's per-point sums, accumulated in double
     if (cv < nred) {
 #pragma unroll
@@ -1587,6 +1596,28 @@ static int launch_one(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_
     case NDT_TAB_COMPACT: return launch_variant<NOFF, NDT_TAB_COMPACT, 256>(byval, grid, dyn, stream, pv, d_probs, seq);
     default: return launch_variant<NOFF, NDT_TAB_DENSE, 256>(byval, grid, dyn, stream, pv, d_probs, seq);
   }
+}
+
+// Start of a single align(): the initial controller state travels in the KERNEL ARGUMENTS (1 KiB) and one small launch
+// writes both state buffers and clears the accumulator banks — instead of a host-to-device copy (SDMA latency) plus a
+// memset in front of the launch chain.
+namespace {
+__global__ __launch_bounds__(256) void ndt_init_kernel(const NdtState st, NdtState* __restrict__ out, long long* __restrict__ bins) {
+  constexpr int STATE_Q = (int)(sizeof(NdtState) / 16);
+  const uint4* src = reinterpret_cast<const uint4*>(&st);
+  uint4* dst = reinterpret_cast<uint4*>(out);
+  for (int k = threadIdx.x; k < 2 * STATE_Q; k += 256) dst[k] = src[k % STATE_Q];
+  if (bins) {
+    uint4* zb = reinterpret_cast<uint4*>(bins);
+    for (int k = threadIdx.x; k < NDT_NBANKS * NDT_BANK_WORDS / 2; k += 256) zb[k] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+}  // namespace
+
+int ndt_init_single(const NdtState& st, NdtState* d_state2, long long* d_bins, hipStream_t stream) {
+  hipLaunchKernelGGL(ndt_init_kernel, dim3(1), dim3(256), 0, stream, st, d_state2, d_bins);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
 }
 
 template <int NOFF, int TAB, int PTS>

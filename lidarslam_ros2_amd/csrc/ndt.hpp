@@ -146,6 +146,9 @@ int ndt_pack_lds_table(VoxelGridDev& grid, BuildScratch& sc, bool per_cell_leaf_
 // round trip.  grid.min_b / div_b / ncells must be set.
 constexpr int VG_DENSE_MAX_CELLS = 16383;
 int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
+// One small launch that writes the initial state (passed in the kernel arguments) into both state buffers and clears the
+// quad kernel's accumulator banks (d_bins nullable).
+int ndt_init_single(const NdtState& st, NdtState* d_state2, long long* d_bins, hipStream_t stream);
 // Host: controller state at the entry of computeTransformation (guess nullable = identity).
 void ndt_fill_initial_state(NdtState& st, const float* guess16, const NdtParamsHost& prm, int n_points);
 // Fill a diagnostic request on the host (lsr_ndt_derivatives).

@@ -34,6 +34,9 @@ for quad, wg, tab in ((1, 128, 2), (1, 64, 2), (0, 256, 2)):
               f"| {ndt.last_result['iterations']} it {ndt.last_result['n_evaluations']} passes", flush=True)
         print(f"      head detail (medians over workgroups, last launch): wave 0 entry -> its loads landed +{h(8, 0):.0f} ns -> barrier passed +{h(1, 8):.0f} ns | "
               f"last wave entry {h(9, 0):+.0f} ns after wave 0, its loads landed +{h(10, 9):.0f} ns", flush=True)
+        if quad:
+            print(f"      main detail (last pass, with Hessian): request read + table landed +{h(11, 7):.0f} ns | phase A +{h(12, 11):.0f} | barrier + phase B +{h(13, 12):.0f} | "
+                  f"barrier +{h(14, 13):.0f} | phase C +{h(2, 14):.0f} | shuffles + split + atomics +{h(3, 2):.0f}", flush=True)
         for hs, name in ((0, "gradient-only"), (1, "with Hessian")):
             r = host[810 + hs].astype(np.float64)
             if r[0]:
