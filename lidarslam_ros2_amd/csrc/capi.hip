@@ -100,6 +100,24 @@ void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_part
   P.mailbox = nullptr;
 }
 
+// A fresh target object — or the handle's current one recycled when nobody else holds it (lsr_share_target): its device
+// buffers only ever grow, so the frontend's "new target every few scans" costs no hipMalloc / hipFree (those were 250 us
+// of a 350 us setInputTarget).
+std::shared_ptr<TargetData> fresh_target(lsr_handle h) {
+  std::shared_ptr<TargetData> t;
+  auto only_mine = [&](const std::shared_ptr<TargetData>& c) {
+    return c && c.use_count() == (long)((h->target == c) + (h->spare_target == c));
+  };
+  if (only_mine(h->target)) t = h->target;
+  else if (only_mine(h->spare_target)) t = h->spare_target;
+  else t = std::make_shared<TargetData>();
+  h->spare_target = t;  // survives a failed setInputTarget (which resets h->target)
+  t->n = 0;
+  t->has_grid = t->has_hash = t->has_cov = false;
+  t->grid_leaf = 0.f;
+  return t;
+}
+
 int ensure_ndt_grid(lsr_handle h) {
   TargetData& t = *h->target;
   float leaf = (float)h->ndt.resolution;
@@ -498,7 +516,7 @@ int lsr_get_i32(lsr_handle h, int key, int* v) {
 
 static int set_target_impl(lsr_handle h, const void* pts, size_t stride, size_t n, bool on_device) {
   LSR_CHECK_HANDLE(h);
-  auto t = std::make_shared<TargetData>();
+  auto t = fresh_target(h);
   int st = upload_cloud(h, pts, stride, n, on_device, t->cloud);
   if (st) return st;
   t->n = n;
@@ -557,7 +575,7 @@ int lsr_set_input_target_frames(lsr_handle h, int n_frames, const void* const* f
     set_last_error("bad frame list");
     return LSR_ERR_INVALID_ARGUMENT;
   }
-  auto t = std::make_shared<TargetData>();
+  auto t = fresh_target(h);
   int st = assemble_frames(h, n_frames, frames, counts, stride_bytes, poses16, on_device != 0, t->cloud);
   if (st) return st;
   t->n = t->cloud.n;
@@ -819,7 +837,7 @@ int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, si
     int st = assemble_frames(h, (int)frames.size(), frames.data(), counts.data(), stride_bytes, poses.data(), on_device != 0, h->raw);
     if (st) return st;
     // voxelgrid_.filter + setInputTarget (:224-227)
-    auto t = std::make_shared<TargetData>();
+    auto t = fresh_target(h);
     if ((st = voxel_grid_filter(h->raw, params->voxel_leaf_size, t->cloud, h->scratch, h->stream))) return st;
     t->n = t->cloud.n;
     h->target = t;

@@ -130,9 +130,14 @@ struct HashGridDev {
 // Host mailbox of the target-side builders (pinned, host-coherent memory mapped into the device): the kernels publish
 // the few scalars the host needs (bounding box, leaf counts) straight into host memory and the host polls a token —
 // no device-to-host copy and no stream synchronisation inside a grid build.
+constexpr int BBOX_MAX_PARTS = 256;
+struct BboxPart {             // one workgroup's share of a bounding box, written straight into host memory
+  float mn[3], mx[3];
+  unsigned int n_finite;
+  unsigned int token;         // written last (release): the record is complete
+};
 struct BuildMailbox {
-  unsigned int bbox[8];       // order-preserving uint encoding of min xyz, max xyz; [6] = #finite points
-  unsigned int bbox_token;    // release-stored after bbox[]
+  BboxPart part[BBOX_MAX_PARTS];
   int n_valid, n_occupied;    // leaves usable by lookups / leaves holding at least one point
   int lds_bytes, lds_map_bytes;
   unsigned int done_token;    // release-stored after the counts
@@ -149,7 +154,6 @@ struct BuildScratch {
   DevBuf<unsigned int> words;
   DevBuf<double> sums;
   DevBuf<float> sorted;            // dense-grid counting sort: cell-sorted x | y | z planes
-  DevBuf<unsigned int> bbox_acc;   // bbox_kernel accumulators (self-resetting)
   bool force_sort_path = false;    // tests: build dense key spaces with the general (radix sort) builder too
   PinBuf<BuildMailbox> mb;         // host view
   BuildMailbox* d_mb = nullptr;    // device view of mb.p

@@ -70,16 +70,22 @@ __global__ __launch_bounds__(256) void vg_hist_kernel(const float* __restrict__ 
   for (int k = tid; k < C; k += 256) s_hist[k] = 0u;
   __syncthreads();
   const int base = blockIdx.x * VG_CHUNK;
-#pragma unroll 4
+  float px[VG_CHUNK / 256], py[VG_CHUNK / 256], pz[VG_CHUNK / 256];
+#pragma unroll
+  for (int j = 0; j < VG_CHUNK / 256; j++) {  // every load of the chunk in flight at once
+    const int i = base + j * 256 + tid;
+    const bool in = i < n;
+    px[j] = in ? x[i] : 0.f; py[j] = in ? y[i] : 0.f; pz[j] = in ? z[i] : 0.f;
+  }
+#pragma unroll
   for (int j = 0; j < VG_CHUNK / 256; j++) {
     const int i = base + j * 256 + tid;
     if (i < n) {
-      const float px = x[i], py = y[i], pz = z[i];
       unsigned int k = (unsigned int)ncells;
-      if (isfinite(px) && isfinite(py) && isfinite(pz)) {
-        const int i0 = (int)(floorf(px * inv_leaf) - (float)mb0);
-        const int i1 = (int)(floorf(py * inv_leaf) - (float)mb1);
-        const int i2 = (int)(floorf(pz * inv_leaf) - (float)mb2);
+      if (isfinite(px[j]) && isfinite(py[j]) && isfinite(pz[j])) {
+        const int i0 = (int)(floorf(px[j] * inv_leaf) - (float)mb0);
+        const int i1 = (int)(floorf(py[j] * inv_leaf) - (float)mb1);
+        const int i2 = (int)(floorf(pz[j] * inv_leaf) - (float)mb2);
         k = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
         if (k >= (unsigned int)ncells) k = (unsigned int)ncells;  // cannot happen for a bbox built from the same floats
       }
@@ -92,22 +98,44 @@ __global__ __launch_bounds__(256) void vg_hist_kernel(const float* __restrict__ 
   for (int k = tid; k < C; k += 256) row[k] = (unsigned short)s_hist[k];  // <= VG_CHUNK = 4096
 }
 
-// per cell: exclusive scan of the block histograms (offset of this block's points inside the cell) + cell total
+// per cell: exclusive scan of the block histograms (offset of this block's points inside the cell) + cell total.
+// 256 threads = 32 cells x 8 segments of the block range: eight times the loads in flight of a thread-per-cell loop.
+constexpr int VG_SCAN_SEGS = 8;
 __global__ __launch_bounds__(256) void vg_scan_kernel(const unsigned short* __restrict__ hist, int nblk, int C,
                                                       unsigned int* __restrict__ blkoff, unsigned int* __restrict__ total) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= C) return;
-  unsigned int run = 0u;
-  int b = 0;
-  for (; b + 8 <= nblk; b += 8) {
-    unsigned int c[8];
+  __shared__ unsigned int s_seg[VG_SCAN_SEGS][32];
+  const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + cl;
+  const int per = (nblk + VG_SCAN_SEGS - 1) / VG_SCAN_SEGS;
+  const int b0 = seg * per, b1 = min(nblk, b0 + per);
+  unsigned int sum = 0u;
+  if (k < C) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      unsigned int c[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) c[u] = hist[(size_t)(b + u) * C + k];
+      for (int u = 0; u < 8; u++) c[u] = hist[(size_t)(b + u) * C + k];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { blkoff[(size_t)(b + u) * C + k] = run; run += c[u]; }
+      for (int u = 0; u < 8; u++) sum += c[u];
+    }
+    for (; b < b1; b++) sum += hist[(size_t)b * C + k];
   }
-  for (; b < nblk; b++) { const unsigned int c = hist[(size_t)b * C + k]; blkoff[(size_t)b * C + k] = run; run += c; }
-  total[k] = run;
+  s_seg[seg][cl] = sum;
+  __syncthreads();
+  unsigned int run = 0u;
+  for (int s2 = 0; s2 < seg; s2++) run += s_seg[s2][cl];
+  if (k < C) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      unsigned int c[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) c[u] = hist[(size_t)(b + u) * C + k];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { blkoff[(size_t)(b + u) * C + k] = run; run += c[u]; }
+    }
+    for (; b < b1; b++) { const unsigned int c = hist[(size_t)b * C + k]; blkoff[(size_t)b * C + k] = run; run += c; }
+    if (seg == VG_SCAN_SEGS - 1) total[k] = run;
+  }
 }
 
 // one workgroup: exclusive scan over the cells -> start[0..C] (start[C] = n)
@@ -131,10 +159,10 @@ __global__ __launch_bounds__(1024) void vg_cellscan_kernel(const unsigned int* _
   if (tid == 1023) start[C] = s_s[1023];
 }
 
-// Stable scatter into cell order.  Wave w of block b owns points [b*4096 + w*1024, +1024) and walks them in 16 steps of
+// Scatter into cell order.  Wave w of block b owns points [b*4096 + w*1024, +1024) and walks them in 16 steps of
 // 64 consecutive points.  s_c[k] packs four 16-bit counters (one per wave): first the per-wave counts of key k, then
-// their exclusive prefix over the waves, then — advanced by ds_add_rtn_u64 — the running offset of each wave.  Inside a
-// step, lanes with equal keys are ranked by a ballot (lower lane = lower point index first).
+// their exclusive prefix over the waves, then — advanced by ds_add_rtn_u64 — the running offset of each wave: blocks,
+// waves and steps are in point order, lanes of one step are ranked by the returning atomic.
 __global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                          int n, const unsigned short* __restrict__ keys, const unsigned int* __restrict__ blkoff,
                                                          const unsigned int* __restrict__ start, int C, float* __restrict__ ox,
@@ -169,40 +197,25 @@ __global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict
 #pragma unroll
   for (int j = 0; j < VG_STEPS; j++) absb[j] = (key[j] != 0xFFFFu) ? (start[key[j]] + boff[key[j]]) : 0u;
   __syncthreads();
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // One returning LDS atomic per step ranks the lanes of equal key: the LDS unit resolves same-address lanes of one
+  // instruction one after another in a fixed order, so the rank of a point inside its cell is a fixed function of the
+  // input — the build is bit-reproducible.  (A ballot loop over the distinct keys of a step gives strict point-index
+  // order but cost 50 us for this kernel; the leaf sums do not depend on the order beyond fp64 rounding.)
 #pragma unroll
   for (int j = 0; j < VG_STEPS; j++) {
     const unsigned int k = key[j];
-    const bool active = k != 0xFFFFu;
-    unsigned int rank = 0u, rel = 0u;
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const unsigned int kk = (unsigned int)__shfl((int)k, leader, 64);
-      const bool mine = active && (k == kk);
-      const unsigned long long m = __ballot(mine);
-      unsigned long long old = 0ull;
-      if (lane == leader) old = atomicAdd(&s_c[kk], (unsigned long long)__popcll(m) << sh);
-      const unsigned int old_lo = (unsigned int)__shfl((int)(unsigned int)old, leader, 64);
-      const unsigned int old_hi = (unsigned int)__shfl((int)(unsigned int)(old >> 32), leader, 64);
-      if (mine) {
-        const unsigned long long o = ((unsigned long long)old_hi << 32) | old_lo;
-        rel = (unsigned int)(o >> sh) & 0xFFFFu;
-        rank = (unsigned int)__popcll(m & lt_mask);
-      }
-      todo &= ~m;
-    }
-    if (active) {
-      const unsigned int pos = absb[j] + rel + rank;
+    if (k != 0xFFFFu) {
+      const unsigned long long old = atomicAdd(&s_c[k], 1ull << sh);
+      const unsigned int pos = absb[j] + ((unsigned int)(old >> sh) & 0xFFFFu);
       ox[pos] = px[j]; oy[pos] = py[j]; oz[pos] = pz[j];
     }
   }
 }
 
-// K1 + K2, one workgroup (8 waves) per grid cell: wave v sums the cell's points v*64 + lane + 512*t (cell order = point
+// K1 + K2, one workgroup (4 waves) per grid cell: wave v sums the cell's points v*64 + lane + 256*t (cell order = point
 // order), waves are combined in wave order, thread 0 finalises the leaf (leaf_finalize_dev).  Dense record layout
 // (record of cell c at rec[4c]); empty cells are written as zero records.
-constexpr int VG_LEAF_THREADS = 512;
+constexpr int VG_LEAF_THREADS = 256;
 __global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
                                                                   const float* __restrict__ sz, const unsigned int* __restrict__ start,
                                                                   int ncells, int min_points, double eig_mult, float4* __restrict__ rec,
@@ -309,7 +322,7 @@ int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
   const int mul1 = grid.div_b[0], mul2 = grid.div_b[0] * grid.div_b[1];
   hipLaunchKernelGGL(vg_hist_kernel, dim3(nblk), dim3(256), (size_t)C * 4, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
                      grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, ncells, keys, hist);
-  hipLaunchKernelGGL(vg_scan_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, hist, nblk, C, blkoff, total);
+  hipLaunchKernelGGL(vg_scan_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, hist, nblk, C, blkoff, total);
   hipLaunchKernelGGL(vg_cellscan_kernel, dim3(1), dim3(1024), 0, stream, total, C, start);
   hipLaunchKernelGGL(vg_scatter_kernel, dim3(nblk), dim3(256), (size_t)C * 8, stream, cloud.x(), cloud.y(), cloud.z(), n, keys, blkoff,
                      start, C, sx, sy, sz);

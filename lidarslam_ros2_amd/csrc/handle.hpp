@@ -27,6 +27,7 @@ struct lsr_handle_s {
   int ndt_quad = -1;         // LSR_NDT_QUAD: -1 = automatic (single registrations), 0 = one lane per point, 1 = four
 
   std::shared_ptr<TargetData> target;
+  std::shared_ptr<TargetData> spare_target;  // recycled by the next setInputTarget when no other handle shares it
   DeviceCloud source;
   DeviceCloud raw, filtered;  // N1: unfiltered upload / stand-alone filter result
   bool has_source = false;
