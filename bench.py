@@ -1,31 +1,40 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark of the registration hot path (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W            (N=1 default)
+  python bench.py --gpus N --steps K --warmup W            (N=1 default; N>1 without a launcher: spawns N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one scan registration as the frontend performs it per LiDAR scan
 (scanmatcher_component.cpp:329,353): setInputSource(30k-pt scan, already resident in HBM) + NDT
 align() against the resident 10-frame submap — BASELINE.json configs[1]: ndt_resolution 5.0,
 vg_size_for_input 0.2, DIRECT7, fixed 30 iterations (max_iterations=30, transformation_epsilon=0 so
-the loop never exits early).  value = registrations/s over all ranks (weak scaling:
-every rank registers its own scan stream against its own copy of the submap; the only exchange is
-one all-gather of the K result records per rank at the end — SURVEY.md §8e).
+the loop never exits early).  The K timed steps are K DIFFERENT scans (a stream:
+positions 0.5 / 1.0 / 1.5 m past the last keyframe, own noise and sub-sample each).  value =
+registrations/s over all ranks (weak scaling: every rank registers its own scan stream against its
+own copy of the submap; the only exchange is one all-gather of the K result records per rank at the
+end — SURVEY.md §8e).
 
 The JSON line also carries
-  roofline      derivative kernel: algorithmic bytes per launch (N*12 + pairs*40 +
-                G*224) / hipEvent-measured launch duration, vs 8 TB/s HBM peak;
-  cpu_baseline  the CPU oracle (C++/OpenMP restatement of ndt_omp — NOT ndt_omp itself) timed on this
-                box's host cores on a bounded sample of the same workload;
-  batched       the same registrations advanced B at a time in shared launches (cfg 4 style);
-  gicp_cfg3     GICP frontend registration (cfg 3);
-  loop_gate     the backend's searchLoop() compute (lsr_search_loop) on a synthetic route that closes a loop.
+  roofline       derivative kernel: algorithmic bytes per launch / hipEvent-measured launch
+                 duration vs 8 TB/s, next to the HBM bytes the PMC counters saw (profiles/pmc_ndt_eval_latest.json);
+  cpu_baseline   the CPU oracle (C++/OpenMP restatement of ndt_omp — NOT ndt_omp itself) on this box's host cores;
+  scan_stream    per-registration latency (median, p10, p90) over >= 50 different scans, cfg 2 and cfg 1 settings,
+                 HBM-resident and host-resident (pageable / pinned) scans;
+  cfg4_loop_batch 64 DISTINCT (target, source, guess) loop-closure candidates, each paying setInputTarget +
+                 setInputSource + align + getFitnessScore (graph_based_slam_component.cpp:181-231), sharded over the ranks
+                 with one all-gather of 64-byte records (lsr_align_batch_sharded);
+  cfg5_dense     120k-pt 64-line scan vs 20-frame submap, ndt_resolution 2.0;
+  gicp_cfg3, loop_gate, set_input_target.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
+import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,125 +45,201 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 785.1 + 8.47) * 1024)  # single 30k-pt pass, see roofline.traffic_source
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_ndt_eval_latest.json")  # written by tools/pmc_ndt.sh (rocprofv3 --pmc passes)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--stream", type=int, default=50, help="scans in the latency-statistics stream (>= 50)")
+    ap.add_argument("--candidates", type=int, default=64, help="loop-closure candidates of the cfg 4 leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--workers", type=int, default=0, help="workload-generation processes (default: host threads / ranks, <= 64)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun spawns the N ranks itself
+# ------------------------------------------------------------------------------------------------------------------
+def self_spawn(args) -> int:
+    import torch
+
+    ndev = torch.cuda.device_count()
+    shared = bool(os.environ.get("LSR_BENCH_FORCE_DIST"))  # exercise the N-rank path on fewer devices (ranks share GPUs)
+    if ndev < args.gpus and not shared:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} device(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", LSR_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def pct(v, q):
+    return float(np.percentile(np.asarray(v, np.float64), q))
+
+
+def lat_stats(ts):
+    ts = np.asarray(ts, np.float64) * 1e3
+    return {"n": int(ts.size), "median_ms": float(np.median(ts)), "p10_ms": pct(ts, 10), "p90_ms": pct(ts, 90), "mean_ms": float(ts.mean()),
+            "registrations_per_s": float(1e3 / np.median(ts))}
+
+
+def _candidate_job(c):
+    from lidarslam_ros2_amd import synth
+
+    k = synth.cfg_loop_candidate(c)
+    return c, k.target, k.source, k.guess, k.truth
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="registrations per shared launch in the 'batched' leg")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
-
-    import torch
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    extras = (not args.no_extras)
+
+    # ---- workloads first: generated by forked worker processes BEFORE this process touches the GPU
+    from lidarslam_ros2_amd import synth
+    from lidarslam_ros2_amd.sharding import shard_range
+
+    t_gen = time.perf_counter()
+    cores = len(os.sched_getaffinity(0))
+    nwork = args.workers or max(1, min(64, cores // max(1, world)))
+    n_stream = max(args.stream if (extras and rank == 0) else 0, min(args.steps + args.warmup, 64))
+    my_cands = list(shard_range(args.candidates, world, rank)) if extras else []
+    with mp.get_context("fork").Pool(nwork) as pool:
+        case = synth.cfg_ndt_30k(seed=0, pool=pool)                 # the 10-frame submap (same on every rank) + its own next scan
+        stream = synth.cfg_scan_stream(n_stream, seed=rank, pool=pool)   # this rank's scan stream
+        cands = pool.map(_candidate_job, my_cands, chunksize=1) if my_cands else []
+        dense = synth.cfg_dense_120k(pool=pool) if (extras and rank == 0 and world == 1) else None
+        gc = synth.cfg_gicp_30k(seed=0, pool=pool) if (extras and rank == 0 and world == 1) else None
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the registration core has no CPU path")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else 0   # ranks share devices only under LSR_BENCH_FORCE_DIST
+    own_device = world <= ndev
+    torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1 or os.environ.get("LSR_BENCH_FORCE_DIST"):  # the env switch exercises the RCCL path on one GPU
+    backend = None
+    if world > 1 or os.environ.get("LSR_BENCH_FORCE_DIST"):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "nccl" if own_device else "gloo"   # RCCL refuses two ranks on one device: shared-device runs gather on the host
         # RCCL prints a version banner on stdout when the communicator is created; stdout must carry exactly one
         # JSON line, so C-level stdout is pointed at stderr until the first collective has run.
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
-    from lidarslam_ros2_amd import DIRECT7, NormalDistributionsTransform, align_batch, synth
+    from lidarslam_ros2_amd import DIRECT7, NormalDistributionsTransform, _capi
     from lidarslam_ros2_amd.posemath import pose_delta
 
-    # ---- workload: cfg 1/2; every rank gets its own scan (different seed) against the same route
-    case = synth.cfg_ndt_30k(seed=rank)
+    lib = _capi.load()
+    fptr = C.POINTER(C.c_float)
     res, max_iter = 5.0, 30
-    stream = torch.cuda.current_stream().cuda_stream
+    tstream = torch.cuda.current_stream().cuda_stream
 
-    def make_ndt():
-        r = NormalDistributionsTransform(device=local_rank, stream=stream)
-        r.setResolution(res)
-        r.setTransformationEpsilon(0.0)
-        r.setMaximumIterations(max_iter)
+    def make_ndt(eps=0.0, mi=max_iter, resolution=res):
+        r = NormalDistributionsTransform(device=dev_index, stream=tstream)
+        r.setResolution(resolution)
+        r.setTransformationEpsilon(eps)
+        r.setMaximumIterations(mi)
         r.setNeighborhoodSearchMethod(DIRECT7)
         return r
 
     ndt = make_ndt()
     tgt_dev = torch.from_numpy(synth.as_pointxyzi(case.target)).cuda()
-    src_dev = torch.from_numpy(synth.as_pointxyzi(case.source)).cuda()   # pcl::PointXYZI records in HBM
     ndt.setInputTarget(tgt_dev)
     grid = ndt.gridInfo()
+    # the stream's scans as pcl::PointXYZI records in HBM, guesses as column-major 4x4
+    src_dev = [torch.from_numpy(synth.as_pointxyzi(s)).cuda() for s, _, _ in stream]
+    g16 = [np.ascontiguousarray(g.T, np.float32).reshape(16) for _, g, _ in stream]
+    n_src_pts = int(src_dev[0].shape[0])
+    fin16 = np.zeros(16, np.float32)
     torch.cuda.synchronize()
-    t_tgt = time.perf_counter()
-    for _ in range(3):
-        ndt.setInputTarget(tgt_dev)          # K1/K2: voxel-covariance grid from the HBM-resident submap (warm)
-    torch.cuda.synchronize()
-    t_tgt = (time.perf_counter() - t_tgt) / 3
 
     # The timed loop drives the C ABI directly (what a C++ caller does): no per-step numpy conversions.
-    import ctypes as C
+    def step(reg, j):
+        _capi.check(lib.lsr_set_input_source_device(reg._h, C.c_void_p(src_dev[j].data_ptr()), 32, n_src_pts), "lsr_set_input_source_device")
+        _capi.check(lib.lsr_align(reg._h, g16[j].ctypes.data_as(fptr), fin16.ctypes.data_as(fptr), C.byref(reg._last), None, 0), "lsr_align")
+        reg._n_source = n_src_pts
 
-    from lidarslam_ros2_amd import _capi
-
-    lib = _capi.load()
-    fptr = C.POINTER(C.c_float)
-    g16 = np.ascontiguousarray(case.guess.T, np.float32).reshape(16)
-    fin16 = np.zeros(16, np.float32)
-    src_ptr, n_src_pts = C.c_void_p(src_dev.data_ptr()), int(src_dev.shape[0])
-
-    def step():
-        _capi.check(lib.lsr_set_input_source_device(ndt._h, src_ptr, 32, n_src_pts), "lsr_set_input_source_device")
-        _capi.check(lib.lsr_align(ndt._h, g16.ctypes.data_as(fptr), fin16.ctypes.data_as(fptr), C.byref(ndt._last), None, 0),
-                    "lsr_align")
-        ndt._n_source = n_src_pts
-
-    for _ in range(args.warmup):
-        step()
+    nss = len(src_dev)
+    for k in range(args.warmup):
+        step(ndt, k % nss)
     torch.cuda.synchronize()
     if dist is not None:
         # warm-up of the one collective of the path too: RCCL sets up its all-gather channels on first use
-        w_rec = torch.zeros((args.steps, 16), dtype=torch.float32, device="cuda")
+        w_rec = torch.zeros((args.steps, 16), dtype=torch.float32, device=coll_dev)
         dist.all_gather([torch.empty_like(w_rec) for _ in range(world)], w_rec)
         torch.cuda.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
     rec_np = np.zeros((args.steps, 16), np.float32)   # 64-byte result records: column-major 4x4, bottom row reused
+    lat = np.zeros(args.steps)
     t0 = time.perf_counter()
+    tk = t0
     for k in range(args.steps):
-        step()
+        step(ndt, (args.warmup + k) % nss)
         rec_np[k] = fin16   # final transformation (column-major) straight into the record
         rec_np[k, 3] = ndt._last.score
         rec_np[k, 7] = ndt._last.iterations
         rec_np[k, 11] = ndt._last.converged
-    rec = torch.from_numpy(rec_np).cuda()
+        tn = time.perf_counter()
+        lat[k] = tn - tk
+        tk = tn
+    rec = torch.from_numpy(rec_np).to(coll_dev)
     if dist is not None:
         gathered = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(gathered, rec)                                      # C1: pose all-gather over xGMI
+        dist.all_gather(gathered, rec)                                      # C1: pose all-gather (RCCL over xGMI)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     last = ndt.last_result
+    j_last = (args.warmup + args.steps - 1) % nss
     gpu_final = fin16.reshape(4, 4).T.copy()   # final transformation of the last timed registration
+    err_t, err_r = pose_delta(gpu_final, stream[j_last][2])
     value = world * args.steps / elapsed
 
     out = {
@@ -163,228 +248,388 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "accumulation_dtype": "f64", "data": "synthetic",
         "config": {"workload": "cfg2: single NDT align(), 30000-pt VLP-32 scan (vg 0.2) vs 10-frame submap (vg 0.1), "
-                               "ndt_resolution 5.0, DIRECT7, max_iterations 30, transformation_epsilon 0",
-                   "target_points": int(case.target.shape[0]), "source_points": int(case.source.shape[0]),
+                               "ndt_resolution 5.0, DIRECT7, max_iterations 30, transformation_epsilon 0; "
+                               f"{args.steps} different scans (stream of {nss})",
+                   "target_points": int(case.target.shape[0]), "source_points": n_src_pts,
                    "voxels_valid": grid["n_valid"], "newton_iterations": last["iterations"],
-                   "derivative_passes_per_align": last["n_evaluations"], "parallelism": f"1 registration stream per GPU x{world}"},
-        "set_input_target_ms": 1e3 * t_tgt,
-        "set_input_target_algorithmic_GBps": case.target.shape[0] * 20 / t_tgt / 1e9,  # ~20 B per target point
+                   "derivative_passes_per_align": last["n_evaluations"], "parallelism": f"1 registration stream per GPU x{world}",
+                   "collective_backend": backend, "ranks_share_a_device": not own_device},
+        "step_latency": lat_stats(lat),
+        "last_step_error_vs_truth": {"translation_m": err_t, "rotation_rad": err_r},
         "ndt_iterations_per_s": world * args.steps * last["iterations"] / elapsed,
         "derivative_passes_per_s": world * args.steps * last["n_evaluations"] / elapsed,
+        "workload_generation_s": t_gen, "workload_workers": nwork,
     }
 
+    # ------------------------------------------------------------------------------------------------------------
+    # cfg 4 (all ranks): 64 distinct candidates sharded over the ranks, one all-gather of 64-byte records
+    # ------------------------------------------------------------------------------------------------------------
+    cfg4 = None
+    if extras and args.candidates > 0:
+        try:
+            cfg4 = run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, torch, synth)
+        except Exception as e:  # the headline line must still be printed
+            cfg4 = {"error": repr(e)}
+
+    stash = {}
     if rank == 0:
+        if cfg4 is not None:
+            out["cfg4_loop_batch"] = cfg4
         # ---- roofline of the dominant kernel (K3+K4 derivative pass), hipEvents around the launch chains
-        ndt.setProfiling(True)
-        ndt.getProfile(reset=True)
-        for _ in range(3):
-            step()
-        prof = ndt.getProfile(reset=True)
-        ndt.setProfiling(False)
-        n_src = int(case.source.shape[0])
-        nblocks = (n_src + 255) // 256
-        launches = max(1, prof["deriv_launches"])
-        avg_us = 1e3 * prof["deriv_ms_total"] / launches
-        pairs = prof["deriv_pairs"]
-        alg_bytes = n_src * 12 + pairs * 40 + nblocks * 224
-        achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "ndt_eval_kernel<7> (derivative pass + fused Newton/More-Thuente controller)",
-                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           # HBM bytes per launch from rocprofv3 PMC passes of this kernel on this workload
-                           # (profiles/r01_pmc_ndt_eval_final.md): FETCH_SIZE 785 KB x2 (gfx950 reports half of wide
-                           # coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE 8 KB.  bench.py cannot collect
-                           # PMCs itself; re-measure with tools/pmc_run.sh when the kernel changes.
-                           "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "profiles/r01_pmc_ndt_eval_final.md",
-                           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_us,
-                           "valid_pairs_per_point": pairs / n_src,
-                           "compulsory_bytes_per_launch": n_src * 12 + grid["n_valid"] * 36,
-                           "note": "avg_launch_us = hipEvents around the launch chains / derivative passes (launch to launch, "
-                                   "the ~2 us dependent-launch gap included; rocprofv3's kernel-only average is in profiles/). "
-                                   "A single 30k-pt scan is 118 workgroups on 256 CUs: latency-bound, voxel table cache-resident; "
-                                   "see batched.roofline for the bandwidth-relevant figure"}
+        try:
+            out["roofline"] = roofline_leg(ndt, step, n_src_pts, grid)
+        except Exception as e:
+            out["roofline"] = {"error": repr(e)}
 
-        # The remaining legs (batched, GICP, loop gate, CPU baseline) are single-GPU reports: at N > 1 the other ranks
-        # would only wait for rank 0, and the CPU baseline is defined at N = 1.
-        if world == 1:
-            # ---- batched leg: B registrations share every launch (loop-closure candidate set / N scans vs submap)
-            try:
-                B = args.batch
-                regs = [ndt] + [make_ndt() for _ in range(B - 1)]
-                for r in regs[1:]:
-                    r.shareTargetOf(ndt)
-                for r in regs:
-                    r.setInputSource(src_dev)
-                guesses = [case.guess] * B
-                for _ in range(2):
-                    align_batch(regs, guesses)
-                torch.cuda.synchronize()
-                tb = time.perf_counter()
-                nb_steps = max(3, args.steps // 4)
-                for _ in range(nb_steps):
-                    for r in regs:
-                        r.setInputSource(src_dev)
-                    finals, bres = align_batch(regs, guesses)
-                torch.cuda.synchronize()
-                tb = time.perf_counter() - tb
-                ndt.setProfiling(True)
-                ndt.getProfile(reset=True)
-                align_batch(regs, guesses)
-                bprof = ndt.getProfile(reset=True)
-                ndt.setProfiling(False)
-                b_us = 1e3 * bprof["deriv_ms_total"] / max(1, bprof["deriv_launches"])
-                nb_batch = min(nblocks, max(4, (1024 + B - 1) // B))   # workgroups per registration in a batch (capi.hip: ndt_nblocks)
-                b_bytes = B * (n_src * 12 + nb_batch * 224) + bprof["deriv_pairs"] * 40
-                b_ach = b_bytes / (b_us * 1e-6) / 1e9
-                out["batched"] = {"batch": B, "value": B * nb_steps / tb, "unit": "registrations/s", "ms_per_batch": 1e3 * tb / nb_steps,
-                                  "roofline": {"bound": "hbm", "achieved": b_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                               "frac": b_ach / HBM_PEAK_GBS, "avg_launch_us": b_us,
-                                               "algorithmic_bytes_per_launch": b_bytes}}
-            except Exception as e:  # the headline line must still be printed
-                out["batched"] = {"error": repr(e)}
-
-            # ---- frontend leg (BASELINE cfg 1): the reference's own settings (transformation_epsilon 0.01, default
-            #      iteration cap) — what ScanMatcherComponent runs per scan; same scan, same resident submap
-            try:
-                front = make_ndt()
-                front.shareTargetOf(ndt)
-                front.setTransformationEpsilon(0.01)
-                front.setMaximumIterations(35)
-
-                def front_step():
-                    _capi.check(lib.lsr_set_input_source_device(front._h, src_ptr, 32, n_src_pts), "lsr_set_input_source_device")
-                    _capi.check(lib.lsr_align(front._h, g16.ctypes.data_as(fptr), fin16.ctypes.data_as(fptr), C.byref(front._last),
-                                              None, 0), "lsr_align")
-
-                for _ in range(5):
-                    front_step()
-                torch.cuda.synchronize()
-                tf = time.perf_counter()
-                nf = 50
-                for _ in range(nf):
-                    front_step()
-                torch.cuda.synchronize()
-                tf = (time.perf_counter() - tf) / nf
-                out["frontend_cfg1"] = {"value": 1.0 / tf, "unit": "registrations/s", "ms_per_registration": 1e3 * tf,
-                                        "newton_iterations": int(front._last.iterations),
-                                        "derivative_passes": int(front._last.n_evaluations),
-                                        "converged": bool(front._last.converged),
-                                        "what": "setInputSource (HBM-resident scan) + align with transformation_epsilon 0.01"}
-            except Exception as e:
-                out["frontend_cfg1"] = {"error": repr(e)}
-
-            # ---- GICP leg (BASELINE cfg 3): same scan, target re-filtered at 0.2, corr dist 5.0, eps 1e-8
-            try:
-                from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
-
-                gc = synth.cfg_gicp_30k(seed=rank)
-                gicp = GeneralizedIterativeClosestPoint(device=local_rank, stream=stream)
-                gicp.setMaxCorrespondenceDistance(5.0)
-                gicp.setTransformationEpsilon(1e-8)
-                g_tgt = torch.from_numpy(synth.as_pointxyzi(gc.target)).cuda()
-                g_src = torch.from_numpy(synth.as_pointxyzi(gc.source)).cuda()
-                tg = time.perf_counter()
-                gicp.setInputTarget(g_tgt)
-                gicp.setInputSource(g_src)
-                gicp.align(gc.guess)                       # first align also pays the target covariances (K5)
-                torch.cuda.synchronize()
-                t_first = time.perf_counter() - tg
-                tg = time.perf_counter()
-                ng = 5
-                for _ in range(ng):
-                    gicp.setInputSource(g_src)             # source covariances are recomputed per scan, as in the reference
-                    gicp.align(gc.guess)
-                torch.cuda.synchronize()
-                tg = time.perf_counter() - tg
-                gdt, gang = pose_delta(gicp.getFinalTransformation(), gc.truth)
-                out["gicp_cfg3"] = {"value": ng / tg, "unit": "registrations/s", "ms_per_registration": 1e3 * tg / ng,
-                                    "first_registration_ms_incl_target_setup": 1e3 * t_first,
-                                    "target_points": int(gc.target.shape[0]), "outer_iterations": gicp.last_result["iterations"],
-                                    "gauss_newton_steps": gicp.last_result["n_evaluations"],
-                                    "correspondences": gicp.last_result["n_correspondences"],
-                                    "error_vs_truth": {"translation_m": gdt, "rotation_rad": gang}}
-            except Exception as e:  # the headline line must still be printed
-                out["gicp_cfg3"] = {"error": repr(e)}
-
-            # ---- loop-closure gate: searchLoop() compute on HBM-resident submaps
-            route = None
-            try:
-                from lidarslam_ros2_amd import LoopClosureParams, SubMap, search_loop
-
-                route = synth.make_loop_route()
-                sms = [SubMap(torch.from_numpy(synth.as_pointxyzi(s["cloud"])).cuda(), s["position"], s["orientation"], s["distance"])
-                       for s in route]
-                lp = dict(threshold_loop_closure_score=1.0, distance_loop_closure=20.0, range_of_searching_loop_closure=10.0,
-                          search_submap_num=2, voxel_leaf_size=0.2)
-                back = NormalDistributionsTransform(device=local_rank, stream=stream)   # graph_based_slam_component.cpp:64-72
-                back.setMaximumIterations(100)
-                back.setResolution(5.0)
-                back.setTransformationEpsilon(0.01)
-                edges = search_loop(back, sms, LoopClosureParams(**lp))
-                torch.cuda.synchronize()
-                tl = time.perf_counter()
-                nl = 10
-                for _ in range(nl):
-                    edges = search_loop(back, sms, LoopClosureParams(**lp))
-                torch.cuda.synchronize()
-                tl = (time.perf_counter() - tl) / nl
-                out["loop_gate"] = {"ms_per_search": 1e3 * tl, "submaps": len(route), "edge": list(edges[0].pair_id),
-                                    "fitness_score": edges[0].fitness_score, "accepted": edges[0].accepted,
-                                    "target_points": edges[0].n_target_points, "source_points": int(route[-1]["cloud"].shape[0]),
-                                    "newton_iterations": edges[0].iterations,
-                                    "what": "source transform + 5-submap window transform/concat + VoxelGrid(0.2) + "
-                                            "setInputTarget + align + getFitnessScore + gate, clouds resident in HBM"}
-            except Exception as e:
-                out["loop_gate"] = {"error": repr(e)}
-
-            # ---- CPU baseline: the oracle (restatement of ndt_omp) on this box's host cores, bounded sample
-            if not args.no_cpu:
+        # The remaining legs are single-GPU reports: at N > 1 the other ranks would only wait for rank 0, and the CPU
+        # baseline is defined at N = 1.
+        if world == 1 and extras:
+            legs = [("set_input_target", lambda: target_leg(ndt, tgt_dev, case)),
+                    ("scan_stream", lambda: stream_leg(args, lib, make_ndt, ndt, stream, src_dev, g16, n_src_pts, torch, synth)),
+                    ("cfg5_dense", lambda: cfg5_leg(make_ndt, dense, torch, synth)),
+                    ("gicp_cfg3", lambda: gicp_leg(gc, dev_index, tstream, torch, synth)),
+                    ("loop_gate", lambda: loop_gate_leg(dev_index, tstream, torch, synth, stash))]
+            for name, fn in legs:
                 try:
-                    from oracle import oracle as O
-
-                    g = O.VoxelGridCovariance(case.target, res)
-                    avail = min(len(os.sched_getaffinity(0)), O.max_threads())
-                    p0 = O.matrix_to_pose(case.guess)
-                    cores, best = 1, float("inf")
-                    cands = [args.cpu_threads] if args.cpu_threads else [c for c in (1, 2, 4, 8, 16, 32, 64, 128) if c <= avail]
-                    for c in cands:  # pick the thread count that is fastest on THIS box (oversubscribed hosts get slower with more)
-                        O.ndt_derivatives(g, case.source, p0, resolution=res, num_threads=c)
-                        tq = time.perf_counter()
-                        for _ in range(2):
-                            O.ndt_derivatives(g, case.source, p0, resolution=res, num_threads=c)
-                        tq = (time.perf_counter() - tq) / 2
-                        if tq < best:
-                            cores, best = c, tq
-                    # bounded sample: whole registrations of the same workload until >= 10 s of CPU work (at most 32)
-                    n_cpu, tc = 0, 0.0
-                    while tc < 10.0 and n_cpu < 32:
-                        tq = time.perf_counter()
-                        ref = O.ndt_align(g, case.source, case.guess, resolution=res, trans_eps=0.0, max_iterations=max_iter,
-                                          num_threads=cores)
-                        tc += time.perf_counter() - tq
-                        n_cpu += 1
-                    dt, ang = pose_delta(gpu_final, ref["final"])
-                    out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "registrations/s", "cores": cores, "kind": "port",
-                                           "sample": f"{n_cpu} registrations of the same workload ({ref['iterations']} Newton iterations, "
-                                                     f"{ref['n_evals'] + ref['n_evals_grad'] + ref['n_hessian_recompute']} derivative passes each)",
-                                           "seconds": tc, "newton_iterations": ref["iterations"], "host_threads_available": avail,
-                                           "ms_per_derivative_pass": 1e3 * best,
-                                           "note": "C++/OpenMP restatement of ndt_omp (oracle/), not ndt_omp itself"}
-                    out["parity_vs_cpu"] = {"translation_m": dt, "rotation_rad": ang}
-                    if route is not None and "error" not in out.get("loop_gate", {}):
-                        tq = time.perf_counter()
-                        ref_edges = O.search_loop(route, **lp, ndt_resolution=5.0, trans_eps=0.01, max_iterations=100, num_threads=cores)
-                        tq = time.perf_counter() - tq
-                        ldt, lang = pose_delta(edges[0].relative_pose, ref_edges[0]["relative_pose"])
-                        out["loop_gate"]["cpu_port_ms_per_search"] = 1e3 * tq
-                        out["loop_gate"]["parity_vs_cpu"] = {"same_edge": list(ref_edges[0]["pair_id"]) == list(edges[0].pair_id),
-                                                             "translation_m": ldt, "rotation_rad": lang}
+                    out[name] = fn()
                 except Exception as e:
-                    out["cpu_baseline"] = {"error": repr(e)}
+                    out[name] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu:
+            try:
+                cpu_leg(args, out, stash, case, stream, j_last, gpu_final, res, max_iter)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def roofline_leg(ndt, step, n_src, grid):
+    ndt.setProfiling(True)
+    ndt.getProfile(reset=True)
+    for _ in range(3):
+        step(ndt, 0)
+    prof = ndt.getProfile(reset=True)
+    ndt.setProfiling(False)
+    nblocks = (n_src + 127) // 128                      # quad kernel: 128 points per workgroup
+    launches = max(1, prof["deriv_launches"])
+    avg_us = 1e3 * prof["deriv_ms_total"] / launches
+    pairs = prof["deriv_pairs"]
+    alg_bytes = n_src * 12 + pairs * 40 + nblocks * 224
+    achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+    r = {"bound": "hbm", "kernel": "ndt_eval_quad_kernel<7> (derivative pass + fused Newton/More-Thuente controller)",
+         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": None, "traffic_source": None,
+         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_us, "valid_pairs_per_point": pairs / n_src,
+         "compulsory_bytes_per_launch": n_src * 12 + grid["n_valid"] * 36,
+         "note": "achieved = ALGORITHMIC bytes (SURVEY.md 8d: N*12 + pairs*40 + G*224; the voxel records are gathered from an LDS "
+                 "copy of the table, so most of these bytes never reach HBM) / hipEvent time per launch (launch to launch, the ~1 us "
+                 "dependent-launch gap included).  `traffic` = HBM bytes per launch by the PMC counters; frac_by_traffic prices "
+                 "those.  A single 30k-pt scan is latency bound (kernel boundary + head + controller on one lane), see DESIGN.md §4"}
+    try:
+        pmc = json.load(open(PMC_FILE))
+        r["traffic"] = int(pmc["bytes_per_launch"])
+        r["traffic_source"] = os.path.relpath(PMC_FILE, ROOT) + " <- " + pmc.get("source", "")
+        r["frac_by_traffic"] = r["traffic"] / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        r["traffic_kernel"] = pmc.get("kernel")
+    except Exception:
+        pass
+    return r
+
+
+def target_leg(ndt, tgt_dev, case):
+    import torch
+
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        ndt.setInputTarget(tgt_dev)          # K1/K2: voxel-covariance grid from the HBM-resident submap
+        ts.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    m = float(np.median(ts))
+    return {"median_ms": 1e3 * m, "p10_ms": 1e3 * pct(ts, 10), "p90_ms": 1e3 * pct(ts, 90), "target_points": int(case.target.shape[0]),
+            "algorithmic_GBps": case.target.shape[0] * 20 / m / 1e9,   # ~20 B per target point
+            "frac_of_hbm_peak": case.target.shape[0] * 20 / m / 1e9 / HBM_PEAK_GBS,
+            "what": "setInputTarget on the HBM-resident 10-frame submap (PointXYZI records): de-interleave + bbox + counting sort + leaf sums + finalise + LDS table image"}
+
+
+def stream_leg(args, lib, make_ndt, ndt, stream, src_dev, g16, n_src_pts, torch, synth):
+    """Per-registration latency over a stream of different scans: cfg 2 and cfg 1 settings, device- and host-resident scans."""
+    from lidarslam_ros2_amd import _capi
+    from lidarslam_ros2_amd.posemath import pose_delta
+
+    fptr = C.POINTER(C.c_float)
+    fin = np.zeros(16, np.float32)
+    n = len(src_dev)
+    out = {"scans": n}
+
+    def run(reg, setter, srcs):
+        ts, its, errs = [], [], []
+        for j in range(min(5, n)):
+            setter(reg, srcs[j]); _capi.check(lib.lsr_align(reg._h, g16[j].ctypes.data_as(fptr), fin.ctypes.data_as(fptr), C.byref(reg._last), None, 0), "lsr_align")
+        for j in range(n):
+            t0 = time.perf_counter()
+            setter(reg, srcs[j])
+            _capi.check(lib.lsr_align(reg._h, g16[j].ctypes.data_as(fptr), fin.ctypes.data_as(fptr), C.byref(reg._last), None, 0), "lsr_align")
+            ts.append(time.perf_counter() - t0)
+            its.append(int(reg._last.iterations))
+            errs.append(pose_delta(fin.reshape(4, 4).T, stream[j][2]))
+        s = lat_stats(ts)
+        s["newton_iterations_median"] = float(np.median(its))
+        s["max_error_vs_truth"] = {"translation_m": float(max(e[0] for e in errs)), "rotation_rad": float(max(e[1] for e in errs))}
+        return s
+
+    def set_dev(reg, t):
+        _capi.check(lib.lsr_set_input_source_device(reg._h, C.c_void_p(t.data_ptr()), 32, n_src_pts), "lsr_set_input_source_device")
+
+    def set_host(reg, a):
+        _capi.check(lib.lsr_set_input_source(reg._h, C.c_void_p(a.ctypes.data if isinstance(a, np.ndarray) else a.data_ptr()), 32, n_src_pts),
+                    "lsr_set_input_source")
+
+    out["cfg2_device_source"] = run(ndt, set_dev, src_dev)
+    front = make_ndt(eps=0.01, mi=35)         # the reference's own settings (scanmatcher_component.cpp:105-113)
+    front.shareTargetOf(ndt)
+    out["cfg1_device_source"] = run(front, set_dev, src_dev)
+    host_pageable = [synth.as_pointxyzi(s) for s, _, _ in stream]
+    out["cfg1_host_source_pageable"] = run(front, set_host, host_pageable)   # what the INTEGRATION.md binding does with a pcl cloud
+    host_pinned = [torch.from_numpy(a).pin_memory() for a in host_pageable]
+    out["cfg1_host_source_pinned"] = run(front, set_host, host_pinned)
+    out["what"] = ("setInputSource + align per scan, host clock around the two C-ABI calls; cfg1 = transformation_epsilon 0.01, "
+                   "max_iterations 35; host sources pay one 960 KB PCIe copy per scan")
+    return out
+
+
+def cfg5_leg(make_ndt, dense, torch, synth):
+    from lidarslam_ros2_amd.posemath import pose_delta
+
+    r = make_ndt(eps=0.01, mi=35, resolution=2.0)
+    tgt = torch.from_numpy(synth.as_pointxyzi(dense.target)).cuda()
+    src = torch.from_numpy(synth.as_pointxyzi(dense.source)).cuda()
+    t0 = time.perf_counter(); r.setInputTarget(tgt); t_first = time.perf_counter() - t0
+    tt = []
+    for _ in range(5):
+        t0 = time.perf_counter(); r.setInputTarget(tgt); tt.append(time.perf_counter() - t0)
+    ts = []
+    for k in range(13):
+        t0 = time.perf_counter(); r.setInputSource(src); r.align(dense.guess); dt = time.perf_counter() - t0
+        if k >= 3:
+            ts.append(dt)
+    r.setProfiling(True); r.getProfile(reset=True); r.align(dense.guess); p = r.getProfile(reset=True); r.setProfiling(False)
+    e = pose_delta(r.getFinalTransformation(), dense.truth)
+    s = lat_stats(ts)
+    n_src = int(dense.source.shape[0])
+    avg_us = 1e3 * p["deriv_ms_total"] / max(1, p["deriv_launches"])
+    alg = n_src * 12 + p["deriv_pairs"] * 40 + ((n_src + 127) // 128) * 224
+    s.update({"target_points": int(dense.target.shape[0]), "source_points": n_src, "grid": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in r.gridInfo().items()},
+              "set_input_target_ms": 1e3 * float(np.median(tt)), "set_input_target_first_ms": 1e3 * t_first,
+              "newton_iterations": r.last_result["iterations"], "derivative_passes": r.last_result["n_evaluations"],
+              "avg_pass_us": avg_us, "algorithmic_bytes_per_pass": alg, "algorithmic_frac_of_hbm_peak": alg / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+              "error_vs_truth": {"translation_m": e[0], "rotation_rad": e[1]},
+              "what": "cfg 5: 120000-pt 64-line scan (vg 0.1) vs 20-frame submap, ndt_resolution 2.0, transformation_epsilon 0.01"})
+    return s
+
+
+def gicp_leg(gc, dev_index, tstream, torch, synth):
+    from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
+    from lidarslam_ros2_amd.posemath import pose_delta
+
+    gicp = GeneralizedIterativeClosestPoint(device=dev_index, stream=tstream)
+    gicp.setMaxCorrespondenceDistance(5.0)
+    gicp.setTransformationEpsilon(1e-8)
+    g_tgt = torch.from_numpy(synth.as_pointxyzi(gc.target)).cuda()
+    g_src = torch.from_numpy(synth.as_pointxyzi(gc.source)).cuda()
+    tg = time.perf_counter()
+    gicp.setInputTarget(g_tgt)
+    gicp.setInputSource(g_src)
+    gicp.align(gc.guess)                       # first align also pays the target covariances (K5)
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - tg
+    ts = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        gicp.setInputSource(g_src)             # source covariances are recomputed per scan, as in the reference
+        gicp.align(gc.guess)
+        ts.append(time.perf_counter() - t0)
+    gdt, gang = pose_delta(gicp.getFinalTransformation(), gc.truth)
+    s = lat_stats(ts[2:])
+    s.update({"first_registration_ms_incl_target_setup": 1e3 * t_first, "target_points": int(gc.target.shape[0]),
+              "outer_iterations": gicp.last_result["iterations"], "gauss_newton_steps": gicp.last_result["n_evaluations"],
+              "correspondences": gicp.last_result["n_correspondences"], "error_vs_truth": {"translation_m": gdt, "rotation_rad": gang},
+              "what": "cfg 3: GICP, same 30k scan, target re-filtered at 0.2, corr dist 5.0, eps 1e-8; setInputSource (20-NN covariances) + align"})
+    return s
+
+
+def loop_gate_leg(dev_index, tstream, torch, synth, stash):
+    from lidarslam_ros2_amd import LoopClosureParams, NormalDistributionsTransform, SubMap, search_loop
+
+    route = synth.make_loop_route()
+    stash["route"] = route
+    sms = [SubMap(torch.from_numpy(synth.as_pointxyzi(s["cloud"])).cuda(), s["position"], s["orientation"], s["distance"]) for s in route]
+    lp = dict(threshold_loop_closure_score=1.0, distance_loop_closure=20.0, range_of_searching_loop_closure=10.0, search_submap_num=2,
+              voxel_leaf_size=0.2)
+    stash["lp"] = lp
+    back = NormalDistributionsTransform(device=dev_index, stream=tstream)   # graph_based_slam_component.cpp:64-72
+    back.setMaximumIterations(100)
+    back.setResolution(5.0)
+    back.setTransformationEpsilon(0.01)
+    edges = search_loop(back, sms, LoopClosureParams(**lp))
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        edges = search_loop(back, sms, LoopClosureParams(**lp))
+        ts.append(time.perf_counter() - t0)
+    stash["edges"] = edges
+    return {"ms_per_search": 1e3 * float(np.median(ts[2:])), "submaps": len(route), "edge": list(edges[0].pair_id),
+            "fitness_score": edges[0].fitness_score, "accepted": edges[0].accepted, "target_points": edges[0].n_target_points,
+            "source_points": int(route[-1]["cloud"].shape[0]), "newton_iterations": edges[0].iterations,
+            "what": "source transform + 5-submap window transform/concat + VoxelGrid(0.2) + setInputTarget + align + getFitnessScore "
+                    "+ gate, clouds resident in HBM"}
+
+
+def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, torch, synth):
+    """BASELINE cfg 4 as SURVEY.md §8d defines it: every candidate is its own (target, source, guess) and pays
+    setInputTarget + setInputSource + align + getFitnessScore (graph_based_slam_component.cpp:181-231, backend settings
+    max_iterations 100, transformation_epsilon 0.01, :64-72).  Candidates are sharded over the ranks (lsr_shard_range) and the
+    64-byte result records all-gathered through the C ABI (lsr_align_batch_sharded: ncclAllGather over xGMI; on ranks that
+    share a device the gather goes through the host)."""
+    from lidarslam_ros2_amd import NormalDistributionsTransform, _capi
+    from lidarslam_ros2_amd.posemath import pose_delta
+
+    n_total = args.candidates
+    fptr = C.POINTER(C.c_float)
+    regs, tgts, srcs, guesses = [], [], [], []
+    for c, target, source, guess, truth in cands:
+        r = NormalDistributionsTransform(device=dev_index, stream=tstream)
+        r.setResolution(5.0); r.setTransformationEpsilon(0.01); r.setMaximumIterations(100)
+        regs.append(r)
+        tgts.append(torch.from_numpy(synth.as_pointxyzi(target)).cuda())
+        srcs.append(torch.from_numpy(synth.as_pointxyzi(source)).cuda())
+        guesses.append(np.ascontiguousarray(np.asarray(guess, np.float32).T).reshape(16))
+    torch.cuda.synchronize()
+    nloc = len(regs)
+    # communicator at the C ABI: ncclUniqueId from rank 0 to everybody through torch.distributed's store
+    comm = C.c_void_p()
+    use_rccl = (world > 1 and backend == "nccl")
+    if use_rccl:
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            _capi.check(lib.lsr_comm_unique_id(ident), "lsr_comm_unique_id")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (C.c_char * 128).from_buffer_copy(box[0])
+        _capi.check(lib.lsr_comm_create(ident, rank, world, dev_index, C.byref(comm)), "lsr_comm_create")
+    else:
+        _capi.check(lib.lsr_comm_create(None, 0, 1, dev_index, C.byref(comm)), "lsr_comm_create")   # one-rank communicator per process
+    hs = (C.c_void_p * max(nloc, 1))(*[r._h for r in regs])
+    G = np.ascontiguousarray(np.stack(guesses), np.float32) if nloc else np.zeros((1, 16), np.float32)
+    n_rec = n_total if use_rccl else nloc
+    recs = (_capi.ShardRecord * max(n_rec, 1))()
+
+    def one_round(batched: bool):
+        """-> seconds for this rank's share; fills recs"""
+        t0 = time.perf_counter()
+        for b, (r, t, s) in enumerate(zip(regs, tgts, srcs)):
+            _capi.check(lib.lsr_set_input_target_device(r._h, C.c_void_p(t.data_ptr()), 32, int(t.shape[0])), "setInputTarget")
+            _capi.check(lib.lsr_set_input_source_device(r._h, C.c_void_p(s.data_ptr()), 32, int(s.shape[0])), "setInputSource")
+            if not batched:
+                fin = np.zeros(16, np.float32)
+                _capi.check(lib.lsr_align(r._h, guesses[b].ctypes.data_as(fptr), fin.ctypes.data_as(fptr), C.byref(r._last), None, 0), "align")
+                f = C.c_double()
+                _capi.check(lib.lsr_get_fitness_score(r._h, 1.7976931348623157e308, C.byref(f)), "getFitnessScore")
+        if batched:
+            if use_rccl:
+                _capi.check(lib.lsr_align_batch_sharded(comm, hs, nloc, n_total, G.ctypes.data_as(fptr), 1, recs), "lsr_align_batch_sharded")
+            elif nloc:
+                _capi.check(lib.lsr_align_batch_sharded(comm, hs, nloc, nloc, G.ctypes.data_as(fptr), 1, recs), "lsr_align_batch_sharded")
+        return time.perf_counter() - t0
+
+    def sync_max(t):
+        if dist is None:
+            return t
+        v = torch.tensor([t], dtype=torch.float64, device=("cuda" if backend == "nccl" else "cpu"))
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+
+    one_round(True)   # warm-up (allocations, RCCL channels)
+    if dist is not None:
+        dist.barrier()
+    t_batched = sync_max(min(one_round(True) for _ in range(3)))
+    t_serial = sync_max(min(one_round(False) for _ in range(2))) if world == 1 else None
+    one_round(True)
+    # parity sanity on this rank's share: registered pose vs ground truth
+    errs = []
+    for b, (c, target, source, guess, truth) in enumerate(cands):
+        rr = recs[(cands[0][0] if use_rccl else 0) + b]
+        T = np.eye(4); T[:3, :4] = np.asarray(rr.T, np.float64).reshape(3, 4)
+        errs.append(pose_delta(T, truth))
+    lib.lsr_comm_destroy(comm)
+    if rank != 0:
+        return None
+    res = {"candidates": n_total, "ranks": world, "candidates_on_rank0": nloc,
+           "value": n_total / t_batched, "unit": "registrations/s", "ms_per_candidate_set": 1e3 * t_batched,
+           "collective": ("ncclAllGather of 64-byte records (lsr_align_batch_sharded)" if use_rccl else
+                          "none (one rank)" if world == 1 else "per-rank tables only: ranks share a device, RCCL needs one device per rank"),
+           "max_error_vs_truth_rank0": {"translation_m": float(max(e[0] for e in errs)) if errs else None,
+                                        "rotation_rad": float(max(e[1] for e in errs)) if errs else None},
+           "fitness_rank0": [float(recs[(cands[0][0] if use_rccl else 0) + b].fitness) for b in range(min(nloc, 4))],
+           "iterations_rank0": [int(recs[(cands[0][0] if use_rccl else 0) + b].iterations) for b in range(nloc)],
+           "what": "per candidate: setInputTarget (661k-pt submap -> voxel grid) + setInputSource + align (max_iterations 100, eps 0.01) + "
+                   "getFitnessScore; all candidates of a rank advance in shared launches (lsr_align_batch)"}
+    if t_serial is not None:
+        res["serial_one_by_one"] = {"value": n_total / t_serial, "unit": "registrations/s", "ms_per_candidate_set": 1e3 * t_serial}
+    return res
+
+
+def cpu_leg(args, out, stash, case, stream, j_last, gpu_final, res, max_iter):
+    """CPU baseline: the oracle (restatement of ndt_omp) on this box's host cores, bounded sample of the SAME workload (the last
+    timed scan of the stream against the same submap); also the parity of the GPU pose against it."""
+    from oracle import oracle as O
+    from lidarslam_ros2_amd.posemath import pose_delta
+
+    src, guess = stream[j_last][0], stream[j_last][1]
+    g = O.VoxelGridCovariance(case.target, res)
+    avail = min(len(os.sched_getaffinity(0)), O.max_threads())
+    p0 = O.matrix_to_pose(guess)
+    cores, best = 1, float("inf")
+    cands = [args.cpu_threads] if args.cpu_threads else [c for c in (1, 2, 4, 8, 16, 32, 64, 128) if c <= avail]
+    for c in cands:  # pick the thread count that is fastest on THIS box (oversubscribed hosts get slower with more)
+        O.ndt_derivatives(g, src, p0, resolution=res, num_threads=c)
+        tq = time.perf_counter()
+        for _ in range(2):
+            O.ndt_derivatives(g, src, p0, resolution=res, num_threads=c)
+        tq = (time.perf_counter() - tq) / 2
+        if tq < best:
+            cores, best = c, tq
+    # bounded sample: whole registrations of the same workload until >= 10 s of CPU work (at most 32)
+    n_cpu, tc = 0, 0.0
+    while tc < 10.0 and n_cpu < 32:
+        tq = time.perf_counter()
+        ref = O.ndt_align(g, src, guess, resolution=res, trans_eps=0.0, max_iterations=max_iter, num_threads=cores)
+        tc += time.perf_counter() - tq
+        n_cpu += 1
+    dt, ang = pose_delta(gpu_final, ref["final"])
+    out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "registrations/s", "cores": cores, "kind": "port",
+                           "sample": f"{n_cpu} registrations of the same workload: the last timed scan of the stream ({ref['iterations']} Newton "
+                                     f"iterations, {ref['n_evals'] + ref['n_evals_grad'] + ref['n_hessian_recompute']} derivative passes each)",
+                           "seconds": tc, "newton_iterations": ref["iterations"], "host_threads_available": avail,
+                           "ms_per_derivative_pass": 1e3 * best,
+                           "note": "C++/OpenMP restatement of ndt_omp (oracle/, built -O2 without -march=native like the reference's own -O2 -g), "
+                                   "not ndt_omp itself; a reported baseline, not the target"}
+    out["parity_vs_cpu"] = {"translation_m": dt, "rotation_rad": ang, "gpu_iterations": out["config"]["newton_iterations"],
+                            "cpu_iterations": ref["iterations"]}
+    route, lp, edges = stash.get("route"), stash.get("lp"), stash.get("edges")
+    if route is not None and "error" not in out.get("loop_gate", {"error": 1}):
+        tq = time.perf_counter()
+        ref_edges = O.search_loop(route, **lp, ndt_resolution=5.0, trans_eps=0.01, max_iterations=100, num_threads=cores)
+        tq = time.perf_counter() - tq
+        ldt, lang = pose_delta(edges[0].relative_pose, ref_edges[0]["relative_pose"])
+        out["loop_gate"]["cpu_port_ms_per_search"] = 1e3 * tq
+        out["loop_gate"]["parity_vs_cpu"] = {"same_edge": list(ref_edges[0]["pair_id"]) == list(edges[0].pair_id), "translation_m": ldt,
+                                             "rotation_rad": lang}
 
 
 if __name__ == "__main__":

@@ -172,6 +172,33 @@ int lsr_has_converged(lsr_handle h, int* out);
 /* registration_->getFitnessScore(max_range = DBL_MAX)  graph_based_slam_component.cpp:231; scanmatcher_component.cpp:376 */
 int lsr_get_fitness_score(lsr_handle h, double max_range, double* out);
 
+/* ---- multi-GPU sharding of a batch (BASELINE.json cfg 4) -----------------------
+ * One process per GPU.  The batch of `global_count` independent registrations — the loop-closure candidate set of
+ * graph_based_slam_component.cpp:188-231 generalised from the nearest candidate to all of them, or N keyframes against
+ * a submap — is split by the static block partition lsr_shard_range(); every rank registers its own share with
+ * lsr_align_batch (no collective on the data path) and ONE ncclAllGather of fixed 64-byte records over xGMI gives every
+ * rank the whole table.  RCCL is loaded on first use; a one-rank communicator needs no RCCL. */
+typedef struct lsr_comm_s* lsr_comm;
+typedef struct lsr_shard_record {   /* 64 bytes */
+  float T[12];                      /* final transformation, ROW-major 3x4 */
+  float score;                      /* lsr_result.score */
+  float iterations;
+  float converged;                  /* 1 / 0 */
+  float fitness;                    /* getFitnessScore() when requested, else NaN */
+} lsr_shard_record;
+/* first index and count of rank's share: the first (n_items % world) ranks get one extra item */
+void lsr_shard_range(int n_items, int world, int rank, int* first, int* count);
+/* rank 0: 128-byte ncclUniqueId to hand to the other ranks (by whatever channel the application has) */
+int lsr_comm_unique_id(void* id128);
+/* every rank: ncclCommInitRank on device_id (id128 may be NULL when world == 1) */
+int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_comm* out);
+int lsr_comm_destroy(lsr_comm c);
+/* local_handles / local_guesses: this rank's share (local_count = lsr_shard_range count), targets and sources already
+ * set; with_fitness != 0 adds getFitnessScore() per registration (graph_based_slam_component.cpp:231).
+ * all_records: global_count entries, in batch order, identical on every rank. */
+int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_count, int global_count, const float* local_guesses,
+                            int with_fitness, lsr_shard_record* all_records);
+
 /* ---- loop-closure gate -------------------------------------------------- */
 /* One lidarslam_msgs/msg/SubMap (SubMap.msg:1-4): accumulated travel distance, geometry_msgs/Pose, and the
  * PointCloud2 payload (xyz fp32 at offset 0 of every record of stride_bytes; pose-local coordinates). */

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "lsr_share_target", "lsr_align", "lsr_align_batch",
     "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_search_loop", "lsr_ndt_grid_info",
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
-    "lsr_debug_angle_tables",
+    "lsr_debug_angle_tables", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
 ]
 
 
@@ -57,6 +57,11 @@ class LoopEdge(C.Structure):
     _fields_ = [("id_from", C.c_int), ("id_to", C.c_int), ("accepted", C.c_int), ("converged", C.c_int),
                 ("iterations", C.c_int), ("n_target_points", C.c_int), ("candidate_distance", C.c_double),
                 ("fitness_score", C.c_double), ("relative_pose", C.c_double * 16), ("final_transformation", C.c_float * 16)]
+
+
+class ShardRecord(C.Structure):
+    _fields_ = [("T", C.c_float * 12), ("score", C.c_float), ("iterations", C.c_float), ("converged", C.c_float),
+                ("fitness", C.c_float)]
 
 
 class RegistrationError(RuntimeError):
@@ -117,10 +122,16 @@ def load() -> C.CDLL:
     L.lsr_nearest_neighbors.argtypes = [vp, fp, ip, fp]
     L.lsr_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.lsr_debug_angle_tables.argtypes = [dp, C.c_int, fp, fp, fp, fp]
+    L.lsr_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
+    L.lsr_shard_range.restype = None
+    L.lsr_comm_unique_id.argtypes = [vp]
+    L.lsr_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.lsr_comm_destroy.argtypes = [vp]
+    L.lsr_align_batch_sharded.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, fp, C.c_int, C.POINTER(ShardRecord)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int or name not in ("lsr_version", "lsr_status_string", "lsr_last_error"):
-            if name not in ("lsr_version", "lsr_status_string", "lsr_last_error"):
+            if name not in ("lsr_version", "lsr_status_string", "lsr_last_error", "lsr_shard_range"):
                 fn.restype = C.c_int
     _lib = L
     return L

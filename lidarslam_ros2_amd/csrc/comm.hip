@@ -1,0 +1,182 @@
+// Multi-GPU sharding of a batch of independent registrations at the C ABI: one process per GPU, static
+// block partition of the batch, no collective on the data path, ONE ncclAllGather of fixed 64-byte result records over
+// xGMI at the end.  RCCL is loaded lazily (dlopen): single-GPU users of the library never touch it.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+#include "handle.hpp"
+
+namespace {
+
+// the five RCCL entry points used, with the types of <rccl/rccl.h> restated (ncclUniqueId = 128 opaque bytes passed by
+// value, ncclComm_t = opaque pointer, ncclResult_t = int with 0 = success, ncclUint8 = 1)
+struct UniqueId { char internal[128]; };
+typedef int (*fn_get_unique_id)(UniqueId*);
+typedef int (*fn_comm_init_rank)(void** comm, int nranks, UniqueId id, int rank);
+typedef int (*fn_comm_destroy)(void* comm);
+typedef int (*fn_all_gather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream);
+typedef const char* (*fn_get_error_string)(int);
+
+struct Rccl {
+  void* lib = nullptr;
+  fn_get_unique_id get_unique_id = nullptr;
+  fn_comm_init_rank comm_init_rank = nullptr;
+  fn_comm_destroy comm_destroy = nullptr;
+  fn_all_gather all_gather = nullptr;
+  fn_get_error_string get_error_string = nullptr;
+};
+
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+    r.get_unique_id = (fn_get_unique_id)dlsym(r.lib, "ncclGetUniqueId");
+    r.comm_init_rank = (fn_comm_init_rank)dlsym(r.lib, "ncclCommInitRank");
+    r.comm_destroy = (fn_comm_destroy)dlsym(r.lib, "ncclCommDestroy");
+    r.all_gather = (fn_all_gather)dlsym(r.lib, "ncclAllGather");
+    r.get_error_string = (fn_get_error_string)dlsym(r.lib, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather) { dlclose(r.lib); r.lib = nullptr; }
+  });
+  return r.lib ? &r : nullptr;
+}
+
+int rccl_fail(const char* what, int code) {
+  Rccl* r = rccl();
+  lsr::set_last_error(std::string(what) + " -> " + ((r && r->get_error_string) ? r->get_error_string(code) : "RCCL error") + " (" +
+                      std::to_string(code) + ")");
+  return LSR_ERR_HIP;
+}
+
+}  // namespace
+
+struct lsr_comm_s {
+  void* comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t stream = nullptr;
+  lsr::DevBuf<lsr_shard_record> d_send, d_recv;
+};
+
+extern "C" {
+
+void lsr_shard_range(int n_items, int world, int rank, int* first, int* count) {
+  if (world < 1) world = 1;
+  const int base = n_items / world, extra = n_items % world;
+  const int start = rank * base + std::min(rank, extra);
+  if (first) *first = start;
+  if (count) *count = base + (rank < extra ? 1 : 0);
+}
+
+int lsr_comm_unique_id(void* id128) {
+  if (!id128) return LSR_ERR_INVALID_ARGUMENT;
+  Rccl* r = rccl();
+  if (!r) { lsr::set_last_error("librccl.so could not be loaded"); return LSR_ERR_NOT_IMPLEMENTED; }
+  UniqueId id;
+  const int rc = r->get_unique_id(&id);
+  if (rc) return rccl_fail("ncclGetUniqueId", rc);
+  std::memcpy(id128, &id, sizeof(id));
+  return LSR_OK;
+}
+
+int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_comm* out) {
+  if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) { lsr::set_last_error("bad communicator arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) { lsr::set_last_error("no such HIP device"); return LSR_ERR_NO_DEVICE; }
+  lsr_comm c = new (std::nothrow) lsr_comm_s();
+  if (!c) return LSR_ERR_HIP;
+  c->rank = rank; c->world = world; c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    lsr::set_last_error("communicator stream could not be created");
+    return LSR_ERR_HIP;
+  }
+  if (world > 1) {  // a one-rank "communicator" needs no RCCL at all
+    Rccl* r = rccl();
+    if (!r) { (void)hipStreamDestroy(c->stream); delete c; lsr::set_last_error("librccl.so could not be loaded"); return LSR_ERR_NOT_IMPLEMENTED; }
+    UniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    const int rc = r->comm_init_rank(&c->comm, world, id, rank);
+    if (rc) { (void)hipStreamDestroy(c->stream); delete c; return rccl_fail("ncclCommInitRank", rc); }
+  }
+  *out = c;
+  return LSR_OK;
+}
+
+int lsr_comm_destroy(lsr_comm c) {
+  if (!c) return LSR_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm) { Rccl* r = rccl(); if (r) (void)r->comm_destroy(c->comm); }
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return LSR_OK;
+}
+
+int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_count, int global_count, const float* local_guesses,
+                            int with_fitness, lsr_shard_record* all_records) {
+  if (!c || global_count <= 0 || !all_records || local_count < 0 || (local_count > 0 && !local_handles)) {
+    lsr::set_last_error("bad sharded-batch arguments");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  int first = 0, mine = 0;
+  lsr_shard_range(global_count, c->world, c->rank, &first, &mine);
+  if (mine != local_count) { lsr::set_last_error("local_count does not match this rank's share of the batch (lsr_shard_range)"); return LSR_ERR_INVALID_ARGUMENT; }
+  // ---- this rank's share: no collective on the data path
+  std::vector<lsr_shard_record> local((size_t)std::max(local_count, 1));
+  if (local_count > 0) {
+    std::vector<float> finals((size_t)local_count * 16);
+    std::vector<lsr_result> res((size_t)local_count);
+    int st = lsr_align_batch(local_handles, local_count, local_guesses, finals.data(), res.data());
+    if (st) return st;
+    for (int b = 0; b < local_count; b++) {
+      lsr_shard_record& R = local[b];
+      const float* M = finals.data() + 16 * b;  // column-major 4x4 -> row-major 3x4
+      for (int r = 0; r < 3; r++) for (int col = 0; col < 4; col++) R.T[r * 4 + col] = M[col * 4 + r];
+      R.score = (float)res[b].score;
+      R.iterations = (float)res[b].iterations;
+      R.converged = res[b].converged ? 1.f : 0.f;
+      R.fitness = NAN;
+      if (with_fitness) {
+        double f = 0;
+        if ((st = lsr_get_fitness_score(local_handles[b], 1.7976931348623157e308, &f))) return st;
+        R.fitness = (float)f;
+      }
+    }
+  }
+  if (c->world == 1) {
+    std::memcpy(all_records, local.data(), sizeof(lsr_shard_record) * (size_t)global_count);
+    return LSR_OK;
+  }
+  // ---- ONE all-gather of fixed-size blocks (padded to the largest share): 64 B x 64 candidates = 4 KiB, latency bound
+  Rccl* r = rccl();
+  if (!r || !c->comm) { lsr::set_last_error("communicator has no RCCL handle"); return LSR_ERR_NOT_IMPLEMENTED; }
+  if (hipSetDevice(c->device) != hipSuccess) return LSR_ERR_HIP;
+  const int max_count = (global_count + c->world - 1) / c->world;
+  int st;
+  if ((st = c->d_send.reserve((size_t)max_count))) return st;
+  if ((st = c->d_recv.reserve((size_t)max_count * c->world))) return st;
+  LSR_HIP(hipMemsetAsync(c->d_send.p, 0, sizeof(lsr_shard_record) * (size_t)max_count, c->stream));
+  if (local_count > 0)
+    LSR_HIP(hipMemcpyAsync(c->d_send.p, local.data(), sizeof(lsr_shard_record) * (size_t)local_count, hipMemcpyHostToDevice, c->stream));
+  const int rc = r->all_gather(c->d_send.p, c->d_recv.p, sizeof(lsr_shard_record) * (size_t)max_count, /*ncclUint8*/ 1, c->comm, c->stream);
+  if (rc) return rccl_fail("ncclAllGather", rc);
+  std::vector<lsr_shard_record> table((size_t)max_count * c->world);
+  LSR_HIP(hipMemcpyAsync(table.data(), c->d_recv.p, sizeof(lsr_shard_record) * table.size(), hipMemcpyDeviceToHost, c->stream));
+  LSR_HIP(hipStreamSynchronize(c->stream));
+  for (int rk = 0; rk < c->world; rk++) {
+    int f = 0, n = 0;
+    lsr_shard_range(global_count, c->world, rk, &f, &n);
+    if (n) std::memcpy(all_records + f, table.data() + (size_t)rk * max_count, sizeof(lsr_shard_record) * (size_t)n);
+  }
+  return LSR_OK;
+}
+
+}  // extern "C"

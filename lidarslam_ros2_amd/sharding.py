@@ -80,3 +80,77 @@ def register_sharded(n_items: int, register_local: Callable[[Sequence[int]], Lis
     local = np.stack(recs).astype(np.float32) if len(recs) else np.zeros((0, RECORD_FLOATS), np.float32)
     table = all_gather_records(local, n_items, device=device)
     return [unpack_record(table[i]) for i in range(n_items)]
+
+
+# ---- the same exchange at the C ABI: lsr_comm_* / lsr_align_batch_sharded (include/lidarslam_reg.h) -------------------
+class Comm:
+    """One rank's RCCL communicator of the C core.  `unique_id` (128 bytes, from Comm.unique_id() on rank 0, handed to the
+    other ranks by any channel: here torch.distributed's store) may be None for a one-rank communicator."""
+
+    def __init__(self, rank: int, world: int, device: int, unique_id: bytes | None = None):
+        import ctypes as C
+
+        from . import _capi as capi
+
+        self._lib = capi.load()
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        ident = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        capi.check(self._lib.lsr_comm_create(ident, rank, world, device, C.byref(h)), "lsr_comm_create")
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _capi as capi
+
+        ident = (C.c_char * 128)()
+        capi.check(capi.load().lsr_comm_unique_id(ident), "lsr_comm_unique_id")
+        return bytes(ident)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lsr_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def c_shard_range(n_items: int, world: int, rank: int) -> range:
+    import ctypes as C
+
+    from . import _capi as capi
+
+    f, n = C.c_int(), C.c_int()
+    capi.load().lsr_shard_range(n_items, world, rank, C.byref(f), C.byref(n))
+    return range(f.value, f.value + n.value)
+
+
+def align_batch_sharded(comm: Comm, local_regs, n_items: int, local_guesses=None, with_fitness: bool = True) -> List[dict]:
+    """lsr_align_batch_sharded: this rank registers `local_regs` (its lsr_shard_range share of the n_items registrations,
+    targets and sources set) in shared launches; one ncclAllGather of 64-byte records; every rank returns all n_items results."""
+    import ctypes as C
+
+    from . import _capi as capi
+
+    lib = capi.load()
+    nloc = len(local_regs)
+    hs = (C.c_void_p * max(nloc, 1))(*[r._h for r in local_regs])
+    g = None
+    if local_guesses is not None and nloc:
+        g = np.ascontiguousarray(np.stack([np.ascontiguousarray(np.asarray(x, np.float32).T).reshape(16) for x in local_guesses]), np.float32)
+    recs = (capi.ShardRecord * n_items)()
+    capi.check(lib.lsr_align_batch_sharded(comm._h, hs, nloc, n_items, g.ctypes.data_as(C.POINTER(C.c_float)) if g is not None else None,
+                                           1 if with_fitness else 0, recs), "lsr_align_batch_sharded")
+    out = []
+    for r in recs:
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :4] = np.asarray(r.T, np.float32).reshape(3, 4)
+        out.append(dict(T=T, score=float(r.score), iterations=int(round(r.iterations)), converged=bool(r.converged > 0.5),
+                        fitness=float(r.fitness)))
+    return out

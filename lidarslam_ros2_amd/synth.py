@@ -102,8 +102,10 @@ def trajectory_pose(x: float) -> np.ndarray:
     return pose_matrix(x, 0.0, 0.0, 0.02 * math.sin(0.1 * x))
 
 
-def raycast(world: World, sensor: Sensor, T: np.ndarray, rng: np.random.Generator) -> np.ndarray:
-    """One revolution from pose T (sensor->map).  Returns hit points in the SENSOR frame, fp32 (n,3)."""
+def raycast_geometry(world: World, sensor: Sensor, T: np.ndarray):
+    """The deterministic (and expensive) half of one revolution from pose T (sensor->map): ray/primitive intersections.
+    Returns (keep, t) — the boolean mask of rays that hit something inside the sensor's range and their ranges.  Has no
+    random state, so the scans of a workload can be intersected in parallel worker processes (make_case(pool=...))."""
     d_s = sensor.directions()
     R, o = T[:3, :3], T[:3, 3]
     d = d_s @ R.T
@@ -142,10 +144,38 @@ def raycast(world: World, sensor: Sensor, T: np.ndarray, rng: np.random.Generato
         tt = np.where(ok, tt, np.inf)
         t_best = np.minimum(t_best, tt)
     keep = np.isfinite(t_best) & (t_best < sensor.max_range) & (t_best > sensor.min_range)
-    rr = t_best[keep] + rng.normal(0.0, sensor.range_noise, int(keep.sum()))
+    return keep, t_best[keep]
+
+
+def raycast_noise(sensor: Sensor, keep: np.ndarray, t: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """The random half: range noise and surface roughness, drawn from `rng` in a fixed order.  Sensor-frame fp32 (n,3)."""
+    d_s = sensor.directions()
+    rr = t + rng.normal(0.0, sensor.range_noise, int(keep.sum()))
     pts = d_s[keep] * rr[:, None]
     pts[:, 2] += rng.normal(0.0, 0.01, pts.shape[0])  # surface roughness
     return pts.astype(np.float32)
+
+
+def raycast(world: World, sensor: Sensor, T: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """One revolution from pose T (sensor->map).  Returns hit points in the SENSOR frame, fp32 (n,3)."""
+    keep, t = raycast_geometry(world, sensor, T)
+    return raycast_noise(sensor, keep, t, rng)
+
+
+def _geometry_job(args):
+    world, sensor_args, T = args
+    return raycast_geometry(world, Sensor(*sensor_args), T)
+
+
+def raycast_many(world: World, sensor: Sensor, poses, rng: np.random.Generator, pool=None) -> list:
+    """Scans from `poses`, in order, consuming `rng` exactly as successive raycast() calls would; the intersections run in
+    `pool` (anything with a .map, e.g. multiprocessing.Pool) when one is given."""
+    if pool is None:
+        return [raycast(world, sensor, T, rng) for T in poses]
+    sargs = (sensor.n_beams, sensor.elev_min_deg, sensor.elev_max_deg, sensor.n_azimuth, sensor.range_noise, sensor.max_range,
+             sensor.min_range)
+    geo = pool.map(_geometry_job, [(world, sargs, T) for T in poses])
+    return [raycast_noise(sensor, keep, t, rng) for keep, t in geo]
 
 
 def voxel_downsample(pts: np.ndarray, leaf: float) -> np.ndarray:
@@ -196,7 +226,7 @@ def make_case(*, sensor: Sensor | None = None, world: World | None = None, n_key
               start_x: float = 0.0, keyframe_spacing: float = 1.5, scan_spacing: float = 0.5,
               vg_map: float = 0.1, vg_input: float = 0.2, n_source: int | None = 30000,
               vg_target: float | None = None, guess_perturb: tuple | None = None, seed: int = 0,
-              azimuth_oversample: int = 1, name: str = "") -> RegistrationCase:
+              azimuth_oversample: int = 1, name: str = "", pool=None) -> RegistrationCase:
     """Frontend-style case: target = n_keyframes scans (each VoxelGrid(vg_map), moved to the map
     frame, concatenated without re-filtering: scanmatcher_component.cpp:452-464); source = the
     next scan, VoxelGrid(vg_input) then cut to exactly n_source points; guess = pose of the
@@ -207,18 +237,18 @@ def make_case(*, sensor: Sensor | None = None, world: World | None = None, n_key
                         sensor.range_noise, sensor.max_range, sensor.min_range)
     world = world or make_world()
     rng = np.random.default_rng(WORLD_SEED + 7919 * seed + 1)
-    chunks = []
-    for k in range(n_keyframes):
-        T = trajectory_pose(start_x + keyframe_spacing * k)
-        scan = voxel_downsample(raycast(world, sensor, T, rng), vg_map)
-        chunks.append(transform_points(T, scan))
-    target = np.concatenate(chunks, 0)
-    if vg_target is not None:  # GICP frontend path re-filters the target (scanmatcher_component.cpp:309-315)
-        target = voxel_downsample(target, vg_target)
     x_last = start_x + keyframe_spacing * (n_keyframes - 1)
     x_src = x_last + scan_spacing
     T_src = trajectory_pose(x_src)
-    src = voxel_downsample(raycast(world, sensor, T_src, rng), vg_input)
+    poses = [trajectory_pose(start_x + keyframe_spacing * k) for k in range(n_keyframes)] + [T_src]
+    scans = raycast_many(world, sensor, poses, rng, pool)   # `pool` only parallelises the intersections: same clouds
+    chunks = []
+    for k in range(n_keyframes):
+        chunks.append(transform_points(poses[k], voxel_downsample(scans[k], vg_map)))
+    target = np.concatenate(chunks, 0)
+    if vg_target is not None:  # GICP frontend path re-filters the target (scanmatcher_component.cpp:309-315)
+        target = voxel_downsample(target, vg_target)
+    src = voxel_downsample(scans[n_keyframes], vg_input)
     if n_source is not None:
         src = subsample_exact(src, n_source, seed=WORLD_SEED + seed)
     if guess_perturb is None:
@@ -230,32 +260,56 @@ def make_case(*, sensor: Sensor | None = None, world: World | None = None, n_key
 
 
 # ---- BASELINE.json configs ---------------------------------------------------------------
-def cfg_ndt_30k(seed: int = 0, start_x: float = 0.0, guess_perturb=None, world: World | None = None) -> RegistrationCase:
+def cfg_ndt_30k(seed: int = 0, start_x: float = 0.0, guess_perturb=None, world: World | None = None, pool=None) -> RegistrationCase:
     """cfg 1/2: 30k-pt VLP-32 scan (vg 0.2) vs 10-frame submap (vg 0.1)."""
     return make_case(sensor=vlp32(), n_keyframes=10, vg_map=0.1, vg_input=0.2, n_source=30000, seed=seed,
                      start_x=start_x, guess_perturb=guess_perturb, world=world, azimuth_oversample=3,
-                     name="ndt_30k_vs_10frame")
+                     name="ndt_30k_vs_10frame", pool=pool)
 
 
-def cfg_gicp_30k(seed: int = 0) -> RegistrationCase:
+def cfg_scan_stream(n_scans: int, seed: int = 0, pool=None, world: World | None = None) -> list:
+    """A stream of DIFFERENT cfg-1/2 scans against the cfg_ndt_30k(seed) submap: scan j is taken 0.5, 1.0 or 1.5 m past
+    the last keyframe (the frontend registers about three scans per map update, trans_for_mapupdate = 1.5 m) with its own
+    noise realisation and sub-sample; guess = the true pose 0.5 m earlier.  Returns [(source (30000,3) f32, guess 4x4 f32,
+    truth 4x4 f64)]; scan 0 is NOT cfg_ndt_30k's own source (different random stream)."""
+    sensor = vlp32()
+    sensor = Sensor(sensor.n_beams, sensor.elev_min_deg, sensor.elev_max_deg, sensor.n_azimuth * 3, sensor.range_noise,
+                    sensor.max_range, sensor.min_range)
+    world = world or make_world()
+    x_last = 1.5 * 9
+    xs = [x_last + 0.5 * (1 + j % 3) for j in range(n_scans)]
+    poses = [trajectory_pose(x) for x in xs]
+    sargs = (sensor.n_beams, sensor.elev_min_deg, sensor.elev_max_deg, sensor.n_azimuth, sensor.range_noise, sensor.max_range,
+             sensor.min_range)
+    jobs = [(world, sargs, T) for T in poses]
+    geo = pool.map(_geometry_job, jobs) if pool is not None else [_geometry_job(j) for j in jobs]
+    out = []
+    for j, (keep, t) in enumerate(geo):
+        rng = np.random.default_rng([WORLD_SEED, 40503, seed, j])
+        src = subsample_exact(voxel_downsample(raycast_noise(sensor, keep, t, rng), 0.2), 30000, seed=WORLD_SEED + 131 * seed + j)
+        out.append((src, trajectory_pose(xs[j] - 0.5).astype(np.float32), poses[j]))
+    return out
+
+
+def cfg_gicp_30k(seed: int = 0, pool=None) -> RegistrationCase:
     """cfg 3: same source; target additionally VoxelGrid(0.2) (scanmatcher_component.cpp:309-315)."""
     return make_case(sensor=vlp32(), n_keyframes=10, vg_map=0.1, vg_input=0.2, n_source=30000, vg_target=0.2,
-                     seed=seed, azimuth_oversample=3, name="gicp_30k_vs_10frame")
+                     seed=seed, azimuth_oversample=3, name="gicp_30k_vs_10frame", pool=pool)
 
 
-def cfg_loop_candidate(c: int) -> RegistrationCase:
+def cfg_loop_candidate(c: int, pool=None) -> RegistrationCase:
     """cfg 4: candidate c starts 3*c m along the route; guess perturbed U(-1,1) m xy, U(-3,3) deg yaw."""
     rng = np.random.default_rng(1000 + c)
     dx, dy = rng.uniform(-1, 1, 2)
     dyaw = math.radians(rng.uniform(-3, 3))
     return cfg_ndt_30k(seed=100 + c, start_x=3.0 * c, guess_perturb=(dx, dy, dyaw),
-                       world=make_world(x_shift=3.0 * c))
+                       world=make_world(x_shift=3.0 * c), pool=pool)
 
 
-def cfg_dense_120k(seed: int = 0) -> RegistrationCase:
+def cfg_dense_120k(seed: int = 0, pool=None) -> RegistrationCase:
     """cfg 5: 64-line scan (vg 0.1) cut to 120k vs 20-frame submap."""
     return make_case(sensor=hdl64(), n_keyframes=20, vg_map=0.1, vg_input=0.1, n_source=120000, seed=seed,
-                     azimuth_oversample=3, name="ndt_120k_vs_20frame")
+                     azimuth_oversample=3, name="ndt_120k_vs_20frame", pool=pool)
 
 
 def small_case(n_source: int = 2000, n_keyframes: int = 3, seed: int = 0, guess_perturb=None,

@@ -56,6 +56,38 @@ def test_table_driven_angle_coefficients_equal_the_scalar_formulas():
     assert ht[20] == np.float32(sy)
 
 
+def test_c_shard_range_is_the_python_partition():
+    """lsr_shard_range (C ABI, device-free) and sharding.shard_range (torch.distributed path) must cut a batch the same way:
+    contiguous shares in rank order, sizes differing by at most one, nothing lost."""
+    from lidarslam_ros2_amd.sharding import c_shard_range, shard_range
+
+    for n in (0, 1, 7, 8, 63, 64, 65):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                a, b = c_shard_range(n, world, r), shard_range(n, world, r)
+                assert (a.start, a.stop) == (b.start, b.stop), (n, world, r)
+                cover += list(a)
+            assert cover == list(range(n))
+
+
+def test_comm_entry_points_fail_cleanly_without_a_device():
+    import torch
+
+    from lidarslam_ros2_amd import _capi
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    lib = _capi.load()
+    h = C.c_void_p()
+    assert lib.lsr_comm_create(None, 0, 1, 0, C.byref(h)) == -2          # LSR_ERR_NO_DEVICE
+    assert lib.lsr_comm_create(None, 1, 1, 0, C.byref(h)) == -1          # rank out of range
+    assert lib.lsr_comm_create(None, 0, 2, 0, C.byref(h)) == -1          # world 2 needs a unique id
+    assert lib.lsr_comm_destroy(None) == 0
+    recs = (_capi.ShardRecord * 1)()
+    assert lib.lsr_align_batch_sharded(None, None, 0, 1, None, 0, recs) == -1
+
+
 def test_no_cpu_fallback_without_a_device():
     """Without a GPU lsr_create must fail loudly (LSR_ERR_NO_DEVICE) — there is no CPU path."""
     import torch

@@ -74,3 +74,85 @@ def test_sharded_candidates_rccl_world2(tmp_path):
         truth = synth.small_case(n_source=2500, n_keyframes=3, seed=c).truth
         dt, ang = pose_delta(a[c], truth)
         assert dt < 0.1 and ang < 5e-3
+
+
+def _make_regs(cases, device):
+    from lidarslam_ros2_amd import NormalDistributionsTransform
+
+    regs = []
+    for c in cases:
+        r = NormalDistributionsTransform(device=device)
+        r.setResolution(5.0)
+        r.setTransformationEpsilon(0.01)
+        r.setMaximumIterations(100)
+        r.setInputTarget(c.target)
+        r.setInputSource(c.source)
+        regs.append(r)
+    return regs
+
+
+def test_c_abi_sharded_batch_with_a_one_rank_communicator():
+    """lsr_align_batch_sharded through a one-rank communicator (no RCCL involved): the records equal what lsr_align_batch
+    plus getFitnessScore give, and every candidate lands on its ground truth."""
+    from lidarslam_ros2_amd import align_batch, synth
+    from lidarslam_ros2_amd.posemath import pose_delta
+    from lidarslam_ros2_amd.sharding import Comm, align_batch_sharded
+
+    cases = [synth.small_case(n_source=2500, n_keyframes=3, seed=c) for c in range(5)]
+    regs = _make_regs(cases, 0)
+    comm = Comm(0, 1, 0)
+    res = align_batch_sharded(comm, regs, len(cases), [c.guess for c in cases], with_fitness=True)
+    finals, ref = align_batch(_make_regs(cases, 0), [c.guess for c in cases])
+    for k, c in enumerate(cases):
+        assert np.array_equal(res[k]["T"], finals[k])
+        assert res[k]["iterations"] == ref[k]["iterations"] and res[k]["converged"] == ref[k]["converged"]
+        assert abs(res[k]["fitness"] - regs[k].getFitnessScore()) <= 1e-6 * abs(res[k]["fitness"])
+        dt, ang = pose_delta(res[k]["T"], c.truth)
+        assert dt < 0.1 and ang < 5e-3
+    comm.close()
+
+
+def _worker_c_abi(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # only carries the 128-byte ncclUniqueId
+    from lidarslam_ros2_amd import synth
+    from lidarslam_ros2_amd.sharding import Comm, align_batch_sharded, c_shard_range
+
+    n_cand = 7
+    box = [Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm = Comm(rank, world, rank, box[0])
+    mine = c_shard_range(n_cand, world, rank)
+    cases = [synth.small_case(n_source=2500, n_keyframes=3, seed=c) for c in mine]
+    res = align_batch_sharded(comm, _make_regs(cases, rank), n_cand, [c.guess for c in cases], with_fitness=True)
+    np.save(os.path.join(out_dir, f"c_rank{rank}.npy"), np.stack([np.r_[r["T"].reshape(-1), r["fitness"], r["iterations"]] for r in res]))
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c_abi_sharded_batch_rccl_world2(tmp_path):
+    """Two ranks, two GPUs, the all-gather done by the C core itself (ncclAllGather behind lsr_align_batch_sharded)."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import torch.multiprocessing as mp
+
+    from lidarslam_ros2_amd import synth
+    from lidarslam_ros2_amd.posemath import pose_delta
+
+    mp.spawn(_worker_c_abi, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "c_rank0.npy"), np.load(tmp_path / "c_rank1.npy")
+    assert np.array_equal(a, b)
+    for c in range(7):
+        truth = synth.small_case(n_source=2500, n_keyframes=3, seed=c).truth
+        dt, ang = pose_delta(a[c, :16].reshape(4, 4), truth)
+        assert dt < 0.1 and ang < 5e-3

@@ -5,7 +5,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lidarslam_ros2_amd import NormalDistributionsTransform, synth
-case = synth.cfg_ndt_30k()
+import multiprocessing as mp
+with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
+    case = synth.cfg_ndt_30k(pool=pool)
 tgt = torch.from_numpy(synth.as_pointxyzi(case.target)).cuda()
 src = torch.from_numpy(synth.as_pointxyzi(case.source)).cuda()
 torch.cuda.synchronize()

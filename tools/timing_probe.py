@@ -11,7 +11,9 @@ lib = _capi.load()
 buf = C.c_void_p()
 lib.lsr_debug_timing_buffer.argtypes = [C.POINTER(C.c_void_p)]
 assert lib.lsr_debug_timing_buffer(C.byref(buf)) == 0
-case = synth.cfg_ndt_30k()
+import multiprocessing as mp
+with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
+    case = synth.cfg_ndt_30k(pool=pool)
 hip = C.CDLL("libamdhip64.so")
 host = np.zeros((1024, 32), np.int64)
 PHASES = ["INIT", "MT_FIRST", "MT_TRIAL", "MT_HESS", "DIAG"]

@@ -2,8 +2,11 @@
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from lidarslam_ros2_amd import NormalDistributionsTransform, synth, align_batch
-case = synth.cfg_ndt_30k()
+import multiprocessing as mp
+from lidarslam_ros2_amd import synth
+with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:   # before the GPU is touched
+    case = synth.cfg_ndt_30k(pool=pool)
+from lidarslam_ros2_amd import NormalDistributionsTransform, align_batch
 ndt = NormalDistributionsTransform(0); ndt.setResolution(5.0); ndt.setTransformationEpsilon(0.0); ndt.setMaximumIterations(30)
 ndt.setInputTarget(case.target); ndt.setInputSource(case.source)
 for i in range(4): ndt.align(case.guess)
