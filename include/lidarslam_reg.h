@@ -90,7 +90,9 @@ typedef struct lsr_result {
   double score;                 /* NDT: trans_probability_ (= score / N); GICP: final mean Mahalanobis cost */
   int32_t n_evaluations;        /* NDT: derivative passes launched; GICP: Gauss-Newton inner steps */
   int32_t n_correspondences;    /* GICP: pairs in the last outer iteration; NDT: 0 */
-  double gpu_ms;                /* device time of this align (hipEvents on the handle's stream) */
+  double gpu_ms;                /* HOST wall-clock time of the align call that produced this result, from the first
+                                   enqueue to the result in host memory; for lsr_align_batch every member carries the
+                                   time of the whole batch.  (Device-side time per derivative pass: lsr_get_profile.) */
 } lsr_result;
 
 typedef struct lsr_profile {
@@ -122,6 +124,14 @@ int lsr_get_i32(lsr_handle h, int key, int* value);
  * Host-memory (`pts` readable by the CPU) and device-memory (`pts` a HIP device pointer) forms. */
 int lsr_set_input_target(lsr_handle h, const void* pts, size_t stride_bytes, size_t n);
 int lsr_set_input_target_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n);
+/* Ordering and lifetime of DEVICE-resident inputs (every *_device entry point and every `on_device != 0` argument): the
+ * core reads them with kernels on the handle's stream (lsr_create's `stream`, or the handle's own).  (1) If another
+ * stream produced the buffer, call lsr_wait_stream(h, that_stream) first — it makes the handle's stream wait for
+ * everything enqueued on the producer so far (event record + hipStreamWaitEvent, no host wait); buffers produced on the
+ * handle's own stream or already complete need nothing.  (2) setInputTarget-type calls return after the read has
+ * completed; lsr_set_input_source_device returns with the read ENQUEUED: keep the buffer alive and unmodified until the
+ * next lsr_align / lsr_align_batch / lsr_get_fitness_score on this handle has returned (or synchronise its stream). */
+int lsr_wait_stream(lsr_handle h, void* producer_stream);
 /* Submap assembly fused with setInputTarget: frame f (strided xyz, counts[f] points) is moved by poses16[16*f ..]
  * (column-major 4x4, pcl::transformPointCloud's fp32 arithmetic) and the frames are concatenated in order — what
  * updateMap() does on the host before setInputTarget (scanmatcher_component.cpp:449-464,307) and searchLoop() for a

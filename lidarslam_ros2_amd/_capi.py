@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "lsr_version", "lsr_status_string", "lsr_last_error", "lsr_device_count", "lsr_create", "lsr_destroy",
     "lsr_set_f64", "lsr_set_i32", "lsr_get_f64", "lsr_get_i32", "lsr_set_input_target", "lsr_set_input_target_device",
     "lsr_set_input_target_frames", "lsr_set_input_source", "lsr_set_input_source_device", "lsr_set_input_source_filtered", "lsr_set_input_source_frontend", "lsr_voxel_grid_filter",
-    "lsr_share_target", "lsr_align", "lsr_align_batch",
+    "lsr_share_target", "lsr_wait_stream", "lsr_align", "lsr_align_batch",
     "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_search_loop", "lsr_ndt_grid_info",
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
     "lsr_debug_angle_tables", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
@@ -102,6 +102,7 @@ def load() -> C.CDLL:
                  "lsr_set_input_source_device"):
         getattr(L, name).argtypes = [vp, vp, C.c_size_t, C.c_size_t]
     L.lsr_share_target.argtypes = [vp, vp]
+    L.lsr_wait_stream.argtypes = [vp, vp]
     L.lsr_set_input_target_frames.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, fp, C.c_int]
     L.lsr_set_input_source_filtered.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.POINTER(C.c_size_t)]
     L.lsr_set_input_source_frontend.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_float, C.c_int,

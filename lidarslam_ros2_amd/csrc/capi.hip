@@ -118,10 +118,20 @@ std::shared_ptr<TargetData> fresh_target(lsr_handle h) {
   return t;
 }
 
+bool target_is_shared(lsr_handle h) {
+  return h->target && h->target.use_count() > (long)(1 + (h->spare_target == h->target));
+}
+
 int ensure_ndt_grid(lsr_handle h) {
   TargetData& t = *h->target;
+  std::lock_guard<std::mutex> lock(t.build_mutex);
   float leaf = (float)h->ndt.resolution;
   if (t.has_grid && t.grid_leaf == leaf) return LSR_OK;
+  if (t.has_grid && target_is_shared(h)) {
+    // rebuilding in place would pull the grid from under the other handles (their d1/d2 and leaf size belong to the old one)
+    set_last_error("the shared target's voxel grid was built at another resolution: sharers must use one ndt_resolution");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
   int st = ndt_build_grid(t.cloud, leaf, t.grid, h->scratch, h->stream);
   if (st) return st;
   t.has_grid = true;
@@ -131,6 +141,7 @@ int ensure_ndt_grid(lsr_handle h) {
 
 int ensure_target_hash(lsr_handle h) {
   TargetData& t = *h->target;
+  std::lock_guard<std::mutex> lock(t.build_mutex);
   if (t.has_hash) return LSR_OK;
   int st = nn_build_hash(t.cloud, nn_pick_cell(t.cloud.n, h), t.hash, h->scratch, h->stream);
   if (st) return st;
@@ -216,6 +227,10 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     if (h->ndt.neighborhood != lead->ndt.neighborhood) { set_last_error("batched handles must share the neighbourhood method"); return LSR_ERR_INVALID_ARGUMENT; }
     int st = ensure_ndt_grid(h);
     if (st) return st;
+    if (h->target->grid.ncells == 0) {  // no finite target point: there is no table a lookup could read
+      set_last_error("the input target holds no finite point");
+      return LSR_ERR_NO_TARGET;
+    }
   }
   int st;
   if ((st = lead->d_state.reserve(2 * (size_t)B))) return st;
@@ -663,6 +678,14 @@ int lsr_voxel_grid_filter(lsr_handle h, const void* pts, size_t stride_bytes, si
   return LSR_OK;
 }
 
+int lsr_wait_stream(lsr_handle h, void* producer_stream) {
+  LSR_CHECK_HANDLE(h);
+  if ((hipStream_t)producer_stream == h->stream) return LSR_OK;  // same stream: already ordered
+  LSR_HIP(hipEventRecord(h->ev0, (hipStream_t)producer_stream));
+  LSR_HIP(hipStreamWaitEvent(h->stream, h->ev0, 0));
+  return LSR_OK;
+}
+
 int lsr_share_target(lsr_handle h, lsr_handle owner) {
   LSR_CHECK_HANDLE(h);
   if (!owner || !owner->target) { set_last_error("owner has no target"); return LSR_ERR_NO_TARGET; }
@@ -942,6 +965,7 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
   if (!h->has_source) return LSR_ERR_NO_SOURCE;
   int st = ensure_ndt_grid(h);
   if (st) return st;
+  if (h->target->grid.ncells == 0) { set_last_error("the input target holds no finite point"); return LSR_ERR_NO_TARGET; }
   if ((st = h->d_state.reserve(2))) return st;
   if ((st = h->h_state.reserve(2))) return st;
   if ((st = h->d_prob.reserve(1))) return st;

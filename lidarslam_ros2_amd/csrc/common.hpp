@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -167,6 +168,7 @@ struct BuildScratch {
 int wait_mailbox_word(const volatile unsigned int* word, unsigned int token, hipStream_t stream, int wait_mode, const char* what);
 
 struct TargetData {
+  std::mutex build_mutex;  // lazy builds (grid, NN hash, covariances) by handles that share this target (lsr_share_target)
   DeviceCloud cloud;
   size_t n = 0;
   bool has_grid = false;

@@ -487,9 +487,15 @@ int ensure_covariances(lsr_handle_s* h) {
     set_last_error("GICP: cloud has fewer points than k_correspondences");
     return LSR_ERR_TOO_FEW_POINTS;
   }
+  std::unique_lock<std::mutex> lock(t.build_mutex);  // target-side lazy builds are shared state (lsr_share_target)
   if (!t.has_hash) {
     if ((st = nn_build_hash(t.cloud, nn_pick_cell(t.cloud.n, h), t.hash, h->scratch, h->stream))) return st;
     t.has_hash = true;
+  }
+  if (t.has_cov && (t.cov_k != h->gicp.k || t.cov_eps != h->gicp.gicp_eps) &&
+      h->target.use_count() > (long)(1 + (h->spare_target == h->target))) {
+    set_last_error("the shared target's covariances were computed with other k_correspondences / gicp_epsilon");
+    return LSR_ERR_INVALID_ARGUMENT;
   }
   if (!t.has_cov || t.cov_k != h->gicp.k || t.cov_eps != h->gicp.gicp_eps) {
     if ((st = nn_build_hash(t.cloud, GICP_COV_CELL, h->source_hash, h->scratch, h->stream))) return st;  // borrowed, rebuilt below
@@ -499,6 +505,7 @@ int ensure_covariances(lsr_handle_s* h) {
     t.cov_eps = h->gicp.gicp_eps;
     h->source_cov_valid = false;
   }
+  lock.unlock();
   if (!h->source_cov_valid) {
     if ((st = nn_build_hash(h->source, GICP_COV_CELL, h->source_hash, h->scratch, h->stream))) return st;
     if ((st = compute_covariances(h, h->source, h->source_hash, h->source_cov))) return st;

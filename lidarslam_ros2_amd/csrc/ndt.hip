@@ -1231,7 +1231,10 @@ __device__ __forceinline__ float dpp_quad_sum(float v) {
 template <int NOFF, int TAB, int PTS>
 __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem P, const int seq) {
   constexpr int THREADS = 4 * PTS;
-  constexpr int PITCH = PTS + 4;           // floats per row of the per-point buffers
+  // floats per row of the per-point buffers, chosen against the 32-lane groups of ds_*_b32: phase A writes rows
+  // ql + 4m at columns pq (4 rows x 8 columns per group): pitch = 8 (mod 32) spreads them over all 32 banks; phase C reads
+  // rows cv at columns cseg + SEGS k (2 rows x 16 columns per group): pitch = 16 (mod 32)
+  constexpr int PITCH_PT = PTS + 8, PITCH_O = PTS + 16;
   constexpr int SEGS = THREADS / 32;       // interleaved segments per value in the workgroup sum
   constexpr int NT = (NOFF + 3) / 4;       // neighbours per lane
   if ((int)blockIdx.x >= P.nblocks) return;
@@ -1241,8 +1244,8 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   LSR_PASS_BEGIN()
   LSR_SPAN_BEGIN(seq)
 
-  __shared__ float s_pt[14][PITCH];   // phase A -> B: per point {score, #pairs, A (3), E (6), x, y, z}
-  __shared__ float s_o[29][PITCH];    // phase B -> C: the 29 per-point terms
+  __shared__ float s_pt[14][PITCH_PT];   // phase A -> B: per point {score, #pairs, A (3), E (6), x, y, z}
+  __shared__ float s_o[29][PITCH_O];     // phase B -> C: the 29 per-point terms
   __shared__ double s_bin[NDT_NBINS][32];
   __shared__ double s_sum[NDT_NRED];
   __shared__ double s_lu[8][2];

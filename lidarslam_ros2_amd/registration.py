@@ -55,6 +55,15 @@ def _col16_to_mat(v) -> np.ndarray:
     return np.asarray(v, np.float32).reshape(4, 4).T.copy()
 
 
+def _order_after_torch(reg, cloud):
+    """A CUDA tensor may be the result of kernels still running on torch's current stream: make the handle's stream wait
+    for that stream (lsr_wait_stream: event record + stream wait, no host wait) before the core reads the tensor."""
+    if _is_torch_cuda(cloud):
+        import torch
+
+        capi.check(reg._lib.lsr_wait_stream(reg._h, C.c_void_p(torch.cuda.current_stream(cloud.device).cuda_stream)), "lsr_wait_stream")
+
+
 class Registration:
     """pcl::Registration<PointXYZI, PointXYZI>-shaped base (SURVEY.md §8b)."""
 
@@ -122,6 +131,7 @@ class Registration:
 
     # -- clouds ------------------------------------------------------------------------------
     def setInputTarget(self, cloud):  # scanmatcher_component.cpp:275,307,315; graph_based_slam_component.cpp:227
+        _order_after_torch(self, cloud)
         p, stride, n, dev, keep = _cloud_args(cloud)
         fn = self._lib.lsr_set_input_target_device if dev else self._lib.lsr_set_input_target
         capi.check(fn(self._h, p, stride, n), "setInputTarget")
@@ -130,6 +140,8 @@ class Registration:
     def setInputTargetFrames(self, frames, poses):
         """Submap assembly on the device: frame f transformed by poses[f] (4x4), concatenated, then
         setInputTarget (scanmatcher_component.cpp:449-464,307).  Frames: host arrays or CUDA tensors, same layout."""
+        for f in frames:
+            _order_after_torch(self, f)
         args = [_cloud_args(f) for f in frames]
         dev = args[0][3]
         if any(a[3] != dev for a in args) or any(a[1] != args[0][1] for a in args):
@@ -144,6 +156,7 @@ class Registration:
         self._n_target = int(sum(a[2] for a in args))
 
     def setInputSource(self, cloud):  # scanmatcher_component.cpp:329; graph_based_slam_component.cpp:181
+        _order_after_torch(self, cloud)
         p, stride, n, dev, keep = _cloud_args(cloud)
         fn = self._lib.lsr_set_input_source_device if dev else self._lib.lsr_set_input_source
         capi.check(fn(self._h, p, stride, n), "setInputSource")
@@ -153,6 +166,7 @@ class Registration:
     def setInputSourceFiltered(self, cloud, leaf: float) -> int:
         """pcl::VoxelGrid(leaf).filter + setInputSource on the device (scanmatcher_component.cpp:324-329);
         returns the number of points kept."""
+        _order_after_torch(self, cloud)
         p, stride, n, dev, keep = _cloud_args(cloud)
         n_out = C.c_size_t()
         capi.check(self._lib.lsr_set_input_source_filtered(self._h, p, stride, n, C.c_float(leaf), 1 if dev else 0,
@@ -163,6 +177,7 @@ class Registration:
     def setInputSourceFrontend(self, cloud, scan_min_range: float, scan_max_range: float, vg_size_for_input: float) -> int:
         """Range filter (scanmatcher_component.cpp:210-218) + VoxelGrid (:324-328) + setInputSource (:329) on the
         device; returns the number of points kept."""
+        _order_after_torch(self, cloud)
         p, stride, n, dev, keep = _cloud_args(cloud)
         n_out = C.c_size_t()
         capi.check(self._lib.lsr_set_input_source_frontend(self._h, p, stride, n, float(scan_min_range), float(scan_max_range),
