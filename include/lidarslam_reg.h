@@ -260,7 +260,8 @@ int lsr_ndt_grid_dump(lsr_handle h, int32_t* idx, int32_t* npts, double* mean, d
  * transform like the first pass of align().  grad: 6, hess: 36 (row-major). */
 int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int compute_hessian, double* score,
                         double* grad, double* hess);
-/* GICP per-point covariances after setInput*: which = 0 source, 1 target; cov: n*9 doubles. */
+/* GICP per-point covariances after setInput*: which = 0 source, 1 target (regularised, as the optimiser uses them);
+ * 2 source, 3 target: the k-neighbour sample covariance BEFORE the eigen-regularisation.  cov: n*9 doubles. */
 int lsr_gicp_covariances(lsr_handle h, int which, double* cov);
 /* 1-NN of the source transformed by T16 (nullable = identity) in the target: idx[n], d2[n]. */
 int lsr_nearest_neighbors(lsr_handle h, const float* T16, int32_t* idx, float* d2);

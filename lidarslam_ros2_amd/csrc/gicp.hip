@@ -126,6 +126,10 @@ __device__ void cov_finish(CovSums& S, int k, double gicp_eps, double* __restric
   C[3] = S.s10 / kk - mean[1] * mean[0]; C[4] = S.s11 / kk - mean[1] * mean[1];
   C[6] = S.s20 / kk - mean[2] * mean[0]; C[7] = S.s21 / kk - mean[2] * mean[1]; C[8] = S.s22 / kk - mean[2] * mean[2];
   C[1] = C[3]; C[2] = C[6]; C[5] = C[7];
+  if (gicp_eps < 0) {  // inspection (lsr_gicp_covariances which = 2 / 3): the sample covariance before regularisation
+    for (int a = 0; a < 9; a++) out[a] = C[a];
+    return;
+  }
   double w[3], V[9];
   sym3_eigen_k5(C, w, V);
   // singular values of a symmetric matrix are |eigenvalues|: the smallest one is replaced by eps
@@ -450,8 +454,9 @@ void mat4_mul_f(const float* A, const float* B, float* C) {  // column-major fp3
   std::memcpy(C, T, sizeof(T));
 }
 
-int compute_covariances(lsr_handle_s* h, const DeviceCloud& cloud, const HashGridDev& grid, DevBuf<double>& cov) {
+int compute_covariances(lsr_handle_s* h, const DeviceCloud& cloud, const HashGridDev& grid, DevBuf<double>& cov, bool raw = false) {
   const int n = (int)cloud.n;
+  const double eps = raw ? -1.0 : h->gicp.gicp_eps;
   int st = cov.reserve((size_t)n * 9);
   if (st) return st;
   if (n == 0) return LSR_OK;
@@ -466,11 +471,11 @@ int compute_covariances(lsr_handle_s* h, const DeviceCloud& cloud, const HashGri
   const int spread = (n <= 65536) ? 2 : 1;   // measured on a 30k-point scan: 420 -> 384 us (4: 410, 8: 360)
   const long threads = (long)n * spread;
   hipLaunchKernelGGL(gicp_cov_kernel, dim3((unsigned)((threads + NN_THREADS - 1) / NN_THREADS)), dim3(NN_THREADS), smem, h->stream, make_view(grid),
-                     cloud.x(), cloud.y(), cloud.z(), n, k, h->gicp.gicp_eps, 2, ring_cap, spread, work, work + 1, cov.p);
+                     cloud.x(), cloud.y(), cloud.z(), n, k, eps, 2, ring_cap, spread, work, work + 1, cov.p);
   LSR_HIP(hipGetLastError());
   if (coop) {
     hipLaunchKernelGGL(gicp_cov_coop_kernel, dim3(1024), dim3(256), 0, h->stream, make_view(grid), cloud.x(), cloud.y(), cloud.z(),
-                       k, h->gicp.gicp_eps, work, work + 1, cov.p);
+                       k, eps, work, work + 1, cov.p);
     LSR_HIP(hipGetLastError());
   }
   return LSR_OK;
@@ -521,6 +526,16 @@ int gicp_get_covariances(lsr_handle_s* h, int which, double* cov) {
   if (!h->has_source) return LSR_ERR_NO_SOURCE;
   int st = ensure_covariances(h);
   if (st) return st;
+  if (which < 0 || which > 3) { set_last_error("which must be 0..3"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (which >= 2) {  // the sample covariances BEFORE the eigen-regularisation (same neighbours, same FLOAT products)
+    const DeviceCloud& cloud = (which == 2) ? h->source : h->target->cloud;
+    if ((st = nn_build_hash(cloud, GICP_COV_CELL, h->source_hash, h->scratch, h->stream))) return st;
+    if ((st = compute_covariances(h, cloud, h->source_hash, h->gicp_ws.raw_cov, true))) return st;
+    LSR_HIP(hipMemcpyAsync(cov, h->gicp_ws.raw_cov.p, sizeof(double) * 9 * cloud.n, hipMemcpyDeviceToHost, h->stream));
+    LSR_HIP(hipStreamSynchronize(h->stream));
+    h->source_cov_valid = false;  // source_hash was borrowed
+    return LSR_OK;
+  }
   const DevBuf<double>& c = which == 0 ? h->source_cov : h->target->cov;
   const size_t n = which == 0 ? h->source.n : h->target->n;
   LSR_HIP(hipMemcpyAsync(cov, c.p, sizeof(double) * 9 * n, hipMemcpyDeviceToHost, h->stream));

@@ -34,6 +34,7 @@ struct GicpWorkspace {
   DevBuf<unsigned char> state;   // per-iteration block {GnState, T16, Rm} + counters
   PinBuf<unsigned char> pin;     // pinned host mirror of the per-iteration block
   DevBuf<int> work;              // K5: count + indices of the points deferred to the wave-cooperative search
+  DevBuf<double> raw_cov;        // inspection only: sample covariances before regularisation
   PinBuf<GicpMailbox> mailbox;
   GicpMailbox* d_mailbox = nullptr;
   unsigned int token = 0;        // one per outer iteration

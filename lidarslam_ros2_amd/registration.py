@@ -357,9 +357,10 @@ class GeneralizedIterativeClosestPoint(Registration):
     def setMaximumOptimizerIterations(self, n: int):
         self._seti(capi.MAX_INNER_ITERATIONS, n, "setMaximumOptimizerIterations")
 
-    def covariances(self, which: str) -> np.ndarray:
-        w = 0 if which == "source" else 1
-        n = self._n_source if w == 0 else self._n_target
+    def covariances(self, which: str, raw: bool = False) -> np.ndarray:
+        """Per-point covariances; raw=True: the k-neighbour sample covariance before the eigen-regularisation."""
+        w = (0 if which == "source" else 1) + (2 if raw else 0)
+        n = self._n_source if w in (0, 2) else self._n_target
         cov = np.zeros((n, 3, 3))
         capi.check(self._lib.lsr_gicp_covariances(self._h, w, cov.ctypes.data_as(C.POINTER(C.c_double))), "covariances")
         return cov

@@ -437,6 +437,10 @@ void orc_gicp_covariances(void* nn_grid, const float* pts, size_t stride_f, size
         c[a * 3 + b] -= mean[a] * mean[b];
         c[b * 3 + a] = c[a * 3 + b];
       }
+    if (gicp_eps < 0) {  // inspection: the sample covariance before the regularisation
+      for (int a = 0; a < 9; a++) cov[9 * (size_t)i + a] = c[a];
+      continue;
+    }
     double w[3], V[9];
     orc::sym3_eigen(c, w, V);
     // singular values of a symmetric matrix = |eigenvalues|; descending order of |w|

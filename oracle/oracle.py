@@ -243,6 +243,11 @@ class NearestNeighbour:
             pass
 
 
+def gicp_raw_covariances(nn: NearestNeighbour, pts: np.ndarray, k: int = 20, num_threads=0):
+    """The k-neighbour sample covariances of computeCovariances BEFORE the SVD regularisation (FLOAT products, double sums)."""
+    return gicp_covariances(nn, pts, k=k, gicp_eps=-1.0, num_threads=num_threads)
+
+
 def gicp_covariances(nn: NearestNeighbour, pts: np.ndarray, k: int = 20, gicp_eps: float = 1e-3, num_threads=0):
     p, pp = _f32(pts)
     cov = np.zeros((p.shape[0], 3, 3))

@@ -49,6 +49,13 @@ def test_covariances_match_oracle(O, case):
         err = np.abs(cov - ref).max(axis=(1, 2))
         assert np.quantile(err, 0.99) < 1e-6
         assert err.max() < 1e-2
+        # BEFORE the regularisation there is nothing ill-conditioned: same neighbours, same FLOAT products summed in
+        # double in the same order -> the sample covariances agree to fp64 rounding (a few ulps of the k-term sums of
+        # squared coordinates ~1e4 m^2: 1e-11 absolute, 1e-10 allowed)
+        raw = g.covariances(which, raw=True)
+        raw_ref = O.gicp_raw_covariances(O.NearestNeighbour(pts, 1.0), pts)
+        assert np.abs(raw - raw_ref).max() < 1e-10
+        assert np.abs(raw - np.swapaxes(raw, 1, 2)).max() == 0.0     # symmetric by construction
 
 
 def test_plane_covariance_is_diag_in_plane_frame(O):
