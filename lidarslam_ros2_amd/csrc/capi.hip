@@ -840,13 +840,49 @@ int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, si
   std::stable_sort(cand.begin(), cand.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
   const int k_eval = std::min({std::max(params->top_k, 1), (int)cand.size(), edge_capacity});
 
+  // One worker registration object per candidate evaluated together.  top_k = 1 (the reference) uses `h` itself; with
+  // top_k > 1 and NDT the k windows are assembled into k auxiliary objects (own target, a device copy of the source, the
+  // caller's stream) and advanced in ONE shared launch chain (align_ndt_batch) instead of k chains one after another.
+  const bool batched = (k_eval > 1 && h->method == LSR_METHOD_NDT);
+  std::vector<lsr_handle> workers((size_t)k_eval, h);
+  if (batched) {
+    while ((int)h->aux.size() < k_eval) {
+      std::unique_ptr<lsr_handle_s> a(new (std::nothrow) lsr_handle_s());
+      if (!a) return LSR_ERR_HIP;
+      a->method = h->method; a->device = h->device; a->stream = h->stream; a->own_stream = false;
+      if (a->d_T16.reserve(16) != LSR_OK) return LSR_ERR_HIP;
+      h->aux.push_back(std::move(a));
+    }
+    for (int e = 0; e < k_eval; e++) {
+      lsr_handle a = h->aux[e].get();
+      a->ndt = h->ndt; a->gicp = h->gicp;
+      a->ndt_threads = h->ndt_threads; a->ndt_table_mode = h->ndt_table_mode; a->ndt_quad = h->ndt_quad;
+      a->scratch.wait_mode = h->scratch.wait_mode; a->scratch.force_sort_path = h->scratch.force_sort_path;
+      int st = a->source.resize(h->source.n);
+      if (st) return st;
+      if (h->source.n) {
+        LSR_HIP(hipMemcpyAsync(a->source.x(), h->source.x(), sizeof(float) * h->source.n, hipMemcpyDeviceToDevice, h->stream));
+        LSR_HIP(hipMemcpyAsync(a->source.y(), h->source.y(), sizeof(float) * h->source.n, hipMemcpyDeviceToDevice, h->stream));
+        LSR_HIP(hipMemcpyAsync(a->source.z(), h->source.z(), sizeof(float) * h->source.n, hipMemcpyDeviceToDevice, h->stream));
+      }
+      a->has_source = true;
+      a->source_cov_valid = false;
+      workers[e] = a;
+    }
+  }
+
   std::vector<const void*> frames;
   std::vector<size_t> counts;
   std::vector<float> poses;
+  std::vector<lsr_result> results((size_t)k_eval);
+  std::vector<int> n_target((size_t)k_eval, 0);
+  for (int e = 0; e < k_eval; e++) std::memset(&results[e], 0, sizeof(lsr_result));
+  // ---- targets: window assembly (:207-222), voxelgrid_.filter + setInputTarget (:224-227)
   for (int e = 0; e < k_eval; e++) {
+    lsr_handle w = workers[e];
     const int id_min = cand[e].second;
-    // target window (:207-222).  The reference only guards the lower end; an index past the last submap would
-    // read out of bounds there, so it is skipped here.
+    // The reference only guards the lower end of the window; an index past the last submap would read out of bounds
+    // there, so it is skipped here.
     frames.clear(); counts.clear(); poses.clear();
     for (int j = 0; j <= 2 * params->search_submap_num; j++) {
       const int idx = id_min + j - params->search_submap_num;
@@ -857,40 +893,61 @@ int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, si
       counts.push_back(submaps[idx].n_points);
       for (int k = 0; k < 16; k++) poses.push_back((float)M[k]);
     }
-    int st = assemble_frames(h, (int)frames.size(), frames.data(), counts.data(), stride_bytes, poses.data(), on_device != 0, h->raw);
+    int st = assemble_frames(w, (int)frames.size(), frames.data(), counts.data(), stride_bytes, poses.data(), on_device != 0, w->raw);
     if (st) return st;
-    // voxelgrid_.filter + setInputTarget (:224-227)
-    auto t = fresh_target(h);
-    if ((st = voxel_grid_filter(h->raw, params->voxel_leaf_size, t->cloud, h->scratch, h->stream))) return st;
+    auto t = fresh_target(w);
+    if ((st = voxel_grid_filter(w->raw, params->voxel_leaf_size, t->cloud, w->scratch, w->stream))) return st;
     t->n = t->cloud.n;
-    h->target = t;
-    st = (h->method == LSR_METHOD_NDT) ? ensure_ndt_grid(h) : ensure_target_hash(h);
-    if (st) { h->target.reset(); return st; }
-    // align(output) without guess (:230) and getFitnessScore() (:231)
-    lsr_loop_edge& E = edges[e];
-    std::memset(&E, 0, sizeof(E));
-    lsr_result res;
-    std::memset(&res, 0, sizeof(res));
-    if (h->method == LSR_METHOD_NDT) {
-      lsr_handle hs[1] = {h};
-      st = align_ndt_batch(hs, 1, nullptr, E.final_transformation, &res);
-    } else {
-      st = gicp_align(h, nullptr, E.final_transformation, &res);
+    w->target = t;
+    n_target[e] = (int)t->n;
+    st = (w->method == LSR_METHOD_NDT) ? ensure_ndt_grid(w) : ensure_target_hash(w);
+    if (st) { w->target.reset(); return st; }
+    if (!batched) {  // serial: align(output) without guess (:230) right away — the next candidate re-uses `h`'s target slot
+      lsr_loop_edge& E = edges[e];
+      std::memset(&E, 0, sizeof(E));
+      if (h->method == LSR_METHOD_NDT) {
+        lsr_handle hs[1] = {h};
+        st = align_ndt_batch(hs, 1, nullptr, E.final_transformation, &results[e]);
+      } else {
+        st = gicp_align(h, nullptr, E.final_transformation, &results[e]);
+      }
+      if (st) return st;
+      if ((st = ensure_target_hash(h))) return st;
+      double fitness = 0;   // getFitnessScore() (:231)
+      if ((st = nn_fitness_score(h->source, h->final_T, h->target->hash, 1.7976931348623157e308, &fitness, h->scratch, h->d_T16, h->stream)))
+        return st;
+      E.fitness_score = fitness;
     }
+  }
+  if (batched) {
+    std::vector<float> finals((size_t)k_eval * 16);
+    int st = align_ndt_batch(workers.data(), k_eval, nullptr, finals.data(), results.data());
     if (st) return st;
-    if ((st = ensure_target_hash(h))) return st;
-    double fitness = 0;
-    if ((st = nn_fitness_score(h->source, h->final_T, h->target->hash, 1.7976931348623157e308, &fitness, h->scratch, h->d_T16,
-                               h->stream)))
-      return st;
+    for (int e = 0; e < k_eval; e++) {
+      lsr_handle w = workers[e];
+      lsr_loop_edge& E = edges[e];
+      std::memset(&E, 0, sizeof(E));
+      std::memcpy(E.final_transformation, finals.data() + 16 * e, sizeof(float) * 16);
+      if ((st = ensure_target_hash(w))) return st;
+      double fitness = 0;
+      if ((st = nn_fitness_score(w->source, w->final_T, w->target->hash, 1.7976931348623157e308, &fitness, w->scratch, w->d_T16, w->stream)))
+        return st;
+      E.fitness_score = fitness;
+    }
+    // `h` reports the best candidate like a single registration would (getFinalTransformation / hasConverged)
+    std::memcpy(h->final_T, edges[0].final_transformation, sizeof(float) * 16);
+    h->converged = results[0].converged;
+  }
+  for (int e = 0; e < k_eval; e++) {
+    const int id_min = cand[e].second;
+    lsr_loop_edge& E = edges[e];
     E.id_from = id_min;
     E.id_to = num_submaps - 1;
-    E.converged = res.converged;
-    E.iterations = res.iterations;
-    E.n_target_points = (int)t->n;
+    E.converged = results[e].converged;
+    E.iterations = results[e].iterations;
+    E.n_target_points = n_target[e];
     E.candidate_distance = cand[e].first;
-    E.fitness_score = fitness;
-    E.accepted = fitness < params->threshold_loop_closure_score ? 1 : 0;
+    E.accepted = E.fitness_score < params->threshold_loop_closure_score ? 1 : 0;
     // relative pose of the loop edge (:236-245): from^-1 * (final * init)
     double fin[16], to[16], from[16], from_inv[16];
     for (int k = 0; k < 16; k++) fin[k] = (double)E.final_transformation[k];

@@ -53,6 +53,9 @@ struct lsr_handle_s {
 
   GicpWorkspace gicp_ws;
 
+  // worker objects of lsr_search_loop(top_k > 1): one per candidate registered in the same launch chain
+  std::vector<std::unique_ptr<lsr_handle_s>> aux;
+
   float final_T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   int converged = 0;
   lsr_profile prof = {0, 0, 0, 0};

@@ -19,8 +19,18 @@ def O():
 
 
 @pytest.fixture(scope="module")
-def cfg12():
-    return synth.cfg_ndt_30k()
+def pool():
+    """Worker processes for the ray casting of the full-size workloads (same clouds as the sequential generator)."""
+    import multiprocessing as mp
+    import os
+
+    with mp.get_context("spawn").Pool(min(32, len(os.sched_getaffinity(0)))) as p:   # spawn: this process may hold a GPU context
+        yield p
+
+
+@pytest.fixture(scope="module")
+def cfg12(pool):
+    return synth.cfg_ndt_30k(pool=pool)
 
 
 def make_ndt(res, eps, max_iter=None):
@@ -84,10 +94,10 @@ def test_cfg2_properties(cfg12):
     assert dt < 5e-3 and ang < 5e-4
 
 
-def test_cfg3_gicp_matches_oracle(O):
+def test_cfg3_gicp_matches_oracle(O, pool):
     from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
 
-    c = synth.cfg_gicp_30k()
+    c = synth.cfg_gicp_30k(pool=pool)
     g = GeneralizedIterativeClosestPoint(device=0)
     g.setMaxCorrespondenceDistance(5.0)
     g.setTransformationEpsilon(1e-8)
@@ -106,42 +116,55 @@ def test_cfg3_gicp_matches_oracle(O):
     assert gt_dt < 0.03 and gt_ang < 1e-3
 
 
-def test_cfg4_candidate_batch_sharded_single_rank(O):
-    """One GPU's share of cfg 4 (64 candidates / 8 GPUs = 8): per candidate setInputTarget +
-    setInputSource + align + getFitnessScore (graph_based_slam_component.cpp:181-231), run as one batch,
-    gathered through the sharding layer (world size 1 here)."""
+def test_cfg4_candidate_batch_sharded_single_rank(O, pool):
+    """One GPU's share of cfg 4 (64 candidates / 8 GPUs = 8): per candidate setInputTarget + setInputSource + align +
+    getFitnessScore (graph_based_slam_component.cpp:181-231), advanced as ONE batch through the C ABI's sharded entry point
+    (lsr_align_batch_sharded, one-rank communicator) and through the torch.distributed layer.  EVERY candidate is held to the
+    oracle: pose inside the north_star bar, same number of Newton iterations, same fitness score."""
     from lidarslam_ros2_amd import align_batch
-    from lidarslam_ros2_amd.sharding import pack_record, register_sharded
+    from lidarslam_ros2_amd.sharding import Comm, align_batch_sharded, pack_record, register_sharded
 
     n_cand = 8
-    cases = [synth.cfg_loop_candidate(c) for c in range(n_cand)]
+    cases = [synth.cfg_loop_candidate(c, pool=pool) for c in range(n_cand)]
 
-    def register_local(indices):
+    def make_regs(indices):
         regs = []
         for i in indices:
             r = make_ndt(5.0, 0.01, 100)               # backend: setMaximumIterations(100)
             r.setInputTarget(cases[i].target)
             r.setInputSource(cases[i].source)
             regs.append(r)
+        return regs
+
+    def register_local(indices):
+        regs = make_regs(indices)
         finals, results = align_batch(regs, [cases[i].guess for i in indices])
         return [pack_record(finals[k], results[k]["score"], results[k]["iterations"], results[k]["converged"],
                             regs[k].getFitnessScore()) for k in range(len(indices))]
 
     out = register_sharded(n_cand, register_local)
-    assert len(out) == n_cand
-    for i, r in enumerate(out):
+    comm = Comm(0, 1, 0)
+    out_c = align_batch_sharded(comm, make_regs(range(n_cand)), n_cand, [c.guess for c in cases], with_fitness=True)
+    comm.close()
+    assert len(out) == n_cand and len(out_c) == n_cand
+    threads = min(32, O.max_threads())
+    for i in range(n_cand):
+        r, rc = out[i], out_c[i]
+        assert np.array_equal(r["T"], rc["T"]) and r["iterations"] == rc["iterations"]       # both layers drive the same core
         dt, ang = pose_delta(r["T"], cases[i].truth)
         assert r["converged"] and dt < 0.08 and ang < 3e-3, (i, dt, ang)
         assert r["fitness"] < 0.2                      # a closed loop passes the reference's gate (score < 0.3 default region)
-    # one candidate against the oracle
-    ref = O.ndt_align(O.VoxelGridCovariance(cases[3].target, 5.0), cases[3].source, cases[3].guess, resolution=5.0,
-                      trans_eps=0.01, max_iterations=100, num_threads=min(32, O.max_threads()))
-    dt, ang = pose_delta(out[3]["T"], ref["final"])
-    assert dt <= 1e-3 and ang <= 1e-4
+        ref = O.ndt_align(O.VoxelGridCovariance(cases[i].target, 5.0), cases[i].source, cases[i].guess, resolution=5.0,
+                          trans_eps=0.01, max_iterations=100, num_threads=threads)
+        dt, ang = pose_delta(r["T"], ref["final"])
+        assert dt <= 1e-3 and ang <= 1e-4, (i, dt, ang)
+        assert r["iterations"] == ref["iterations"], i
+        fit = O.NearestNeighbour(cases[i].target, 1.0).fitness_score(cases[i].source, ref["final"], num_threads=threads)
+        assert abs(r["fitness"] - fit) <= 1e-4 * fit, i
 
 
-def test_cfg5_dense_scan_matches_oracle(O):
-    c = synth.cfg_dense_120k()
+def test_cfg5_dense_scan_matches_oracle(O, pool):
+    c = synth.cfg_dense_120k(pool=pool)
     assert c.source.shape == (120000, 3)
     ndt = make_ndt(2.0, 0.01)
     ndt.setInputTarget(c.target)
