@@ -142,7 +142,12 @@ struct BuildMailbox {
   int n_valid, n_occupied;    // leaves usable by lookups / leaves holding at least one point
   int lds_bytes, lds_map_bytes;
   unsigned int done_token;    // release-stored after the counts
-  unsigned int pad[2];
+  // small scalars other builders hand to the host the same way (NN grid: occupied coarse cells; fitness score: sum, count)
+  int value;
+  unsigned int value_token;
+  double fit_sum, fit_cnt;
+  unsigned int fit_token;
+  unsigned int pad[3];
 };
 
 // How a host thread waits on a mailbox word (lsr_set_i32(LSR_WAIT_MODE)): a ROS2 MultiThreadedExecutor runs two

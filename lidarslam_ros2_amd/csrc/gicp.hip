@@ -9,6 +9,7 @@
 // the inner solver here is GN with the reference's stopping rule (|grad| < 1e-2 or max_inner
 // iterations).  Same cost and correspondences => same minimiser; the oracle carries both solvers.
 #include <chrono>
+#include <thread>
 
 #include "handle.hpp"
 #include "nn_device.hpp"
@@ -41,10 +42,31 @@ struct GnState {
   int max_inner;
 };
 
-struct IterBlock {    // uploaded once per outer iteration
+// Outer loop of GeneralizedIterativeClosestPoint::computeTransformation, kept ON THE DEVICE: the update
+// launch that ends an inner loop also does the outer bookkeeping (transformation_ from x, the delta stop rule, the next
+// Mahalanobis rotation) and tells the following launches what to do through `phase`:
+//   even = the correspondence pass of outer iteration phase/2 has to run; odd = its inner Gauss-Newton loop is running.
+// Every launch of the chain (correspondence / accumulation / update, enqueued by the host in a fixed pattern) reads the
+// phase at its head and exits when it has nothing to do; only the single-workgroup update launch ever writes it.
+struct OuterState {
+  float trans[16], prev[16], G[16];   // transformation_, previous_transformation_, guess (column-major)
+  double rot_eps, trans_eps;
+  double last_cost;
+  int nr_iterations, max_iterations, converged, outer_done;
+  int phase;       // see above
+  int corr_mark;   // = the (even) phase whose correspondence pass has run (written by every workgroup of that pass)
+  int last_cnt, gn_steps;
+  unsigned int token;
+  int pad;
+};
+
+struct IterBlock {    // uploaded once per align
   GnState st;
-  float T16[16];      // transformation_ (column-major)
+  float T16[16];      // transformation_ (column-major) the correspondence pass moves the points by
   double Rm[9];       // rotation of transformation_ * guess, fp64
+  OuterState out;
+  int count;          // pairs found by the correspondence pass
+  int pad[3];
 };
 
 __host__ __device__ inline void gn_apply_state(GnState& S) {
@@ -214,20 +236,38 @@ __global__ __launch_bounds__(NN_THREADS) void gicp_corr_kernel(NNGridView G, con
                                                                const double* __restrict__ Rm, float thr2, const double* __restrict__ C1,
                                                                const double* __restrict__ C2, const float* __restrict__ tx,
                                                                const float* __restrict__ ty, const float* __restrict__ tz,
-                                                               PairRec* __restrict__ pairs, int* __restrict__ count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+                                                               PairRec* __restrict__ pairs, int* __restrict__ count,
+                                                               OuterState* __restrict__ O, int spread, int* __restrict__ last_nn) {
+  const int ph = O->phase;
+  if (O->outer_done || (ph & 1)) return;  // the inner loop of this outer iteration is still running (or all is over)
+  // `spread` (1, 2): only every spread-th lane carries a point.  A wave walks the union of its lanes' search paths, and a
+  // 30k-point scan is fewer waves than the chip has SIMDs: thinner waves finish sooner (as in gicp_cov_kernel).
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t / spread;
+  if (threadIdx.x == 0) O->corr_mark = ph;  // same value from every workgroup: tells the launches behind that the pairs are fresh
+  const bool mine = (i < n) && (t % spread) == 0;
+  PairRec r;
+  r.valid = 0;
+  r.q[0] = r.q[1] = r.q[2] = 0.f;
+  for (int k = 0; k < 6; k++) r.M[k] = 0.0;
+  if (mine) {
   const float a = ox[i], b = oy[i], c = oz[i];
   const float qx = xform_rn(T16[0], T16[4], T16[8], T16[12], a, b, c);
   const float qy = xform_rn(T16[1], T16[5], T16[9], T16[13], a, b, c);
   const float qz = xform_rn(T16[2], T16[6], T16[10], T16[14], a, b, c);
   Best1 best;
   best.init();
-  nn_query(G, qx, qy, qz, 1, thr2, best, -1);
-  PairRec r;
-  r.valid = 0;
-  r.q[0] = r.q[1] = r.q[2] = 0.f;
-  for (int k = 0; k < 6; k++) r.M[k] = 0.0;
+  // The previous outer iteration's neighbour is offered first: between two outer iterations the cloud moves by
+  // millimetres, so it is usually THE neighbour again and lets the search stop at the first shell whose bound it beats.
+  // Exact all the same: Best1 orders candidates by (distance, index), whatever the order they are seen in.
+  int fine_rings = 1;
+  const int seed = (ph > 0) ? last_nn[i] : -1;
+  if (seed >= 0) {
+    best.offer(dist2_rn(qx, qy, qz, tx[seed], ty[seed], tz[seed]), seed);   // the very arithmetic of the grid scan
+    fine_rings = 0;
+  }
+  nn_query(G, qx, qy, qz, fine_rings, thr2, best, -1);
+  last_nn[i] = best.idx;
   if (best.idx >= 0 && best.d2 < thr2) {
     const int j = best.idx;
     const double* c1 = C1 + (size_t)i * 9;
@@ -250,9 +290,12 @@ __global__ __launch_bounds__(NN_THREADS) void gicp_corr_kernel(NNGridView G, con
     r.M[5] = (S[0] * S[4] - S[1] * S[3]) * id;
     r.q[0] = tx[j]; r.q[1] = ty[j]; r.q[2] = tz[j];
     r.valid = 1;
-    atomicAdd(count, 1);
   }
   pairs[i] = r;
+  }
+  // one atomic per wave (ballot + popcount) instead of one per matched point
+  const unsigned long long found = __ballot(r.valid != 0);
+  if (found && (threadIdx.x & 63) == (__ffsll((long long)__ballot(1)) - 1)) atomicAdd(count, __popcll(found));
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -264,8 +307,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // K7: one Gauss-Newton accumulation pass at the state's x.
 __global__ __launch_bounds__(GN_THREADS) void gicp_gn_kernel(const float* __restrict__ ox, const float* __restrict__ oy,
                                                              const float* __restrict__ oz, int n, const PairRec* __restrict__ pairs,
-                                                             const GnState* __restrict__ S, double* __restrict__ partials) {
-  if (S->inner_done) return;
+                                                             const GnState* __restrict__ S, const OuterState* __restrict__ O,
+                                                             double* __restrict__ partials) {
+  {
+    const int ph = O->phase;
+    if (O->outer_done || (!(ph & 1) && O->corr_mark != ph)) return;  // nothing to accumulate until fresh pairs exist
+  }
   __shared__ double s_red[GN_THREADS / 64][GN_NRED];
   float T[12];
 #pragma unroll
@@ -372,11 +419,47 @@ __device__ void solve6_gn(const double* H, const double* b, double* x) {
   }
 }
 
-__global__ __launch_bounds__(256) void gicp_update_kernel(GnState* __restrict__ S, const double* __restrict__ partials, int nblocks,
-                                                          const int* __restrict__ count, GicpMailbox* mb, unsigned int token,
-                                                          int launch_index) {
+// column-major fp32 product (previous_transformation_ * guess)
+__host__ __device__ inline void mat4_mul_cm(const float* A, const float* B, float* C) {
+  float T[16];
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) {
+      float s = 0;
+      for (int k = 0; k < 4; k++) s += A[k * 4 + r] * B[c * 4 + k];
+      T[c * 4 + r] = s;
+    }
+  for (int k = 0; k < 16; k++) C[k] = T[k];
+}
+
+// Prepare outer iteration k: Mahalanobis rotation of (transformation_ * guess), the optimiser's start x from
+// transformation_, previous_transformation_ = transformation_ — what the top of the reference's while loop does.
+__host__ __device__ inline void gicp_begin_outer(IterBlock& B) {
+  OuterState& O = B.out;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double v = 0;
+      for (int k = 0; k < 4; k++) v += (double)O.trans[k * 4 + i] * (double)O.G[j * 4 + k];
+      B.Rm[i * 3 + j] = v;
+    }
+  GnState& S = B.st;
+  const int max_inner = S.max_inner;
+  S.x[0] = O.trans[12]; S.x[1] = O.trans[13]; S.x[2] = O.trans[14];
+  S.x[3] = atan2((double)O.trans[6], (double)O.trans[10]);
+  S.x[4] = asin(-(double)O.trans[2]);
+  S.x[5] = atan2((double)O.trans[1], (double)O.trans[0]);
+  S.f = 0; S.gnorm = 0; S.m = 0; S.inner_iter = 0; S.inner_done = 0; S.max_inner = max_inner;
+  gn_apply_state(S);
+  for (int k = 0; k < 16; k++) { B.T16[k] = O.trans[k]; O.prev[k] = O.trans[k]; }
+  B.count = 0;
+}
+
+__global__ __launch_bounds__(256) void gicp_update_kernel(IterBlock* __restrict__ B, const double* __restrict__ partials, int nblocks,
+                                                          GicpMailbox* mb, unsigned int token, int launch_index) {
+  GnState* S = &B->st;
+  OuterState* O = &B->out;
   const unsigned long long progress = ((unsigned long long)token << 32) | (unsigned int)launch_index;
-  if (S->inner_done) {
+  const int ph = O->phase;
+  if (O->outer_done || (!(ph & 1) && O->corr_mark != ph)) {  // all over, or no fresh pairs yet: nothing to consume
     if (threadIdx.x == 0) __hip_atomic_store(&mb->progress, progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
@@ -399,9 +482,10 @@ __global__ __launch_bounds__(256) void gicp_update_kernel(GnState* __restrict__ 
   __syncthreads();
   if (t != 0) return;
   bool finished = false;
-  if (S->inner_iter == 0 && S->m == 0) {  // first step of this outer iteration: adopt K6's pair count
-    S->m = *count;
-    if (S->m < 4) finished = true;  // the reference's NotEnoughPointsException: leave x alone, the host ends the outer loop
+  if (!(ph & 1)) {  // first step of this outer iteration: the correspondence pass has just run, adopt its pair count
+    O->phase = ph + 1;
+    S->m = B->count;
+    if (S->m < 4) finished = true;  // the reference's NotEnoughPointsException: leave x alone, the outer loop ends
   }
   if (!finished) {
     const double m = (double)S->m;
@@ -430,28 +514,55 @@ __global__ __launch_bounds__(256) void gicp_update_kernel(GnState* __restrict__ 
     }
   }
   if (finished) {
-    S->inner_done = 1;
-    // the inner loop of this outer iteration has ended: publish what the host's outer bookkeeping needs, flag last
-    for (int k = 0; k < 6; k++) mb->x[k] = S->x[k];
-    mb->f = S->f;
-    mb->gnorm = S->gnorm;
-    mb->m = S->m;
-    mb->inner_iter = S->inner_iter;
-    __threadfence_system();
-    __hip_atomic_store(&mb->done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- the inner loop of this outer iteration has ended: the reference's outer bookkeeping
+    bool stop = false;
+    O->last_cnt = S->m;
+    if (S->m < 4) {
+      stop = true;  // NotEnoughPointsException is caught, the loop is left unconverged
+    } else {
+      O->gn_steps += S->inner_iter;
+      O->last_cost = S->f;
+      if (!(S->gnorm == S->gnorm)) {
+        stop = true;  // NaN: the reference's solver exception path
+      } else {
+        GnState tmp = *S;  // transformation_ = applyState(identity, x)
+        gn_apply_state(tmp);
+        float* tr = O->trans;
+        tr[0] = tmp.T[0]; tr[4] = tmp.T[1]; tr[8] = tmp.T[2];  tr[12] = tmp.T[3];
+        tr[1] = tmp.T[4]; tr[5] = tmp.T[5]; tr[9] = tmp.T[6];  tr[13] = tmp.T[7];
+        tr[2] = tmp.T[8]; tr[6] = tmp.T[9]; tr[10] = tmp.T[10]; tr[14] = tmp.T[11];
+        tr[3] = tr[7] = tr[11] = 0.f; tr[15] = 1.f;
+        double delta = 0;
+        for (int k = 0; k < 4; k++)
+          for (int l = 0; l < 4; l++) {
+            const double ratio = (k < 3 && l < 3) ? 1. / O->rot_eps : 1. / O->trans_eps;
+            const double c_delta = ratio * fabs((double)O->prev[l * 4 + k] - (double)tr[l * 4 + k]);
+            if (c_delta > delta) delta = c_delta;
+          }
+        O->nr_iterations++;
+        if (O->nr_iterations >= O->max_iterations || delta < 1) {
+          O->converged = 1;
+          for (int k = 0; k < 16; k++) O->prev[k] = tr[k];
+          stop = true;
+        }
+      }
+    }
+    if (stop) {
+      O->outer_done = 1;
+      mat4_mul_cm(O->prev, O->G, mb->final_T);  // final_transformation_ = previous_transformation_ * guess
+      mb->converged = O->converged;
+      mb->nr_iterations = O->nr_iterations;
+      mb->last_cnt = O->last_cnt;
+      mb->gn_steps = O->gn_steps;
+      mb->last_cost = O->last_cost;
+      __threadfence_system();
+      __hip_atomic_store(&mb->done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      gicp_begin_outer(*B);
+      O->phase = (O->phase | 1) + 1;  // next even phase: the correspondence pass of the next outer iteration
+    }
   }
   __hip_atomic_store(&mb->progress, progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-void mat4_mul_f(const float* A, const float* B, float* C) {  // column-major fp32 product
-  float T[16];
-  for (int c = 0; c < 4; c++)
-    for (int r = 0; r < 4; r++) {
-      float s = 0;
-      for (int k = 0; k < 4; k++) s += A[k * 4 + r] * B[c * 4 + k];
-      T[c * 4 + r] = s;
-    }
-  std::memcpy(C, T, sizeof(T));
 }
 
 int compute_covariances(lsr_handle_s* h, const DeviceCloud& cloud, const HashGridDev& grid, DevBuf<double>& cov, bool raw = false) {
@@ -554,7 +665,7 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   const float* G = guess ? guess : I16;
 
-  // workspace: out cloud | pairs | partials | state | count | T16 + G16 | Rm
+  // workspace: out cloud | pairs | partials | per-align block {inner state, T16, Rm, outer state, count} | guess
   const int nblocks = std::max(1, std::min((n + GN_THREADS - 1) / GN_THREADS, 512));
   GicpWorkspace& ws = h->gicp_ws;
   if ((st = ws.out.resize(n))) return st;
@@ -564,8 +675,6 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   if ((st = ws.pin.reserve(sizeof(IterBlock) + 64))) return st;
   double* d_partials = ws.buf.p;
   IterBlock* d_blk = reinterpret_cast<IterBlock*>(ws.state.p);
-  int* d_count = reinterpret_cast<int*>(ws.state.p + sizeof(IterBlock) + 16);
-  float* d_G16 = reinterpret_cast<float*>(ws.state.p + sizeof(IterBlock) + 64);
   PairRec* d_pairs = reinterpret_cast<PairRec*>(ws.pairs.p);
 
   if (!ws.d_mailbox) {
@@ -574,135 +683,91 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
     LSR_HIP(hipHostGetDevicePointer((void**)&ws.d_mailbox, ws.mailbox.p, 0));
   }
   const GicpMailbox* mb = ws.mailbox.p;
+  unsigned int token = ++ws.token;
+  if (token == 0) token = ++ws.token;  // 0 is the mailbox's idle value
   const auto t_begin = std::chrono::steady_clock::now();
-  LSR_HIP(hipMemcpyAsync(d_G16, G, 16 * sizeof(float), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(gicp_apply_guess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->source.x(), h->source.y(), h->source.z(),
-                     n, d_G16, ws.out.x(), ws.out.y(), ws.out.z());
 
-  float trans[16], prev[16];
-  std::memcpy(trans, I16, sizeof(I16));
-  std::memcpy(prev, I16, sizeof(I16));
+  // ---- the whole align as ONE upload: outer state at the entry of computeTransformation + the first outer iteration
+  IterBlock* hb = reinterpret_cast<IterBlock*>(ws.pin.p);
+  std::memset(hb, 0, sizeof(IterBlock));
+  OuterState& O = hb->out;
+  std::memcpy(O.trans, I16, sizeof(I16));
+  std::memcpy(O.prev, I16, sizeof(I16));
+  std::memcpy(O.G, G, sizeof(I16));
+  O.rot_eps = h->gicp.rot_eps;
+  O.trans_eps = h->gicp.trans_eps;
+  O.max_iterations = h->gicp.max_iterations;
+  O.corr_mark = -1;
+  O.token = token;
+  hb->st.max_inner = h->gicp.max_inner;
+  gicp_begin_outer(*hb);
+  LSR_HIP(hipMemcpyAsync(d_blk, hb, sizeof(IterBlock), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gicp_apply_guess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->source.x(), h->source.y(), h->source.z(),
+                     n, d_blk->out.G, ws.out.x(), ws.out.y(), ws.out.z());
   const float thr2 = (float)(h->gicp.max_corr_dist * h->gicp.max_corr_dist);
-  int nr_iterations = 0, last_cnt = 0, gn_steps = 0, prev_inner = 4;
-  bool converged = false;
-  double last_cost = 0;
-  GnState hs;
-  while (!converged) {
-    double Rm[9];
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) {
-        double v = 0;
-        for (int k = 0; k < 4; k++) v += (double)trans[k * 4 + i] * (double)G[j * 4 + k];
-        Rm[i * 3 + j] = v;
-      }
-    std::memset(&hs, 0, sizeof(hs));
-    hs.x[0] = trans[12]; hs.x[1] = trans[13]; hs.x[2] = trans[14];
-    hs.x[3] = atan2((double)trans[6], (double)trans[10]);
-    hs.x[4] = asin(-(double)trans[2]);
-    hs.x[5] = atan2((double)trans[1], (double)trans[0]);
-    hs.max_inner = h->gicp.max_inner;
-    gn_apply_state(hs);
-    // one pinned block per outer iteration: {GnState | T16 | Rm}, one H2D copy, one sync at the end
-    IterBlock* hb = reinterpret_cast<IterBlock*>(h->gicp_ws.pin.p);
-    hb->st = hs;
-    std::memcpy(hb->T16, trans, sizeof(hb->T16));
-    std::memcpy(hb->Rm, Rm, sizeof(hb->Rm));
-    LSR_HIP(hipMemcpyAsync(d_blk, hb, sizeof(IterBlock), hipMemcpyHostToDevice, s));
-    LSR_HIP(hipMemsetAsync(d_count, 0, sizeof(int), s));
-    hipLaunchKernelGGL(gicp_corr_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS), dim3(NN_THREADS), 0, s, make_view(t.hash),
-                       ws.out.x(), ws.out.y(), ws.out.z(), n, d_blk->T16, d_blk->Rm, thr2, h->source_cov.p, t.cov.p, t.cloud.x(),
-                       t.cloud.y(), t.cloud.z(), d_pairs, d_count);
-    std::memcpy(prev, trans, sizeof(prev));
-    // Inner Gauss-Newton chain, fed by polling the host mailbox (GicpMailbox): gicp_update_kernel reports every step that
-    // has run and publishes {x, f, |g|, m, steps} when the inner loop ends — no copy back, no stream synchronisation.
-    // The first outer iteration typically needs several steps, later ones one or two: enqueue one more than the previous
-    // outer iteration used and top up only if the device runs dry (steps past convergence exit at their head).
-    unsigned int token = ++ws.token;
-    if (token == 0) token = ++ws.token;  // 0 is the mailbox's idle value
-    const int cap = h->gicp.max_inner + 1;
-    int launched = 0;
-    auto enqueue_steps = [&](int c) {
-      for (int it = 0; it < c; it++) {
-        hipLaunchKernelGGL(gicp_gn_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, ws.out.x(), ws.out.y(), ws.out.z(), n, d_pairs,
-                           &d_blk->st, d_partials);
-        hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(256), 0, s, &d_blk->st, d_partials, nblocks, d_count, ws.d_mailbox,
-                           token, launched + it + 1);
-      }
-      launched += c;
-    };
-    enqueue_steps(std::max(1, std::min((nr_iterations == 0) ? 4 : std::max(2, std::min(4, prev_inner + 1)), cap)));
-    LSR_HIP(hipGetLastError());
-    {
-      unsigned long long last_progress = 0;
-      auto t_progress = std::chrono::steady_clock::now();
-      for (unsigned long long spins = 1;; spins++) {
-        if (__atomic_load_n(&mb->done, __ATOMIC_ACQUIRE) == token) break;
-        const unsigned long long pr = __atomic_load_n(&mb->progress, __ATOMIC_RELAXED);
-        const int ran = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : 0;
-        if (ran >= launched) {  // everything enqueued has run and the loop is not over
-          if (launched >= cap) {  // cannot happen: the step with inner_iter == max_inner ends the loop
-            set_last_error("GICP inner loop did not finish within max_inner_iterations + 1 steps");
-            return LSR_ERR_HIP;
-          }
-          enqueue_steps(std::min(2, cap - launched));
-          LSR_HIP(hipGetLastError());
-          continue;
-        }
-        if ((spins & 0x3FFF) == 0) {  // a device that stops making progress must not hang the caller forever
-          const auto now = std::chrono::steady_clock::now();
-          if (pr != last_progress) { last_progress = pr; t_progress = now; }
-          if (std::chrono::duration<double>(now - t_progress).count() > 30.0) {
-            set_last_error(std::string("GICP launch chain made no progress for 30 s (stream: ") + hipGetErrorString(hipStreamQuery(s)) + ")");
-            return LSR_ERR_HIP;
-          }
-        }
-        __builtin_ia32_pause();
-      }
+
+  // ---- launch chain.  A group = one correspondence pass + `steps` x (accumulate, update); every launch gates itself on
+  // the device-side phase, so a group enqueued too early (the previous inner loop still running) or too late (the align
+  // over) costs ~2 us per launch and nothing else.  The host keeps groups queued ahead and polls the mailbox.
+  const int spread = (n <= 65536) ? 2 : 1;
+  if ((st = ws.last_nn.reserve((size_t)n + 1))) return st;
+  int updates = 0;
+  auto enqueue_group = [&](int steps) {
+    hipLaunchKernelGGL(gicp_corr_kernel, dim3((unsigned)(((long)n * spread + NN_THREADS - 1) / NN_THREADS)), dim3(NN_THREADS), 0, s,
+                       make_view(t.hash), ws.out.x(), ws.out.y(), ws.out.z(), n, d_blk->T16, d_blk->Rm, thr2, h->source_cov.p, t.cov.p,
+                       t.cloud.x(), t.cloud.y(), t.cloud.z(), d_pairs, &d_blk->count, &d_blk->out, spread, ws.last_nn.p);
+    for (int it = 0; it < steps; it++) {
+      hipLaunchKernelGGL(gicp_gn_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, ws.out.x(), ws.out.y(), ws.out.z(), n, d_pairs,
+                         &d_blk->st, &d_blk->out, d_partials);
+      updates++;
+      hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(256), 0, s, d_blk, d_partials, nblocks, ws.d_mailbox, token, updates);
     }
-    hs.m = mb->m;
-    hs.inner_iter = mb->inner_iter;
-    hs.f = mb->f;
-    hs.gnorm = mb->gnorm;
-    for (int k = 0; k < 6; k++) hs.x[k] = mb->x[k];
-    last_cnt = hs.m;
-    if (hs.m < 4) break;  // reference: NotEnoughPointsException is caught, loop left unconverged
-    gn_steps += hs.inner_iter;
-    prev_inner = hs.inner_iter + 1;  // evaluations = steps + the converged one
-    last_cost = hs.f;
-    if (!(hs.gnorm == hs.gnorm)) break;  // NaN: the reference's solver exception path
-    // transformation_ = applyState(identity, x)
-    {
-      GnState tmp = hs;
-      gn_apply_state(tmp);
-      trans[0] = tmp.T[0]; trans[4] = tmp.T[1]; trans[8] = tmp.T[2];  trans[12] = tmp.T[3];
-      trans[1] = tmp.T[4]; trans[5] = tmp.T[5]; trans[9] = tmp.T[6];  trans[13] = tmp.T[7];
-      trans[2] = tmp.T[8]; trans[6] = tmp.T[9]; trans[10] = tmp.T[10]; trans[14] = tmp.T[11];
-      trans[3] = trans[7] = trans[11] = 0.f; trans[15] = 1.f;
-    }
-    double delta = 0;
-    for (int k = 0; k < 4; k++)
-      for (int l = 0; l < 4; l++) {
-        const double ratio = (k < 3 && l < 3) ? 1. / h->gicp.rot_eps : 1. / h->gicp.trans_eps;
-        const double c_delta = ratio * std::fabs((double)prev[l * 4 + k] - (double)trans[l * 4 + k]);
-        if (c_delta > delta) delta = c_delta;
+  };
+  // the first outer iteration typically needs 3-4 Gauss-Newton steps, later ones one or two (+ the evaluation that ends them)
+  enqueue_group(4);
+  enqueue_group(3);
+  enqueue_group(3);
+  LSR_HIP(hipGetLastError());
+  const int wait_mode = h->scratch.wait_mode;
+  const long hard_cap = (long)(h->gicp.max_iterations + 2) * (h->gicp.max_inner + 2) + 16;  // update launches an align can need
+  {
+    unsigned long long last_progress = 0;
+    auto t_progress = std::chrono::steady_clock::now();
+    for (unsigned long long spins = 1;; spins++) {
+      if (__atomic_load_n(&mb->done, __ATOMIC_ACQUIRE) == token) break;
+      const unsigned long long pr = __atomic_load_n(&mb->progress, __ATOMIC_RELAXED);
+      const int ran = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : 0;
+      if (updates - ran < 5) {  // fewer than two groups left in the queue: top up
+        if (updates > hard_cap) { set_last_error("GICP launch chain did not finish within its launch cap"); return LSR_ERR_HIP; }
+        enqueue_group(3);
+        enqueue_group(3);
+        LSR_HIP(hipGetLastError());
+        continue;
       }
-    nr_iterations++;
-    if (nr_iterations >= h->gicp.max_iterations || delta < 1) {
-      converged = true;
-      std::memcpy(prev, trans, sizeof(prev));
+      if ((spins & 0x3FFF) == 0 || wait_mode == WAIT_SLEEP) {  // a device that stops making progress must not hang the caller forever
+        const auto now = std::chrono::steady_clock::now();
+        if (pr != last_progress) { last_progress = pr; t_progress = now; }
+        if (std::chrono::duration<double>(now - t_progress).count() > 30.0) {
+          set_last_error(std::string("GICP launch chain made no progress for 30 s (stream: ") + hipGetErrorString(hipStreamQuery(s)) + ")");
+          return LSR_ERR_HIP;
+        }
+      }
+      if (wait_mode == WAIT_YIELD) std::this_thread::yield();
+      else if (wait_mode == WAIT_SLEEP) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      else __builtin_ia32_pause();
     }
   }
-  // host clock from the first enqueue to the last raised flag (the steps still queued exit at their head)
+  // host clock from the first enqueue to the raised flag (the launches still queued exit at their head)
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-  mat4_mul_f(prev, G, h->final_T);  // final_transformation_ = previous_transformation_ * guess
-  h->converged = converged ? 1 : 0;
+  std::memcpy(h->final_T, mb->final_T, sizeof(float) * 16);
+  h->converged = mb->converged;
   if (final_T) std::memcpy(final_T, h->final_T, sizeof(float) * 16);
   if (res) {
     res->converged = h->converged;
-    res->iterations = nr_iterations;
-    res->score = last_cost;
-    res->n_evaluations = gn_steps;
-    res->n_correspondences = last_cnt;
+    res->iterations = mb->nr_iterations;
+    res->score = mb->last_cost;
+    res->n_evaluations = mb->gn_steps;
+    res->n_correspondences = mb->last_cnt;
     res->gpu_ms = ms;
   }
   return LSR_OK;

@@ -17,14 +17,15 @@ struct GicpParamsHost {
   int k = 20;
 };
 
-// Host mailbox of the inner Gauss-Newton loop (pinned, host-coherent, mapped into the device): gicp_update_kernel reports
-// how many of the enqueued steps have run and, when the inner loop of an outer iteration ends, the state the host needs
-// for the outer bookkeeping — no device-to-host copy, no stream synchronisation per outer iteration.
+// Host mailbox of a GICP align (pinned, host-coherent, mapped into the device): the launch chain reports how many of
+// the enqueued update launches have run and, when the OUTER loop ends, the result — no device-to-host copy, no stream
+// synchronisation and no host bookkeeping per outer iteration (the host only keeps launches queued).
 struct GicpMailbox {
-  unsigned long long progress;   // (token << 32) | update launches of this outer iteration that have run
-  unsigned int done;             // = token once the inner loop has ended; written last (release, system scope)
-  int m, inner_iter, pad;
-  double x[6], f, gnorm;
+  unsigned long long progress;   // (token << 32) | update launches of this align that have run
+  unsigned int done;             // = token once the align has ended; written last (release, system scope)
+  int converged, nr_iterations, last_cnt, gn_steps, pad;
+  double last_cost;
+  float final_T[16];             // column-major: previous_transformation_ * guess
 };
 
 struct GicpWorkspace {
@@ -35,9 +36,10 @@ struct GicpWorkspace {
   PinBuf<unsigned char> pin;     // pinned host mirror of the per-iteration block
   DevBuf<int> work;              // K5: count + indices of the points deferred to the wave-cooperative search
   DevBuf<double> raw_cov;        // inspection only: sample covariances before regularisation
+  DevBuf<int> last_nn;           // K6: each source point's neighbour in the previous outer iteration (search seed)
   PinBuf<GicpMailbox> mailbox;
   GicpMailbox* d_mailbox = nullptr;
-  unsigned int token = 0;        // one per outer iteration
+  unsigned int token = 0;        // one per align
 };
 
 int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res);

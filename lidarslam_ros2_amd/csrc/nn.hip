@@ -140,6 +140,29 @@ __global__ __launch_bounds__(256) void fitness_partial_kernel(const int* __restr
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = s_sum[0]; part[2 * blockIdx.x + 1] = s_cnt[0]; }
 }
 
+// second stage (one workgroup, fixed order): {sum, count} of the 256 partials straight into the host mailbox
+__global__ __launch_bounds__(256) void fitness_final_kernel(const double* __restrict__ part, BuildMailbox* __restrict__ mb, unsigned int token) {
+  __shared__ double s_sum[256], s_cnt[256];
+  s_sum[threadIdx.x] = part[2 * threadIdx.x];
+  s_cnt[threadIdx.x] = part[2 * threadIdx.x + 1];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sum = 0, cnt = 0;
+    for (int b = 0; b < 256; b++) { sum += s_sum[b]; cnt += s_cnt[b]; }   // the order the host used to add them in
+    mb->fit_sum = sum;
+    mb->fit_cnt = cnt;
+    __threadfence_system();
+    __hip_atomic_store(&mb->fit_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// one device int into the host mailbox (instead of a device-to-host copy + stream synchronisation)
+__global__ void publish_value_kernel(const int* __restrict__ src, BuildMailbox* __restrict__ mb, unsigned int token) {
+  mb->value = *src;
+  __threadfence_system();
+  __hip_atomic_store(&mb->value_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 
 // ---- N2: submap assembly — pcl::transformPointCloud per keyframe + concatenation, on the device ----------
@@ -221,9 +244,13 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
                      grid.packed.p);
   hipLaunchKernelGGL(nn_coarse_key_kernel, dim3(nb), dim3(256), 0, stream, key_out, n, sentinel, ckey);
   if ((st = run_length_encode_u32(ckey, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
-  int n_runs = 0;
-  LSR_HIP(hipMemcpyAsync(&n_runs, d_nruns, sizeof(int), hipMemcpyDeviceToHost, stream));
-  LSR_HIP(hipStreamSynchronize(stream));
+  // the number of occupied coarse cells reaches the host through the mailbox (one polled word)
+  if ((st = sc.ensure_mailbox())) return st;
+  unsigned int token = ++sc.token;
+  if (token == 0) token = ++sc.token;
+  hipLaunchKernelGGL(publish_value_kernel, dim3(1), dim3(1), 0, stream, d_nruns, sc.d_mb, token);
+  if ((st = wait_mailbox_word(&sc.mb.p->value_token, token, stream, sc.wait_mode, "NN grid build"))) return st;
+  const int n_runs = sc.mb.p->value;
   if ((st = exclusive_scan_i32(run_cnt, run_off, n_runs, sc.temp, stream))) return st;
   if ((st = grid.block_off.reserve((size_t)n_runs + 1))) return st;
   if ((st = grid.fine_start.reserve((size_t)n_runs * FINE_STRIDE))) return st;
@@ -294,11 +321,13 @@ int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const Has
   if ((st = nn_search_device(source, d_T16.p, grid, 1, max_d2, d_idx, d_d2, stream))) return st;
   const int nb = 256;
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(nb), dim3(256), 0, stream, d_idx, d_d2, (int)source.n, max_range, d_part);
-  double part[2 * 256];
-  LSR_HIP(hipMemcpyAsync(part, d_part, sizeof(part), hipMemcpyDeviceToHost, stream));
-  LSR_HIP(hipStreamSynchronize(stream));
-  double sum = 0, cnt = 0;
-  for (int b = 0; b < nb; b++) { sum += part[2 * b]; cnt += part[2 * b + 1]; }
+  if ((st = sc.ensure_mailbox())) return st;
+  unsigned int token = ++sc.token;
+  if (token == 0) token = ++sc.token;
+  hipLaunchKernelGGL(fitness_final_kernel, dim3(1), dim3(256), 0, stream, d_part, sc.d_mb, token);
+  LSR_HIP(hipGetLastError());
+  if ((st = wait_mailbox_word(&sc.mb.p->fit_token, token, stream, sc.wait_mode, "fitness score"))) return st;
+  const double sum = sc.mb.p->fit_sum, cnt = sc.mb.p->fit_cnt;
   *out = (cnt > 0) ? sum / cnt : 1.7976931348623157e308;  // std::numeric_limits<double>::max()
   return LSR_OK;
 }
