@@ -151,9 +151,32 @@ int lsr_set_input_source_filtered(lsr_handle h, const void* pts, size_t stride_b
 /* The frontend's whole per-scan preprocessing on the device: min-max range filter
  * (`scan_min_range < sqrt(x^2+y^2) < scan_max_range`, scanmatcher_component.cpp:210-218) -> VoxelGrid
  * (vg_size_for_input, :324-328) -> setInputSource (:329).  A sensor_msgs/PointCloud2 payload with x@0,y@4,z@8
- * (point_step = stride_bytes, e.g. 32 for the PointXYZI layout pcl::toROSMsg writes) can be passed as is. */
+ * (point_step = stride_bytes, e.g. 32 for the PointXYZI layout pcl::toROSMsg writes) can be passed as is; other field
+ * offsets and the intensity field: lsr_set_input_source_pc2. */
 int lsr_set_input_source_frontend(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, double scan_min_range,
                                   double scan_max_range, float vg_size_for_input, int on_device, size_t* n_out);
+/* ---- sensor_msgs/PointCloud2 codec ---------------------------------------------
+ * A PointCloud2 `data` buffer is `width*height` records of `point_step` bytes with FLOAT32 fields at the byte offsets its
+ * `fields` array names; pcl::fromROSMsg (scanmatcher_component.cpp:201-202) reads them wherever they are and
+ * pcl::toROSMsg (:279,284; lidarslam_msgs/msg/SubMap.msg:4) writes pcl::PointXYZI's layout {x@0, y@4, z@8, intensity@16,
+ * point_step 32}.  The binding passes the message's own offsets; offset_intensity < 0 = the message has none. */
+typedef struct lsr_pc2_layout {
+  uint32_t point_step;
+  uint32_t offset_x, offset_y, offset_z;
+  int32_t offset_intensity;
+} lsr_pc2_layout;
+/* fromROSMsg -> min-max range filter (:210-218) -> VoxelGrid(vg_size_for_input) (:324-328) -> setInputSource (:329) from the
+ * raw message payload, on the device.  Intensity is carried the way pcl::VoxelGrid does with its default
+ * downsample_all_data: the leaf mean (float accumulation, points in ascending index). */
+int lsr_set_input_source_pc2(lsr_handle h, const void* data, size_t n_points, const lsr_pc2_layout* layout, double scan_min_range,
+                             double scan_max_range, float vg_size_for_input, int on_device, size_t* n_out);
+/* toROSMsg of the handle's current input source (e.g. the filtered scan, to publish it or to store it in a SubMap):
+ * n records of layout->point_step bytes, x / y / z / intensity at the layout's offsets, every other byte zero. */
+int lsr_get_source_pc2(lsr_handle h, void* out_data, size_t capacity_points, const lsr_pc2_layout* layout, size_t* n_out);
+/* pcl::VoxelGrid::filter, message payload in, message payload out (map side: :266-269, 443-447;
+ * graph_based_slam_component.cpp:224-226), intensity averaged per leaf like the coordinates. */
+int lsr_voxel_grid_filter_pc2(lsr_handle h, const void* data, size_t n_points, const lsr_pc2_layout* in_layout, float leaf, void* out_data,
+                              size_t capacity_points, const lsr_pc2_layout* out_layout, size_t* n_out);
 /* The same filter as a stand-alone operation, host in / host out (map side: scanmatcher_component.cpp:266-269,
  * 443-447; graph_based_slam_component.cpp:224-226).  Writes xyz at offset 0 of each out_stride_bytes record. */
 int lsr_voxel_grid_filter(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, float leaf, void* out_pts,
@@ -164,10 +187,11 @@ int lsr_share_target(lsr_handle h, lsr_handle owner);
 
 /* registration_->align(output, guess)    scanmatcher_component.cpp:353; graph_based_slam_component.cpp:230
  * guess: col-major 4x4 or NULL (= identity, the backend's align(output)).  final_transformation: out, 16 floats.
- * output_pts (nullable): host buffer of n_source records of out_stride_bytes; xyz of the source
- * transformed by the final transformation are written at offset 0 of every record, the remaining bytes of
- * each record are zeroed (PCL keeps the source's other fields there; both reference callers discard
- * `output`, scanmatcher_component.cpp:350-353, graph_based_slam_component.cpp:229-230 — pass NULL to skip it). */
+ * output_pts (nullable): host buffer of n_source records of out_stride_bytes.  PCL's align() copies the source into
+ * `output` and then overwrites x, y, z with the transformed coordinates: here ONLY the 12 xyz bytes at offset 0 of every
+ * record are written, the rest of each record is left exactly as the caller passed it (pre-fill it with the source
+ * records to get PCL's result, other fields included).  Both reference callers discard `output`
+ * (scanmatcher_component.cpp:350-353, graph_based_slam_component.cpp:229-230) — pass NULL to skip it. */
 int lsr_align(lsr_handle h, const float* guess, float* final_transformation, lsr_result* result,
               void* output_pts, size_t out_stride_bytes);
 /* B independent registrations advanced together in shared launches (loop-closure candidate set /

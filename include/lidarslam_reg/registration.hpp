@@ -103,23 +103,13 @@ class Registration {
   }
   void alignImpl(CloudSource& output, const float* guess) {
     const size_t n = input_ ? input_->points.size() : 0;
-    output.points.resize(n);
-    // PCL copies the source into `output` and then overwrites xyz with the transformed coordinates, every other
-    // field (intensity, ...) stays: the core returns packed xyz, scattered into the records here.
-    xyz_.resize(3 * n);
-    int st = lsr_align(h_, guess, final_.m, &last_, n ? (void*)xyz_.data() : nullptr, 3 * sizeof(float));
+    // PCL copies the source into `output` and then overwrites xyz with the transformed coordinates, every other field
+    // (intensity, ...) stays: the C ABI writes exactly the xyz bytes of every record, so the copy below is all it takes.
+    if (n) output.points.assign(input_->points.begin(), input_->points.end()); else output.points.clear();
+    int st = lsr_align(h_, guess, final_.m, &last_, n ? (void*)output.points.data() : nullptr, sizeof(output.points[0]));
     if (st != LSR_OK) {
       check(st, "align");
       last_.converged = 0;
-    }
-    for (size_t i = 0; i < n; i++) {
-      output.points[i] = input_->points[i];
-      if (st == LSR_OK) {
-        float* rec = reinterpret_cast<float*>(&output.points[i]);  // x,y,z are the first three floats of the record
-        rec[0] = xyz_[3 * i];
-        rec[1] = xyz_[3 * i + 1];
-        rec[2] = xyz_[3 * i + 2];
-      }
     }
   }
   lsr_handle h_ = nullptr;
@@ -127,7 +117,6 @@ class Registration {
   PointCloudTargetConstPtr target_;
   Matrix4f final_;
   lsr_result last_;
-  std::vector<float> xyz_;  // packed transformed source of the last align()
 };
 
 // pclomp::NormalDistributionsTransform<PointSource,PointTarget>   scanmatcher_component.cpp:105-113

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "lsr_share_target", "lsr_wait_stream", "lsr_align", "lsr_align_batch",
     "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_search_loop", "lsr_ndt_grid_info",
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
-    "lsr_debug_angle_tables", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
+    "lsr_debug_angle_tables", "lsr_set_input_source_pc2", "lsr_get_source_pc2", "lsr_voxel_grid_filter_pc2", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
 ]
 
 
@@ -57,6 +57,11 @@ class LoopEdge(C.Structure):
     _fields_ = [("id_from", C.c_int), ("id_to", C.c_int), ("accepted", C.c_int), ("converged", C.c_int),
                 ("iterations", C.c_int), ("n_target_points", C.c_int), ("candidate_distance", C.c_double),
                 ("fitness_score", C.c_double), ("relative_pose", C.c_double * 16), ("final_transformation", C.c_float * 16)]
+
+
+class Pc2Layout(C.Structure):
+    _fields_ = [("point_step", C.c_uint32), ("offset_x", C.c_uint32), ("offset_y", C.c_uint32), ("offset_z", C.c_uint32),
+                ("offset_intensity", C.c_int32)]
 
 
 class ShardRecord(C.Structure):
@@ -123,6 +128,11 @@ def load() -> C.CDLL:
     L.lsr_nearest_neighbors.argtypes = [vp, fp, ip, fp]
     L.lsr_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.lsr_debug_angle_tables.argtypes = [dp, C.c_int, fp, fp, fp, fp]
+    L.lsr_set_input_source_pc2.argtypes = [vp, vp, C.c_size_t, C.POINTER(Pc2Layout), C.c_double, C.c_double, C.c_float, C.c_int,
+                                           C.POINTER(C.c_size_t)]
+    L.lsr_get_source_pc2.argtypes = [vp, vp, C.c_size_t, C.POINTER(Pc2Layout), C.POINTER(C.c_size_t)]
+    L.lsr_voxel_grid_filter_pc2.argtypes = [vp, vp, C.c_size_t, C.POINTER(Pc2Layout), C.c_float, vp, C.c_size_t, C.POINTER(Pc2Layout),
+                                            C.POINTER(C.c_size_t)]
     L.lsr_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
     L.lsr_shard_range.restype = None
     L.lsr_comm_unique_id.argtypes = [vp]

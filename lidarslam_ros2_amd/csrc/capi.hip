@@ -678,6 +678,88 @@ int lsr_voxel_grid_filter(lsr_handle h, const void* pts, size_t stride_bytes, si
   return LSR_OK;
 }
 
+// ---- N4: PointCloud2 codec ---------------------------------------------------------------------
+namespace {
+int check_layout(const lsr_pc2_layout* L) {
+  if (!L || L->point_step < 12 || (L->point_step % 4) != 0) { set_last_error("PointCloud2 layout: point_step must be a multiple of 4 and >= 12"); return LSR_ERR_INVALID_ARGUMENT; }
+  const uint32_t offs[3] = {L->offset_x, L->offset_y, L->offset_z};
+  for (uint32_t o : offs)
+    if ((o % 4) != 0 || o + 4 > L->point_step) { set_last_error("PointCloud2 layout: x/y/z offsets must be 4-byte aligned and inside point_step"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (L->offset_intensity >= 0 && ((L->offset_intensity % 4) != 0 || (uint32_t)L->offset_intensity + 4 > L->point_step)) {
+    set_last_error("PointCloud2 layout: intensity offset must be 4-byte aligned and inside point_step (or < 0 for none)");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
+  return LSR_OK;
+}
+
+// payload -> SoA planes (+ intensity) on the device
+int read_pc2(lsr_handle h, const void* data, size_t n, const lsr_pc2_layout* L, bool on_device, DeviceCloud& out) {
+  if (n > 0 && !data) { set_last_error("null PointCloud2 data"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (n > (size_t)INT32_MAX / 2) { set_last_error("cloud too large"); return LSR_ERR_INVALID_ARGUMENT; }
+  const void* d = data;
+  if (!on_device && n > 0) {
+    int st = h->staging.reserve(n * L->point_step);
+    if (st) return st;
+    LSR_HIP(hipMemcpyAsync(h->staging.p, data, n * L->point_step, hipMemcpyHostToDevice, h->stream));
+    d = h->staging.p;
+  }
+  return pc2_read(d, (int)L->point_step, (int)L->offset_x, (int)L->offset_y, (int)L->offset_z, L->offset_intensity, n, out, h->stream);
+}
+
+// SoA planes -> host payload (bytes outside the four fields are zero)
+int write_pc2_host(lsr_handle h, const DeviceCloud& cloud, void* out_data, size_t capacity, const lsr_pc2_layout* L, size_t* n_out) {
+  *n_out = cloud.n;
+  if (cloud.n > capacity) { set_last_error("output buffer too small"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (cloud.n == 0) return LSR_OK;
+  const size_t bytes = cloud.n * L->point_step;
+  int st = h->staging.reserve(bytes);
+  if (st) return st;
+  LSR_HIP(hipMemsetAsync(h->staging.p, 0, bytes, h->stream));
+  if ((st = pc2_write(cloud, h->staging.p, (int)L->point_step, (int)L->offset_x, (int)L->offset_y, (int)L->offset_z, L->offset_intensity, h->stream)))
+    return st;
+  LSR_HIP(hipMemcpyAsync(out_data, h->staging.p, bytes, hipMemcpyDeviceToHost, h->stream));
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+}  // namespace
+
+int lsr_set_input_source_pc2(lsr_handle h, const void* data, size_t n_points, const lsr_pc2_layout* layout, double scan_min_range,
+                             double scan_max_range, float vg_size_for_input, int on_device, size_t* n_out) {
+  LSR_CHECK_HANDLE(h);
+  int st = check_layout(layout);
+  if (st) return st;
+  if (!(vg_size_for_input > 0)) { set_last_error("leaf size must be > 0"); return LSR_ERR_INVALID_ARGUMENT; }
+  if ((st = read_pc2(h, data, n_points, layout, on_device != 0, h->raw))) return st;
+  if ((st = range_mask(h->raw, scan_min_range, scan_max_range, h->stream))) return st;
+  if ((st = voxel_grid_filter(h->raw, vg_size_for_input, h->source, h->scratch, h->stream))) return st;
+  h->has_source = true;
+  h->source_cov_valid = false;
+  if (n_out) *n_out = h->source.n;
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
+int lsr_get_source_pc2(lsr_handle h, void* out_data, size_t capacity_points, const lsr_pc2_layout* layout, size_t* n_out) {
+  LSR_CHECK_HANDLE(h);
+  int st = check_layout(layout);
+  if (st) return st;
+  if (!n_out || (capacity_points > 0 && !out_data)) { set_last_error("bad argument"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (!h->has_source) { set_last_error("no input source"); return LSR_ERR_NO_SOURCE; }
+  return write_pc2_host(h, h->source, out_data, capacity_points, layout, n_out);
+}
+
+int lsr_voxel_grid_filter_pc2(lsr_handle h, const void* data, size_t n_points, const lsr_pc2_layout* in_layout, float leaf, void* out_data,
+                              size_t capacity_points, const lsr_pc2_layout* out_layout, size_t* n_out) {
+  LSR_CHECK_HANDLE(h);
+  int st = check_layout(in_layout);
+  if (st) return st;
+  if ((st = check_layout(out_layout))) return st;
+  if (!(leaf > 0) || !n_out) { set_last_error("bad argument"); return LSR_ERR_INVALID_ARGUMENT; }
+  if ((st = read_pc2(h, data, n_points, in_layout, false, h->raw))) return st;
+  if ((st = voxel_grid_filter(h->raw, leaf, h->filtered, h->scratch, h->stream))) return st;
+  return write_pc2_host(h, h->filtered, out_data, capacity_points, out_layout, n_out);
+}
+
 int lsr_wait_stream(lsr_handle h, void* producer_stream) {
   LSR_CHECK_HANDLE(h);
   if ((hipStream_t)producer_stream == h->stream) return LSR_OK;  // same stream: already ordered
@@ -731,13 +813,18 @@ int lsr_align(lsr_handle h, const float* guess, float* final_transformation, lsr
   if (st) return st;
   if (output_pts) {
     if (out_stride_bytes < 12 || (out_stride_bytes % 4) != 0) { set_last_error("bad output stride"); return LSR_ERR_INVALID_ARGUMENT; }
-    size_t bytes = h->source.n * out_stride_bytes;
-    if ((st = h->staging.reserve(bytes))) return st;
+    // PCL's align() first copies the source records into `output` and then overwrites x, y, z with the transformed
+    // coordinates; every other field (intensity, ...) stays.  Same here: only the 12 xyz bytes of each record are written,
+    // whatever the caller put in the rest of the record survives (12 bytes per point cross PCIe, packed).
+    const size_t n = h->source.n;
+    if ((st = h->staging.reserve(n * 12))) return st;
+    if ((st = h->out_xyz.reserve(n * 3))) return st;
     LSR_HIP(hipMemcpyAsync(h->d_T16.p, h->final_T, 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    LSR_HIP(hipMemsetAsync(h->staging.p, 0, bytes, h->stream));
-    if ((st = transform_to_strided(h->source, h->d_T16.p, h->staging.p, out_stride_bytes, h->stream))) return st;
-    LSR_HIP(hipMemcpyAsync(output_pts, h->staging.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    if ((st = transform_to_strided(h->source, h->d_T16.p, h->staging.p, 12, h->stream))) return st;
+    LSR_HIP(hipMemcpyAsync(h->out_xyz.p, h->staging.p, n * 12, hipMemcpyDeviceToHost, h->stream));
     LSR_HIP(hipStreamSynchronize(h->stream));
+    unsigned char* o = static_cast<unsigned char*>(output_pts);
+    for (size_t i = 0; i < n; i++) std::memcpy(o + i * out_stride_bytes, h->out_xyz.p + 3 * i, 12);
   }
   return LSR_OK;
 }

@@ -76,17 +76,20 @@ struct PinBuf {
 struct DeviceCloud {
   DevBuf<float> buf;
   size_t n = 0;
+  bool has_i = false;        // a fourth plane carries the intensity field (PointCloud2 codec path)
   float* x() const { return buf.p; }
   float* y() const { return buf.p + pitch; }
   float* z() const { return buf.p + 2 * pitch; }
+  float* i() const { return has_i ? buf.p + 3 * pitch : nullptr; }
   size_t pitch = 0;
-  int resize(size_t count) {
+  int resize(size_t count, bool with_intensity = false) {
     size_t pt = (count + 63) & ~size_t(63);
     if (pt == 0) pt = 64;
-    int st = buf.reserve(3 * pt);
+    int st = buf.reserve(4 * pt);   // room for the intensity plane whether or not this cloud uses it
     if (st) return st;
     pitch = pt;
     n = count;
+    has_i = with_intensity;
     return LSR_OK;
   }
 };

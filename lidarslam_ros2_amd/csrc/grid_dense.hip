@@ -50,6 +50,26 @@ int wait_mailbox_word(const volatile unsigned int* word, unsigned int token, hip
 }
 
 namespace {
+__global__ void publish_int_kernel(const int* __restrict__ src, BuildMailbox* __restrict__ mb, unsigned int token) {
+  mb->value = *src;
+  __threadfence_system();
+  __hip_atomic_store(&mb->value_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+int publish_device_int(const int* d_value, BuildScratch& sc, hipStream_t stream, int* out) {
+  int st = sc.ensure_mailbox();
+  if (st) return st;
+  unsigned int token = ++sc.token;
+  if (token == 0) token = ++sc.token;
+  hipLaunchKernelGGL(publish_int_kernel, dim3(1), dim3(1), 0, stream, d_value, sc.d_mb, token);
+  LSR_HIP(hipGetLastError());
+  if ((st = wait_mailbox_word(&sc.mb.p->value_token, token, stream, sc.wait_mode, "device counter"))) return st;
+  *out = sc.mb.p->value;
+  return LSR_OK;
+}
+
+namespace {
 
 constexpr int VG_CHUNK = 4096;  // points per workgroup: 4 waves x 16 steps x 64 lanes
 constexpr int VG_STEPS = 16;

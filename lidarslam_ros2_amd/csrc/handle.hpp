@@ -37,6 +37,7 @@ struct lsr_handle_s {
 
   BuildScratch scratch;
   DevBuf<unsigned char> staging;
+  PinBuf<float> out_xyz;      // align(output): packed transformed xyz on their way into the caller's records
 
   // NDT run-time buffers (batch-capable: the leader of a batch owns arrays for all members)
   DevBuf<NdtState> d_state;

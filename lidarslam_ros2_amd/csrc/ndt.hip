@@ -1920,26 +1920,32 @@ static int bits_for(unsigned int max_key) {  // radix bits needed to order keys 
 // ---- N1: pcl::VoxelGrid::filter (centroid per occupied leaf, output ordered by leaf index) -------------
 // scanmatcher/src/scanmatcher_component.cpp:324-328 (every scan, vg_size_for_input), :266-269, :443-447
 // (map side, vg_size_for_map), graph_based_slam/src/graph_based_slam_component.cpp:224-226.
-// Same key/sort machinery as K1; one thread per leaf sums its (few) points in ascending point order in
-// fp64 and rounds the centroid to fp32 (PCL accumulates in fp32 in std::sort order, which is not
-// reproducible; the fp64 sum is within an ulp or two of it and deterministic).
+// Same key/sort machinery as K1; one thread per leaf sums its (few) points in ascending point order in FLOAT, as
+// pcl::CentroidPoint does (PCL's own order inside a leaf is whatever std::sort leaves: unspecified; ascending index is
+// the oracle's choice and this kernel's) — all fields, intensity included (downsample_all_data_).
 namespace {
 __global__ __launch_bounds__(256) void leaf_centroid_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                            const float* __restrict__ z, const int* __restrict__ order,
+                                                            const float* __restrict__ z, const float* __restrict__ w /*nullable*/,
+                                                            const int* __restrict__ order,
                                                             const unsigned int* __restrict__ run_key, const int* __restrict__ run_off,
                                                             const int* __restrict__ run_cnt, int n_runs, unsigned int sentinel,
-                                                            float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz) {
+                                                            float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
+                                                            float* __restrict__ ow) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_runs) return;
   if (run_key[r] == sentinel) return;  // the run of non-finite points (always last) is dropped
   const int off = run_off[r], cnt = run_cnt[r];
-  double sx = 0, sy = 0, sz = 0;
+  // FLOAT accumulators, points in ascending index (stable sort): the very additions pcl::CentroidPoint performs
+  // (AccumulatorXYZ / AccumulatorIntensity are float), so the centroid is bit-identical to the CPU restatement
+  float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
   for (int j = 0; j < cnt; j++) {
     const int pi = order[off + j];
-    sx += (double)x[pi]; sy += (double)y[pi]; sz += (double)z[pi];
+    sx += x[pi]; sy += y[pi]; sz += z[pi];
+    if (w) sw += w[pi];
   }
-  const double inv = 1.0 / (double)cnt;
-  ox[r] = (float)(sx * inv); oy[r] = (float)(sy * inv); oz[r] = (float)(sz * inv);
+  const float m = (float)cnt;
+  ox[r] = sx / m; oy[r] = sy / m; oz[r] = sz / m;
+  if (ow) ow[r] = w ? sw / m : 0.f;
 }
 }  // namespace
 
@@ -1969,12 +1975,12 @@ int range_mask(DeviceCloud& cloud, double rmin, double rmax, hipStream_t stream)
 int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, BuildScratch& sc, hipStream_t stream) {
   const int n = (int)cloud.n;
   out.n = 0;
-  if (n == 0) return out.resize(0);
+  if (n == 0) return out.resize(0, cloud.has_i);
   float mn[3], mx[3];
   unsigned int n_finite = 0;
   int st = cloud_bbox(cloud, mn, mx, &n_finite, sc, stream);
   if (st) return st;
-  if (n_finite == 0) return out.resize(0);
+  if (n_finite == 0) return out.resize(0, cloud.has_i);
   const float inv_leaf = 1.0f / leaf;
   int64_t d[3];
   for (int k = 0; k < 3; k++) d[k] = (int64_t)((mx[k] - mn[k]) * inv_leaf) + 1;
@@ -2002,13 +2008,12 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
   if ((st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), sc.temp, stream))) return st;
   if ((st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
   int n_runs = 0;
-  LSR_HIP(hipMemcpyAsync(&n_runs, d_nruns, sizeof(int), hipMemcpyDeviceToHost, stream));
-  LSR_HIP(hipStreamSynchronize(stream));
+  if ((st = publish_device_int(d_nruns, sc, stream, &n_runs))) return st;   // host mailbox: no D2H copy, no stream sync
   if ((st = exclusive_scan_i32(run_cnt, run_off, n_runs, sc.temp, stream))) return st;
   const int n_out = n_runs - ((n_finite < (unsigned int)n) ? 1 : 0);  // minus the sentinel run
-  if ((st = out.resize(n_out))) return st;
-  hipLaunchKernelGGL(leaf_centroid_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(),
-                     val_out, run_key, run_off, run_cnt, n_runs, sentinel, out.x(), out.y(), out.z());
+  if ((st = out.resize(n_out, cloud.has_i))) return st;
+  hipLaunchKernelGGL(leaf_centroid_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), cloud.i(),
+                     val_out, run_key, run_off, run_cnt, n_runs, sentinel, out.x(), out.y(), out.z(), out.i());
   LSR_HIP(hipGetLastError());
   return LSR_OK;
 }
@@ -2029,6 +2034,52 @@ int interleave(const DeviceCloud& in, void* d_out, size_t stride_bytes, hipStrea
   if (in.n == 0) return LSR_OK;
   hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)((in.n + 255) / 256)), dim3(256), 0, stream, in.x(), in.y(), in.z(),
                      (int)in.n, (unsigned char*)d_out, stride_bytes);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+// ---- N4: sensor_msgs/PointCloud2 <-> SoA planes with arbitrary float32 field offsets --------------------------------
+// pcl::fromROSMsg (scanmatcher_component.cpp:201-202) reads x / y / z / intensity wherever the message's fields put them;
+// pcl::toROSMsg (:279,284; SubMap.msg:4) writes pcl::PointXYZI's layout.  Offsets are in bytes inside a point_step record.
+namespace {
+__global__ __launch_bounds__(256) void pc2_read_kernel(const unsigned char* __restrict__ data, int step, int ox, int oy, int oz, int oi,
+                                                       int n, float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
+                                                       float* __restrict__ w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* rec = data + (size_t)i * step;
+  x[i] = *reinterpret_cast<const float*>(rec + ox);
+  y[i] = *reinterpret_cast<const float*>(rec + oy);
+  z[i] = *reinterpret_cast<const float*>(rec + oz);
+  if (w) w[i] = (oi >= 0) ? *reinterpret_cast<const float*>(rec + oi) : 0.f;
+}
+__global__ __launch_bounds__(256) void pc2_write_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                        const float* __restrict__ w, int n, unsigned char* __restrict__ data, int step,
+                                                        int ox, int oy, int oz, int oi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned char* rec = data + (size_t)i * step;
+  *reinterpret_cast<float*>(rec + ox) = x[i];
+  *reinterpret_cast<float*>(rec + oy) = y[i];
+  *reinterpret_cast<float*>(rec + oz) = z[i];
+  if (oi >= 0) *reinterpret_cast<float*>(rec + oi) = w ? w[i] : 0.f;
+}
+}  // namespace
+
+int pc2_read(const void* d_data, int step, int ox, int oy, int oz, int oi, size_t n, DeviceCloud& out, hipStream_t stream) {
+  int st = out.resize(n, oi >= 0);
+  if (st) return st;
+  if (n == 0) return LSR_OK;
+  hipLaunchKernelGGL(pc2_read_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const unsigned char*)d_data, step, ox, oy, oz,
+                     oi, (int)n, out.x(), out.y(), out.z(), out.i());
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+int pc2_write(const DeviceCloud& in, void* d_data, int step, int ox, int oy, int oz, int oi, hipStream_t stream) {
+  if (in.n == 0) return LSR_OK;
+  hipLaunchKernelGGL(pc2_write_kernel, dim3((unsigned)((in.n + 255) / 256)), dim3(256), 0, stream, in.x(), in.y(), in.z(), in.i(), (int)in.n,
+                     (unsigned char*)d_data, step, ox, oy, oz, oi);
   LSR_HIP(hipGetLastError());
   return LSR_OK;
 }

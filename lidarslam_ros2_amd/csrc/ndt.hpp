@@ -157,6 +157,13 @@ void ndt_fill_diag_state(NdtState& st, const double* p6, const float* T16, int c
 // Host helper: default state constants for an align.
 void ndt_fill_align_constants(NdtState& st, const NdtParamsHost& prm, int n_points);
 
+// One device int to the host through the build mailbox (a 1-thread launch + one polled word instead of a device-to-host
+// copy and a stream synchronisation).  Defined in grid_dense.hip.
+int publish_device_int(const int* d_value, BuildScratch& sc, hipStream_t stream, int* out);
+// N4: PointCloud2 payload (float32 fields at byte offsets ox/oy/oz/oi inside point_step records; oi < 0: no intensity)
+// <-> SoA planes, device to device.
+int pc2_read(const void* d_data, int step, int ox, int oy, int oz, int oi, size_t n, DeviceCloud& out, hipStream_t stream);
+int pc2_write(const DeviceCloud& in, void* d_data, int step, int ox, int oy, int oz, int oi, hipStream_t stream);
 // N1: pcl::VoxelGrid::filter on the device (centroid per leaf, leaf-index order).
 int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, BuildScratch& sc, hipStream_t stream);
 int range_mask(DeviceCloud& cloud, double rmin, double rmax, hipStream_t stream);

@@ -156,12 +156,6 @@ __global__ __launch_bounds__(256) void fitness_final_kernel(const double* __rest
   }
 }
 
-// one device int into the host mailbox (instead of a device-to-host copy + stream synchronisation)
-__global__ void publish_value_kernel(const int* __restrict__ src, BuildMailbox* __restrict__ mb, unsigned int token) {
-  mb->value = *src;
-  __threadfence_system();
-  __hip_atomic_store(&mb->value_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 }  // namespace
 
@@ -245,12 +239,8 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
   hipLaunchKernelGGL(nn_coarse_key_kernel, dim3(nb), dim3(256), 0, stream, key_out, n, sentinel, ckey);
   if ((st = run_length_encode_u32(ckey, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
   // the number of occupied coarse cells reaches the host through the mailbox (one polled word)
-  if ((st = sc.ensure_mailbox())) return st;
-  unsigned int token = ++sc.token;
-  if (token == 0) token = ++sc.token;
-  hipLaunchKernelGGL(publish_value_kernel, dim3(1), dim3(1), 0, stream, d_nruns, sc.d_mb, token);
-  if ((st = wait_mailbox_word(&sc.mb.p->value_token, token, stream, sc.wait_mode, "NN grid build"))) return st;
-  const int n_runs = sc.mb.p->value;
+  int n_runs = 0;
+  if ((st = publish_device_int(d_nruns, sc, stream, &n_runs))) return st;
   if ((st = exclusive_scan_i32(run_cnt, run_off, n_runs, sc.temp, stream))) return st;
   if ((st = grid.block_off.reserve((size_t)n_runs + 1))) return st;
   if ((st = grid.fine_start.reserve((size_t)n_runs * FINE_STRIDE))) return st;

@@ -186,6 +186,50 @@ class Registration:
         self._n_source = int(n_out.value)
         return self._n_source
 
+    # -- sensor_msgs/PointCloud2 codec ----------------------------------------------
+    @staticmethod
+    def _layout(point_step, offsets):
+        ox, oy, oz, oi = offsets
+        return capi.Pc2Layout(int(point_step), int(ox), int(oy), int(oz), int(-1 if oi is None else oi))
+
+    def setInputSourcePointCloud2(self, data, n_points: int, point_step: int, offsets, scan_min_range: float, scan_max_range: float,
+                                  vg_size_for_input: float) -> int:
+        """pcl::fromROSMsg + range filter + VoxelGrid + setInputSource from a raw PointCloud2 `data` buffer (bytes / uint8 numpy
+        array / CUDA uint8 tensor); offsets = (x, y, z, intensity or None) in bytes.  Returns the number of points kept."""
+        lay = self._layout(point_step, offsets)
+        n_out = C.c_size_t()
+        if _is_torch_cuda(data):
+            _order_after_torch(self, data)
+            ptr, dev, keep = C.c_void_p(data.data_ptr()), 1, data
+        else:
+            keep = np.frombuffer(data, np.uint8) if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data).view(np.uint8)
+            ptr, dev = C.c_void_p(keep.ctypes.data), 0
+        capi.check(self._lib.lsr_set_input_source_pc2(self._h, ptr, int(n_points), C.byref(lay), float(scan_min_range), float(scan_max_range),
+                                                      C.c_float(vg_size_for_input), dev, C.byref(n_out)), "setInputSourcePointCloud2")
+        self._n_source = int(n_out.value)
+        return self._n_source
+
+    def getInputSourcePointCloud2(self, point_step: int = 32, offsets=(0, 4, 8, 16)) -> np.ndarray:
+        """pcl::toROSMsg of the current input source: (n, point_step) uint8 records (default: pcl::PointXYZI's layout)."""
+        lay = self._layout(point_step, offsets)
+        out = np.zeros((max(self._n_source, 1), point_step), np.uint8)
+        n_out = C.c_size_t()
+        capi.check(self._lib.lsr_get_source_pc2(self._h, C.c_void_p(out.ctypes.data), out.shape[0], C.byref(lay), C.byref(n_out)),
+                   "getInputSourcePointCloud2")
+        return out[: n_out.value].copy()
+
+    def voxelGridFilterPointCloud2(self, data, n_points: int, point_step: int, offsets, leaf: float, out_point_step: int = 32,
+                                   out_offsets=(0, 4, 8, 16)) -> np.ndarray:
+        """pcl::VoxelGrid(leaf).filter on a PointCloud2 payload (host), all four fields averaged per leaf; -> (m, out_point_step) uint8."""
+        li, lo = self._layout(point_step, offsets), self._layout(out_point_step, out_offsets)
+        src = np.frombuffer(data, np.uint8) if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data).view(np.uint8)
+        out = np.zeros((max(int(n_points), 1), out_point_step), np.uint8)
+        n_out = C.c_size_t()
+        capi.check(self._lib.lsr_voxel_grid_filter_pc2(self._h, C.c_void_p(src.ctypes.data), int(n_points), C.byref(li), C.c_float(leaf),
+                                                       C.c_void_p(out.ctypes.data), out.shape[0], C.byref(lo), C.byref(n_out)),
+                   "voxelGridFilterPointCloud2")
+        return out[: n_out.value].copy()
+
     def voxelGridFilter(self, cloud, leaf: float) -> np.ndarray:
         """Stand-alone pcl::VoxelGrid(leaf).filter on the device; host (n,c>=3) in, (m,3) fp32 out."""
         p, stride, n, dev, keep = _cloud_args(cloud)

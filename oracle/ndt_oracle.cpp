@@ -752,7 +752,17 @@ int orc_ndt_align(void* gp, const float* src, size_t stride_floats, size_t n, co
 // in VoxelGridCovariance, points sorted by leaf index, centroid per leaf accumulated in FLOAT
 // (CentroidPoint's AccumulatorXYZ is Eigen::Vector3f), output in ascending leaf order.  std::sort's order
 // inside a leaf is unspecified upstream; ascending point index is used here.
+int orc_voxel_grid_filter_impl(const float* pts, size_t stride_f, size_t n, float leaf, float* out, int intensity_col);
 int orc_voxel_grid_filter(const float* pts, size_t stride_f, size_t n, float leaf, float* out_xyz) {
+  return orc_voxel_grid_filter_impl(pts, stride_f, n, leaf, out_xyz, -1);
+}
+// with downsample_all_data_ (PCL's default) every field is averaged: out_xyzi = 4 floats per leaf {x, y, z, intensity},
+// intensity read from column `intensity_col` of the input records (AccumulatorIntensity is a float sum too)
+int orc_voxel_grid_filter_xyzi(const float* pts, size_t stride_f, size_t n, float leaf, int intensity_col, float* out_xyzi) {
+  return orc_voxel_grid_filter_impl(pts, stride_f, n, leaf, out_xyzi, intensity_col);
+}
+int orc_voxel_grid_filter_impl(const float* pts, size_t stride_f, size_t n, float leaf, float* out_xyz, int intensity_col) {
+  const int ow = intensity_col >= 0 ? 4 : 3;
   const float inv = 1.0f / leaf;
   float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
   float mx[3] = {-mn[0], -mn[1], -mn[2]};
@@ -784,14 +794,16 @@ int orc_voxel_grid_filter(const float* pts, size_t stride_f, size_t n, float lea
   size_t a = 0;
   while (a < iv.size()) {
     size_t b = a;
-    float acc[3] = {0, 0, 0};
+    float acc[4] = {0, 0, 0, 0};
     while (b < iv.size() && iv[b].first == iv[a].first) {
       const float* p = pts + (size_t)iv[b].second * stride_f;
       acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
+      if (intensity_col >= 0) acc[3] += p[intensity_col];
       b++;
     }
     float m = (float)(b - a);
-    out_xyz[3 * cnt] = acc[0] / m; out_xyz[3 * cnt + 1] = acc[1] / m; out_xyz[3 * cnt + 2] = acc[2] / m;
+    out_xyz[ow * cnt] = acc[0] / m; out_xyz[ow * cnt + 1] = acc[1] / m; out_xyz[ow * cnt + 2] = acc[2] / m;
+    if (intensity_col >= 0) out_xyz[ow * cnt + 3] = acc[3] / m;
     cnt++;
     a = b;
   }

@@ -70,6 +70,8 @@ def lib():
         L.orc_max_threads.restype = C.c_int
         L.orc_voxel_grid_filter.restype = C.c_int
         L.orc_voxel_grid_filter.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_float, fp]
+        L.orc_voxel_grid_filter_xyzi.restype = C.c_int
+        L.orc_voxel_grid_filter_xyzi.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, fp]
         if hasattr(L, "orc_nn_build"):
             L.orc_nn_build.restype = vp
             L.orc_nn_build.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_float]
@@ -124,6 +126,16 @@ def matrix_to_pose(M) -> np.ndarray:
     p = np.zeros(6, np.float64)
     lib().orc_matrix_to_pose(Mc.ctypes.data_as(C.POINTER(C.c_float)), _f64p(p))
     return p
+
+
+def voxel_grid_filter_xyzi(pts: np.ndarray, leaf: float, intensity_col: int) -> np.ndarray:
+    """pcl::VoxelGrid::filter with downsample_all_data (PCL's default): (m, 4) = leaf means of x, y, z and of the intensity
+    found in column `intensity_col` of the input records."""
+    a, ap = _f32(pts)
+    out = np.zeros((a.shape[0], 4), np.float32)
+    n = lib().orc_voxel_grid_filter_xyzi(ap, a.shape[1], a.shape[0], C.c_float(leaf), int(intensity_col),
+                                         out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:n].copy()
 
 
 def voxel_grid_filter(pts: np.ndarray, leaf: float) -> np.ndarray:
