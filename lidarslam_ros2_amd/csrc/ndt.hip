@@ -501,6 +501,62 @@ __device__ __forceinline__ void build_request(NdtState* S, double* f /*8*/, floa
   barrier_lds_only();
 }
 
+// Ordering of LDS traffic inside ONE wave: its lanes run in lockstep and the LDS unit executes a wave's operations in
+// order, so "lane 0 wrote, every lane reads" needs no workgroup barrier — only that the compiler keeps the order and the
+// writes have been issued.
+__device__ __forceinline__ void wave_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// build_request() for a caller that runs the whole controller step on wave 0 (quad kernel): same work, the 64 lanes of
+// one wave, no workgroup barrier.  ent_a = k_angle_entries[lane], ent_b = k_angle_entries[64 + lane] (lane < 8).
+__device__ __forceinline__ void build_request_wave0(NdtState* S, double* f /*8*/, float* cs_f /*6*/, const unsigned int ent_a,
+                                                    const unsigned int ent_b) {
+  const int lane = threadIdx.x;  // 0..63
+  const int mode = S->pad1;
+  if (mode == 0) return;  // wave-uniform
+  if (lane < 3) {
+    const double a = S->x_t[3 + lane];
+    double sn, cn;
+    if (fabs(a) < 10e-5) { cn = 1.0; sn = 0.0; } else { sincos(a, &sn, &cn); }
+    f[1 + lane] = cn;
+    f[4 + lane] = sn;
+  } else if (lane < 6) {
+    const float a = (float)S->x_t[lane];
+    float sn, cn;
+    sincosf(a, &sn, &cn);
+    cs_f[lane - 3] = cn;
+    cs_f[lane] = sn;
+  } else if (lane == 6) {
+    f[0] = 1.0;
+    f[7] = 0.0;
+  }
+  wave_lds_fence();
+  const bool with_hang = (mode & 2) != 0;
+  if (lane < 24 || with_hang) {
+    double val = angle_entry_value(ent_a, f);
+    if (lane == 24 + 20 && S->d1_sign < 0) val = -val;
+    if (lane < 24) S->jang[lane] = (float)val; else S->hang[lane - 24] = (float)val;
+  }
+  if (with_hang && lane < 8) S->hang[40 + lane] = (float)angle_entry_value(ent_b, f);  // entries 64..71
+  if (lane == 63) {
+    // fp32 (Translation * Rx * Ry * Rz), as pose_to_T12
+    const float fcx = cs_f[0], fcy = cs_f[1], fcz = cs_f[2], fsx = cs_f[3], fsy = cs_f[4], fsz = cs_f[5];
+    const float a00 = fcy, a02 = fsy;
+    const float a10 = fsx * fsy, a11 = fcx, a12 = -fsx * fcy;
+    const float a20 = -fcx * fsy, a21 = fsx, a22 = fcx * fcy;
+    float* T = S->T;
+    T[0] = a00 * fcz; T[1] = -a00 * fsz; T[2] = a02;
+    T[4] = a10 * fcz + a11 * fsz; T[5] = -a10 * fsz + a11 * fcz; T[6] = a12;
+    T[8] = a20 * fcz + a21 * fsz; T[9] = -a20 * fsz + a21 * fcz; T[10] = a22;
+    T[3] = (float)S->x_t[0]; T[7] = (float)S->x_t[1]; T[11] = (float)S->x_t[2];
+    T12_to_colmajor16(T, S->final_T);  // final_transformation_ is assigned before every MT pass
+  }
+  if (lane == 0) S->pad1 = 0;
+  wave_lds_fence();
+}
+
 // K4: consume the sums of the pass that just finished and decide what happens next.
 // Runs on one lane of EVERY workgroup (redundantly, same inputs, same result).  sums: [0]=score [1..6]=grad
 // [7]=pairs [8..28]=H upper.
@@ -1261,7 +1317,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   const int stride = P.nblocks * PTS;
   int i = blockIdx.x * PTS + pq;
   float x = 0.f, y = 0.f, z = 0.f;
-  unsigned int ang_entry = 0u;
+  unsigned int ang_entry = 0u, ang_entry_b = 0u;
   {
     const uint4* gq = reinterpret_cast<const uint4*>(Sin);
     const uint4 stq = (tid < STATE_Q) ? gq[tid] : make_uint4(0u, 0u, 0u, 0u);
@@ -1283,7 +1339,8 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
     if (tid < STATE_Q) s_state_q[tid] = stq;
     // issued after the shared lines have landed, on purpose (see the one-lane kernel): these fly across the head's barriers
     if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
-    if (tid < 72) ang_entry = k_angle_entries[tid];
+    if (tid < 64) ang_entry = k_angle_entries[tid];
+    if (tid < 8) ang_entry_b = k_angle_entries[64 + tid];
   }
   LSR_STAMP_T(8, 0)
   LSR_STAMP_T(10, THREADS - 64)
@@ -1312,28 +1369,35 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + (size_t)c * 1024),
                                          (__attribute__((address_space(3))) void*)(dst + (size_t)c * 1024), 16, 0, 0);
   }
-  if (seq > 0) {
-    if (tid < NDT_NRED) {
-      // fold the bins smallest quantum first (fixed order); a raised poison slot (overflow / NaN partial) poisons all sums
-      double t = (((s_bin[4][tid] + s_bin[3][tid]) + s_bin[2][tid]) + s_bin[1][tid]) + s_bin[0][tid];
-      if (s_bin[0][31] != 0.0 || s_bin[1][31] != 0.0) t = __longlong_as_double(0x7FF8000000000000ll);
-      s_sum[tid] = t;
+  // ---- the controller step lives on WAVE 0 alone: totals, Newton / More-Thuente decision, next request, state write-back —
+  // ordered by the wave's own lockstep, no workgroup barrier between them (each s_barrier with 8 waves cost ~0.2-0.3 us and
+  // there were four).  The other waves have issued the table DMA and wait at the one barrier below.
+  if (tid < 64) {
+    if (seq > 0) {
+      if (tid < NDT_NRED) {
+        // fold the bins smallest quantum first (fixed order); a raised poison slot (overflow / NaN partial) poisons all sums
+        double t = (((s_bin[4][tid] + s_bin[3][tid]) + s_bin[2][tid]) + s_bin[1][tid]) + s_bin[0][tid];
+        if (s_bin[0][31] != 0.0 || s_bin[1][31] != 0.0) t = __longlong_as_double(0x7FF8000000000000ll);
+        s_sum[tid] = t;
+      }
+      wave_lds_fence();
+      LSR_STAMP(6)
+      LSR_CTL_BEGIN(L)
+      if (tid == 0) ndt_controller(L, (const LdsDouble*)s_sum);
+      wave_lds_fence();
+      LSR_CTL_END(0)
+      LSR_STAMP(5)
+      build_request_wave0(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[4][0]), ang_entry, ang_entry_b);
+      LSR_CTL_END(2)
+      LSR_STAMP(4)
     }
-    barrier_lds_only();
-    LSR_STAMP(6)
-    LSR_CTL_BEGIN(L)
-    if (tid == 0) ndt_controller(L, (const LdsDouble*)s_sum);
-    barrier_lds_only();
-    LSR_CTL_END(0)
-    LSR_STAMP(5)
-    build_request<THREADS>(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[4][0]), ang_entry);
-    LSR_CTL_END(2)
-    LSR_STAMP(4)
+    if (blockIdx.x == 0) {
+      uint4* gq = reinterpret_cast<uint4*>(Sout);
+      gq[tid] = s_state_q[tid];
+      if (tid + 64 < STATE_Q) gq[tid + 64] = s_state_q[tid + 64];
+    }
   }
-  if (blockIdx.x == 0) {
-    uint4* gq = reinterpret_cast<uint4*>(Sout);
-    if (tid < STATE_Q) gq[tid] = s_state_q[tid];
-  }
+  __syncthreads();  // the request is complete and the table DMA has landed (vmcnt(0) + barrier)
   if (uniform_i(L->done)) {
     // the controller has just finished this align(): publish the result into the host mailbox, flag last
     if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0) {
@@ -1365,7 +1429,6 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
 #pragma unroll
   for (int k = 0; k < 12; k++) T[k] = uniform_f(L->T[k]);
   const float leaf = P.leaf;
-  __syncthreads();  // the table DMA has landed (vmcnt(0) + barrier)
   LSR_STAMP(11)
 
   const unsigned short* s_map = reinterpret_cast<const unsigned short*>(s_table);

@@ -84,6 +84,66 @@ __global__ __launch_bounds__(256) void nn_fine_table_kernel(const unsigned int* 
   }
 }
 
+// ---- bucket build (dense key spaces): histogram of the (coarse, fine) keys by integer atomics, exclusive scan, scatter through
+// the same counters — no sort.  The order of the points INSIDE a fine cell is whatever the atomics made it; every consumer
+// ranks candidates by (distance, original index), so results do not depend on it.
+__global__ __launch_bounds__(256) void nnb_hist_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                       int n, float inv_cell, int o0, int o1, int o2, int c0, int c1, unsigned int sentinel,
+                                                       unsigned int* __restrict__ key, int* __restrict__ hist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned int k = sentinel;
+  const float px = x[i], py = y[i], pz = z[i];
+  if (isfinite(px) && isfinite(py) && isfinite(pz)) {
+    const int fx = (int)floorf(px * inv_cell) - o0, fy = (int)floorf(py * inv_cell) - o1, fz = (int)floorf(pz * inv_cell) - o2;
+    const unsigned int coarse = (unsigned int)((fx >> 3) + c0 * ((fy >> 3) + c1 * (fz >> 3)));
+    k = coarse * FINE_PER_BLOCK + (unsigned int)((fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6));
+    atomicAdd(&hist[k], 1);
+  }
+  key[i] = k;
+}
+
+// position = start of the point's fine cell + what is left of the cell's counter (filled from the back)
+__global__ __launch_bounds__(256) void nnb_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                          int n, const unsigned int* __restrict__ key, unsigned int sentinel,
+                                                          const int* __restrict__ start, int* __restrict__ hist, float4* __restrict__ packed,
+                                                          int* __restrict__ order) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int k = key[i];
+  if (k == sentinel) return;  // non-finite points are not part of the grid
+  const int pos = start[k] + atomicSub(&hist[k], 1) - 1;
+  packed[pos] = make_float4(x[i], y[i], z[i], __int_as_float(i));
+  order[pos] = i;
+}
+
+__global__ __launch_bounds__(256) void nnb_flag_kernel(const int* __restrict__ start, int ccells, int* __restrict__ flag) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ccells) return;
+  flag[c] = (start[(size_t)(c + 1) * FINE_PER_BLOCK] - start[(size_t)c * FINE_PER_BLOCK]) > 0 ? 1 : 0;
+}
+
+// one wave per coarse cell: block id (rank among the occupied cells, in cell order) and its 513 fine-cell starts
+__global__ __launch_bounds__(256) void nnb_table_kernel(const int* __restrict__ start, const int* __restrict__ flag, const int* __restrict__ rank,
+                                                        int ccells, int* __restrict__ coarse_block, int* __restrict__ block_off,
+                                                        int* __restrict__ fine_start) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (c >= ccells) return;
+  if (!flag[c]) {
+    if (lane == 0) coarse_block[c] = -1;
+    return;
+  }
+  const int b = rank[c];
+  const int* st = start + (size_t)c * FINE_PER_BLOCK;
+  if (lane == 0) {
+    coarse_block[c] = b;
+    block_off[b] = st[0];
+    block_off[b + 1] = st[FINE_PER_BLOCK];  // the next block (if any) rewrites the same value
+  }
+  for (int f = lane; f <= FINE_PER_BLOCK; f += 64) fine_start[(size_t)b * FINE_STRIDE + f] = st[f];
+}
+
 // ---- query kernels -------------------------------------------------------------------------------
 __global__ __launch_bounds__(NN_THREADS) void nn1_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
                                                          const float* __restrict__ qz, int n, const float* __restrict__ T16,
@@ -212,6 +272,37 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
   if (ccells * FINE_PER_BLOCK >= 0xFFFFFFFFull) {
     set_last_error("cloud extent too large for the NN grid at this cell size");
     return LSR_ERR_INDEX_OVERFLOW;
+  }
+  const size_t nkeys = ccells * FINE_PER_BLOCK;
+  if (nkeys <= NN_BUCKET_MAX_KEYS && !sc.force_sort_path) {
+    // ---- bucket build: no sort, no host round trip after the bounding box
+    const size_t blocks_cap = std::min(ccells, (size_t)n);  // occupied coarse cells <= points
+    if ((st = sc.words.reserve(32 + (size_t)n + 2 * (nkeys + 1) + 2 * ccells + 64))) return st;
+    unsigned int* key = sc.words.p + 32;
+    int* hist = (int*)(key + n);
+    int* start = hist + (nkeys + 1);
+    int* flag = start + (nkeys + 1);
+    int* rank = flag + ccells;
+    if ((st = grid.order.reserve(n))) return st;
+    if ((st = grid.packed.reserve(n))) return st;
+    if ((st = grid.coarse_block.reserve(ccells))) return st;
+    if ((st = grid.block_off.reserve(blocks_cap + 1))) return st;
+    if ((st = grid.fine_start.reserve(blocks_cap * FINE_STRIDE))) return st;
+    const int nbk = (n + 255) / 256;
+    const unsigned int sentinel_b = (unsigned int)nkeys;
+    LSR_HIP(hipMemsetAsync(hist, 0, (nkeys + 1) * sizeof(int), stream));
+    hipLaunchKernelGGL(nnb_hist_kernel, dim3(nbk), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv, grid.org[0], grid.org[1],
+                       grid.org[2], grid.cdim[0], grid.cdim[1], sentinel_b, key, hist);
+    if ((st = exclusive_scan_i32(hist, start, nkeys + 1, sc.temp, stream))) return st;
+    hipLaunchKernelGGL(nnb_flag_kernel, dim3((unsigned)((ccells + 255) / 256)), dim3(256), 0, stream, start, (int)ccells, flag);
+    if ((st = exclusive_scan_i32(flag, rank, ccells, sc.temp, stream))) return st;
+    hipLaunchKernelGGL(nnb_scatter_kernel, dim3(nbk), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, key, sentinel_b, start, hist,
+                       grid.packed.p, grid.order.p);
+    hipLaunchKernelGGL(nnb_table_kernel, dim3((unsigned)((ccells + 3) / 4)), dim3(256), 0, stream, start, flag, rank, (int)ccells,
+                       grid.coarse_block.p, grid.block_off.p, grid.fine_start.p);
+    LSR_HIP(hipGetLastError());
+    grid.n_blocks = 1;  // "not empty" (n_finite > 0); the exact count stays on the device, nobody on the host needs it
+    return LSR_OK;
   }
   // scratch: key_in | key_out | val_in | ckey | run_key | run_cnt | run_off | nruns   (n words each)
   if ((st = sc.words.reserve(32 + 7 * (size_t)n + 16))) return st;

@@ -14,6 +14,7 @@ namespace nnd {
 constexpr int NN_THREADS = 128;
 constexpr int FINE_PER_BLOCK = 512;
 constexpr int FINE_STRIDE = 513;
+constexpr size_t NN_BUCKET_MAX_KEYS = (size_t)16 << 20;  // (coarse, fine) key spaces up to this size are built by bucketing, not sorting
 constexpr int NN_MAX_FINE_RINGS = 4;  // fine-cell shells tried before falling back to coarse shells
 
 struct NNGridView {

@@ -77,3 +77,30 @@ def test_fitness_score_no_overlap_and_errors(O, case):
     r.align()
     # nothing within 1 m^2: PCL returns std::numeric_limits<double>::max()
     assert r.getFitnessScore(1.0) == 1.7976931348623157e308
+
+
+def test_bucket_built_grid_equals_sort_built_grid(case):
+    """The NN grid of a dense key space is built by bucketing (integer histogram + scan + scatter through the counters, the
+    order inside a fine cell left to the atomics), larger ones by a radix sort: both must answer every query identically —
+    candidates are ranked by (distance, original index), never by their position in a cell."""
+    from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
+
+    out = []
+    for builder in (0, 1):
+        g = GeneralizedIterativeClosestPoint(device=0)
+        g.setTuning(grid_builder=builder)
+        g.setInputTarget(case.target)
+        g.setInputSource(case.source)
+        T = case.guess
+        idx, d2 = g.nearestNeighbors(T)
+        g.align(case.guess)
+        out.append((idx, d2, g.getFitnessScore(), g.getFinalTransformation(), g.covariances("source")))
+        # repeated builds answer identically too (the atomics may order a cell differently every time)
+        g.setInputTarget(case.target)
+        idx2, d22 = g.nearestNeighbors(T)
+        assert np.array_equal(idx, idx2) and np.array_equal(d2, d22)
+    a, b = out
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2] == b[2]
+    assert np.array_equal(a[3], b[3])
+    assert np.array_equal(a[4], b[4])
