@@ -145,12 +145,18 @@ __global__ __launch_bounds__(256) void nnb_table_kernel(const int* __restrict__ 
 }
 
 // ---- query kernels -------------------------------------------------------------------------------
+// One thread per query walks fine shells 0..ring_cap; a query not proven by then (far-range scan points whose nearest
+// target point is metres away) goes to `work` ([0] = count, [1..] = query indices) and is finished by nn1_coop_kernel,
+// one wave per query — the per-thread walk of those few queries was ~85 % of this kernel's time on a 30k-point scan
+// against a 660k-point submap (every wave waits for its slowest lane's hundreds of dependent cell probes).
+// `spread`: only every spread-th lane carries a query (a 30k-point scan is fewer waves than the chip has SIMDs).
 __global__ __launch_bounds__(NN_THREADS) void nn1_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
                                                          const float* __restrict__ qz, int n, const float* __restrict__ T16,
-                                                         int fine_rings, float max_d2, int* __restrict__ idx,
-                                                         float* __restrict__ d2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+                                                         int fine_rings, int ring_cap, int spread, float max_d2, int* __restrict__ work,
+                                                         int* __restrict__ idx, float* __restrict__ d2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t / spread;
+  if (i >= n || (t % spread) != 0) return;
   const float x = qx[i], y = qy[i], z = qz[i];
   float tx = x, ty = y, tz = z;
   if (T16) {
@@ -160,9 +166,38 @@ __global__ __launch_bounds__(NN_THREADS) void nn1_kernel(NNGridView G, const flo
   }
   Best1 c;
   c.init();
-  nn_query(G, tx, ty, tz, fine_rings, max_d2, c, -1);
+  if (!nn_query(G, tx, ty, tz, fine_rings, max_d2, c, -1, ring_cap)) {
+    work[1 + atomicAdd(work, 1)] = i;
+    return;
+  }
   idx[i] = c.idx;
   d2[i] = c.d2;
+}
+
+// tail of nn1_kernel: one wave per deferred query; same (distance, index) order, same fp32 distances => same answer
+__global__ __launch_bounds__(256) void nn1_coop_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                       const float* __restrict__ qz, const float* __restrict__ T16, float max_d2,
+                                                       const int* __restrict__ work, int* __restrict__ idx, float* __restrict__ d2) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int n_work = work[0];
+  for (int w = wave; w < n_work; w += n_waves) {
+    const int i = work[1 + w];
+    const float x = qx[i], y = qy[i], z = qz[i];
+    float tx = x, ty = y, tz = z;
+    if (T16) {
+      tx = xform_rn(T16[0], T16[4], T16[8], T16[12], x, y, z);
+      ty = xform_rn(T16[1], T16[5], T16[9], T16[13], x, y, z);
+      tz = xform_rn(T16[2], T16[6], T16[10], T16[14], x, y, z);
+    }
+    CoopList mine;
+    coop_knn(G, tx, ty, tz, 1, max_d2, -1, mine);
+    if (lane == 0) {
+      const bool found = mine.i != INT_MAX;
+      idx[i] = found ? mine.i : -1;
+      d2[i] = found ? mine.d : INFINITY;
+    }
+  }
 }
 
 __global__ __launch_bounds__(NN_THREADS) void knn_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
@@ -344,7 +379,7 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
 }
 
 int nn_search_device(const DeviceCloud& q, const float* d_T16, const HashGridDev& grid, int fine_rings, float max_d2,
-                     int* d_idx, float* d_d2, hipStream_t stream) {
+                     int* d_idx, float* d_d2, hipStream_t stream, int* d_work) {
   const int n = (int)q.n;
   if (n == 0) return LSR_OK;
   if (grid.n_blocks == 0) {
@@ -352,8 +387,16 @@ int nn_search_device(const DeviceCloud& q, const float* d_T16, const HashGridDev
     LSR_HIP(hipMemsetAsync(d_d2, 0x7F, sizeof(float) * n, stream));  // 0x7F7F7F7F ~ 3.4e38
     return LSR_OK;
   }
-  hipLaunchKernelGGL(nn1_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS), dim3(NN_THREADS), 0, stream, make_view(grid), q.x(),
-                     q.y(), q.z(), n, d_T16, fine_rings, max_d2, d_idx, d_d2);
+  // d_work (n + 1 ints) given: two-stage search — per-thread walk capped at two fine shells, wave-cooperative tail
+  const int ring_cap = d_work ? 2 : -1;
+  const int spread = (d_work && n <= 65536) ? 2 : 1;
+  if (d_work) LSR_HIP(hipMemsetAsync(d_work, 0, sizeof(int), stream));
+  const long threads = (long)n * spread;
+  hipLaunchKernelGGL(nn1_kernel, dim3((unsigned)((threads + NN_THREADS - 1) / NN_THREADS)), dim3(NN_THREADS), 0, stream, make_view(grid),
+                     q.x(), q.y(), q.z(), n, d_T16, fine_rings, ring_cap, spread, max_d2, d_work, d_idx, d_d2);
+  if (d_work)
+    hipLaunchKernelGGL(nn1_coop_kernel, dim3(1024), dim3(256), 0, stream, make_view(grid), q.x(), q.y(), q.z(), d_T16, max_d2, d_work,
+                       d_idx, d_d2);
   LSR_HIP(hipGetLastError());
   return LSR_OK;
 }
@@ -369,11 +412,12 @@ int knn_search_device(const DeviceCloud& q, const HashGridDev& grid, int k, int 
   return LSR_OK;
 }
 
-static int nn_scratch(BuildScratch& sc, size_t n, int** d_idx, float** d_d2, double** d_part) {
-  int st = sc.words.reserve(32 + 2 * n + 16);
+static int nn_scratch(BuildScratch& sc, size_t n, int** d_idx, float** d_d2, double** d_part, int** d_work) {
+  int st = sc.words.reserve(32 + 3 * n + 32);
   if (st) return st;
   *d_idx = (int*)(sc.words.p + 32);
   *d_d2 = (float*)(sc.words.p + 32 + n);
+  *d_work = (int*)(sc.words.p + 32 + 2 * n);   // [0] = deferred count, [1..n] = deferred query indices
   if ((st = sc.sums.reserve(2 * 256 + 8))) return st;
   *d_part = sc.sums.p;
   return LSR_OK;
@@ -381,11 +425,11 @@ static int nn_scratch(BuildScratch& sc, size_t n, int** d_idx, float** d_d2, dou
 
 int nn_search_host(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, int32_t* idx, float* d2,
                    BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream) {
-  int* d_idx; float* d_d2; double* d_part;
-  int st = nn_scratch(sc, source.n, &d_idx, &d_d2, &d_part);
+  int* d_idx; float* d_d2; double* d_part; int* d_work;
+  int st = nn_scratch(sc, source.n, &d_idx, &d_d2, &d_part, &d_work);
   if (st) return st;
   LSR_HIP(hipMemcpyAsync(d_T16.p, T16_host, 16 * sizeof(float), hipMemcpyHostToDevice, stream));
-  if ((st = nn_search_device(source, d_T16.p, grid, 1, INFINITY, d_idx, d_d2, stream))) return st;
+  if ((st = nn_search_device(source, d_T16.p, grid, 1, INFINITY, d_idx, d_d2, stream, d_work))) return st;
   LSR_HIP(hipMemcpyAsync(idx, d_idx, sizeof(int) * source.n, hipMemcpyDeviceToHost, stream));
   LSR_HIP(hipMemcpyAsync(d2, d_d2, sizeof(float) * source.n, hipMemcpyDeviceToHost, stream));
   LSR_HIP(hipStreamSynchronize(stream));
@@ -394,12 +438,12 @@ int nn_search_host(const DeviceCloud& source, const float* T16_host, const HashG
 
 int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, double* out,
                      BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream) {
-  int* d_idx; float* d_d2; double* d_part;
-  int st = nn_scratch(sc, source.n, &d_idx, &d_d2, &d_part);
+  int* d_idx; float* d_d2; double* d_part; int* d_work;
+  int st = nn_scratch(sc, source.n, &d_idx, &d_d2, &d_part, &d_work);
   if (st) return st;
   LSR_HIP(hipMemcpyAsync(d_T16.p, T16_host, 16 * sizeof(float), hipMemcpyHostToDevice, stream));
   const float max_d2 = (max_range >= 3.0e38) ? INFINITY : (float)max_range * 1.0001f;
-  if ((st = nn_search_device(source, d_T16.p, grid, 1, max_d2, d_idx, d_d2, stream))) return st;
+  if ((st = nn_search_device(source, d_T16.p, grid, 1, max_d2, d_idx, d_d2, stream, d_work))) return st;
   const int nb = 256;
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(nb), dim3(256), 0, stream, d_idx, d_d2, (int)source.n, max_range, d_part);
   if ((st = sc.ensure_mailbox())) return st;

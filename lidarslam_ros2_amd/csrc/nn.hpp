@@ -16,7 +16,7 @@ int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const Has
                      BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream);
 // Device-side entry points (results stay in HBM): 1-NN of T*q (T nullable) and k-NN of q.
 int nn_search_device(const DeviceCloud& q, const float* d_T16, const HashGridDev& grid, int fine_rings, float max_d2,
-                     int* d_idx, float* d_d2, hipStream_t stream);
+                     int* d_idx, float* d_d2, hipStream_t stream, int* d_work = nullptr);  // d_work: n + 1 ints => two-stage search
 int knn_search_device(const DeviceCloud& q, const HashGridDev& grid, int k, int fine_rings, int* d_idx, float* d_d2,
                       hipStream_t stream);
 int nn_search_host(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, int32_t* idx, float* d2,
