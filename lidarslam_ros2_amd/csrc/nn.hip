@@ -174,6 +174,33 @@ __global__ __launch_bounds__(NN_THREADS) void nn1_kernel(NNGridView G, const flo
   d2[i] = c.d2;
 }
 
+// The same first stage on four lanes per query (nn1_query_quad): a quarter of the dependent-load chain per lane.
+__global__ __launch_bounds__(NN_THREADS) void nn1_quad_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                              const float* __restrict__ qz, int n, const float* __restrict__ T16,
+                                                              int fine_rings, int ring_cap, float max_d2, int* __restrict__ work,
+                                                              int* __restrict__ idx, float* __restrict__ d2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 2, sub = t & 3;
+  if (i >= n) return;   // n * 4 threads: a quad is never split by this test
+  const float x = qx[i], y = qy[i], z = qz[i];
+  float tx = x, ty = y, tz = z;
+  if (T16) {
+    tx = xform_rn(T16[0], T16[4], T16[8], T16[12], x, y, z);
+    ty = xform_rn(T16[1], T16[5], T16[9], T16[13], x, y, z);
+    tz = xform_rn(T16[2], T16[6], T16[10], T16[14], x, y, z);
+  }
+  Best1 c;
+  c.init();
+  const bool proven = nn1_query_quad(G, tx, ty, tz, fine_rings, max_d2, c, ring_cap, sub);
+  if (sub != 0) return;
+  if (!proven) {
+    work[1 + atomicAdd(work, 1)] = i;
+    return;
+  }
+  idx[i] = c.idx;
+  d2[i] = c.d2;
+}
+
 // tail of nn1_kernel: one wave per deferred query; same (distance, index) order, same fp32 distances => same answer
 __global__ __launch_bounds__(256) void nn1_coop_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
                                                        const float* __restrict__ qz, const float* __restrict__ T16, float max_d2,
@@ -391,9 +418,15 @@ int nn_search_device(const DeviceCloud& q, const float* d_T16, const HashGridDev
   const int ring_cap = d_work ? 2 : -1;
   const int spread = (d_work && n <= 65536) ? 2 : 1;
   if (d_work) LSR_HIP(hipMemsetAsync(d_work, 0, sizeof(int), stream));
-  const long threads = (long)n * spread;
-  hipLaunchKernelGGL(nn1_kernel, dim3((unsigned)((threads + NN_THREADS - 1) / NN_THREADS)), dim3(NN_THREADS), 0, stream, make_view(grid),
-                     q.x(), q.y(), q.z(), n, d_T16, fine_rings, ring_cap, spread, max_d2, d_work, d_idx, d_d2);
+  if (d_work && n <= 262144) {   // small query sets (a scan): four lanes per query
+    const long threads = (long)n * 4;
+    hipLaunchKernelGGL(nn1_quad_kernel, dim3((unsigned)((threads + NN_THREADS - 1) / NN_THREADS)), dim3(NN_THREADS), 0, stream,
+                       make_view(grid), q.x(), q.y(), q.z(), n, d_T16, fine_rings, ring_cap, max_d2, d_work, d_idx, d_d2);
+  } else {
+    const long threads = (long)n * spread;
+    hipLaunchKernelGGL(nn1_kernel, dim3((unsigned)((threads + NN_THREADS - 1) / NN_THREADS)), dim3(NN_THREADS), 0, stream, make_view(grid),
+                       q.x(), q.y(), q.z(), n, d_T16, fine_rings, ring_cap, spread, max_d2, d_work, d_idx, d_d2);
+  }
   if (d_work)
     hipLaunchKernelGGL(nn1_coop_kernel, dim3(1024), dim3(256), 0, stream, make_view(grid), q.x(), q.y(), q.z(), d_T16, max_d2, d_work,
                        d_idx, d_d2);

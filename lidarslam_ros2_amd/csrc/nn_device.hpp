@@ -146,6 +146,17 @@ struct BestK {
   }
 };
 
+// Cells [x0, x1] of an x-row that can still hold a point closer than the current worst: `rem2` = worst d^2 minus the
+// row's squared y/z gap (>= 0 for a row that was not pruned).  A point p of the row beats the worst only if
+// |p.x - qx| <= sqrt(rem2); cells are floorf(p.x * inv_cell) - org, a monotone map, so clipping the row to the cells of
+// qx -+ reach (reach padded against the rounding of the subtraction) loses no such point.
+__device__ __forceinline__ void row_clip_x(const NNGridView& G, float qx, float rem2, int& x0, int& x1) {
+  const float reach = sqrtf(fmaxf(rem2, 0.f)) * 1.0001f + 4.0e-6f * (fabsf(qx) + G.cell);
+  const float lo = floorf((qx - reach) * G.inv_cell), hi = floorf((qx + reach) * G.inv_cell);
+  if (lo > -1.0e9f) x0 = max(x0, (int)lo - G.org[0]);
+  if (hi < 1.0e9f) x1 = min(x1, (int)hi - G.org[0]);
+}
+
 // Candidates [beg, end) of the cell-sorted arrays.  A wave walks its 64 queries' ranges in lock step and every
 // batch of coordinate loads costs one full memory round trip (one wave per SIMD: nothing else hides it), so the
 // points are fetched NN_SCAN_BATCH at a time, one 16-byte load each ({x, y, z, original index}: no dependent index
@@ -210,11 +221,23 @@ __device__ bool nn_query(const NNGridView& G, float qx, float qy, float qz, int 
           const int y = fq[1] + dy;
           if (y < 0 || y >= fdim[1]) continue;
           const bool full_row = whole_block || (abs(dz) == r) || (abs(dy) == r);
+          // Row pruning: every point of this row is at least `gyz` away in the y/z plane; once the list is full and its
+          // worst entry is strictly closer, the row cannot change the answer (ties included: the bound is strict).
+          // The slack covers the rounding of floorf(p * inv_cell) against (index * cell) for cells that are not powers of 2.
+          float gyz2 = 0.f;
+          if (r > 0) {
+            const float ylo = (float)(y + G.org[1]) * G.cell, zlo = (float)(z + G.org[2]) * G.cell;
+            const float gy = fmaxf(fmaxf(ylo - q[1], q[1] - (ylo + G.cell)) - 2.0e-6f * (fabsf(q[1]) + G.cell), 0.f);
+            const float gz = fmaxf(fmaxf(zlo - q[2], q[2] - (zlo + G.cell)) - 2.0e-6f * (fabsf(q[2]) + G.cell), 0.f);
+            gyz2 = (gy * gy + gz * gz) * 0.9999f;
+            if ((c.full() && gyz2 > c.worst()) || gyz2 > max_d2) { LSR_NN_COUNT(rows_pruned, 1); continue; }
+          }
           const int cbase = G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3));
           const int fyz = ((y & 7) << 3) | ((z & 7) << 6);
           for (int part = 0; part < (full_row ? 1 : 2); part++) {
             const int xs = full_row ? fq[0] - r : (part ? fq[0] + r : fq[0] - r);
-            const int x0 = max(xs, 0), x1 = min(full_row ? fq[0] + r : xs, fdim[0] - 1);
+            int x0 = max(xs, 0), x1 = min(full_row ? fq[0] + r : xs, fdim[0] - 1);
+            if (r > 0 && c.full()) row_clip_x(G, qx, c.worst() - gyz2, x0, x1);   // cells of the row that can still matter
             for (int cx = x0 >> 3; cx <= (x1 >> 3); cx++) {   // empty when x0 > x1
               LSR_NN_COUNT(fine_probes, 1);
               const int blk = G.coarse_block[cbase + cx];
@@ -306,6 +329,89 @@ __device__ bool nn_query(const NNGridView& G, float qx, float qy, float qz, int 
 }
 
 #ifndef LSR_HOST_EMU   // (wave intrinsics: not part of the host emulation in tools/nn_host_emu)
+// ---- exact 1-NN on FOUR lanes per query -------------------------------------------------------------------------
+// Lanes 4p..4p+3 of a wave carry the same query (`sub` = lane & 3).  The search of one query is a chain of dependent
+// loads (coarse map -> fine table -> candidates) and a scan is fewer waves than the chip has SIMDs, so the time of the
+// per-thread walk is the length of that chain; here the own cell's candidates are split in quarters and the rows of
+// the later shells are dealt round-robin to the four lanes, which merge their bests (same (distance, index) order)
+// after every shell, so the shell bound is tested on the merged result and all four leave together.
+// Same candidates, same fp32 distances, a total order => the answer of nn_query.  Fine shells 0..ring_cap only:
+// false = not proven (the caller defers the query to coop_knn).  `c` may come in seeded (identically on the four lanes).
+__device__ __forceinline__ void best1_merge_quad(Best1& c) {
+#pragma unroll
+  for (int m = 1; m <= 2; m <<= 1) {
+    const float od = __shfl_xor(c.d2, m, 64);
+    const int oi = __shfl_xor(c.idx, m, 64);
+    if (oi >= 0 && (od < c.d2 || (od == c.d2 && oi < c.idx) || c.idx < 0)) { c.d2 = od; c.idx = oi; }
+  }
+}
+
+__device__ bool nn1_query_quad(const NNGridView& G, float qx, float qy, float qz, int fine_rings, float max_d2, Best1& c,
+                               int ring_cap, int sub) {
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return true;
+  const float fxf = floorf(qx * G.inv_cell), fyf = floorf(qy * G.inv_cell), fzf = floorf(qz * G.inv_cell);
+  if (!(fabsf(fxf) < 1.0e9f && fabsf(fyf) < 1.0e9f && fabsf(fzf) < 1.0e9f)) return true;
+  const int fq[3] = {(int)fxf - G.org[0], (int)fyf - G.org[1], (int)fzf - G.org[2]};
+  const float q[3] = {qx, qy, qz};
+  const int fdim[3] = {G.cdim[0] * 8, G.cdim[1] * 8, G.cdim[2] * 8};
+  for (int k = 0; k < 3; k++)
+    if (fq[k] + NN_MAX_FINE_RINGS < 0 || fq[k] - NN_MAX_FINE_RINGS >= fdim[k]) return false;
+  fine_rings = min(max(fine_rings, 0), NN_MAX_FINE_RINGS);
+  const int last_ring = max(fine_rings, min(ring_cap, NN_MAX_FINE_RINGS));
+  for (int r = 0; r <= last_ring; r++) {
+    int dealt = 0;   // rows of this shell seen so far (identical on the four lanes)
+    for (int dz = -r; dz <= r; dz++) {
+      const int z = fq[2] + dz;
+      if (z < 0 || z >= fdim[2]) continue;
+      for (int dy = -r; dy <= r; dy++) {
+        const int y = fq[1] + dy;
+        if (y < 0 || y >= fdim[1]) continue;
+        const bool full_row = (abs(dz) == r) || (abs(dy) == r);
+        for (int part = 0; part < (full_row ? 1 : 2); part++) {
+          const bool take = (r == 0) || ((dealt++ & 3) == sub);
+          if (!take) continue;
+          float gyz2 = 0.f;
+          if (r > 0) {   // row pruning, as in nn_query
+            const float ylo = (float)(y + G.org[1]) * G.cell, zlo = (float)(z + G.org[2]) * G.cell;
+            const float gy = fmaxf(fmaxf(ylo - q[1], q[1] - (ylo + G.cell)) - 2.0e-6f * (fabsf(q[1]) + G.cell), 0.f);
+            const float gz = fmaxf(fmaxf(zlo - q[2], q[2] - (zlo + G.cell)) - 2.0e-6f * (fabsf(q[2]) + G.cell), 0.f);
+            gyz2 = (gy * gy + gz * gz) * 0.9999f;
+            if ((c.full() && gyz2 > c.worst()) || gyz2 > max_d2) continue;
+          }
+          const int cbase = G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3));
+          const int fyz = ((y & 7) << 3) | ((z & 7) << 6);
+          const int xs = full_row ? fq[0] - r : (part ? fq[0] + r : fq[0] - r);
+          int x0 = max(xs, 0), x1 = min(full_row ? fq[0] + r : xs, fdim[0] - 1);
+          if (r > 0 && c.full()) row_clip_x(G, qx, c.worst() - gyz2, x0, x1);
+          for (int cx = x0 >> 3; cx <= (x1 >> 3); cx++) {
+            const int blk = G.coarse_block[cbase + cx];
+            if (blk < 0) continue;
+            const int xa = max(x0, cx * 8) & 7, xb = min(x1, cx * 8 + 7) & 7;
+            const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + fyz;
+            int beg = fs[xa], end = fs[xb + 1];
+            if (r == 0) {   // the own cell: a quarter of its candidates per lane
+              const int quarter = (end - beg + 3) >> 2;
+              beg += sub * quarter;
+              end = min(end, beg + quarter);
+            }
+            if (beg < end) scan_range(G, beg, end, qx, qy, qz, c, -1);
+          }
+        }
+      }
+    }
+    best1_merge_quad(c);
+    float lo = INFINITY;
+    for (int k = 0; k < 3; k++) {
+      const float base = (float)(fq[k] + G.org[k]) * G.cell;
+      lo = fminf(lo, fminf(q[k] - (base - (float)r * G.cell), (base + (float)(r + 1) * G.cell) - q[k]));
+    }
+    lo = fmaxf(lo, 0.f);
+    const float lo2 = lo * lo * 0.9999f;
+    if (r >= fine_rings && ((c.full() && c.worst() <= lo2) || lo2 > max_d2)) return true;
+  }
+  return false;
+}
+
 // ---- wave-cooperative exact k-NN (k <= 64) for the queries the per-thread walk gave up on ---------------------
 // One 64-lane wave per query.  The k best (distance, index) pairs live one per lane, sorted ascending in lanes
 // 0..k-1 (empty = (inf, INT_MAX)); coarse cells are visited shell by shell with the same box-distance pruning and

@@ -26,7 +26,7 @@ namespace lsr { template <typename T> struct DevBuf { T* p = nullptr; };
 struct DeviceCloud { float* x() const { return nullptr; } float* y() const { return nullptr; } float* z() const { return nullptr; } };
 struct HashGridDev { float cell; int org[3]; int cdim[3]; DevBuf<int> coarse_block, block_off, fine_start, order; DevBuf<float4> packed; }; }
 #define LSR_COMMON_HPP_STUB
-struct Counters { long ranges, candidates, fine_probes, phase2_queries, coarse_blocks, offers_taken, shifts; } g_cnt;
+struct Counters { long ranges, candidates, fine_probes, phase2_queries, coarse_blocks, offers_taken, shifts, rows_pruned; } g_cnt;
 #define LSR_NN_COUNT(what, n) (g_cnt.what += (n))
 #include "nn_device_emu.hpp"
 using namespace lsr::nnd;
