@@ -503,7 +503,7 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
     fptr = C.POINTER(C.c_float)
     regs, tgts, srcs, guesses = [], [], [], []
     for c, target, source, guess, truth in cands:
-        r = NormalDistributionsTransform(device=dev_index, stream=tstream)
+        r = NormalDistributionsTransform(device=dev_index)     # its own stream: the staged batch entries overlap the candidates
         r.setResolution(5.0); r.setTransformationEpsilon(0.01); r.setMaximumIterations(100)
         regs.append(r)
         tgts.append(torch.from_numpy(synth.as_pointxyzi(target)).cuda())
@@ -529,11 +529,19 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
     n_rec = n_total if use_rccl else nloc
     recs = (_capi.ShardRecord * max(n_rec, 1))()
 
+    tptr = (C.c_void_p * max(nloc, 1))(*[C.c_void_p(t.data_ptr()) for t in tgts])
+    tcnt = (C.c_size_t * max(nloc, 1))(*[int(t.shape[0]) for t in tgts])
+
     def one_round(batched: bool):
-        """-> seconds for this rank's share; fills recs"""
+        """-> seconds for this rank's share; fills recs.  batched: the staged C-ABI entries (lsr_set_input_target_batch, the
+        shared launch chain, lsr_get_fitness_score_batch inside lsr_align_batch_sharded); else the reference's loop, one
+        candidate after the other."""
         t0 = time.perf_counter()
+        if batched and nloc:
+            _capi.check(lib.lsr_set_input_target_batch(hs, nloc, tptr, tcnt, 32, 1), "lsr_set_input_target_batch")
         for b, (r, t, s) in enumerate(zip(regs, tgts, srcs)):
-            _capi.check(lib.lsr_set_input_target_device(r._h, C.c_void_p(t.data_ptr()), 32, int(t.shape[0])), "setInputTarget")
+            if not batched:
+                _capi.check(lib.lsr_set_input_target_device(r._h, C.c_void_p(t.data_ptr()), 32, int(t.shape[0])), "setInputTarget")
             _capi.check(lib.lsr_set_input_source_device(r._h, C.c_void_p(s.data_ptr()), 32, int(s.shape[0])), "setInputSource")
             if not batched:
                 fin = np.zeros(16, np.float32)

@@ -124,6 +124,13 @@ int lsr_get_i32(lsr_handle h, int key, int* value);
  * Host-memory (`pts` readable by the CPU) and device-memory (`pts` a HIP device pointer) forms. */
 int lsr_set_input_target(lsr_handle h, const void* pts, size_t stride_bytes, size_t n);
 int lsr_set_input_target_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n);
+/* The same for a SET of candidates — one setInputTarget per candidate submap window, graph_based_slam_component.cpp:181-227
+ * (BASELINE cfg 4).  handles[b] receives clouds[b] (counts[b] records of stride_bytes; all host or all device pointers).
+ * Same result per object as `count` calls of lsr_set_input_target, but the builds overlap on the device: every stage of
+ * every member is enqueued (on its own object's stream) before the host waits for the first.  On error no member keeps a
+ * target.  An object may appear only once. */
+int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const* clouds, const size_t* counts,
+                               size_t stride_bytes, int on_device);
 /* Ordering and lifetime of DEVICE-resident inputs (every *_device entry point and every `on_device != 0` argument): the
  * core reads them with kernels on the handle's stream (lsr_create's `stream`, or the handle's own).  (1) If another
  * stream produced the buffer, call lsr_wait_stream(h, that_stream) first — it makes the handle's stream wait for
@@ -205,6 +212,9 @@ int lsr_get_final_transformation(lsr_handle h, float* out16);
 int lsr_has_converged(lsr_handle h, int* out);
 /* registration_->getFitnessScore(max_range = DBL_MAX)  graph_based_slam_component.cpp:231; scanmatcher_component.cpp:376 */
 int lsr_get_fitness_score(lsr_handle h, double max_range, double* out);
+/* registration_->getFitnessScore() of every candidate of a set (graph_based_slam_component.cpp:231 inside the candidate loop):
+ * out[b] = what lsr_get_fitness_score(handles[b], max_range, ..) returns; all searches are enqueued before the first wait. */
+int lsr_get_fitness_score_batch(lsr_handle* handles, int count, double max_range, double* out);
 
 /* ---- multi-GPU sharding of a batch (BASELINE.json cfg 4) -----------------------
  * One process per GPU.  The batch of `global_count` independent registrations — the loop-closure candidate set of

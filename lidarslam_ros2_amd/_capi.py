@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_search_loop", "lsr_ndt_grid_info",
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
     "lsr_debug_angle_tables", "lsr_set_input_source_pc2", "lsr_get_source_pc2", "lsr_voxel_grid_filter_pc2", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
+    "lsr_set_input_target_batch", "lsr_get_fitness_score_batch",
 ]
 
 
@@ -119,6 +120,8 @@ def load() -> C.CDLL:
     L.lsr_get_final_transformation.argtypes = [vp, fp]
     L.lsr_has_converged.argtypes = [vp, ip]
     L.lsr_get_fitness_score.argtypes = [vp, C.c_double, dp]
+    L.lsr_get_fitness_score_batch.argtypes = [C.POINTER(vp), C.c_int, C.c_double, dp]
+    L.lsr_set_input_target_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.c_int]
     L.lsr_search_loop.argtypes = [vp, C.POINTER(SubMap), C.c_int, C.c_size_t, C.c_int, C.POINTER(LoopParams),
                                   C.POINTER(LoopEdge), C.c_int, ip]
     L.lsr_ndt_grid_info.argtypes = [vp, ip]

@@ -232,6 +232,13 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
       return LSR_ERR_NO_TARGET;
     }
   }
+  // The shared launches run on the lead's stream; a member on another stream may still have its setInputSource /
+  // setInputTarget kernels in flight there: order the lead's stream after each of them (event + stream wait, no host wait)
+  for (int b = 1; b < B; b++) {
+    if (hs[b]->stream == lead->stream) continue;
+    LSR_HIP(hipEventRecord(hs[b]->ev1, hs[b]->stream));
+    LSR_HIP(hipStreamWaitEvent(lead->stream, hs[b]->ev1, 0));
+  }
   int st;
   if ((st = lead->d_state.reserve(2 * (size_t)B))) return st;
   if ((st = lead->h_state.reserve(2 * (size_t)B))) return st;
@@ -604,6 +611,58 @@ int lsr_set_input_target_frames(lsr_handle h, int n_frames, const void* const* f
 int lsr_set_input_target(lsr_handle h, const void* pts, size_t stride_bytes, size_t n) {
   return set_target_impl(h, pts, stride_bytes, n, false);
 }
+
+// setInputTarget for a set of candidates (graph_based_slam_component.cpp:181-227 runs once per candidate): the same work
+// per object as lsr_set_input_target, staged so that the builds overlap on the device — every upload and bounding-box
+// pass is enqueued (each on its object's stream) before the first box is waited for, every grid build before the first
+// result is read.
+int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const* clouds, const size_t* counts, size_t stride_bytes,
+                               int on_device) {
+  if (count < 0 || (count > 0 && (!handles || !clouds || !counts))) { set_last_error("bad batch arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  for (int b = 0; b < count; b++) {
+    LSR_CHECK_HANDLE(handles[b]);
+    for (int a = 0; a < b; a++)
+      if (handles[a] == handles[b]) { set_last_error("the same object appears twice in the batch"); return LSR_ERR_INVALID_ARGUMENT; }
+  }
+  auto fail = [&](int st) {
+    for (int b = 0; b < count; b++) {   // nothing half-built stays behind
+      (void)hipStreamSynchronize(handles[b]->stream);
+      handles[b]->scratch.grid_pending = false;
+      handles[b]->scratch.bbox_parts = 0;
+      handles[b]->target.reset();
+    }
+    return st;
+  };
+  int st;
+  for (int b = 0; b < count; b++) {   // stage 0: uploads + bounding boxes
+    lsr_handle h = handles[b];
+    auto t = fresh_target(h);
+    if ((st = upload_cloud(h, clouds[b], stride_bytes, counts[b], on_device != 0, t->cloud))) return fail(st);
+    t->n = counts[b];
+    h->target = t;
+    if ((st = cloud_bbox_begin(t->cloud, h->scratch, h->stream))) return fail(st);
+  }
+  for (int b = 0; b < count; b++) {   // stage 1: the rest of every build
+    lsr_handle h = handles[b];
+    TargetData& t = *h->target;
+    if (h->method == LSR_METHOD_NDT) {
+      if ((st = ndt_build_grid_begin(t.cloud, (float)h->ndt.resolution, t.grid, h->scratch, h->stream))) return fail(st);
+    } else {
+      if ((st = ensure_target_hash(h))) return fail(st);
+    }
+  }
+  for (int b = 0; b < count; b++) {   // stage 2: results
+    lsr_handle h = handles[b];
+    TargetData& t = *h->target;
+    if (h->method == LSR_METHOD_NDT) {
+      if ((st = ndt_build_grid_end(t.grid, h->scratch, h->stream))) return fail(st);
+      t.has_grid = true;
+      t.grid_leaf = (float)h->ndt.resolution;
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { set_last_error("stream error in the target batch"); return fail(LSR_ERR_HIP); }
+  }
+  return LSR_OK;
+}
 int lsr_set_input_target_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n) {
   return set_target_impl(h, dev_pts, stride_bytes, n, true);
 }
@@ -851,6 +910,33 @@ int lsr_get_fitness_score(lsr_handle h, double max_range, double* out) {
   int st = ensure_target_hash(h);
   if (st) return st;
   return nn_fitness_score(h->source, h->final_T, h->target->hash, max_range, out, h->scratch, h->d_T16, h->stream);
+}
+
+// getFitnessScore for a set of candidates (graph_based_slam_component.cpp:231 per candidate): every search + reduction is
+// enqueued on its object's stream before the first result is waited for.
+int lsr_get_fitness_score_batch(lsr_handle* handles, int count, double max_range, double* out) {
+  if (count < 0 || (count > 0 && (!handles || !out))) { set_last_error("bad batch arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  int st;
+  for (int b = 0; b < count; b++) {
+    lsr_handle h = handles[b];
+    LSR_CHECK_HANDLE(h);
+    if (!h->target || h->target->n == 0) { set_last_error("getFitnessScore before setInputTarget"); return LSR_ERR_NO_TARGET; }
+    if (!h->has_source) { set_last_error("getFitnessScore before setInputSource"); return LSR_ERR_NO_SOURCE; }
+  }
+  int begun = 0;
+  for (; begun < count; begun++) {
+    lsr_handle h = handles[begun];
+    if ((st = ensure_target_hash(h))) break;
+    if ((st = nn_fitness_begin(h->source, h->final_T, h->target->hash, max_range, h->scratch, h->d_T16, h->stream))) break;
+  }
+  int first_error = (begun < count) ? st : LSR_OK;
+  for (int b = 0; b < begun; b++) {   // collect what was enqueued even after an error: no reduction stays in flight
+    double v = 0;
+    st = nn_fitness_end(handles[b]->scratch, handles[b]->stream, &v);
+    if (st && !first_error) first_error = st;
+    out[b] = v;
+  }
+  return first_error;
 }
 
 // ---- N3: loop-closure gate ---------------------------------------------------------------------

@@ -144,11 +144,11 @@ int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_cou
       R.iterations = (float)res[b].iterations;
       R.converged = res[b].converged ? 1.f : 0.f;
       R.fitness = NAN;
-      if (with_fitness) {
-        double f = 0;
-        if ((st = lsr_get_fitness_score(local_handles[b], 1.7976931348623157e308, &f))) return st;
-        R.fitness = (float)f;
-      }
+    }
+    if (with_fitness) {   // every candidate's search + reduction enqueued before the first result is read
+      std::vector<double> fit((size_t)local_count);
+      if ((st = lsr_get_fitness_score_batch(local_handles, local_count, 1.7976931348623157e308, fit.data()))) return st;
+      for (int b = 0; b < local_count; b++) local[b].fitness = (float)fit[b];
     }
   }
   if (c->world == 1) {

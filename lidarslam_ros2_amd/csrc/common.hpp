@@ -82,7 +82,13 @@ struct DeviceCloud {
   float* z() const { return buf.p + 2 * pitch; }
   float* i() const { return has_i ? buf.p + 3 * pitch : nullptr; }
   size_t pitch = 0;
+  // bounding box of the finite points, remembered by cloud_bbox() until the next resize() (every writer of a cloud
+  // resizes it first): setInputTarget's grid build and the NN-grid build of getFitnessScore share one pass and one poll
+  mutable bool bbox_valid = false;
+  mutable float bbox_mn[3] = {0, 0, 0}, bbox_mx[3] = {0, 0, 0};
+  mutable unsigned int bbox_finite = 0;
   int resize(size_t count, bool with_intensity = false) {
+    bbox_valid = false;
     size_t pt = (count + 63) & ~size_t(63);
     if (pt == 0) pt = 64;
     int st = buf.reserve(4 * pt);   // room for the intensity plane whether or not this cloud uses it
@@ -168,6 +174,12 @@ struct BuildScratch {
   BuildMailbox* d_mb = nullptr;    // device view of mb.p
   unsigned int token = 0;
   int wait_mode = WAIT_SPIN;
+  // staged builds (a batch enqueues every stage of every member before it waits): what is in flight on this scratch
+  int bbox_parts = 0;              // workgroup records of an enqueued bounding-box pass not yet collected
+  unsigned int bbox_token = 0;
+  bool grid_pending = false;       // a dense voxel-grid build whose result has not been read from the mailbox yet
+  unsigned int grid_token = 0;
+  unsigned int fit_token = 0;      // an enqueued fitness reduction (0: none)
   int ensure_mailbox();
 };
 

@@ -1949,11 +1949,11 @@ int transform_to_strided(const DeviceCloud& src, const float* d_T16, void* d_out
 
 // Bounding box over the finite points of a cloud: one launch, the per-workgroup records arrive in the host mailbox and
 // the host folds them (no copy, no stream synchronisation).
-int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_finite, BuildScratch& sc, hipStream_t stream) {
+// Two halves, so that a batch of builds can enqueue every bounding-box pass before waiting for the first one.
+int cloud_bbox_begin(const DeviceCloud& cloud, BuildScratch& sc, hipStream_t stream) {
   const int n = (int)cloud.n;
-  *n_finite = 0;
-  for (int k = 0; k < 3; k++) { mn[k] = 0.f; mx[k] = 0.f; }
-  if (n <= 0) return LSR_OK;
+  sc.bbox_parts = 0;
+  if (n <= 0 || cloud.bbox_valid) return LSR_OK;
   int st = sc.ensure_mailbox();
   if (st) return st;
   unsigned int token = ++sc.token;
@@ -1961,17 +1961,45 @@ int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_f
   const int nb = std::max(1, std::min((n + 1023) / 1024, BBOX_MAX_PARTS));  // four points per thread per trip
   hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, sc.d_mb, token);
   LSR_HIP(hipGetLastError());
+  sc.bbox_parts = nb;
+  sc.bbox_token = token;
+  return LSR_OK;
+}
+
+int cloud_bbox_end(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_finite, BuildScratch& sc, hipStream_t stream) {
+  *n_finite = 0;
+  for (int k = 0; k < 3; k++) { mn[k] = 0.f; mx[k] = 0.f; }
+  if ((int)cloud.n <= 0) return LSR_OK;
+  if (cloud.bbox_valid) {
+    *n_finite = cloud.bbox_finite;
+    for (int k = 0; k < 3; k++) { mn[k] = cloud.bbox_mn[k]; mx[k] = cloud.bbox_mx[k]; }
+    return LSR_OK;
+  }
+  const int nb = sc.bbox_parts;
+  if (nb <= 0) { set_last_error("bounding box collected before it was enqueued"); return LSR_ERR_HIP; }
+  const unsigned int token = sc.bbox_token;
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   unsigned int cnt = 0;
+  int st;
   for (int b = nb - 1; b >= 0; b--) {  // the last workgroups finish last: wait there first, the rest is usually in already
     if ((st = wait_mailbox_word(&sc.mb.p->part[b].token, token, stream, sc.wait_mode, "bounding box"))) return st;
     const BboxPart& P = sc.mb.p->part[b];
     cnt += P.n_finite;
     for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], P.mn[k]); hi[k] = std::fmax(hi[k], P.mx[k]); }
   }
+  sc.bbox_parts = 0;
   *n_finite = cnt;
   if (cnt) for (int k = 0; k < 3; k++) { mn[k] = lo[k]; mx[k] = hi[k]; }
+  cloud.bbox_valid = true;
+  cloud.bbox_finite = cnt;
+  for (int k = 0; k < 3; k++) { cloud.bbox_mn[k] = mn[k]; cloud.bbox_mx[k] = mx[k]; }
   return LSR_OK;
+}
+
+int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_finite, BuildScratch& sc, hipStream_t stream) {
+  int st = cloud_bbox_begin(cloud, sc, stream);
+  if (st) return st;
+  return cloud_bbox_end(cloud, mn, mx, n_finite, sc, stream);
 }
 
 static int bits_for(unsigned int max_key) {  // radix bits needed to order keys in [0, max_key]
@@ -2236,6 +2264,28 @@ int ndt_pack_lds_table(VoxelGridDev& grid, BuildScratch& sc, bool per_cell_leaf_
 }
 
 int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  int st = cloud_bbox_begin(cloud, sc, stream);
+  if (st) return st;
+  if ((st = ndt_build_grid_begin(cloud, leaf, grid, sc, stream))) return st;
+  return ndt_build_grid_end(grid, sc, stream);
+}
+
+// Collect a build left pending by ndt_build_grid_begin (host poll #2).
+int ndt_build_grid_end(VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  if (!sc.grid_pending) return LSR_OK;
+  sc.grid_pending = false;
+  int st = wait_mailbox_word(&sc.mb.p->done_token, sc.grid_token, stream, sc.wait_mode, "voxel grid build");
+  if (st) return st;
+  grid.n_valid = sc.mb.p->n_valid;
+  grid.lds_bytes = sc.mb.p->lds_bytes;
+  grid.lds_map_bytes = sc.mb.p->lds_map_bytes;
+  return LSR_OK;
+}
+
+// Everything up to the last enqueue; the bounding-box pass must have been enqueued (cloud_bbox_begin) or be cached.
+// Dense key spaces leave the build pending (sc.grid_pending): ndt_build_grid_end() collects it.
+int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  sc.grid_pending = false;
   DevBuf<char>& temp = sc.temp;
   DevBuf<unsigned int>& scratch = sc.words;
   DevBuf<double>& sums = sc.sums;
@@ -2250,7 +2300,7 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
 
   float mn[3], mx[3];
   unsigned int n_finite = 0;
-  int st = cloud_bbox(cloud, mn, mx, &n_finite, sc, stream);   // host poll #1
+  int st = cloud_bbox_end(cloud, mn, mx, &n_finite, sc, stream);   // host poll #1
   if (st) return st;
   if (n_finite == 0) return LSR_OK;  // no finite point: empty grid
   int64_t d[3];
@@ -2273,10 +2323,8 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
     // dense key space: hand-written counting sort, no further host round trip until the final poll (grid_dense.hip)
     if ((st = ndt_build_grid_dense(cloud, leaf, grid, sc, stream))) return st;
     if ((st = ndt_pack_lds_table(grid, sc, true, token, stream))) return st;
-    if ((st = wait_mailbox_word(&sc.mb.p->done_token, token, stream, sc.wait_mode, "voxel grid build"))) return st;  // host poll #2
-    grid.n_valid = sc.mb.p->n_valid;
-    grid.lds_bytes = sc.mb.p->lds_bytes;
-    grid.lds_map_bytes = sc.mb.p->lds_map_bytes;
+    sc.grid_pending = true;
+    sc.grid_token = token;
     return LSR_OK;
   }
 

@@ -118,9 +118,15 @@ struct NdtParamsHost {
 void ndt_gauss_constants(double resolution, double outlier_ratio, double* d1, double* d2);
 
 int cloud_bbox(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_finite, BuildScratch& sc, hipStream_t stream);
+int cloud_bbox_begin(const DeviceCloud& cloud, BuildScratch& sc, hipStream_t stream);   // enqueue only
+int cloud_bbox_end(const DeviceCloud& cloud, float* mn, float* mx, unsigned int* n_finite, BuildScratch& sc, hipStream_t stream);
 
 // K1/K2: build grid from the SoA cloud.  Returns once the grid is complete (host polls the build mailbox twice).
 int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
+// The same in two halves (after cloud_bbox_begin): _begin waits for the bounding box and enqueues the rest, _end waits for
+// the result.  A batch of targets runs every _begin before the first _end, so the builds overlap on the device.
+int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
+int ndt_build_grid_end(VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
 
 // Geometry of a launch chain (fixed for the whole align()).
 struct NdtLaunchCfg {

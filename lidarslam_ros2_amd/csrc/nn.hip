@@ -469,8 +469,10 @@ int nn_search_host(const DeviceCloud& source, const float* T16_host, const HashG
   return LSR_OK;
 }
 
-int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, double* out,
-                     BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream) {
+// getFitnessScore in two halves: _begin enqueues search + reduction (the result goes to the build mailbox), _end waits for
+// it.  A batch of candidates runs every _begin (each on its own handle's stream) before the first _end.
+int nn_fitness_begin(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, BuildScratch& sc,
+                     DevBuf<float>& d_T16, hipStream_t stream) {
   int* d_idx; float* d_d2; double* d_part; int* d_work;
   int st = nn_scratch(sc, source.n, &d_idx, &d_d2, &d_part, &d_work);
   if (st) return st;
@@ -484,10 +486,26 @@ int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const Has
   if (token == 0) token = ++sc.token;
   hipLaunchKernelGGL(fitness_final_kernel, dim3(1), dim3(256), 0, stream, d_part, sc.d_mb, token);
   LSR_HIP(hipGetLastError());
-  if ((st = wait_mailbox_word(&sc.mb.p->fit_token, token, stream, sc.wait_mode, "fitness score"))) return st;
+  sc.fit_token = token;
+  return LSR_OK;
+}
+
+int nn_fitness_end(BuildScratch& sc, hipStream_t stream, double* out) {
+  if (sc.fit_token == 0) { set_last_error("fitness score collected before it was enqueued"); return LSR_ERR_HIP; }
+  const unsigned int token = sc.fit_token;
+  sc.fit_token = 0;
+  int st = wait_mailbox_word(&sc.mb.p->fit_token, token, stream, sc.wait_mode, "fitness score");
+  if (st) return st;
   const double sum = sc.mb.p->fit_sum, cnt = sc.mb.p->fit_cnt;
   *out = (cnt > 0) ? sum / cnt : 1.7976931348623157e308;  // std::numeric_limits<double>::max()
   return LSR_OK;
+}
+
+int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, double* out,
+                     BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream) {
+  int st = nn_fitness_begin(source, T16_host, grid, max_range, sc, d_T16, stream);
+  if (st) return st;
+  return nn_fitness_end(sc, stream, out);
 }
 
 }  // namespace lsr

@@ -14,6 +14,9 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
 // mean squared 1-NN distance of T*source in the target, over pairs with d2 <= max_range.
 int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, double* out,
                      BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream);
+int nn_fitness_begin(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, BuildScratch& sc,
+                     DevBuf<float>& d_T16, hipStream_t stream);
+int nn_fitness_end(BuildScratch& sc, hipStream_t stream, double* out);
 // Device-side entry points (results stay in HBM): 1-NN of T*q (T nullable) and k-NN of q.
 int nn_search_device(const DeviceCloud& q, const float* d_T16, const HashGridDev& grid, int fine_rings, float max_d2,
                      int* d_idx, float* d_d2, hipStream_t stream, int* d_work = nullptr);  // d_work: n + 1 ints => two-stage search

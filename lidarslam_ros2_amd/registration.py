@@ -414,6 +414,39 @@ class GeneralizedIterativeClosestPoint(Registration):
         self._n_target = _cloud_args(cloud)[2]
 
 
+def set_input_target_batch(regs: Sequence[Registration], clouds):
+    """setInputTarget of every candidate of a set with the builds overlapped on the device (lsr_set_input_target_batch;
+    graph_based_slam_component.cpp:181-227 per candidate).  regs[b] receives clouds[b]; all host arrays or all CUDA tensors."""
+    lib = capi.load()
+    B = len(regs)
+    if len(clouds) != B:
+        raise ValueError("one cloud per registration object")
+    for r, c in zip(regs, clouds):
+        _order_after_torch(r, c)
+    args = [_cloud_args(c) for c in clouds]
+    if B and (any(a[3] != args[0][3] for a in args) or any(a[1] != args[0][1] for a in args)):
+        raise ValueError("clouds must all be host or all device, with one record stride")
+    hs = (C.c_void_p * B)(*[r._h for r in regs])
+    ptrs = (C.c_void_p * B)(*[a[0] for a in args])
+    counts = (C.c_size_t * B)(*[a[2] for a in args])
+    capi.check(lib.lsr_set_input_target_batch(hs, B, ptrs, counts, args[0][1] if B else 12, 1 if (B and args[0][3]) else 0),
+               "set_input_target_batch")
+    for r, a in zip(regs, args):
+        r._keep["target"] = None
+        if hasattr(r, "_n_target"):
+            r._n_target = a[2]
+
+
+def fitness_score_batch(regs: Sequence[Registration], max_range: float = 1.7976931348623157e308):
+    """getFitnessScore of every candidate of a set, all searches enqueued before the first wait (lsr_get_fitness_score_batch)."""
+    lib = capi.load()
+    B = len(regs)
+    hs = (C.c_void_p * B)(*[r._h for r in regs])
+    out = (C.c_double * max(B, 1))()
+    capi.check(lib.lsr_get_fitness_score_batch(hs, B, float(max_range), out), "fitness_score_batch")
+    return [float(out[b]) for b in range(B)]
+
+
 def align_batch(regs: Sequence[Registration], guesses=None):
     """Advance B registrations together in shared launches (BASELINE.json cfg 4).  Returns
     (finals (B,4,4) fp32, list of result dicts)."""

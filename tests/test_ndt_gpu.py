@@ -315,3 +315,51 @@ def test_wait_modes_give_the_same_result(O, case, wait_mode):
         r.align(case.guess)
     assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())
     assert a.getFinalNumIteration() == b.getFinalNumIteration()
+
+
+def test_target_batch_and_fitness_batch_equal_the_single_calls(case):
+    """lsr_set_input_target_batch / lsr_get_fitness_score_batch stage the same work as the per-object calls so that the
+    builds overlap on the device: grids, registrations and scores must be IDENTICAL to the one-at-a-time results."""
+    import torch
+
+    from lidarslam_ros2_amd import align_batch
+    from lidarslam_ros2_amd.registration import fitness_score_batch, set_input_target_batch
+
+    rng = np.random.default_rng(5)
+    B = 5
+    targets, sources, guesses = [], [], []
+    for b in range(B):   # distinct targets: a different subset of the submap each, shifted
+        keep = rng.random(case.target.shape[0]) < (0.6 + 0.08 * b)
+        shift = np.array([0.3 * b, -0.2 * b, 0.0], np.float32)
+        targets.append(synth.as_pointxyzi(case.target[keep] + shift))
+        sources.append(synth.as_pointxyzi(case.source + shift))
+        guesses.append(case.guess.copy())
+        guesses[-1][:3, 3] += shift
+    singles = []
+    for b in range(B):
+        r = make_ndt(2.0, 0.01, 40)
+        r.setInputTarget(targets[b]); r.setInputSource(sources[b]); r.align(guesses[b])
+        singles.append((r.gridDump(), r.getFinalTransformation().copy(), r.getFinalNumIteration(), r.getFitnessScore()))
+    for on_device in (False, True):
+        regs = [make_ndt(2.0, 0.01, 40) for _ in range(B)]
+        clouds = [torch.from_numpy(t).cuda() for t in targets] if on_device else targets
+        torch.cuda.synchronize()
+        set_input_target_batch(regs, clouds)
+        for b, r in enumerate(regs):
+            d = r.gridDump()
+            assert np.array_equal(d["idx"], singles[b][0]["idx"]) and np.array_equal(d["n"], singles[b][0]["n"])
+            assert np.array_equal(d["mean"], singles[b][0]["mean"]) and np.array_equal(d["icov"], singles[b][0]["icov"])
+            r.setInputSource(torch.from_numpy(sources[b]).cuda() if on_device else sources[b])
+        finals, results = align_batch(regs, guesses)
+        fits = fitness_score_batch(regs)
+        for b in range(B):
+            dt, ang = pose_delta(finals[b], singles[b][1])
+            assert dt < 1e-5 and ang < 1e-6        # batch launches group the partial sums differently from a single align
+            assert results[b]["iterations"] == singles[b][2]
+            assert abs(fits[b] - regs[b].getFitnessScore()) == 0.0           # same kernels, same order
+            assert abs(fits[b] - singles[b][3]) <= 1e-6 * singles[b][3]
+    # a second batch on the same objects recycles the target buffers
+    set_input_target_batch(regs, clouds)
+    assert regs[0].gridInfo()["n_leaves"] == len(singles[0][0]["idx"])
+    with pytest.raises(Exception):
+        set_input_target_batch([regs[0], regs[0]], clouds[:2])
