@@ -218,6 +218,36 @@ __global__ __launch_bounds__(256) void gicp_cov_coop_kernel(NNGridView G, const 
   }
 }
 
+// K5, wave-cooperative form (k <= 64): one wave per point finds its k neighbours over the fine grid (coop_search) and
+// stores their indices, nearest first; gicp_cov_from_nbr_kernel then sums and regularises one point per thread — the same
+// neighbours in the same summation order as the per-thread kernel, so the covariances are bit-identical to it.
+__global__ __launch_bounds__(256) void gicp_knn_wave_kernel(NNGridView G, const float* __restrict__ px, const float* __restrict__ py,
+                                                            const float* __restrict__ pz, int n, int k, int* __restrict__ nbr) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int i = wave; i < n; i += n_waves) {
+    CoopList mine;
+    mine.d = INFINITY;
+    mine.i = INT_MAX;
+    coop_search<false>(G, px[i], py[i], pz[i], k, 2, INFINITY, -1, mine);
+    if (lane < k) nbr[(size_t)i * k + lane] = (mine.i == INT_MAX) ? -1 : mine.i;
+  }
+}
+
+__global__ __launch_bounds__(256) void gicp_cov_from_nbr_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                                const float* __restrict__ pz, int n, int k, double gicp_eps,
+                                                                const int* __restrict__ nbr, double* __restrict__ cov) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  CovSums S;
+  for (int j = 0; j < k; j++) {
+    const int o = nbr[(size_t)i * k + j];
+    if (o < 0) continue;  // cloud smaller than k (rejected on the host); keeps the kernel safe
+    S.add(px[o], py[o], pz[o]);
+  }
+  cov_finish(S, k, gicp_eps, cov + (size_t)i * 9);
+}
+
 // output = guess * input (fp32, reference order of operations)
 __global__ __launch_bounds__(256) void gicp_apply_guess_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                const float* __restrict__ z, int n, const float* __restrict__ G16,
@@ -292,6 +322,84 @@ __global__ __launch_bounds__(NN_THREADS) void gicp_corr_kernel(NNGridView G, con
     r.valid = 1;
   }
   pairs[i] = r;
+  }
+  // one atomic per wave (ballot + popcount) instead of one per matched point
+  const unsigned long long found = __ballot(r.valid != 0);
+  if (found && (threadIdx.x & 63) == (__ffsll((long long)__ballot(1)) - 1)) atomicAdd(count, __popcll(found));
+}
+
+// K6, wave-cooperative form.  Search: one wave per source point (coop_search<1-NN>), seeded with the previous outer
+// iteration's neighbour.  Pairs: one thread per point builds the Mahalanobis matrix of its correspondence.
+__global__ __launch_bounds__(256) void gicp_corr_search_kernel(NNGridView G, const float* __restrict__ ox, const float* __restrict__ oy,
+                                                               const float* __restrict__ oz, int n, const float* __restrict__ T16,
+                                                               float thr2, const float* __restrict__ tx, const float* __restrict__ ty,
+                                                               const float* __restrict__ tz, const OuterState* __restrict__ O,
+                                                               int* __restrict__ last_nn, float* __restrict__ nn_d2) {
+  const int ph = O->phase;
+  if (O->outer_done || (ph & 1)) return;  // the inner loop of this outer iteration is still running (or all is over)
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int i = wave; i < n; i += n_waves) {
+    const float a = ox[i], b = oy[i], c = oz[i];
+    const float qx = xform_rn(T16[0], T16[4], T16[8], T16[12], a, b, c);
+    const float qy = xform_rn(T16[1], T16[5], T16[9], T16[13], a, b, c);
+    const float qz = xform_rn(T16[2], T16[6], T16[10], T16[14], a, b, c);
+    CoopList mine;
+    mine.d = INFINITY;
+    mine.i = INT_MAX;
+    int fine_rings = 1;
+    const int seed = (ph > 0) ? last_nn[i] : -1;
+    if (seed >= 0) {   // usually THE neighbour again: its distance prunes the search from the first shell on (exact all the same)
+      mine.d = dist2_rn(qx, qy, qz, tx[seed], ty[seed], tz[seed]);
+      mine.i = seed;
+      fine_rings = 0;
+    }
+    coop_search<true>(G, qx, qy, qz, 1, fine_rings, thr2, -1, mine);
+    if (lane == 0) {
+      last_nn[i] = (mine.i == INT_MAX) ? -1 : mine.i;
+      nn_d2[i] = mine.d;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gicp_corr_pairs_kernel(int n, const double* __restrict__ Rm, float thr2, const double* __restrict__ C1,
+                                                              const double* __restrict__ C2, const float* __restrict__ tx,
+                                                              const float* __restrict__ ty, const float* __restrict__ tz,
+                                                              const int* __restrict__ last_nn, const float* __restrict__ nn_d2,
+                                                              PairRec* __restrict__ pairs, int* __restrict__ count, OuterState* __restrict__ O) {
+  const int ph = O->phase;
+  if (O->outer_done || (ph & 1)) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x == 0) O->corr_mark = ph;  // same value from every workgroup: tells the launches behind that the pairs are fresh
+  PairRec r;
+  r.valid = 0;
+  r.q[0] = r.q[1] = r.q[2] = 0.f;
+  for (int k = 0; k < 6; k++) r.M[k] = 0.0;
+  if (i < n) {
+    const int j = last_nn[i];
+    if (j >= 0 && nn_d2[i] < thr2) {
+      const double* c1 = C1 + (size_t)i * 9;
+      const double* c2 = C2 + (size_t)j * 9;
+      double RC[9], S[9];
+      for (int u = 0; u < 3; u++)
+        for (int v = 0; v < 3; v++) RC[u * 3 + v] = Rm[u * 3] * c1[v] + Rm[u * 3 + 1] * c1[3 + v] + Rm[u * 3 + 2] * c1[6 + v];
+      for (int u = 0; u < 3; u++)
+        for (int v = 0; v < 3; v++)
+          S[u * 3 + v] = RC[u * 3] * Rm[v * 3] + RC[u * 3 + 1] * Rm[v * 3 + 1] + RC[u * 3 + 2] * Rm[v * 3 + 2] + c2[u * 3 + v];
+      // general 3x3 inverse by cofactors (what temp.inverse() does)
+      const double k00 = S[4] * S[8] - S[5] * S[7], k01 = S[5] * S[6] - S[3] * S[8], k02 = S[3] * S[7] - S[4] * S[6];
+      const double det = S[0] * k00 + S[1] * k01 + S[2] * k02;
+      const double id = 1.0 / det;
+      r.M[0] = k00 * id;
+      r.M[1] = (S[2] * S[7] - S[1] * S[8]) * id;
+      r.M[2] = (S[1] * S[5] - S[2] * S[4]) * id;
+      r.M[3] = (S[0] * S[8] - S[2] * S[6]) * id;
+      r.M[4] = (S[2] * S[3] - S[0] * S[5]) * id;
+      r.M[5] = (S[0] * S[4] - S[1] * S[3]) * id;
+      r.q[0] = tx[j]; r.q[1] = ty[j]; r.q[2] = tz[j];
+      r.valid = 1;
+    }
+    pairs[i] = r;
   }
   // one atomic per wave (ballot + popcount) instead of one per matched point
   const unsigned long long found = __ballot(r.valid != 0);
@@ -578,6 +686,17 @@ int compute_covariances(lsr_handle_s* h, const DeviceCloud& cloud, const HashGri
   int* work = h->gicp_ws.work.p;
   const bool coop = (k <= 64);
   const int ring_cap = coop ? 2 : -1;  // k > 64 does not fit one wave: the per-thread walk finishes everything
+  if (coop && nn_coop_enabled()) {   // one wave per point, then one thread per point
+    if ((st = h->gicp_ws.work.reserve((size_t)n * k + 1))) return st;
+    int* nbr = h->gicp_ws.work.p;
+    const long threads = (long)n * 64;
+    hipLaunchKernelGGL(gicp_knn_wave_kernel, dim3((unsigned)std::min<long>((threads + 255) / 256, 1 << 20)), dim3(256), 0, h->stream,
+                       make_view(grid), cloud.x(), cloud.y(), cloud.z(), n, k, nbr);
+    hipLaunchKernelGGL(gicp_cov_from_nbr_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, cloud.x(), cloud.y(), cloud.z(), n, k,
+                       eps, nbr, cov.p);
+    LSR_HIP(hipGetLastError());
+    return LSR_OK;
+  }
   LSR_HIP(hipMemsetAsync(work, 0, sizeof(int), h->stream));
   const int spread = (n <= 65536) ? 2 : 1;   // measured on a 30k-point scan: 420 -> 384 us (4: 410, 8: 360)
   const long threads = (long)n * spread;
@@ -712,7 +831,16 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   const int spread = (n <= 65536) ? 2 : 1;
   if ((st = ws.last_nn.reserve((size_t)n + 1))) return st;
   int updates = 0;
+  const bool coop_corr = nn_coop_enabled();
+  if (coop_corr && (st = ws.nn_d2.reserve((size_t)n + 1))) return st;
   auto enqueue_group = [&](int steps) {
+    if (coop_corr) {
+      hipLaunchKernelGGL(gicp_corr_search_kernel, dim3((unsigned)(((long)n * 64 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
+                         ws.out.x(), ws.out.y(), ws.out.z(), n, d_blk->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &d_blk->out,
+                         ws.last_nn.p, ws.nn_d2.p);
+      hipLaunchKernelGGL(gicp_corr_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_blk->Rm, thr2, h->source_cov.p, t.cov.p,
+                         t.cloud.x(), t.cloud.y(), t.cloud.z(), ws.last_nn.p, ws.nn_d2.p, d_pairs, &d_blk->count, &d_blk->out);
+    } else
     hipLaunchKernelGGL(gicp_corr_kernel, dim3((unsigned)(((long)n * spread + NN_THREADS - 1) / NN_THREADS)), dim3(NN_THREADS), 0, s,
                        make_view(t.hash), ws.out.x(), ws.out.y(), ws.out.z(), n, d_blk->T16, d_blk->Rm, thr2, h->source_cov.p, t.cov.p,
                        t.cloud.x(), t.cloud.y(), t.cloud.z(), d_pairs, &d_blk->count, &d_blk->out, spread, ws.last_nn.p);

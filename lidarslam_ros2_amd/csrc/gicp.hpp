@@ -37,6 +37,7 @@ struct GicpWorkspace {
   DevBuf<int> work;              // K5: count + indices of the points deferred to the wave-cooperative search
   DevBuf<double> raw_cov;        // inspection only: sample covariances before regularisation
   DevBuf<int> last_nn;           // K6: each source point's neighbour in the previous outer iteration (search seed)
+  DevBuf<float> nn_d2;           // K6: its squared distance (search kernel -> pair kernel)
   PinBuf<GicpMailbox> mailbox;
   GicpMailbox* d_mailbox = nullptr;
   unsigned int token = 0;        // one per align

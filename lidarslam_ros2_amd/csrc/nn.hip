@@ -201,6 +201,32 @@ __global__ __launch_bounds__(NN_THREADS) void nn1_quad_kernel(NNGridView G, cons
   d2[i] = c.d2;
 }
 
+// One wave per query (coop_search over the fine grid, coarse cells when needed): the form used for scan-sized query sets.
+__global__ __launch_bounds__(256) void nn1_wave_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                       const float* __restrict__ qz, int n, const float* __restrict__ T16, int fine_rings,
+                                                       float max_d2, int* __restrict__ idx, float* __restrict__ d2) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int i = wave; i < n; i += n_waves) {
+    const float x = qx[i], y = qy[i], z = qz[i];
+    float tx = x, ty = y, tz = z;
+    if (T16) {
+      tx = xform_rn(T16[0], T16[4], T16[8], T16[12], x, y, z);
+      ty = xform_rn(T16[1], T16[5], T16[9], T16[13], x, y, z);
+      tz = xform_rn(T16[2], T16[6], T16[10], T16[14], x, y, z);
+    }
+    CoopList mine;
+    mine.d = INFINITY;
+    mine.i = INT_MAX;
+    coop_search<true>(G, tx, ty, tz, 1, fine_rings, max_d2, -1, mine);
+    if (lane == 0) {
+      const bool found = mine.i != INT_MAX;
+      idx[i] = found ? mine.i : -1;
+      d2[i] = found ? mine.d : INFINITY;
+    }
+  }
+}
+
 // tail of nn1_kernel: one wave per deferred query; same (distance, index) order, same fp32 distances => same answer
 __global__ __launch_bounds__(256) void nn1_coop_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
                                                        const float* __restrict__ qz, const float* __restrict__ T16, float max_d2,
@@ -405,6 +431,11 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
   return LSR_OK;
 }
 
+bool nn_coop_enabled() {
+  static const bool on = [] { const char* e = getenv("LSR_NN_COOP"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 int nn_search_device(const DeviceCloud& q, const float* d_T16, const HashGridDev& grid, int fine_rings, float max_d2,
                      int* d_idx, float* d_d2, hipStream_t stream, int* d_work) {
   const int n = (int)q.n;
@@ -417,6 +448,12 @@ int nn_search_device(const DeviceCloud& q, const float* d_T16, const HashGridDev
   // d_work (n + 1 ints) given: two-stage search — per-thread walk capped at two fine shells, wave-cooperative tail
   const int ring_cap = d_work ? 2 : -1;
   const int spread = (d_work && n <= 65536) ? 2 : 1;
+  if (d_work && n <= 262144 && nn_coop_enabled()) {   // small query sets (a scan): one wave per query
+    hipLaunchKernelGGL(nn1_wave_kernel, dim3((unsigned)(((long)n * 64 + 255) / 256)), dim3(256), 0, stream, make_view(grid), q.x(), q.y(),
+                       q.z(), n, d_T16, fine_rings, max_d2, d_idx, d_d2);
+    LSR_HIP(hipGetLastError());
+    return LSR_OK;
+  }
   if (d_work) LSR_HIP(hipMemsetAsync(d_work, 0, sizeof(int), stream));
   if (d_work && n <= 262144) {   // small query sets (a scan): four lanes per query
     const long threads = (long)n * 4;

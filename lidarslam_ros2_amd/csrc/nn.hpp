@@ -14,6 +14,8 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
 // mean squared 1-NN distance of T*source in the target, over pairs with d2 <= max_range.
 int nn_fitness_score(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, double* out,
                      BuildScratch& sc, DevBuf<float>& d_T16, hipStream_t stream);
+// A/B switch for the wave-cooperative searches (env LSR_NN_COOP=0 selects the per-thread walks); read once.
+bool nn_coop_enabled();
 int nn_fitness_begin(const DeviceCloud& source, const float* T16_host, const HashGridDev& grid, double max_range, BuildScratch& sc,
                      DevBuf<float>& d_T16, hipStream_t stream);
 int nn_fitness_end(BuildScratch& sc, hipStream_t stream, double* out);

@@ -505,6 +505,174 @@ __device__ __forceinline__ void coop_knn(const NNGridView& G, float qx, float qy
     if ((worst_i != INT_MAX && worst <= loc2) || loc2 > max_d2) return;
   }
 }
+// ---- wave-cooperative exact k-NN over the FINE grid (k <= 64; k == 1 has its own list-free form) ------------------
+// One 64-lane wave per query.  The per-thread walk (nn_query) is a chain of dependent loads that one lane drags its wave
+// through, and a scan is fewer such waves than the chip has SIMDs: latency bound.  Here the 64 lanes share ONE query:
+// every (row, coarse segment) of a fine shell is probed by its own lane (one round of coarse-map loads, one of
+// fine-table loads for the whole shell), the candidate ranges are laid end to end with a wave prefix sum and read 64 at a
+// time, coalesced; a shell is a handful of round trips whatever its number of cells, and a scan is 30 000 short waves:
+// throughput bound.  Same candidates, same fp32 distances, same (distance, index) order as nn_query => same answer.
+// Shells 0..NN_MAX_FINE_RINGS with the same bound test; returns false when that did not prove the result (the caller
+// finishes with coop_knn over the coarse cells, which starts afresh).
+struct FineSeg {
+  int beg, len;
+};
+
+// Slot `slot` of shell r: slot = ((row * 2 + part) * 2 + cseg); row = (dz + r) * (2r+1) + (dy + r); part = the two end
+// cells of an inner row (full rows use part 0 only); cseg = the (up to two) coarse cells an x-range of <= 9 cells touches.
+__device__ __forceinline__ FineSeg fine_segment(const NNGridView& G, const int* fq, const int* fdim, const float* q, int r, int slot,
+                                                bool full, float worst, float max_d2) {
+  FineSeg out;
+  out.beg = 0;
+  out.len = 0;
+  const int w = 2 * r + 1;
+  const unsigned magic = (r == 0) ? 65536u : (r == 1) ? 21846u : (r == 2) ? 13108u : (r == 3) ? 9363u : 7282u;  // ceil(2^16 / w)
+  const int cseg = slot & 1, part = (slot >> 1) & 1, row = slot >> 2;
+  if (row >= w * w) return out;
+  const int rz = (int)(((unsigned)row * magic) >> 16);
+  const int dz = rz - r, dy = row - rz * w - r;
+  const int z = fq[2] + dz, y = fq[1] + dy;
+  if (z < 0 || z >= fdim[2] || y < 0 || y >= fdim[1]) return out;
+  const bool full_row = (abs(dz) == r) || (abs(dy) == r);
+  if (full_row && part) return out;
+  float gyz2 = 0.f;
+  if (r > 0) {   // row pruning + x clip, exactly as in nn_query
+    const float ylo = (float)(y + G.org[1]) * G.cell, zlo = (float)(z + G.org[2]) * G.cell;
+    const float gy = fmaxf(fmaxf(ylo - q[1], q[1] - (ylo + G.cell)) - 2.0e-6f * (fabsf(q[1]) + G.cell), 0.f);
+    const float gz = fmaxf(fmaxf(zlo - q[2], q[2] - (zlo + G.cell)) - 2.0e-6f * (fabsf(q[2]) + G.cell), 0.f);
+    gyz2 = (gy * gy + gz * gz) * 0.9999f;
+    if ((full && gyz2 > worst) || gyz2 > max_d2) return out;
+  }
+  const int xs = full_row ? fq[0] - r : (part ? fq[0] + r : fq[0] - r);
+  int x0 = max(xs, 0), x1 = min(full_row ? fq[0] + r : xs, fdim[0] - 1);
+  if (r > 0 && full) row_clip_x(G, q[0], worst - gyz2, x0, x1);
+  if (x0 > x1) return out;
+  const int cx = (x0 >> 3) + cseg;
+  if (cx > (x1 >> 3)) return out;
+  const int blk = G.coarse_block[G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3)) + cx];
+  if (blk < 0) return out;
+  const int xa = max(x0, cx * 8) & 7, xb = min(x1, cx * 8 + 7) & 7;
+  const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((y & 7) << 3) | ((z & 7) << 6));
+  out.beg = fs[xa];
+  out.len = fs[xb + 1] - out.beg;
+  return out;
+}
+
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// k-th best list one entry per lane (sorted ascending in lanes 0..k-1), as in coop_knn.  K1: `mine` is the wave's best,
+// identical on every lane on return (seed it identically on every lane, or with (INFINITY, INT_MAX)).
+template <bool K1>
+__device__ __forceinline__ bool coop_fine_knn(const NNGridView& G, float qx, float qy, float qz, int k, int fine_rings, float max_d2,
+                                              int self_skip, CoopList& mine) {
+  const int lane = threadIdx.x & 63;
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return true;
+  const float fxf = floorf(qx * G.inv_cell), fyf = floorf(qy * G.inv_cell), fzf = floorf(qz * G.inv_cell);
+  if (!(fabsf(fxf) < 1.0e9f && fabsf(fyf) < 1.0e9f && fabsf(fzf) < 1.0e9f)) return true;
+  const int fq[3] = {(int)fxf - G.org[0], (int)fyf - G.org[1], (int)fzf - G.org[2]};
+  const float q[3] = {qx, qy, qz};
+  const int fdim[3] = {G.cdim[0] * 8, G.cdim[1] * 8, G.cdim[2] * 8};
+  for (int a = 0; a < 3; a++)
+    if (fq[a] + NN_MAX_FINE_RINGS < 0 || fq[a] - NN_MAX_FINE_RINGS >= fdim[a]) return false;
+  fine_rings = min(max(fine_rings, 0), NN_MAX_FINE_RINGS);
+  // wave-uniform view of the list's worst entry
+  float worst = K1 ? mine.d : INFINITY;
+  int worst_i = K1 ? mine.i : INT_MAX;
+  for (int r = 0; r <= NN_MAX_FINE_RINGS; r++) {
+    const int w = 2 * r + 1;
+    const int n_slots = 4 * w * w;
+    for (int s0 = 0; s0 < n_slots; s0 += 64) {
+      const bool full = worst_i != INT_MAX;
+      const FineSeg seg = fine_segment(G, fq, fdim, q, r, s0 + lane, full, worst, max_d2);
+      const int incl = wave_incl_scan_i(seg.len, lane);
+      const int excl = incl - seg.len;
+      const int total = __shfl(incl, 63, 64);
+      for (int t0 = 0; t0 < total; t0 += 64) {
+        const int f = t0 + lane;
+        const bool valid = f < total;
+        // the segment that holds flat position f: the largest lane whose exclusive offset is <= f
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+          const int cand = lo + step;
+          const int o = __shfl(excl, cand, 64);
+          if (o <= f) lo = cand;
+        }
+        const int sb = __shfl(seg.beg, lo, 64), so = __shfl(excl, lo, 64);
+        const float4 pt = G.p[valid ? sb + (f - so) : 0];
+        const float d = dist2_rn(qx, qy, qz, pt.x, pt.y, pt.z);
+        const int oi = __float_as_int(pt.w);
+        if (K1) {
+          if (valid && oi != self_skip && (d < mine.d || (d == mine.d && oi < mine.i))) { mine.d = d; mine.i = oi; }
+        } else {
+          const bool qual = valid && (oi != self_skip) && (d < worst || (d == worst && oi < worst_i));
+          unsigned long long mask = __ballot(qual);
+          while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const float dn = __shfl(d, src, 64);
+            const int in = __shfl(oi, src, 64);
+            if (!(dn < worst || (dn == worst && in < worst_i))) continue;
+            const unsigned long long before = __ballot(lane < k && (mine.d < dn || (mine.d == dn && mine.i < in)));
+            const int pos = __popcll(before);
+            const float up_d = __shfl_up(mine.d, 1, 64);
+            const int up_i = __shfl_up(mine.i, 1, 64);
+            if (lane < k) {
+              if (lane > pos) { mine.d = up_d; mine.i = up_i; }
+              else if (lane == pos) { mine.d = dn; mine.i = in; }
+            }
+            worst = __shfl(mine.d, k - 1, 64);
+            worst_i = __shfl(mine.i, k - 1, 64);
+          }
+        }
+      }
+      if (K1) {   // merge the lanes' bests: every lane continues with the wave's best (its distance prunes the next chunk)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+          const float od = __shfl_xor(mine.d, m, 64);
+          const int oi = __shfl_xor(mine.i, m, 64);
+          if (od < mine.d || (od == mine.d && oi < mine.i)) { mine.d = od; mine.i = oi; }
+        }
+        worst = mine.d;
+        worst_i = mine.i;
+      }
+    }
+    float lo = INFINITY;
+    for (int a = 0; a < 3; a++) {
+      const float base = (float)(fq[a] + G.org[a]) * G.cell;
+      lo = fminf(lo, fminf(q[a] - (base - (float)r * G.cell), (base + (float)(r + 1) * G.cell) - q[a]));
+    }
+    lo = fmaxf(lo, 0.f);
+    const float lo2 = lo * lo * 0.9999f;
+    if (r >= fine_rings && ((worst_i != INT_MAX && worst <= lo2) || lo2 > max_d2)) return true;
+  }
+  return false;
+}
+
+// Exact k-NN of one query by one wave: fine shells first, coarse cells when they do not prove the result.
+template <bool K1>
+__device__ __forceinline__ void coop_search(const NNGridView& G, float qx, float qy, float qz, int k, int fine_rings, float max_d2,
+                                            int self_skip, CoopList& mine) {
+  const CoopList seed = mine;
+  if (coop_fine_knn<K1>(G, qx, qy, qz, k, fine_rings, max_d2, self_skip, mine)) return;
+  coop_knn(G, qx, qy, qz, k, max_d2, self_skip, mine);   // starts afresh (it visits every cell itself)
+  if (K1) {
+    // coop_knn keeps the list in lane 0..k-1; hand the best (and a seed that beats it) to every lane
+    float d = __shfl(mine.d, 0, 64);
+    int i = __shfl(mine.i, 0, 64);
+    if (seed.i != INT_MAX && (seed.d < d || (seed.d == d && seed.i < i))) { d = seed.d; i = seed.i; }
+    mine.d = d;
+    mine.i = i;
+  }
+}
+
 #endif  // LSR_HOST_EMU
 
 
