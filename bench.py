@@ -587,6 +587,27 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
            "iterations_rank0": [int(recs[(cands[0][0] if use_rccl else 0) + b].iterations) for b in range(nloc)],
            "what": "per candidate: setInputTarget (661k-pt submap -> voxel grid) + setInputSource + align (max_iterations 100, eps 0.01) + "
                    "getFitnessScore; all candidates of a rank advance in shared launches (lsr_align_batch)"}
+    # every candidate rank 0 holds a record for, against the committed CPU-oracle fixture (tests/golden/make_cfg4_fixture.py)
+    fx_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "cfg4_candidates_oracle.npz")
+    if os.path.exists(fx_path) and nloc:
+        fx = np.load(fx_path)
+        first = cands[0][0]
+        idxs = list(range(n_total)) if use_rccl else [first + b for b in range(nloc)]
+        dts, angs, fits, it_equal = [], [], [], True
+        for c in idxs:
+            if c >= fx["final"].shape[0]:
+                continue
+            rr = recs[c if use_rccl else c - first]
+            T = np.eye(4); T[:3, :4] = np.asarray(rr.T, np.float64).reshape(3, 4)
+            dt, ang = pose_delta(T, fx["final"][c])
+            dts.append(dt); angs.append(ang)
+            it_equal = it_equal and int(rr.iterations) == int(fx["iterations"][c])
+            fits.append(abs(float(rr.fitness) - float(fx["fitness"][c])) / float(fx["fitness"][c]))
+        if dts:
+            res["vs_cpu_oracle_fixture"] = {"candidates_checked": len(dts), "max_translation_m": float(max(dts)),
+                                            "max_rotation_rad": float(max(angs)), "newton_iterations_all_equal": bool(it_equal),
+                                            "max_fitness_rel_diff": float(max(fits)),
+                                            "fixture": "tests/golden/cfg4_candidates_oracle.npz (CPU oracle, all 64 candidates)"}
     if t_serial is not None:
         res["serial_one_by_one"] = {"value": n_total / t_serial, "unit": "registrations/s", "ms_per_candidate_set": 1e3 * t_serial}
     return res

@@ -76,12 +76,13 @@ typedef enum lsr_key {
                                          1 = compact global table, 2 = whole table staged in LDS (when it fits) */
   LSR_GRID_BUILDER = 42,              /* 0 = automatic (counting sort for <= 16383 grid cells, radix sort beyond), 1 = always
                                          the radix-sort builder */
-  LSR_NDT_QUAD = 44,                  /* single NDT registrations: 1 = four lanes per source point on every CU with exact
-                                         integer-binned accumulation, 0 = one lane per point with partial rows, -1 = automatic */
-  LSR_WAIT_MODE = 43                  /* how the calling thread waits for the device inside align() / setInputTarget():
+  LSR_WAIT_MODE = 43,                 /* how the calling thread waits for the device inside align() / setInputTarget():
                                          0 = spin (lowest latency, pins one core per running call), 1 = sched_yield between
                                          polls, 2 = sleep 20 us between polls (a ROS2 MultiThreadedExecutor runs two
-                                         registration objects side by side, lidarslam/src/lidarslam.cpp:12-17) */
+                                         registration objects side by side, lidarslam/src/lidarslam.cpp:12-17).
+                                         Environment preset: LSR_WAIT_MODE=spin|yield|sleep (or 0|1|2) */
+  LSR_NDT_QUAD = 44                   /* single NDT registrations: 1 = four lanes per source point on every CU with exact
+                                         integer-binned accumulation, 0 = one lane per point with partial rows, -1 = automatic */
 } lsr_key;
 
 typedef struct lsr_result {

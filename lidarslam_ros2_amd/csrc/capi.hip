@@ -409,7 +409,11 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) h->ndt_threads = v; }
   if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 2) h->ndt_table_mode = v; }
   if (const char* e = std::getenv("LSR_NDT_QUAD")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_quad = v; }
-  if (const char* e = std::getenv("LSR_WAIT_MODE")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->scratch.wait_mode = v; }
+  if (const char* e = std::getenv("LSR_WAIT_MODE")) {   // 0 | 1 | 2 or spin | yield | sleep
+    const std::string w(e);
+    const int v = (w == "spin") ? 0 : (w == "yield") ? 1 : (w == "sleep") ? 2 : (w.size() == 1 && w[0] >= '0' && w[0] <= '2') ? w[0] - '0' : -1;
+    if (v >= 0) h->scratch.wait_mode = v;
+  }
   if (const char* e = std::getenv("LSR_GRID_BUILDER")) { h->scratch.force_sort_path = (std::atoi(e) == 1); }
   if (stream) {
     h->stream = (hipStream_t)stream;

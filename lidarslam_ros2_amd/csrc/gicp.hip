@@ -18,6 +18,12 @@ namespace lsr {
 
 using namespace nnd;
 
+// A/B switch (env LSR_GICP_FUSED=0 selects the accumulate + update launch pairs); read once.
+static bool gicp_fused_enabled() {
+  static const bool on = [] { const char* e = getenv("LSR_GICP_FUSED"); return !(e && e[0] == '0'); }();
+  return on && nn_coop_enabled();
+}
+
 namespace {
 
 constexpr int GN_THREADS = 256;
@@ -66,7 +72,8 @@ struct IterBlock {    // uploaded once per align
   double Rm[9];       // rotation of transformation_ * guess, fp64
   OuterState out;
   int count;          // pairs found by the correspondence pass
-  int pad[3];
+  int have_partials;  // fused chain: the previous step left partial rows at the current x (to be consumed by the next step)
+  int pad[2];
 };
 
 __host__ __device__ inline void gn_apply_state(GnState& S) {
@@ -673,6 +680,214 @@ __global__ __launch_bounds__(256) void gicp_update_kernel(IterBlock* __restrict_
   __hip_atomic_store(&mb->progress, progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- fused Gauss-Newton chain ("pull", as the NDT chain): step s first consumes what step s-1 accumulated — every
+// workgroup, redundantly and deterministically, on an LDS copy of the iteration block: fixed-order sum of the partial rows,
+// gradient test, 6x6 solve, state update, and at the end of an inner loop the reference's outer bookkeeping — then
+// accumulates its share of the pairs at the NEW state.  One launch per inner iteration instead of two (accumulate, update),
+// and no single-workgroup launch on the critical path.  The block is double buffered by step parity (step s reads
+// blk[s & 1], workgroup 0 writes blk[(s + 1) & 1]); the correspondence launches between steps s-1 and s work on blk[s & 1].
+// Returns true when this launch has pairs to accumulate at the state it leaves in B.
+__device__ bool gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb, unsigned int token, bool publish) {
+  GnState* S = &Bk.st;
+  OuterState* O = &Bk.out;
+  if (!Bk.have_partials) {
+    // first step of this outer iteration: the correspondence pass has just run, adopt its pair count
+    O->phase = O->phase + 1;
+    S->m = Bk.count;
+    if (S->m >= 4) {   // (fewer: the reference's NotEnoughPointsException — x is left alone, the outer loop ends below)
+      Bk.have_partials = 1;
+      return true;      // evaluate at the start x
+    }
+  } else {
+    const double m = (double)S->m;
+    double g[6], H[36];
+    S->f = s_sum[0] / m;
+    for (int k = 0; k < 6; k++) g[k] = 2.0 * s_sum[1 + k] / m;
+    int idx = 7;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) {
+        H[i * 6 + j] = H[j * 6 + i] = 2.0 * s_sum[idx] / m;
+        idx++;
+      }
+    double gn = 0;
+    for (int k = 0; k < 6; k++) gn += g[k] * g[k];
+    gn = sqrt(gn);
+    S->gnorm = gn;
+    if (!(gn < 1e-2 || S->inner_iter >= S->max_inner || !(gn == gn))) {  // else BFGS testGradient(1e-2) / max_inner_iterations_: loop over
+      double neg[6], dx[6];
+      for (int k = 0; k < 6; k++) neg[k] = -g[k];
+      solve6_gn(H, neg, dx);
+      for (int k = 0; k < 6; k++) S->x[k] += dx[k];
+      S->inner_iter++;
+      gn_apply_state(*S);
+      return true;      // evaluate at the new x
+    }
+  }
+  // ---- the inner loop of this outer iteration has ended: the reference's outer bookkeeping
+  Bk.have_partials = 0;
+  bool stop = false;
+  O->last_cnt = S->m;
+  if (S->m < 4) {
+    stop = true;  // NotEnoughPointsException is caught, the loop is left unconverged
+  } else {
+    O->gn_steps += S->inner_iter;
+    O->last_cost = S->f;
+    if (!(S->gnorm == S->gnorm)) {
+      stop = true;  // NaN: the reference's solver exception path
+    } else {
+      GnState tmp = *S;  // transformation_ = applyState(identity, x)
+      gn_apply_state(tmp);
+      float* tr = O->trans;
+      tr[0] = tmp.T[0]; tr[4] = tmp.T[1]; tr[8] = tmp.T[2];  tr[12] = tmp.T[3];
+      tr[1] = tmp.T[4]; tr[5] = tmp.T[5]; tr[9] = tmp.T[6];  tr[13] = tmp.T[7];
+      tr[2] = tmp.T[8]; tr[6] = tmp.T[9]; tr[10] = tmp.T[10]; tr[14] = tmp.T[11];
+      tr[3] = tr[7] = tr[11] = 0.f; tr[15] = 1.f;
+      double delta = 0;
+      for (int k = 0; k < 4; k++)
+        for (int l = 0; l < 4; l++) {
+          const double ratio = (k < 3 && l < 3) ? 1. / O->rot_eps : 1. / O->trans_eps;
+          const double c_delta = ratio * fabs((double)O->prev[l * 4 + k] - (double)tr[l * 4 + k]);
+          if (c_delta > delta) delta = c_delta;
+        }
+      O->nr_iterations++;
+      if (O->nr_iterations >= O->max_iterations || delta < 1) {
+        O->converged = 1;
+        for (int k = 0; k < 16; k++) O->prev[k] = tr[k];
+        stop = true;
+      }
+    }
+  }
+  if (stop) {
+    O->outer_done = 1;
+    if (publish) {
+      mat4_mul_cm(O->prev, O->G, mb->final_T);  // final_transformation_ = previous_transformation_ * guess
+      mb->converged = O->converged;
+      mb->nr_iterations = O->nr_iterations;
+      mb->last_cnt = O->last_cnt;
+      mb->gn_steps = O->gn_steps;
+      mb->last_cost = O->last_cost;
+      __threadfence_system();
+      __hip_atomic_store(&mb->done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  } else {
+    gicp_begin_outer(Bk);
+    O->phase = (O->phase | 1) + 1;  // next even phase: the correspondence pass of the next outer iteration
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gicp_step_kernel(IterBlock* __restrict__ blk2, int step, const float* __restrict__ ox,
+                                                               const float* __restrict__ oy, const float* __restrict__ oz, int n,
+                                                               const PairRec* __restrict__ pairs, double* __restrict__ partials2,
+                                                               int nblocks, GicpMailbox* mb, unsigned int token, int launch_index) {
+  static_assert(sizeof(IterBlock) % 8 == 0, "IterBlock is copied as 8-byte words");
+  __shared__ __attribute__((aligned(16))) unsigned long long s_raw[sizeof(IterBlock) / 8];
+  __shared__ double s_grp[8][32];
+  __shared__ double s_sum[32];
+  __shared__ double s_red[GN_THREADS / 64][GN_NRED];
+  __shared__ int s_do;
+  IterBlock& Bk = *reinterpret_cast<IterBlock*>(s_raw);
+  const int t = threadIdx.x;
+  constexpr int NW = (int)(sizeof(IterBlock) / 8);
+  {
+    const unsigned long long* in = reinterpret_cast<const unsigned long long*>(blk2 + (step & 1));
+    for (int w = t; w < NW; w += GN_THREADS) s_raw[w] = in[w];
+  }
+  __syncthreads();
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(blk2 + ((step + 1) & 1));
+  const unsigned long long progress = ((unsigned long long)token << 32) | (unsigned int)launch_index;
+  const int ph = Bk.out.phase;
+  if (Bk.out.outer_done || (!(ph & 1) && Bk.out.corr_mark != ph)) {  // all over, or no fresh pairs yet: carry the block forward
+    if (blockIdx.x == 0) {
+      for (int w = t; w < NW; w += GN_THREADS) out[w] = s_raw[w];
+      if (t == 0) __hip_atomic_store(&mb->progress, progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  if (Bk.have_partials) {   // rows the previous step left in the other bank: 8 groups x 32 values, fixed order
+    const double* rows = partials2 + (size_t)((step + 1) & 1) * nblocks * 32;
+    const int v = t & 31, grp = t >> 5;
+    double acc = 0.0;
+    if (v < GN_NRED)
+      for (int b = grp; b < nblocks; b += 8) acc += rows[(size_t)b * 32 + v];
+    s_grp[grp][v] = acc;
+    __syncthreads();
+    if (t < 32) {
+      double v2 = 0.0;
+      for (int g2 = 0; g2 < 8; g2++) v2 += s_grp[g2][t];
+      s_sum[t] = v2;
+    }
+  }
+  __syncthreads();
+  if (t == 0) s_do = gicp_advance(Bk, s_sum, mb, token, blockIdx.x == 0) ? 1 : 0;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int w = t; w < NW; w += GN_THREADS) out[w] = s_raw[w];
+    if (t == 0) __hip_atomic_store(&mb->progress, progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (!s_do) return;
+  // ---- accumulate at the state just left in Bk (the body of gicp_gn_kernel)
+  const GnState* S = &Bk.st;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = S->T[k];
+  double acc[GN_NRED];
+#pragma unroll
+  for (int k = 0; k < GN_NRED; k++) acc[k] = 0.0;
+  for (int i = blockIdx.x * GN_THREADS + threadIdx.x; i < n; i += gridDim.x * GN_THREADS) {
+    const PairRec r = pairs[i];
+    if (!r.valid) continue;
+    const float a = ox[i], b = oy[i], c = oz[i];
+    const float ppx = xform_rn(T[0], T[1], T[2], T[3], a, b, c);
+    const float ppy = xform_rn(T[4], T[5], T[6], T[7], a, b, c);
+    const float ppz = xform_rn(T[8], T[9], T[10], T[11], a, b, c);
+    const double res[3] = {(double)(ppx - r.q[0]), (double)(ppy - r.q[1]), (double)(ppz - r.q[2])};
+    const double p[3] = {(double)a, (double)b, (double)c};
+    const double M00 = r.M[0], M01 = r.M[1], M02 = r.M[2], M11 = r.M[3], M12 = r.M[4], M22 = r.M[5];
+    double J[3][3];  // rotation columns: dR_k * p
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double* D = S->dR + 9 * k;
+#pragma unroll
+      for (int u = 0; u < 3; u++) J[u][k] = D[u * 3] * p[0] + D[u * 3 + 1] * p[1] + D[u * 3 + 2] * p[2];
+    }
+    const double Mr0 = M00 * res[0] + M01 * res[1] + M02 * res[2];
+    const double Mr1 = M01 * res[0] + M11 * res[1] + M12 * res[2];
+    const double Mr2 = M02 * res[0] + M12 * res[1] + M22 * res[2];
+    acc[0] += res[0] * Mr0 + res[1] * Mr1 + res[2] * Mr2;
+    acc[1] += Mr0; acc[2] += Mr1; acc[3] += Mr2;
+    double MJ[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      acc[4 + k] += J[0][k] * Mr0 + J[1][k] * Mr1 + J[2][k] * Mr2;
+      MJ[0][k] = M00 * J[0][k] + M01 * J[1][k] + M02 * J[2][k];
+      MJ[1][k] = M01 * J[0][k] + M11 * J[1][k] + M12 * J[2][k];
+      MJ[2][k] = M02 * J[0][k] + M12 * J[1][k] + M22 * J[2][k];
+    }
+    acc[7] += M00; acc[8] += M01; acc[9] += M02; acc[10] += MJ[0][0]; acc[11] += MJ[0][1]; acc[12] += MJ[0][2];
+    acc[13] += M11; acc[14] += M12; acc[15] += MJ[1][0]; acc[16] += MJ[1][1]; acc[17] += MJ[1][2];
+    acc[18] += M22; acc[19] += MJ[2][0]; acc[20] += MJ[2][1]; acc[21] += MJ[2][2];
+    acc[22] += J[0][0] * MJ[0][0] + J[1][0] * MJ[1][0] + J[2][0] * MJ[2][0];
+    acc[23] += J[0][0] * MJ[0][1] + J[1][0] * MJ[1][1] + J[2][0] * MJ[2][1];
+    acc[24] += J[0][0] * MJ[0][2] + J[1][0] * MJ[1][2] + J[2][0] * MJ[2][2];
+    acc[25] += J[0][1] * MJ[0][1] + J[1][1] * MJ[1][1] + J[2][1] * MJ[2][1];
+    acc[26] += J[0][1] * MJ[0][2] + J[1][1] * MJ[1][2] + J[2][1] * MJ[2][2];
+    acc[27] += J[0][2] * MJ[0][2] + J[1][2] * MJ[1][2] + J[2][2] * MJ[2][2];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < GN_NRED; k++) {
+    const double v = wave_sum_d(acc[k]);
+    if (lane == 0) s_red[wid][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < GN_NRED) {
+    double v = s_red[0][threadIdx.x];
+    for (int w = 1; w < GN_THREADS / 64; w++) v += s_red[w][threadIdx.x];
+    partials2[(size_t)(step & 1) * nblocks * 32 + (size_t)blockIdx.x * 32 + threadIdx.x] = v;
+  }
+}
+
 int compute_covariances(lsr_handle_s* h, const DeviceCloud& cloud, const HashGridDev& grid, DevBuf<double>& cov, bool raw = false) {
   const int n = (int)cloud.n;
   const double eps = raw ? -1.0 : h->gicp.gicp_eps;
@@ -789,8 +1004,8 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   GicpWorkspace& ws = h->gicp_ws;
   if ((st = ws.out.resize(n))) return st;
   if ((st = ws.pairs.reserve((size_t)n * sizeof(PairRec)))) return st;
-  if ((st = ws.buf.reserve((size_t)nblocks * 32 + 64))) return st;
-  if ((st = ws.state.reserve(sizeof(IterBlock) + 256))) return st;
+  if ((st = ws.buf.reserve((size_t)2 * nblocks * 32 + 64))) return st;   // two banks of partial rows (fused chain)
+  if ((st = ws.state.reserve(2 * sizeof(IterBlock) + 256))) return st;   // the block is double buffered by step parity
   if ((st = ws.pin.reserve(sizeof(IterBlock) + 64))) return st;
   double* d_partials = ws.buf.p;
   IterBlock* d_blk = reinterpret_cast<IterBlock*>(ws.state.p);
@@ -833,7 +1048,22 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   int updates = 0;
   const bool coop_corr = nn_coop_enabled();
   if (coop_corr && (st = ws.nn_d2.reserve((size_t)n + 1))) return st;
+  const bool fused = gicp_fused_enabled();
   auto enqueue_group = [&](int steps) {
+    if (fused) {   // the correspondence launches work on the block the next step will read
+      IterBlock* cur = d_blk + (updates & 1);
+      hipLaunchKernelGGL(gicp_corr_search_kernel, dim3((unsigned)(((long)n * 64 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
+                         ws.out.x(), ws.out.y(), ws.out.z(), n, cur->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &cur->out,
+                         ws.last_nn.p, ws.nn_d2.p);
+      hipLaunchKernelGGL(gicp_corr_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cur->Rm, thr2, h->source_cov.p, t.cov.p,
+                         t.cloud.x(), t.cloud.y(), t.cloud.z(), ws.last_nn.p, ws.nn_d2.p, d_pairs, &cur->count, &cur->out);
+      for (int it = 0; it < steps; it++) {
+        hipLaunchKernelGGL(gicp_step_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, d_blk, updates, ws.out.x(), ws.out.y(), ws.out.z(), n,
+                           d_pairs, d_partials, nblocks, ws.d_mailbox, token, updates + 1);
+        updates++;
+      }
+      return;
+    }
     if (coop_corr) {
       hipLaunchKernelGGL(gicp_corr_search_kernel, dim3((unsigned)(((long)n * 64 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
                          ws.out.x(), ws.out.y(), ws.out.z(), n, d_blk->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &d_blk->out,
@@ -851,8 +1081,9 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
       hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(256), 0, s, d_blk, d_partials, nblocks, ws.d_mailbox, token, updates);
     }
   };
-  // the first outer iteration typically needs 3-4 Gauss-Newton steps, later ones one or two (+ the evaluation that ends them)
-  enqueue_group(4);
+  // the first outer iteration typically needs 3-4 Gauss-Newton steps, later ones one or two; the fused chain needs one step
+  // more per outer iteration (the step that finds the loop finished accumulates nothing)
+  enqueue_group(fused ? 5 : 4);
   enqueue_group(3);
   enqueue_group(3);
   LSR_HIP(hipGetLastError());

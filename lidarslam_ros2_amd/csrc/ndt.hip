@@ -1760,17 +1760,6 @@ int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, cons
 // ===========================================================================================
 namespace {
 
-__device__ __forceinline__ unsigned int f2ord(float f) {
-  unsigned int u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-inline float ord2f(unsigned int u) {
-  unsigned int v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
-  float f;
-  std::memcpy(&f, &v, 4);
-  return f;
-}
-
 // bbox over finite points: every workgroup reduces its share and writes ONE 32-byte record {min xyz, max xyz, #finite,
 // token} straight into the host mailbox; the host folds the (<= 256) records.  No device atomics, no arrival ticket, no
 // fence, no read-back copy: cross-workgroup atomics on seven addresses cost this kernel 15-25 us, the streaming

@@ -180,3 +180,53 @@ def test_covariances_isolated_outliers_take_the_cooperative_path(O):
     ref = O.gicp_covariances(O.NearestNeighbour(pts), pts, num_threads=min(16, O.max_threads()))
     _assert_cov_close(cov, ref)
     _assert_cov_close(g.covariances("target"), ref)
+
+
+_VARIANT_CODE = r"""
+import json, sys
+import numpy as np
+from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint, synth
+c = synth.small_case(n_source=3000, n_keyframes=3)
+g = GeneralizedIterativeClosestPoint(device=0)
+g.setMaxCorrespondenceDistance(5.0)
+g.setTransformationEpsilon(1e-8)
+g.setInputTarget(c.target)
+g.setInputSource(c.source)
+g.align(c.guess)
+out = {"T": np.asarray(g.getFinalTransformation(), np.float32).tobytes().hex(), "it": int(g.getFinalNumIteration()),
+       "fit": float(g.getFitnessScore()).hex(), "cov_src": np.asarray(g.covariances("source")).tobytes().hex(),
+       "res": {k: v for k, v in g.last_result.items() if k != "gpu_ms"}}
+# far outliers: queries the fine shells cannot prove (coarse-cell search)
+src2 = np.vstack([c.source[:500], c.source[:8] + np.float32([60.0, -45.0, 9.0])]).astype(np.float32)
+g.setInputSource(src2)
+g.align(c.guess)
+out["fit_outliers"] = float(g.getFitnessScore()).hex()
+print("VARIANT " + json.dumps(out))
+"""
+
+
+def _run_variant(env_extra):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env.update(env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, "-c", _VARIANT_CODE], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("VARIANT ")][-1]
+    return json.loads(line[len("VARIANT "):])
+
+
+def test_search_and_chain_variants_give_identical_results():
+    """The wave-cooperative searches (default) against the per-thread walks (LSR_NN_COOP=0), and the fused Gauss-Newton
+    chain (default) against the accumulate + update launch pairs (LSR_GICP_FUSED=0): exact searches with one (distance, index)
+    order and the same summation orders, so covariances, correspondences, poses, iteration counts and fitness scores must
+    be bit-identical, outliers beyond the fine shells included."""
+    base = _run_variant({})
+    for env in ({"LSR_NN_COOP": "0"}, {"LSR_GICP_FUSED": "0"}):
+        other = _run_variant(env)
+        assert other == base, (env, {k: (base[k] == other[k]) for k in base})
