@@ -491,13 +491,18 @@ __global__ __launch_bounds__(GN_THREADS) void gicp_gn_kernel(const float* __rest
   }
 }
 
-// delta = H^{-1} b, Gaussian elimination with partial pivoting (registers)
+// delta = H^{-1} b, Gaussian elimination with partial pivoting (registers).  A rank-deficient J^T M J (collinear or too few
+// correspondences: some motion is unobservable) has a pivot that vanishes against the matrix' scale; the full undamped
+// step would be inf/NaN or astronomically large, so the step is dropped (delta = 0): the inner loop then ends on its
+// iteration cap with x unchanged and align() returns a finite pose (healthy systems never come near the threshold).
 __device__ void solve6_gn(const double* H, const double* b, double* x) {
   double A[6][7];
+  double scale = 0.0;
   for (int i = 0; i < 6; i++) {
-    for (int j = 0; j < 6; j++) A[i][j] = H[i * 6 + j];
+    for (int j = 0; j < 6; j++) { A[i][j] = H[i * 6 + j]; scale = fmax(scale, fabs(A[i][j])); }
     A[i][6] = b[i];
   }
+  bool singular = !(scale > 0.0) || !(scale < 1.0e300);
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     double best = fabs(A[k][k]);
@@ -507,6 +512,7 @@ __device__ void solve6_gn(const double* H, const double* b, double* x) {
       const double v = fabs(A[i][k]);
       if (v > best) { best = v; piv = i; }
     }
+    if (!(best > 1.0e-13 * scale)) singular = true;
 #pragma unroll
     for (int i = k + 1; i < 6; i++) {
       const bool sw = (piv == i);
@@ -532,6 +538,8 @@ __device__ void solve6_gn(const double* H, const double* b, double* x) {
     for (int j = k + 1; j < 6; j++) s -= A[k][j] * x[j];
     x[k] = s / A[k][k];
   }
+  if (singular)
+    for (int k = 0; k < 6; k++) x[k] = 0.0;
 }
 
 // column-major fp32 product (previous_transformation_ * guess)

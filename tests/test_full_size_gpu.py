@@ -178,3 +178,29 @@ def test_cfg5_dense_scan_matches_oracle(O, pool):
     dt, ang = pose_delta(T, ref["final"])
     assert dt <= 1e-3 and ang <= 1e-4, (dt, ang, ndt.last_result, ref["iterations"])
     assert ndt.getFinalNumIteration() == ref["iterations"]
+
+
+def test_cfg4_hard_candidates_match_the_cpu_fixture(pool):
+    """The four cfg-4 candidates on which NDT with the backend's settings stops in a local optimum (0.2 - 1.0 m from the truth):
+    the GPU path must stop in the SAME place after the SAME number of Newton iterations as the CPU oracle
+    (tests/golden/cfg4_candidates_oracle.npz, generated by tests/golden/make_cfg4_fixture.py; bench.py checks all 64)."""
+    import os
+
+    from lidarslam_ros2_amd import align_batch
+    from lidarslam_ros2_amd.registration import fitness_score_batch, set_input_target_batch
+
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_candidates_oracle.npz"))
+    hard = [11, 30, 43, 48]
+    cases = [synth.cfg_loop_candidate(c, pool=pool) for c in hard]
+    regs = [make_ndt(5.0, 0.01, 100) for _ in hard]
+    set_input_target_batch(regs, [c.target for c in cases])
+    for r, c in zip(regs, cases):
+        r.setInputSource(c.source)
+    finals, results = align_batch(regs, [c.guess for c in cases])
+    fits = fitness_score_batch(regs)
+    for k, c in enumerate(hard):
+        dt, ang = pose_delta(finals[k], fx["final"][c])
+        assert dt <= 1e-3 and ang <= 1e-4, (c, dt, ang)
+        assert results[k]["iterations"] == int(fx["iterations"][c]), c
+        assert abs(fits[k] - fx["fitness"][c]) <= 1e-4 * fx["fitness"][c], c
+        assert pose_delta(fx["final"][c], fx["truth"][c])[0] > 0.15      # these really are the local-optimum cases

@@ -230,3 +230,23 @@ def test_search_and_chain_variants_give_identical_results():
     for env in ({"LSR_NN_COOP": "0"}, {"LSR_GICP_FUSED": "0"}):
         other = _run_variant(env)
         assert other == base, (env, {k: (base[k] == other[k]) for k in base})
+
+
+def test_rank_deficient_system_returns_a_finite_pose():
+    """Collinear clouds: rotation about the line is unobservable, J^T M J is rank deficient.  The undamped Gauss-Newton
+    step of such a system is inf/NaN or astronomically large; the solver drops it: align() must come back
+    with a finite transformation and a status, never NaN and never a hang."""
+    from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
+
+    t = np.linspace(-20.0, 20.0, 400, dtype=np.float32)
+    line = np.stack([t, np.zeros_like(t), np.zeros_like(t)], axis=1)
+    src = line[::2] + np.float32([0.05, 0.0, 0.0])
+    g = GeneralizedIterativeClosestPoint(device=0)
+    g.setMaxCorrespondenceDistance(5.0)
+    g.setInputTarget(line)
+    g.setInputSource(src)
+    g.align(np.eye(4, dtype=np.float32))
+    T = g.getFinalTransformation()
+    assert np.all(np.isfinite(T)), T
+    assert np.abs(T[:3, 3]).max() < 5.0        # no astronomically large step was taken
+    assert g.getFinalNumIteration() >= 1

@@ -290,3 +290,15 @@ def test_c_abi_argument_validation_needs_no_device():
     n = C.c_int(-5)
     st = lib.lsr_device_count(C.byref(n))
     assert (st == 0 and n.value >= 0) or (st == -2 and n.value == 0)
+
+
+def test_cfg4_fixture_is_well_formed():
+    """tests/golden/cfg4_candidates_oracle.npz (CPU oracle on the 64 cfg-4 candidates; bench.py and the GPU tests compare with it)."""
+    import os
+
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_candidates_oracle.npz"))
+    assert fx["final"].shape == (64, 4, 4) and fx["iterations"].shape == (64,) and fx["fitness"].shape == (64,)
+    R = fx["final"][:, :3, :3]
+    assert np.abs(R @ np.transpose(R, (0, 2, 1)) - np.eye(3)).max() < 1e-5      # fp32-composed rotations
+    assert np.all(fx["converged"]) and fx["iterations"].min() >= 1 and fx["iterations"].max() <= 100
+    assert np.all(fx["fitness"] > 0) and np.all(np.isfinite(fx["fitness"]))
