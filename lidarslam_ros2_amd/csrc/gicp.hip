@@ -337,16 +337,125 @@ __global__ __launch_bounds__(NN_THREADS) void gicp_corr_kernel(NNGridView G, con
 
 // K6, wave-cooperative form.  Search: one wave per source point (coop_search<1-NN>), seeded with the previous outer
 // iteration's neighbour.  Pairs: one thread per point builds the Mahalanobis matrix of its correspondence.
+// Seeded form (outer iterations after the first), SIXTEEN lanes per point.  The previous neighbour's distance d is an upper
+// bound on the answer, so the answer lies in the ball of radius d around the moved point: the fine cells that ball touches
+// (at most 3 per axis, else the point goes to `work` for the general search) are ALL the search has to read — no shells,
+// no bound tests.  One row of <= 3 cells per (y, z) pair, one lane per (row, coarse segment), the candidates of the group
+// laid end to end and read 16 at a time; four points per wave.  Exact: every point at distance <= d is in one of those
+// cells (the cell index is a monotone map; the reach is padded against rounding), ties included.
+// work[0] = number of deferred points (zeroed by the pair kernel after use), work[1..] = their indices.
+__global__ __launch_bounds__(256) void gicp_corr_ball_kernel(NNGridView G, const float* __restrict__ ox, const float* __restrict__ oy,
+                                                             const float* __restrict__ oz, int n, const float* __restrict__ T16,
+                                                             float thr2, const float* __restrict__ tx, const float* __restrict__ ty,
+                                                             const float* __restrict__ tz, const OuterState* __restrict__ O,
+                                                             int* __restrict__ last_nn, float* __restrict__ nn_d2, int* __restrict__ work) {
+  const int ph = O->phase;
+  if (O->outer_done || (ph & 1) || ph == 0) return;  // the first outer iteration has no seeds: the general search does it
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 4, gl = t & 15;
+  if (i >= n) return;   // n * 16 threads: a group is never split by this test
+  const float a = ox[i], b = oy[i], c = oz[i];
+  const float q[3] = {xform_rn(T16[0], T16[4], T16[8], T16[12], a, b, c), xform_rn(T16[1], T16[5], T16[9], T16[13], a, b, c),
+                      xform_rn(T16[2], T16[6], T16[10], T16[14], a, b, c)};
+  const int seed = last_nn[i];
+  bool general = seed < 0 || !(isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]));
+  float bd = INFINITY;
+  int bi = INT_MAX;
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  if (!general) {
+    bd = dist2_rn(q[0], q[1], q[2], tx[seed], ty[seed], tz[seed]);
+    bi = seed;
+    if (!(bd < thr2)) general = true;   // the seed itself is beyond the gate: the ball would be the gate's
+  }
+  if (!general) {
+    const float root = sqrtf(bd) * 1.0001f;
+    for (int k = 0; k < 3; k++) {
+      const float reach = root + 4.0e-6f * (fabsf(q[k]) + G.cell);
+      const float fl = floorf((q[k] - reach) * G.inv_cell), fh = floorf((q[k] + reach) * G.inv_cell);
+      if (!(fabsf(fl) < 1.0e9f && fabsf(fh) < 1.0e9f)) { general = true; break; }
+      lo[k] = max((int)fl - G.org[k], 0);
+      hi[k] = min((int)fh - G.org[k], G.cdim[k] * 8 - 1);
+      if (hi[k] - lo[k] > 2) general = true;   // more than 3 cells on this axis
+    }
+  }
+  if (general) {
+    if (gl == 0) work[1 + atomicAdd(work, 1)] = i;
+    return;
+  }
+  const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;   // >= 1 unless the ball misses the grid (then no slot is valid)
+  const int n_slots = (ny > 0 && nz > 0 && hi[0] >= lo[0]) ? ny * nz * 2 : 0;
+  for (int s0 = 0; s0 < n_slots; s0 += 16) {
+    const int slot = s0 + gl;
+    int beg = 0, len = 0;
+    if (slot < n_slots) {
+      const int cseg = slot & 1, row = slot >> 1;
+      const int dz = (row >= 2 * ny) ? 2 : (row >= ny) ? 1 : 0;
+      const int y = lo[1] + (row - dz * ny), z = lo[2] + dz;
+      const int cx = (lo[0] >> 3) + cseg;
+      if (cx <= (hi[0] >> 3)) {
+        const int blk = G.coarse_block[G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3)) + cx];
+        if (blk >= 0) {
+          const int xa = max(lo[0], cx * 8) & 7, xb = min(hi[0], cx * 8 + 7) & 7;
+          const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((y & 7) << 3) | ((z & 7) << 6));
+          beg = fs[xa];
+          len = fs[xb + 1] - beg;
+        }
+      }
+    }
+    // the group's candidates end to end: inclusive scan over the 16 lanes, then 16 candidates per round
+    int incl = len;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const int v = __shfl_up(incl, d, 16);
+      if (gl >= d) incl += v;
+    }
+    const int excl = incl - len;
+    const int total = __shfl(incl, 15, 16);
+    for (int t0 = 0; t0 < total; t0 += 16) {
+      const int f = t0 + gl;
+      int sl = 0;
+#pragma unroll
+      for (int step = 8; step >= 1; step >>= 1) {
+        const int cand = sl + step;
+        const int o = __shfl(excl, cand, 16);
+        if (o <= f) sl = cand;
+      }
+      const int sb = __shfl(beg, sl, 16), so = __shfl(excl, sl, 16);
+      if (f < total) {
+        const float4 pt = G.p[sb + (f - so)];
+        const float d = dist2_rn(q[0], q[1], q[2], pt.x, pt.y, pt.z);
+        const int oi = __float_as_int(pt.w);
+        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    const float od = __shfl_xor(bd, m, 16);
+    const int oi = __shfl_xor(bi, m, 16);
+    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+  }
+  if (gl == 0) {
+    last_nn[i] = bi;
+    nn_d2[i] = bd;
+  }
+}
+
 __global__ __launch_bounds__(256) void gicp_corr_search_kernel(NNGridView G, const float* __restrict__ ox, const float* __restrict__ oy,
                                                                const float* __restrict__ oz, int n, const float* __restrict__ T16,
                                                                float thr2, const float* __restrict__ tx, const float* __restrict__ ty,
                                                                const float* __restrict__ tz, const OuterState* __restrict__ O,
-                                                               int* __restrict__ last_nn, float* __restrict__ nn_d2) {
+                                                               int* __restrict__ last_nn, float* __restrict__ nn_d2,
+                                                               const int* __restrict__ work /* nullable */) {
   const int ph = O->phase;
   if (O->outer_done || (ph & 1)) return;  // the inner loop of this outer iteration is still running (or all is over)
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
   const int lane = threadIdx.x & 63;
-  for (int i = wave; i < n; i += n_waves) {
+  // with a work list: the first outer iteration searches every point, later ones only what the seeded kernel deferred
+  const bool listed = work && ph > 0;
+  const int n_items = listed ? work[0] : n;
+  for (int w = wave; w < n_items; w += n_waves) {
+    const int i = listed ? work[1 + w] : w;
     const float a = ox[i], b = oy[i], c = oz[i];
     const float qx = xform_rn(T16[0], T16[4], T16[8], T16[12], a, b, c);
     const float qy = xform_rn(T16[1], T16[5], T16[9], T16[13], a, b, c);
@@ -373,11 +482,13 @@ __global__ __launch_bounds__(256) void gicp_corr_pairs_kernel(int n, const doubl
                                                               const double* __restrict__ C2, const float* __restrict__ tx,
                                                               const float* __restrict__ ty, const float* __restrict__ tz,
                                                               const int* __restrict__ last_nn, const float* __restrict__ nn_d2,
-                                                              PairRec* __restrict__ pairs, int* __restrict__ count, OuterState* __restrict__ O) {
+                                                              PairRec* __restrict__ pairs, int* __restrict__ count, OuterState* __restrict__ O,
+                                                              int* __restrict__ work /* nullable */) {
   const int ph = O->phase;
   if (O->outer_done || (ph & 1)) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (threadIdx.x == 0) O->corr_mark = ph;  // same value from every workgroup: tells the launches behind that the pairs are fresh
+  if (work && i == 0) work[0] = 0;          // the deferred-point list of this pass has been consumed
   PairRec r;
   r.valid = 0;
   r.q[0] = r.q[1] = r.q[2] = 0.f;
@@ -1057,14 +1168,27 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
   const bool coop_corr = nn_coop_enabled();
   if (coop_corr && (st = ws.nn_d2.reserve((size_t)n + 1))) return st;
   const bool fused = gicp_fused_enabled();
+  // seeded 16-lane search for the outer iterations after the first (env LSR_GICP_BALL=0: the general search every time)
+  static const bool ball_on = [] { const char* e = getenv("LSR_GICP_BALL"); return !(e && e[0] == '0'); }();
+  const bool ball = fused && ball_on;
+  int* d_work = nullptr;
+  if (ball) {
+    if ((st = ws.corr_work.reserve((size_t)n + 2))) return st;
+    d_work = ws.corr_work.p;
+    LSR_HIP(hipMemsetAsync(d_work, 0, sizeof(int), s));
+  }
   auto enqueue_group = [&](int steps) {
     if (fused) {   // the correspondence launches work on the block the next step will read
       IterBlock* cur = d_blk + (updates & 1);
+      if (ball)
+        hipLaunchKernelGGL(gicp_corr_ball_kernel, dim3((unsigned)(((long)n * 16 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
+                           ws.out.x(), ws.out.y(), ws.out.z(), n, cur->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &cur->out,
+                           ws.last_nn.p, ws.nn_d2.p, d_work);
       hipLaunchKernelGGL(gicp_corr_search_kernel, dim3((unsigned)(((long)n * 64 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
                          ws.out.x(), ws.out.y(), ws.out.z(), n, cur->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &cur->out,
-                         ws.last_nn.p, ws.nn_d2.p);
+                         ws.last_nn.p, ws.nn_d2.p, d_work);
       hipLaunchKernelGGL(gicp_corr_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cur->Rm, thr2, h->source_cov.p, t.cov.p,
-                         t.cloud.x(), t.cloud.y(), t.cloud.z(), ws.last_nn.p, ws.nn_d2.p, d_pairs, &cur->count, &cur->out);
+                         t.cloud.x(), t.cloud.y(), t.cloud.z(), ws.last_nn.p, ws.nn_d2.p, d_pairs, &cur->count, &cur->out, d_work);
       for (int it = 0; it < steps; it++) {
         hipLaunchKernelGGL(gicp_step_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, d_blk, updates, ws.out.x(), ws.out.y(), ws.out.z(), n,
                            d_pairs, d_partials, nblocks, ws.d_mailbox, token, updates + 1);
@@ -1075,9 +1199,9 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
     if (coop_corr) {
       hipLaunchKernelGGL(gicp_corr_search_kernel, dim3((unsigned)(((long)n * 64 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
                          ws.out.x(), ws.out.y(), ws.out.z(), n, d_blk->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &d_blk->out,
-                         ws.last_nn.p, ws.nn_d2.p);
+                         ws.last_nn.p, ws.nn_d2.p, (const int*)nullptr);
       hipLaunchKernelGGL(gicp_corr_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_blk->Rm, thr2, h->source_cov.p, t.cov.p,
-                         t.cloud.x(), t.cloud.y(), t.cloud.z(), ws.last_nn.p, ws.nn_d2.p, d_pairs, &d_blk->count, &d_blk->out);
+                         t.cloud.x(), t.cloud.y(), t.cloud.z(), ws.last_nn.p, ws.nn_d2.p, d_pairs, &d_blk->count, &d_blk->out, (int*)nullptr);
     } else
     hipLaunchKernelGGL(gicp_corr_kernel, dim3((unsigned)(((long)n * spread + NN_THREADS - 1) / NN_THREADS)), dim3(NN_THREADS), 0, s,
                        make_view(t.hash), ws.out.x(), ws.out.y(), ws.out.z(), n, d_blk->T16, d_blk->Rm, thr2, h->source_cov.p, t.cov.p,

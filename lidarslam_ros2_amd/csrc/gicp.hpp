@@ -38,6 +38,7 @@ struct GicpWorkspace {
   DevBuf<double> raw_cov;        // inspection only: sample covariances before regularisation
   DevBuf<int> last_nn;           // K6: each source point's neighbour in the previous outer iteration (search seed)
   DevBuf<float> nn_d2;           // K6: its squared distance (search kernel -> pair kernel)
+  DevBuf<int> corr_work;         // K6: [0] = count, [1..] = points the seeded search hands to the general one
   PinBuf<GicpMailbox> mailbox;
   GicpMailbox* d_mailbox = nullptr;
   unsigned int token = 0;        // one per align

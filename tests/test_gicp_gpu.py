@@ -227,7 +227,7 @@ def test_search_and_chain_variants_give_identical_results():
     order and the same summation orders, so covariances, correspondences, poses, iteration counts and fitness scores must
     be bit-identical, outliers beyond the fine shells included."""
     base = _run_variant({})
-    for env in ({"LSR_NN_COOP": "0"}, {"LSR_GICP_FUSED": "0"}):
+    for env in ({"LSR_NN_COOP": "0"}, {"LSR_GICP_FUSED": "0"}, {"LSR_GICP_BALL": "0"}):
         other = _run_variant(env)
         assert other == base, (env, {k: (base[k] == other[k]) for k in base})
 
