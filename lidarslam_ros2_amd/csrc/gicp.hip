@@ -76,9 +76,9 @@ struct IterBlock {    // uploaded once per align
   int pad[2];
 };
 
-__host__ __device__ inline void gn_apply_state(GnState& S) {
-  const float a = (float)S.x[3], b = (float)S.x[4], c = (float)S.x[5];
-  const float ca = cosf(a), sa = sinf(a), cb = cosf(b), sb = sinf(b), cc = cosf(c), sc = sinf(c);
+// f6 = {cos a, sin a, cos b, sin b, cos c, sin c} of the FLOAT angles, d6 = the same of the double angles (x[3..5])
+__host__ __device__ inline void gn_apply_state_trig(GnState& S, const float* f6, const double* d6) {
+  const float ca = f6[0], sa = f6[1], cb = f6[2], sb = f6[3], cc = f6[4], sc = f6[5];
   // A = Rz * Ry ; R = A * Rx   (float products, as Eigen::AngleAxisf chains them)
   const float a00 = cc * cb, a01 = -sc, a02 = cc * sb;
   const float a10 = sc * cb, a11 = cc, a12 = sc * sb;
@@ -87,8 +87,7 @@ __host__ __device__ inline void gn_apply_state(GnState& S) {
   S.T[4] = a10; S.T[5] = a11 * ca + a12 * sa; S.T[6] = -a11 * sa + a12 * ca;
   S.T[8] = a20; S.T[9] = a21 * ca + a22 * sa; S.T[10] = -a21 * sa + a22 * ca;
   S.T[3] = (float)S.x[0]; S.T[7] = (float)S.x[1]; S.T[11] = (float)S.x[2];
-  const double phi = S.x[3], theta = S.x[4], psi = S.x[5];
-  const double cphi = cos(phi), sphi = sin(phi), ct = cos(theta), st = sin(theta), cpsi = cos(psi), spsi = sin(psi);
+  const double cphi = d6[0], sphi = d6[1], ct = d6[2], st = d6[3], cpsi = d6[4], spsi = d6[5];
   double* A = S.dR;
   double* B = S.dR + 9;
   double* Cc = S.dR + 18;
@@ -101,6 +100,13 @@ __host__ __device__ inline void gn_apply_state(GnState& S) {
   Cc[0] = -ct * spsi; Cc[1] = -cphi * cpsi - sphi * spsi * st; Cc[2] = cpsi * sphi - cphi * spsi * st;
   Cc[3] = cpsi * ct;  Cc[4] = -cphi * spsi + cpsi * sphi * st; Cc[5] = sphi * spsi + cphi * cpsi * st;
   Cc[6] = 0; Cc[7] = 0; Cc[8] = 0;
+}
+
+__host__ __device__ inline void gn_apply_state(GnState& S) {
+  const float a = (float)S.x[3], b = (float)S.x[4], c = (float)S.x[5];
+  const float f6[6] = {cosf(a), sinf(a), cosf(b), sinf(b), cosf(c), sinf(c)};
+  const double d6[6] = {cos(S.x[3]), sin(S.x[3]), cos(S.x[4]), sin(S.x[4]), cos(S.x[5]), sin(S.x[5])};
+  gn_apply_state_trig(S, f6, d6);
 }
 
 // ---- small fp64 3x3 helpers ----------------------------------------------------------------------
@@ -667,7 +673,8 @@ __host__ __device__ inline void mat4_mul_cm(const float* A, const float* B, floa
 
 // Prepare outer iteration k: Mahalanobis rotation of (transformation_ * guess), the optimiser's start x from
 // transformation_, previous_transformation_ = transformation_ — what the top of the reference's while loop does.
-__host__ __device__ inline void gicp_begin_outer(IterBlock& B) {
+// (everything but the trigonometry of the new x: gn_apply_state() has to follow)
+__host__ __device__ inline void gicp_begin_outer_pre(IterBlock& B) {
   OuterState& O = B.out;
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
@@ -682,9 +689,13 @@ __host__ __device__ inline void gicp_begin_outer(IterBlock& B) {
   S.x[4] = asin(-(double)O.trans[2]);
   S.x[5] = atan2((double)O.trans[1], (double)O.trans[0]);
   S.f = 0; S.gnorm = 0; S.m = 0; S.inner_iter = 0; S.inner_done = 0; S.max_inner = max_inner;
-  gn_apply_state(S);
   for (int k = 0; k < 16; k++) { B.T16[k] = O.trans[k]; O.prev[k] = O.trans[k]; }
   B.count = 0;
+}
+
+__host__ __device__ inline void gicp_begin_outer(IterBlock& B) {
+  gicp_begin_outer_pre(B);
+  gn_apply_state(B.st);
 }
 
 __global__ __launch_bounds__(256) void gicp_update_kernel(IterBlock* __restrict__ B, const double* __restrict__ partials, int nblocks,
@@ -806,7 +817,7 @@ __global__ __launch_bounds__(256) void gicp_update_kernel(IterBlock* __restrict_
 // and no single-workgroup launch on the critical path.  The block is double buffered by step parity (step s reads
 // blk[s & 1], workgroup 0 writes blk[(s + 1) & 1]); the correspondence launches between steps s-1 and s work on blk[s & 1].
 // Returns true when this launch has pairs to accumulate at the state it leaves in B.
-__device__ bool gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb, unsigned int token, bool publish) {
+__device__ int gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb, unsigned int token, bool publish) {
   GnState* S = &Bk.st;
   OuterState* O = &Bk.out;
   if (!Bk.have_partials) {
@@ -815,7 +826,7 @@ __device__ bool gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb
     S->m = Bk.count;
     if (S->m >= 4) {   // (fewer: the reference's NotEnoughPointsException — x is left alone, the outer loop ends below)
       Bk.have_partials = 1;
-      return true;      // evaluate at the start x
+      return 1;         // evaluate at the start x
     }
   } else {
     const double m = (double)S->m;
@@ -838,8 +849,7 @@ __device__ bool gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb
       solve6_gn(H, neg, dx);
       for (int k = 0; k < 6; k++) S->x[k] += dx[k];
       S->inner_iter++;
-      gn_apply_state(*S);
-      return true;      // evaluate at the new x
+      return 1 | 2;     // evaluate at the new x, whose trigonometry the caller spreads over lanes
     }
   }
   // ---- the inner loop of this outer iteration has ended: the reference's outer bookkeeping
@@ -854,12 +864,11 @@ __device__ bool gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb
     if (!(S->gnorm == S->gnorm)) {
       stop = true;  // NaN: the reference's solver exception path
     } else {
-      GnState tmp = *S;  // transformation_ = applyState(identity, x)
-      gn_apply_state(tmp);
+      // transformation_ = applyState(identity, x): x has not moved since S->T was composed from it
       float* tr = O->trans;
-      tr[0] = tmp.T[0]; tr[4] = tmp.T[1]; tr[8] = tmp.T[2];  tr[12] = tmp.T[3];
-      tr[1] = tmp.T[4]; tr[5] = tmp.T[5]; tr[9] = tmp.T[6];  tr[13] = tmp.T[7];
-      tr[2] = tmp.T[8]; tr[6] = tmp.T[9]; tr[10] = tmp.T[10]; tr[14] = tmp.T[11];
+      tr[0] = S->T[0]; tr[4] = S->T[1]; tr[8] = S->T[2];  tr[12] = S->T[3];
+      tr[1] = S->T[4]; tr[5] = S->T[5]; tr[9] = S->T[6];  tr[13] = S->T[7];
+      tr[2] = S->T[8]; tr[6] = S->T[9]; tr[10] = S->T[10]; tr[14] = S->T[11];
       tr[3] = tr[7] = tr[11] = 0.f; tr[15] = 1.f;
       double delta = 0;
       for (int k = 0; k < 4; k++)
@@ -888,11 +897,11 @@ __device__ bool gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb
       __threadfence_system();
       __hip_atomic_store(&mb->done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-  } else {
-    gicp_begin_outer(Bk);
-    O->phase = (O->phase | 1) + 1;  // next even phase: the correspondence pass of the next outer iteration
+    return 0;
   }
-  return false;
+  gicp_begin_outer_pre(Bk);
+  O->phase = (O->phase | 1) + 1;  // next even phase: the correspondence pass of the next outer iteration
+  return 2;                       // nothing to accumulate, but the new start x needs its trigonometry
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gicp_step_kernel(IterBlock* __restrict__ blk2, int step, const float* __restrict__ ox,
@@ -938,13 +947,29 @@ __global__ __launch_bounds__(GN_THREADS) void gicp_step_kernel(IterBlock* __rest
     }
   }
   __syncthreads();
-  if (t == 0) s_do = gicp_advance(Bk, s_sum, mb, token, blockIdx.x == 0) ? 1 : 0;
+  __shared__ float s_f6[6];
+  __shared__ double s_d6[6];
+  if (t == 0) s_do = gicp_advance(Bk, s_sum, mb, token, blockIdx.x == 0);
   __syncthreads();
+  if (s_do & 2) {   // sin/cos of the three angles: fp32 on lanes 0..2 of wave 0, fp64 on lanes 0..2 of wave 1, side by side
+    if (t < 3) {
+      const float ang = (float)Bk.st.x[3 + t];
+      s_f6[2 * t] = cosf(ang);
+      s_f6[2 * t + 1] = sinf(ang);
+    } else if (t >= 64 && t < 67) {
+      const double ang = Bk.st.x[3 + (t - 64)];
+      s_d6[2 * (t - 64)] = cos(ang);
+      s_d6[2 * (t - 64) + 1] = sin(ang);
+    }
+    __syncthreads();
+    if (t == 0) gn_apply_state_trig(Bk.st, s_f6, s_d6);
+    __syncthreads();
+  }
   if (blockIdx.x == 0) {
     for (int w = t; w < NW; w += GN_THREADS) out[w] = s_raw[w];
     if (t == 0) __hip_atomic_store(&mb->progress, progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (!s_do) return;
+  if (!(s_do & 1)) return;
   // ---- accumulate at the state just left in Bk (the body of gicp_gn_kernel)
   const GnState* S = &Bk.st;
   float T[12];
@@ -1184,7 +1209,11 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
         hipLaunchKernelGGL(gicp_corr_ball_kernel, dim3((unsigned)(((long)n * 16 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
                            ws.out.x(), ws.out.y(), ws.out.z(), n, cur->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &cur->out,
                            ws.last_nn.p, ws.nn_d2.p, d_work);
-      hipLaunchKernelGGL(gicp_corr_search_kernel, dim3((unsigned)(((long)n * 64 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
+      // the first group is the first outer iteration (every point, one wave each); later groups only run the general search
+      // on what the seeded kernel deferred (grid-stride over the list: a small grid, not 7 500 workgroups that exit)
+      const unsigned full_grid = (unsigned)(((long)n * 64 + 255) / 256);
+      const unsigned gen_grid = (ball && updates > 0) ? std::min(full_grid, 256u) : full_grid;
+      hipLaunchKernelGGL(gicp_corr_search_kernel, dim3(gen_grid), dim3(256), 0, s, make_view(t.hash),
                          ws.out.x(), ws.out.y(), ws.out.z(), n, cur->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &cur->out,
                          ws.last_nn.p, ws.nn_d2.p, d_work);
       hipLaunchKernelGGL(gicp_corr_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cur->Rm, thr2, h->source_cov.p, t.cov.p,
