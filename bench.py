@@ -123,12 +123,29 @@ def main():
     nwork = args.workers or max(1, min(64, cores // max(1, world)))
     n_stream = max(args.stream if (extras and rank == 0) else 0, min(args.steps + args.warmup, 64))
     my_cands = list(shard_range(args.candidates, world, rank)) if extras else []
-    with mp.get_context("fork").Pool(nwork) as pool:
-        case = synth.cfg_ndt_30k(seed=0, pool=pool)                 # the 10-frame submap (same on every rank) + its own next scan
-        stream = synth.cfg_scan_stream(n_stream, seed=rank, pool=pool)   # this rank's scan stream
-        cands = pool.map(_candidate_job, my_cands, chunksize=1) if my_cands else []
-        dense = synth.cfg_dense_120k(pool=pool) if (extras and rank == 0 and world == 1) else None
-        gc = synth.cfg_gicp_30k(seed=0, pool=pool) if (extras and rank == 0 and world == 1) else None
+    # LSR_BENCH_CACHE_DIR (tools/round_profiles.sh sets it): the deterministic synthetic clouds are kept on disk so that the
+    # rocprofv3 / PMC re-runs of this command inside one GPU session do not ray-cast them again.  Nothing timed changes.
+    cache = None
+    if os.environ.get("LSR_BENCH_CACHE_DIR"):
+        cache = os.path.join(os.environ["LSR_BENCH_CACHE_DIR"],
+                             f"bench_r{rank}w{world}_s{n_stream}_c{args.candidates}_e{int(extras)}.pkl")
+    if cache and os.path.exists(cache):
+        import pickle
+        with open(cache, "rb") as f:
+            case, stream, cands, dense, gc = pickle.load(f)
+    else:
+        with mp.get_context("fork").Pool(nwork) as pool:
+            case = synth.cfg_ndt_30k(seed=0, pool=pool)                 # the 10-frame submap (same on every rank) + its own next scan
+            stream = synth.cfg_scan_stream(n_stream, seed=rank, pool=pool)   # this rank's scan stream
+            cands = pool.map(_candidate_job, my_cands, chunksize=1) if my_cands else []
+            dense = synth.cfg_dense_120k(pool=pool) if (extras and rank == 0 and world == 1) else None
+            gc = synth.cfg_gicp_30k(seed=0, pool=pool) if (extras and rank == 0 and world == 1) else None
+        if cache:
+            import pickle
+            os.makedirs(os.path.dirname(cache), exist_ok=True)
+            with open(cache + ".tmp", "wb") as f:
+                pickle.dump((case, stream, cands, dense, gc), f, protocol=4)
+            os.replace(cache + ".tmp", cache)
     t_gen = time.perf_counter() - t_gen
 
     import torch

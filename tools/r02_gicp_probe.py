@@ -4,8 +4,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multiprocessing as mp
 from lidarslam_ros2_amd import synth
-with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
-    gc = synth.cfg_gicp_30k(pool=pool)
+def _make():
+    with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
+        return synth.cfg_gicp_30k(pool=pool)
+from _cache import cached
+gc = cached("probe_cfg_gicp_30k", _make)
 import torch
 from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint
 from lidarslam_ros2_amd.posemath import pose_delta

@@ -8,6 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 P=$REPO/gpurun_out/profiles_$TAG
 rm -rf $P; mkdir -p $P
 cd $REPO
+export LSR_BENCH_CACHE_DIR=/tmp/lsr_bench_cache   # synthetic clouds ray-cast once per session (bench.py, tools/_cache.py)
 # 1. default bench run (the driver's command), JSON line kept
 timeout 900 python bench.py > $P/${TAG}_bench_final.json 2> $P/bench.err; echo "bench rc=$?"
 # 2. PMC passes on the derivative kernel -> traffic file read by bench.py

@@ -5,8 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lidarslam_ros2_amd import NormalDistributionsTransform, synth
 import multiprocessing as mp
-with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
-    case = synth.cfg_ndt_30k(pool=pool)
+def _make():
+    with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
+        return synth.cfg_ndt_30k(pool=pool)
+from _cache import cached
+case = cached("probe_cfg_ndt_30k", _make)
 tgt = torch.from_numpy(synth.as_pointxyzi(case.target)).cuda()
 torch.cuda.synchronize()
 for builder in (0, 1):

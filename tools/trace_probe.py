@@ -4,8 +4,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multiprocessing as mp
 from lidarslam_ros2_amd import synth
-with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:   # before the GPU is touched
-    case = synth.cfg_ndt_30k(pool=pool)
+def _make():
+    with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
+        return synth.cfg_ndt_30k(pool=pool)
+from _cache import cached
+case = cached("probe_cfg_ndt_30k", _make)
 from lidarslam_ros2_amd import NormalDistributionsTransform, align_batch
 ndt = NormalDistributionsTransform(0); ndt.setResolution(5.0); ndt.setTransformationEpsilon(0.0); ndt.setMaximumIterations(30)
 ndt.setInputTarget(case.target); ndt.setInputSource(case.source)
