@@ -281,22 +281,46 @@ def main():
     # ------------------------------------------------------------------------------------------------------------
     # cfg 4 (all ranks): 64 distinct candidates sharded over the ranks, one all-gather of 64-byte records
     # ------------------------------------------------------------------------------------------------------------
-    cfg4 = None
-    if extras and args.candidates > 0:
+    # ---- roofline of the dominant kernel (K3+K4 derivative pass), hipEvents around the launch chains (rank 0; before the
+    # multi-rank leg so that it is in the line whatever happens there)
+    if rank == 0:
         try:
-            cfg4 = run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, torch, synth)
-        except Exception as e:  # the headline line must still be printed
-            cfg4 = {"error": repr(e)}
+            out["roofline"] = roofline_leg(ndt, step, n_src_pts, grid)
+        except Exception as e:
+            out["roofline"] = {"error": repr(e)}
+
+    cfg4 = None
+    cfg4_hung = False
+    if extras and args.candidates > 0:
+        box = {}
+
+        def _leg():
+            try:
+                torch.cuda.set_device(dev_index)   # the current device is per thread
+                box["v"] = run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, torch, synth)
+            except Exception as e:  # the headline line must still be printed
+                box["v"] = {"error": repr(e)}
+
+        if world > 1:
+            # A rank that fails inside communicator creation leaves the others waiting in RCCL's bootstrap: the leg runs under
+            # a watchdog, and a rank whose leg does not come back prints (rank 0) / leaves without the final barrier.
+            import threading
+            th = threading.Thread(target=_leg, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("LSR_BENCH_CFG4_TIMEOUT", "240")))
+            if th.is_alive():
+                cfg4_hung = True
+                cfg4 = {"error": "the multi-rank cfg 4 leg did not finish within its watchdog time"}
+            else:
+                cfg4 = box.get("v")
+        else:
+            _leg()
+            cfg4 = box.get("v")
 
     stash = {}
     if rank == 0:
         if cfg4 is not None:
             out["cfg4_loop_batch"] = cfg4
-        # ---- roofline of the dominant kernel (K3+K4 derivative pass), hipEvents around the launch chains
-        try:
-            out["roofline"] = roofline_leg(ndt, step, n_src_pts, grid)
-        except Exception as e:
-            out["roofline"] = {"error": repr(e)}
 
         # The remaining legs are single-GPU reports: at N > 1 the other ranks would only wait for rank 0, and the CPU
         # baseline is defined at N = 1.
@@ -318,6 +342,10 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
+    if cfg4_hung:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)   # the stuck leg holds a thread inside the collective library: no orderly shutdown is possible
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

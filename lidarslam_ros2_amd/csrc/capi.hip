@@ -623,11 +623,15 @@ int lsr_set_input_target(lsr_handle h, const void* pts, size_t stride_bytes, siz
 int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const* clouds, const size_t* counts, size_t stride_bytes,
                                int on_device) {
   if (count < 0 || (count > 0 && (!handles || !clouds || !counts))) { set_last_error("bad batch arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (count == 0) return LSR_OK;
   for (int b = 0; b < count; b++) {
-    LSR_CHECK_HANDLE(handles[b]);
+    if (!handles[b]) { set_last_error("null handle"); return LSR_ERR_INVALID_ARGUMENT; }
+    if (handles[b]->device != handles[0]->device) { set_last_error("batched objects must live on one device"); return LSR_ERR_INVALID_ARGUMENT; }
     for (int a = 0; a < b; a++)
       if (handles[a] == handles[b]) { set_last_error("the same object appears twice in the batch"); return LSR_ERR_INVALID_ARGUMENT; }
   }
+  DeviceGuard guard(handles[0]->device);   // for the whole call (the stages below enqueue on every member's stream)
+  if (!guard.ok) { set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
   auto fail = [&](int st) {
     for (int b = 0; b < count; b++) {   // nothing half-built stays behind
       (void)hipStreamSynchronize(handles[b]->stream);
@@ -921,12 +925,16 @@ int lsr_get_fitness_score(lsr_handle h, double max_range, double* out) {
 int lsr_get_fitness_score_batch(lsr_handle* handles, int count, double max_range, double* out) {
   if (count < 0 || (count > 0 && (!handles || !out))) { set_last_error("bad batch arguments"); return LSR_ERR_INVALID_ARGUMENT; }
   int st;
+  if (count == 0) return LSR_OK;
   for (int b = 0; b < count; b++) {
     lsr_handle h = handles[b];
-    LSR_CHECK_HANDLE(h);
+    if (!h) { set_last_error("null handle"); return LSR_ERR_INVALID_ARGUMENT; }
+    if (h->device != handles[0]->device) { set_last_error("batched objects must live on one device"); return LSR_ERR_INVALID_ARGUMENT; }
     if (!h->target || h->target->n == 0) { set_last_error("getFitnessScore before setInputTarget"); return LSR_ERR_NO_TARGET; }
     if (!h->has_source) { set_last_error("getFitnessScore before setInputSource"); return LSR_ERR_NO_SOURCE; }
   }
+  DeviceGuard guard(handles[0]->device);
+  if (!guard.ok) { set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
   int begun = 0;
   for (; begun < count; begun++) {
     lsr_handle h = handles[begun];
