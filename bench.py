@@ -638,7 +638,7 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
         fx = np.load(fx_path)
         first = cands[0][0]
         idxs = list(range(n_total)) if use_rccl else [first + b for b in range(nloc)]
-        dts, angs, fits, it_equal = [], [], [], True
+        dts, angs, fits, it_equal, outliers = [], [], [], True, {}
         for c in idxs:
             if c >= fx["final"].shape[0]:
                 continue
@@ -646,12 +646,18 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
             T = np.eye(4); T[:3, :4] = np.asarray(rr.T, np.float64).reshape(3, 4)
             dt, ang = pose_delta(T, fx["final"][c])
             dts.append(dt); angs.append(ang)
+            if dt > 1e-3 or ang > 1e-4:
+                outliers[str(c)] = {"translation_m": float(dt), "rotation_rad": float(ang), "newton_iterations": int(rr.iterations)}
             it_equal = it_equal and int(rr.iterations) == int(fx["iterations"][c])
             fits.append(abs(float(rr.fitness) - float(fx["fitness"][c])) / float(fx["fitness"][c]))
         if dts:
             res["vs_cpu_oracle_fixture"] = {"candidates_checked": len(dts), "max_translation_m": float(max(dts)),
                                             "max_rotation_rad": float(max(angs)), "newton_iterations_all_equal": bool(it_equal),
                                             "max_fitness_rel_diff": float(max(fits)),
+                                            "within_1e-3m_1e-4rad": len(dts) - len(outliers), "beyond": outliers,
+                                            "note": "candidates 21 and 34 walk ~30 clamped 0.1 m steps along an ill-conditioned Newton direction at "
+                                                    "eps 0.01; two CPU builds of the oracle (with / without FMA contraction) differ by 1.3e-3 m on "
+                                                    "34 as well (tests/sensitivity_cfg4.py, DESIGN.md 2)",
                                             "fixture": "tests/golden/cfg4_candidates_oracle.npz (CPU oracle, all 64 candidates)"}
     if t_serial is not None:
         res["serial_one_by_one"] = {"value": n_total / t_serial, "unit": "registrations/s", "ms_per_candidate_set": 1e3 * t_serial}
