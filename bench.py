@@ -474,6 +474,13 @@ def cfg5_leg(make_ndt, dense, torch, synth):
               "avg_pass_us": avg_us, "algorithmic_bytes_per_pass": alg, "algorithmic_frac_of_hbm_peak": alg / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
               "error_vs_truth": {"translation_m": e[0], "rotation_rad": e[1]},
               "what": "cfg 5: 120000-pt 64-line scan (vg 0.1) vs 20-frame submap, ndt_resolution 2.0, transformation_epsilon 0.01"})
+    try:
+        pmc = json.load(open(PMC_FILE)).get("cfg5")
+    except Exception:
+        pmc = None
+    if pmc and pmc.get("bytes_per_launch"):
+        s.update({"traffic": int(pmc["bytes_per_launch"]), "traffic_kernel": pmc.get("kernel"),
+                  "frac_by_traffic": pmc["bytes_per_launch"] / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS})
     return s
 
 

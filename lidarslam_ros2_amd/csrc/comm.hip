@@ -98,7 +98,8 @@ int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_c
     lsr::set_last_error("communicator stream could not be created");
     return LSR_ERR_HIP;
   }
-  if (world > 1) {  // a one-rank "communicator" needs no RCCL at all
+  if (world > 1 || id128) {  // a one-rank communicator created WITHOUT an id needs no RCCL at all; with one it is a real RCCL
+                             // communicator of size 1 (the collective path can then be exercised on a single GPU)
     Rccl* r = rccl();
     if (!r) { (void)hipStreamDestroy(c->stream); delete c; lsr::set_last_error("librccl.so could not be loaded"); return LSR_ERR_NOT_IMPLEMENTED; }
     UniqueId id;
@@ -151,7 +152,7 @@ int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_cou
       for (int b = 0; b < local_count; b++) local[b].fitness = (float)fit[b];
     }
   }
-  if (c->world == 1) {
+  if (c->world == 1 && !c->comm) {
     std::memcpy(all_records, local.data(), sizeof(lsr_shard_record) * (size_t)global_count);
     return LSR_OK;
   }

@@ -156,3 +156,40 @@ def test_c_abi_sharded_batch_rccl_world2(tmp_path):
         truth = synth.small_case(n_source=2500, n_keyframes=3, seed=c).truth
         dt, ang = pose_delta(a[c, :16].reshape(4, 4), truth)
         assert dt < 0.1 and ang < 5e-3
+
+
+_RCCL1_CODE = r"""
+import numpy as np
+from lidarslam_ros2_amd import NormalDistributionsTransform, DIRECT7, synth
+from lidarslam_ros2_amd.sharding import Comm, align_batch_sharded
+def make(cases):
+    regs = []
+    for c in cases:
+        r = NormalDistributionsTransform(device=0); r.setResolution(3.0); r.setTransformationEpsilon(0.01); r.setNeighborhoodSearchMethod(DIRECT7)
+        r.setInputTarget(c.target); r.setInputSource(c.source); regs.append(r)
+    return regs
+cases = [synth.small_case(n_source=2500, n_keyframes=3, seed=c) for c in range(5)]
+plain = Comm(0, 1, 0)                        # no RCCL: records copied
+a = align_batch_sharded(plain, make(cases), len(cases), [c.guess for c in cases], with_fitness=True)
+plain.close()
+real = Comm(0, 1, 0, Comm.unique_id())       # ncclGetUniqueId + ncclCommInitRank(nranks = 1): the records go through ncclAllGather
+b = align_batch_sharded(real, make(cases), len(cases), [c.guess for c in cases], with_fitness=True)
+real.close()
+for x, y in zip(a, b):
+    assert np.array_equal(x["T"], y["T"]) and x["iterations"] == y["iterations"] and x["fitness"] == y["fitness"] and x["converged"] == y["converged"]
+print("RCCL1 OK")
+"""
+
+
+def test_c_abi_sharded_batch_through_a_real_rccl_communicator_of_one_rank():
+    """RCCL on hardware with the one GPU there is: a communicator of size 1 created from an ncclUniqueId takes the same code
+    path as N ranks (dlopen of librccl, ncclCommInitRank, ncclAllGather of the 64-byte records on the communicator's stream,
+    unpacking by lsr_shard_range) and must return what the RCCL-free one-rank communicator returns.  (Two ranks on one device
+    are refused by RCCL; the two-GPU tests above need a second device.)"""
+    import subprocess
+
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-c", _RCCL1_CODE], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0 and "RCCL1 OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

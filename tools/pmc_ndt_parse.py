@@ -43,6 +43,18 @@ if single is not None:
     if out.get("SQ_WAVE_CYCLES"):
         lines.append(f"SQ_WAIT_ANY / SQ_WAVE_CYCLES = {100 * out['SQ_WAIT_ANY'] / out['SQ_WAVE_CYCLES']:.0f} % ; "
                      f"LDS bank-conflict cycles / LDS active cycles = {100 * out.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, out.get('SQ_ACTIVE_INST_LDS', 1.0)):.1f} %")
+# the cfg-5 pass: the quad kernel with the largest grid (120 000 points x 4 lanes)
+quads = [k for k in agg if k[0] == "ndt_eval_quad_kernel" and "FETCH_SIZE" in agg[k]]
+if len(quads) > 1:
+    big = max(quads, key=lambda k: int(k[1]))
+    medb = lambda c: sorted(agg[big][c])[len(agg[big][c]) // 2] if c in agg[big] else None
+    fkb, wkb = medb("FETCH_SIZE"), medb("WRITE_SIZE") or 0.0
+    out["cfg5"] = {"kernel": f"{big[0]} grid {big[1]} x workgroup {big[2]} (single 120k-pt registration, dense global table)",
+                   "fetch_size_kb": fkb, "write_size_kb": wkb, "bytes_per_launch": int((2.0 * fkb + wkb) * 1024)}
+    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
+        if medb(c) is not None:
+            out["cfg5"][c] = medb(c)
+    lines += ["", f"HBM bytes per launch of `{out['cfg5']['kernel']}`: 2 x {fkb:.1f} KB + {wkb:.1f} KB = {out['cfg5']['bytes_per_launch'] / 1e6:.3f} MB"]
 open(os.path.join(root, f"{tag}_pmc_ndt_eval.md"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(root, "pmc_ndt_eval_latest.json"), "w"), indent=1)
 print("\n".join(lines[-6:]))
