@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void gicp_knn_wave_kernel(NNGridView G, const 
     CoopList mine;
     mine.d = INFINITY;
     mine.i = INT_MAX;
-    coop_search<false>(G, px[i], py[i], pz[i], k, 2, INFINITY, -1, mine);
+    coop_search<false>(G, px[i], py[i], pz[i], k, 1, INFINITY, -1, mine);   // bound tested from shell 1 on: dense regions never read shell 2
     if (lane < k) nbr[(size_t)i * k + lane] = (mine.i == INT_MAX) ? -1 : mine.i;
   }
 }
