@@ -84,6 +84,11 @@ typedef enum lsr_key {
   LSR_NDT_QUAD = 44                   /* single NDT registrations: 1 = four lanes per source point on every CU with exact
                                          integer-binned accumulation, 0 = one lane per point with partial rows, -1 = automatic */
 } lsr_key;
+/* Environment presets read when an object is created: LSR_NDT_WORKGROUP, LSR_NDT_TABLE_MODE, LSR_NDT_QUAD, LSR_GRID_BUILDER,
+ * LSR_WAIT_MODE (the keys above).  Diagnostic A/B switches read once per process, all with bit-identical results
+ * (tests/test_gicp_gpu.py::test_search_and_chain_variants_give_identical_results): LSR_NN_COOP=0 (per-thread neighbour
+ * walks instead of one wave per query), LSR_GICP_FUSED=0 (accumulate + update launch pairs instead of the fused
+ * Gauss-Newton step), LSR_GICP_BALL=0 (general correspondence search on every outer iteration). */
 
 typedef struct lsr_result {
   int32_t converged;            /* hasConverged()                             scanmatcher_component.cpp:375 */
