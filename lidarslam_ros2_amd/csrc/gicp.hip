@@ -373,17 +373,7 @@ __global__ __launch_bounds__(256) void gicp_corr_ball_kernel(NNGridView G, const
     bi = seed;
     if (!(bd < thr2)) general = true;   // the seed itself is beyond the gate: the ball would be the gate's
   }
-  if (!general) {
-    const float root = sqrtf(bd) * 1.0001f;
-    for (int k = 0; k < 3; k++) {
-      const float reach = root + 4.0e-6f * (fabsf(q[k]) + G.cell);
-      const float fl = floorf((q[k] - reach) * G.inv_cell), fh = floorf((q[k] + reach) * G.inv_cell);
-      if (!(fabsf(fl) < 1.0e9f && fabsf(fh) < 1.0e9f)) { general = true; break; }
-      lo[k] = max((int)fl - G.org[k], 0);
-      hi[k] = min((int)fh - G.org[k], G.cdim[k] * 8 - 1);
-      if (hi[k] - lo[k] > 2) general = true;   // more than 3 cells on this axis
-    }
-  }
+  if (!general && !ball_cell_range(G, q, bd, 3, lo, hi)) general = true;   // more than 3 cells on some axis
   if (general) {
     if (gl == 0) work[1 + atomicAdd(work, 1)] = i;
     return;

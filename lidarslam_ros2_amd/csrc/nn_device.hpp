@@ -328,6 +328,70 @@ __device__ bool nn_query(const NNGridView& G, float qx, float qy, float qz, int 
   return true;
 }
 
+// Fine cells [lo, hi] (per axis, clamped to the grid) that the ball of squared radius d2 around q touches: every point p with
+// |p - q|^2 <= d2 has its cell in that box (the cell index floorf(p * inv_cell) is a monotone map of the coordinate, and the
+// reach is padded against the rounding of q -+ reach).  false when some axis spans more than max_cells cells or the
+// numbers are out of range — the caller then uses the general search.  An empty box (lo > hi) is a valid answer.
+__device__ __forceinline__ bool ball_cell_range(const NNGridView& G, const float* q, float d2, int max_cells, int* lo, int* hi) {
+  const float root = sqrtf(d2) * 1.0001f;
+  for (int k = 0; k < 3; k++) {
+    const float reach = root + 4.0e-6f * (fabsf(q[k]) + G.cell);
+    const float fl = floorf((q[k] - reach) * G.inv_cell), fh = floorf((q[k] + reach) * G.inv_cell);
+    if (!(fabsf(fl) < 1.0e9f && fabsf(fh) < 1.0e9f)) return false;
+    lo[k] = max((int)fl - G.org[k], 0);
+    hi[k] = min((int)fh - G.org[k], G.cdim[k] * 8 - 1);
+    if (hi[k] - lo[k] > max_cells - 1) return false;
+  }
+  return true;
+}
+
+// ---- one (row, coarse segment) of a fine shell, for the wave-cooperative searches below (pure: also compiled by the host
+// emulation, tests/test_nn_host_emu_cpu.py checks that the slots of a shell cover its cells exactly once and that pruning
+// and clipping never drop a point that could matter)
+struct FineSeg {
+  int beg, len;
+};
+
+// Slot `slot` of shell r: slot = ((row * 2 + part) * 2 + cseg); row = (dz + r) * (2r+1) + (dy + r); part = the two end
+// cells of an inner row (full rows use part 0 only); cseg = the (up to two) coarse cells an x-range of <= 9 cells touches.
+__device__ __forceinline__ FineSeg fine_segment(const NNGridView& G, const int* fq, const int* fdim, const float* q, int r, int slot,
+                                                bool full, float worst, float max_d2) {
+  FineSeg out;
+  out.beg = 0;
+  out.len = 0;
+  const int w = 2 * r + 1;
+  const unsigned magic = (r == 0) ? 65536u : (r == 1) ? 21846u : (r == 2) ? 13108u : (r == 3) ? 9363u : 7282u;  // ceil(2^16 / w)
+  const int cseg = slot & 1, part = (slot >> 1) & 1, row = slot >> 2;
+  if (row >= w * w) return out;
+  const int rz = (int)(((unsigned)row * magic) >> 16);
+  const int dz = rz - r, dy = row - rz * w - r;
+  const int z = fq[2] + dz, y = fq[1] + dy;
+  if (z < 0 || z >= fdim[2] || y < 0 || y >= fdim[1]) return out;
+  const bool full_row = (abs(dz) == r) || (abs(dy) == r);
+  if (full_row && part) return out;
+  float gyz2 = 0.f;
+  if (r > 0) {   // row pruning + x clip, exactly as in nn_query
+    const float ylo = (float)(y + G.org[1]) * G.cell, zlo = (float)(z + G.org[2]) * G.cell;
+    const float gy = fmaxf(fmaxf(ylo - q[1], q[1] - (ylo + G.cell)) - 2.0e-6f * (fabsf(q[1]) + G.cell), 0.f);
+    const float gz = fmaxf(fmaxf(zlo - q[2], q[2] - (zlo + G.cell)) - 2.0e-6f * (fabsf(q[2]) + G.cell), 0.f);
+    gyz2 = (gy * gy + gz * gz) * 0.9999f;
+    if ((full && gyz2 > worst) || gyz2 > max_d2) return out;
+  }
+  const int xs = full_row ? fq[0] - r : (part ? fq[0] + r : fq[0] - r);
+  int x0 = max(xs, 0), x1 = min(full_row ? fq[0] + r : xs, fdim[0] - 1);
+  if (r > 0 && full) row_clip_x(G, q[0], worst - gyz2, x0, x1);
+  if (x0 > x1) return out;
+  const int cx = (x0 >> 3) + cseg;
+  if (cx > (x1 >> 3)) return out;
+  const int blk = G.coarse_block[G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3)) + cx];
+  if (blk < 0) return out;
+  const int xa = max(x0, cx * 8) & 7, xb = min(x1, cx * 8 + 7) & 7;
+  const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((y & 7) << 3) | ((z & 7) << 6));
+  out.beg = fs[xa];
+  out.len = fs[xb + 1] - out.beg;
+  return out;
+}
+
 #ifndef LSR_HOST_EMU   // (wave intrinsics: not part of the host emulation in tools/nn_host_emu)
 // ---- exact 1-NN on FOUR lanes per query -------------------------------------------------------------------------
 // Lanes 4p..4p+3 of a wave carry the same query (`sub` = lane & 3).  The search of one query is a chain of dependent
@@ -514,50 +578,6 @@ __device__ __forceinline__ void coop_knn(const NNGridView& G, float qx, float qy
 // throughput bound.  Same candidates, same fp32 distances, same (distance, index) order as nn_query => same answer.
 // Shells 0..NN_MAX_FINE_RINGS with the same bound test; returns false when that did not prove the result (the caller
 // finishes with coop_knn over the coarse cells, which starts afresh).
-struct FineSeg {
-  int beg, len;
-};
-
-// Slot `slot` of shell r: slot = ((row * 2 + part) * 2 + cseg); row = (dz + r) * (2r+1) + (dy + r); part = the two end
-// cells of an inner row (full rows use part 0 only); cseg = the (up to two) coarse cells an x-range of <= 9 cells touches.
-__device__ __forceinline__ FineSeg fine_segment(const NNGridView& G, const int* fq, const int* fdim, const float* q, int r, int slot,
-                                                bool full, float worst, float max_d2) {
-  FineSeg out;
-  out.beg = 0;
-  out.len = 0;
-  const int w = 2 * r + 1;
-  const unsigned magic = (r == 0) ? 65536u : (r == 1) ? 21846u : (r == 2) ? 13108u : (r == 3) ? 9363u : 7282u;  // ceil(2^16 / w)
-  const int cseg = slot & 1, part = (slot >> 1) & 1, row = slot >> 2;
-  if (row >= w * w) return out;
-  const int rz = (int)(((unsigned)row * magic) >> 16);
-  const int dz = rz - r, dy = row - rz * w - r;
-  const int z = fq[2] + dz, y = fq[1] + dy;
-  if (z < 0 || z >= fdim[2] || y < 0 || y >= fdim[1]) return out;
-  const bool full_row = (abs(dz) == r) || (abs(dy) == r);
-  if (full_row && part) return out;
-  float gyz2 = 0.f;
-  if (r > 0) {   // row pruning + x clip, exactly as in nn_query
-    const float ylo = (float)(y + G.org[1]) * G.cell, zlo = (float)(z + G.org[2]) * G.cell;
-    const float gy = fmaxf(fmaxf(ylo - q[1], q[1] - (ylo + G.cell)) - 2.0e-6f * (fabsf(q[1]) + G.cell), 0.f);
-    const float gz = fmaxf(fmaxf(zlo - q[2], q[2] - (zlo + G.cell)) - 2.0e-6f * (fabsf(q[2]) + G.cell), 0.f);
-    gyz2 = (gy * gy + gz * gz) * 0.9999f;
-    if ((full && gyz2 > worst) || gyz2 > max_d2) return out;
-  }
-  const int xs = full_row ? fq[0] - r : (part ? fq[0] + r : fq[0] - r);
-  int x0 = max(xs, 0), x1 = min(full_row ? fq[0] + r : xs, fdim[0] - 1);
-  if (r > 0 && full) row_clip_x(G, q[0], worst - gyz2, x0, x1);
-  if (x0 > x1) return out;
-  const int cx = (x0 >> 3) + cseg;
-  if (cx > (x1 >> 3)) return out;
-  const int blk = G.coarse_block[G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3)) + cx];
-  if (blk < 0) return out;
-  const int xa = max(x0, cx * 8) & 7, xb = min(x1, cx * 8 + 7) & 7;
-  const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((y & 7) << 3) | ((z & 7) << 6));
-  out.beg = fs[xa];
-  out.len = fs[xb + 1] - out.beg;
-  return out;
-}
-
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
