@@ -126,14 +126,16 @@ int lsr_get_f64(lsr_handle h, int key, double* value);
 int lsr_get_i32(lsr_handle h, int key, int* value);
 
 /* registration_->setInputTarget(cloud)   scanmatcher_component.cpp:275,307,315; graph_based_slam_component.cpp:227
- * NDT: builds the voxel-covariance grid on the device.  GICP: uploads + 20-NN covariances.
+ * NDT: builds the voxel-covariance grid on the device.  GICP: uploads and builds the neighbour-search grid; the 20-NN
+ * covariances of the target are computed by the first align() that needs them, as the reference does.
  * Host-memory (`pts` readable by the CPU) and device-memory (`pts` a HIP device pointer) forms. */
 int lsr_set_input_target(lsr_handle h, const void* pts, size_t stride_bytes, size_t n);
 int lsr_set_input_target_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n);
 /* The same for a SET of candidates — one setInputTarget per candidate submap window, graph_based_slam_component.cpp:181-227
  * (BASELINE cfg 4).  handles[b] receives clouds[b] (counts[b] records of stride_bytes; all host or all device pointers).
  * Same result per object as `count` calls of lsr_set_input_target, but the builds overlap on the device: every stage of
- * every member is enqueued (on its own object's stream) before the host waits for the first.  On error no member keeps a
+ * every member is enqueued (on its own object's stream) before the host waits for the first — objects that were created on
+ * one shared stream get the same results without the overlap.  All members on one device.  On error no member keeps a
  * target.  An object may appear only once. */
 int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const* clouds, const size_t* counts,
                                size_t stride_bytes, int on_device);
