@@ -97,6 +97,59 @@ class Registration {
     final_ = Matrix4f::Identity();
     std::memset(&last_, 0, sizeof(last_));
   }
+ public:
+  // ---- candidate sets: the loop of GraphBasedSlamComponent::searchLoop (graph_based_slam_component.cpp:181-231: per candidate
+  // setInputTarget, align, getFitnessScore) over a SET of registration objects, staged so that the candidates overlap on the
+  // device (lsr_set_input_target_batch / lsr_align_batch / lsr_get_fitness_score_batch).  Results are read from each object
+  // afterwards (getFinalTransformation, hasConverged, ...).  All objects on one device, each appearing once.
+  static bool setInputTargets(const std::vector<Registration*>& regs, const std::vector<PointCloudTargetConstPtr>& clouds) {
+    if (regs.size() != clouds.size()) return false;
+    std::vector<lsr_handle> hs;
+    std::vector<const void*> ptrs;
+    std::vector<size_t> counts;
+    for (size_t b = 0; b < regs.size(); b++) {
+      regs[b]->target_ = clouds[b];
+      hs.push_back(regs[b]->h_);
+      ptrs.push_back(clouds[b]->points.data());
+      counts.push_back(clouds[b]->points.size());
+    }
+    const int st = lsr_set_input_target_batch(hs.data(), (int)hs.size(), ptrs.data(), counts.data(), sizeof(PointTarget), 0);
+    if (st != LSR_OK) std::fprintf(stderr, "[lidarslam_reg::setInputTargets] %s: %s\n", lsr_status_string(st), lsr_last_error());
+    return st == LSR_OK;
+  }
+  // one shared launch chain for all members (NDT; GICP members are registered one after the other); `output` clouds are not
+  // materialised (both reference callers discard them)
+  static bool alignBatch(const std::vector<Registration*>& regs, const std::vector<Matrix4f>& guesses) {
+    if (regs.empty() || regs.size() != guesses.size()) return false;
+    std::vector<lsr_handle> hs;
+    std::vector<float> g(16 * regs.size()), f(16 * regs.size());
+    std::vector<lsr_result> res(regs.size());
+    for (size_t b = 0; b < regs.size(); b++) {
+      hs.push_back(regs[b]->h_);
+      std::memcpy(g.data() + 16 * b, guesses[b].m, sizeof(float) * 16);
+    }
+    const int st = lsr_align_batch(hs.data(), (int)hs.size(), g.data(), f.data(), res.data());
+    if (st != LSR_OK) {
+      std::fprintf(stderr, "[lidarslam_reg::alignBatch] %s: %s\n", lsr_status_string(st), lsr_last_error());
+      for (auto* r : regs) r->last_.converged = 0;
+      return false;
+    }
+    for (size_t b = 0; b < regs.size(); b++) {
+      std::memcpy(regs[b]->final_.m, f.data() + 16 * b, sizeof(float) * 16);
+      regs[b]->last_ = res[b];
+    }
+    return true;
+  }
+  static std::vector<double> getFitnessScores(const std::vector<Registration*>& regs, double max_range = DBL_MAX) {
+    std::vector<lsr_handle> hs;
+    for (auto* r : regs) hs.push_back(r->h_);
+    std::vector<double> out(regs.size(), DBL_MAX);
+    const int st = lsr_get_fitness_score_batch(hs.data(), (int)hs.size(), max_range, out.data());
+    if (st != LSR_OK) std::fprintf(stderr, "[lidarslam_reg::getFitnessScores] %s: %s\n", lsr_status_string(st), lsr_last_error());
+    return out;
+  }
+
+ protected:
   void check(int st, const char* where) const {
     // PCL logs errors and carries on; mirror that: report, leave the previous pose in place.
     if (st != LSR_OK) std::fprintf(stderr, "[lidarslam_reg::%s] %s: %s\n", where, lsr_status_string(st), lsr_last_error());

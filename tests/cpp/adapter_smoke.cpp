@@ -61,6 +61,45 @@ int main() {
   }
   std::printf("OUTPUT fields_ok=%d\n", fields_ok);
 
+  // A candidate set through the staged batch helpers: three objects, three shifted targets; every member must end where the
+  // same registration ends on its own (graph_based_slam_component.cpp:181-231).
+  {
+    std::vector<std::shared_ptr<NDT>> own;
+    std::vector<Reg*> regs;
+    std::vector<std::shared_ptr<const Cloud>> targets;
+    std::vector<lidarslam_reg::Matrix4f> guesses;
+    float single_t[3][3];
+    double single_fit[3];
+    for (int c = 0; c < 3; c++) {
+      auto t2 = std::make_shared<Cloud>();
+      for (const auto& p : tgt->points) t2->points.push_back({p.x + 0.05f * c, p.y - 0.03f * c, p.z, 1.f, 0, 0, 0, 0});
+      targets.push_back(t2);
+      std::shared_ptr<NDT> n(new NDT());
+      n->setResolution(5.0f); n->setTransformationEpsilon(0.01); n->setNeighborhoodSearchMethod(lidarslam_reg::DIRECT7);
+      n->setInputTarget(t2); n->setInputSource(src);
+      Cloud out1;
+      n->align(out1, lidarslam_reg::Matrix4f::Identity());
+      auto T1 = n->getFinalTransformation();
+      for (int k = 0; k < 3; k++) single_t[c][k] = T1(k, 3);
+      single_fit[c] = n->getFitnessScore();
+      std::shared_ptr<NDT> m(new NDT());
+      m->setResolution(5.0f); m->setTransformationEpsilon(0.01); m->setNeighborhoodSearchMethod(lidarslam_reg::DIRECT7);
+      m->setInputSource(src);
+      own.push_back(m);
+      regs.push_back(m.get());
+      guesses.push_back(lidarslam_reg::Matrix4f::Identity());
+    }
+    bool ok = Reg::setInputTargets(regs, targets) && Reg::alignBatch(regs, guesses);
+    const std::vector<double> fits = Reg::getFitnessScores(regs);
+    for (int c = 0; c < 3 && ok; c++) {
+      auto Tb = regs[c]->getFinalTransformation();
+      for (int k = 0; k < 3; k++)
+        if (!(std::fabs(Tb(k, 3) - single_t[c][k]) < 1e-4f)) ok = false;   // batch launches group the partial sums differently
+      if (!regs[c]->hasConverged() || !(std::fabs(fits[c] - single_fit[c]) <= 1e-4 * single_fit[c])) ok = false;
+    }
+    std::printf("BATCH ok=%d\n", ok ? 1 : 0);
+  }
+
   // searchLoop() through the C ABI: four "submaps" sharing the target cloud; the last one has
   // travelled far enough and sits next to the first, so exactly one candidate (id 0) is registered.
   std::vector<lsr_submap> sm(4);

@@ -252,6 +252,7 @@ def test_cpp_adapter_runs_the_frontend_call_sequence(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
     assert out.startswith("OK converged=1"), out
     assert "OUTPUT fields_ok=1" in out, out      # align(output): xyz transformed, intensity etc. kept (PCL semantics)
+    assert "BATCH ok=1" in out, out               # candidate set through setInputTargets / alignBatch / getFitnessScores
     assert "LOOP st=0 n=1 from=0 to=3 accepted=1" in out, out
 
 
