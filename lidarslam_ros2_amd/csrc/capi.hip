@@ -20,18 +20,6 @@ using namespace lsr;
 
 namespace {
 
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = true;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
-
 #define LSR_CHECK_HANDLE(h)                      \
   if (!(h)) {                                    \
     set_last_error("null handle");               \
@@ -69,21 +57,40 @@ int upload_cloud(lsr_handle h, const void* pts, size_t stride, size_t n, bool on
 // Workgroups per registration.  A single registration spreads one point per thread over as many CUs as
 // it can (latency); a batch wants ~4 resident workgroups per CU in total and lets every thread stride
 // over several points, which amortises the reduction and the partial-row traffic (throughput).
-int ndt_nblocks(size_t n, int batch = 1, int threads = NDT_THREADS) {
+int ndt_nblocks(size_t n, int batch = 1, int threads = NDT_THREADS, bool quad = false) {
   int nb = (int)((n + threads - 1) / threads);
   nb = std::max(1, std::min(nb, NDT_MAX_BLOCKS));
-  if (batch > 1) {
+  if (batch > 1 && !quad) {
     int per = std::max(4, (4 * 256 + batch - 1) / batch);  // the batch kernel runs 4 workgroups per CU
     nb = std::min(nb, per);
   }
   return nb;
 }
 
-void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_partials, int batch = 1, int threads = NDT_THREADS) {
+// LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock; 160 KiB on gfx950): the table modes that
+// stage into LDS are only chosen when their buffers fit, anything else reads the global table.
+int device_lds_bytes(int device) {
+  static int cached[64] = {};
+  if (device >= 0 && device < 64 && cached[device] > 0) return cached[device];
+  // one workgroup may use a CU's whole LDS on AMD hardware: the larger of the two attributes (runtimes differ in which one
+  // reports the 160 KiB of gfx950); 64 KiB when neither answers
+  int per_block = 0, per_cu = 0;
+  if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) per_block = 0;
+  if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess) per_cu = 0;
+  int v = std::max(per_block, per_cu);
+  if (v <= 0) v = 64 * 1024;
+  if (device >= 0 && device < 64) cached[device] = v;
+  return v;
+}
+constexpr int NDT_QUAD_STATIC_LDS = 32 * 1024;   // static LDS of the quad kernel next to its table / tile buffer (27 KiB + margin)
+constexpr int NDT_ROW_STATIC_LDS = 12 * 1024;    // ... of the one-lane kernel (256 threads)
+
+void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_partials, const NdtLaunchCfg& cfg) {
   const VoxelGridDev& g = h->target->grid;
-  P.sx = h->source.x(); P.sy = h->source.y(); P.sz = h->source.z();
+  const DeviceCloud& src = (cfg.tab == NDT_TAB_TILE) ? h->source_sorted : h->source;   // tile mode reads the tile-ordered copy
+  P.sx = src.x(); P.sy = src.y(); P.sz = src.z();
   P.n = (int)h->source.n;
-  P.nblocks = ndt_nblocks(h->source.n, batch, threads);
+  P.nblocks = ndt_nblocks(h->source.n, cfg.batch, cfg.threads, cfg.quad != 0);
   P.lds_image = g.lds_image.p;
   P.lds_map_bytes = g.lds_map_bytes;
   P.lds_bytes = g.lds_bytes;
@@ -93,11 +100,47 @@ void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_part
   P.mul1 = g.div_b[0];
   P.mul2 = g.div_b[0] * g.div_b[1];
   P.leaf = g.leaf;
-  P.pad = 0;
+  P.tile_bytes = (cfg.tab == NDT_TAB_TILE) ? cfg.lds_bytes : 0;
   P.st = d_state;
   P.partials = d_partials;
   P.bins = h->d_bins.p;
   P.mailbox = nullptr;
+}
+
+// Where the derivative pass reads the leaf records, and with which kernel.  grids: the batch's targets.
+//  every table fits LDS            -> NDT_TAB_LDS   (quad kernel for one registration, one-lane kernel for a batch)
+//  dense tables that do not fit    -> NDT_TAB_TILE  (quad kernel, also for batches; source ordered by voxel tile per align)
+//  tables beyond 4 Mi cells        -> NDT_TAB_COMPACT (global gathers through cell_slot)
+// table_mode: the lead object's LSR_NDT_TABLE_MODE override (-1 automatic).
+void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg) {
+  bool all_lds = true, all_dense = true;
+  int lds_max = 0;
+  for (int b = 0; b < B; b++) {
+    const VoxelGridDev& g = hs[b]->target->grid;
+    all_lds = all_lds && g.lds_bytes > 0;
+    all_dense = all_dense && g.dense;
+    lds_max = std::max(lds_max, g.lds_bytes);
+  }
+  const int lds_cap = device_lds_bytes(lead->device);
+  const int override_mode = lead->ndt_table_mode;
+  const bool want_quad_single = (B == 1 && lead->ndt_quad != 0);
+  const int static_lds = want_quad_single ? NDT_QUAD_STATIC_LDS : NDT_ROW_STATIC_LDS;
+  const int table_cap = std::min(want_quad_single ? NDT_LDS_TABLE_MAX_QUAD : NDT_LDS_TABLE_MAX, lds_cap - static_lds);
+  const bool lds_ok = all_lds && lds_max <= table_cap;
+  const bool tile_ok = all_dense && lead->ndt_quad != 0 && NDT_TILE_BYTES + NDT_QUAD_STATIC_LDS <= lds_cap;
+  int tab;
+  if (override_mode == NDT_TAB_COMPACT) tab = NDT_TAB_COMPACT;
+  else if (override_mode == NDT_TAB_DENSE && all_dense) tab = NDT_TAB_DENSE;
+  else if (override_mode == NDT_TAB_TILE && tile_ok) tab = NDT_TAB_TILE;
+  else if (override_mode == NDT_TAB_LDS && lds_ok) tab = NDT_TAB_LDS;
+  else if (lds_ok) tab = NDT_TAB_LDS;
+  else if (tile_ok) tab = NDT_TAB_TILE;
+  else tab = all_dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT;
+  cfg.tab = tab;
+  cfg.quad = (want_quad_single || tab == NDT_TAB_TILE) ? 1 : 0;
+  cfg.lds_bytes = (tab == NDT_TAB_LDS) ? lds_max : (tab == NDT_TAB_TILE ? NDT_TILE_BYTES : 0);
+  if (cfg.quad) cfg.threads = (lead->ndt_threads == 64 || lead->ndt_threads == 128) ? lead->ndt_threads : NDT_QUAD_POINTS;  // POINTS per workgroup
+  else cfg.threads = (lead->ndt_threads == 128 || lead->ndt_threads == 256) ? lead->ndt_threads : NDT_THREADS;
 }
 
 // A fresh target object — or the handle's current one recycled when nobody else holds it (lsr_share_target): its device
@@ -244,35 +287,18 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   if ((st = lead->h_state.reserve(2 * (size_t)B))) return st;
   if ((st = lead->d_prob.reserve(B))) return st;
   if ((st = lead->h_prob.reserve(B))) return st;
-  // launch geometry: where the leaf records are read from, workgroup size (lead handle's tuning keys, 0 / -1 = automatic)
+  // launch geometry: where the leaf records are read from, which kernel, workgroup size (lead handle's tuning keys, 0 / -1 = automatic)
   NdtLaunchCfg cfg;
   cfg.batch = B;
   cfg.neighborhood = lead->ndt.neighborhood;
-  cfg.threads = (lead->ndt_threads == 128 || lead->ndt_threads == 256) ? lead->ndt_threads : NDT_THREADS;
-  // single registrations run four lanes per point on every CU (quad kernel) unless the tuning key says otherwise
-  cfg.quad = (B == 1 && lead->ndt_quad != 0) ? 1 : 0;
-  if (cfg.quad) cfg.threads = (lead->ndt_threads == 64 || lead->ndt_threads == 128) ? lead->ndt_threads : NDT_QUAD_POINTS;  // POINTS per workgroup
-  {
-    bool all_lds = true, all_dense = true;
-    int lds_max = 0;
-    for (int b = 0; b < B; b++) {
-      const VoxelGridDev& g = hs[b]->target->grid;
-      all_lds = all_lds && g.lds_bytes > 0;
-      all_dense = all_dense && g.dense;
-      lds_max = std::max(lds_max, g.lds_bytes);
-    }
-    int tab = all_lds ? NDT_TAB_LDS : (all_dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT);
-    if (lead->ndt_table_mode == NDT_TAB_DENSE && all_dense) tab = NDT_TAB_DENSE;   // tuning override (only where valid)
-    if (lead->ndt_table_mode == NDT_TAB_COMPACT) tab = NDT_TAB_COMPACT;
-    if (cfg.quad && tab == NDT_TAB_LDS && lds_max > NDT_LDS_TABLE_MAX_QUAD) tab = all_dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT;
-    cfg.tab = tab;
-    cfg.lds_bytes = (tab == NDT_TAB_LDS) ? lds_max : 0;
+  choose_table_mode(lead, hs, B, cfg);
+  if (cfg.quad) {   // accumulator banks of the quad kernel, one set per member, cleared before launch 0
+    if ((st = lead->d_bins.reserve((size_t)B * NDT_NBANKS * NDT_BANK_WORDS))) return st;
   }
-  if (cfg.quad && (st = lead->d_bins.reserve((size_t)NDT_NBANKS * NDT_BANK_WORDS))) return st;  // cleared by ndt_init_single
   size_t tot_blocks = 0;
   int max_blocks = 1;
   for (int b = 0; b < B; b++) {
-    int nb = ndt_nblocks(hs[b]->source.n, B, cfg.threads);
+    int nb = ndt_nblocks(hs[b]->source.n, B, cfg.threads, cfg.quad != 0);
     tot_blocks += nb;
     max_blocks = std::max(max_blocks, nb);
   }
@@ -283,10 +309,15 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   long pts = 0;
   for (int b = 0; b < B; b++) {
     lsr_handle h = hs[b];
-    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_partials.p + 2 * blk_off * NDT_NRED, B, cfg.threads);
-    blk_off += lead->h_prob.p[b].nblocks;
     ndt_fill_initial_state(lead->h_state.p[2 * b], guesses ? guesses + 16 * b : nullptr, h->ndt, (int)h->source.n);
     lead->h_state.p[2 * b + 1] = lead->h_state.p[2 * b];
+    if (cfg.tab == NDT_TAB_TILE) {
+      // order this member's source by voxel tile of its guess-moved points (4 launches on the chain's stream)
+      if ((st = ndt_sort_source(h->source, lead->h_state.p[2 * b].T, h->target->grid, h->source_sorted, h->scratch, lead->stream))) return st;
+    }
+    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_partials.p + 2 * blk_off * NDT_NRED, cfg);
+    lead->h_prob.p[b].bins = cfg.quad ? lead->d_bins.p + (size_t)b * NDT_NBANKS * NDT_BANK_WORDS : nullptr;
+    blk_off += lead->h_prob.p[b].nblocks;
     min_evals = std::max(min_evals, ndt_min_evals(h->ndt));
     hard_cap = std::max(hard_cap, ndt_hard_cap(h->ndt));
     pts += (long)h->source.n;
@@ -311,6 +342,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     if ((st = ndt_init_single(lead->h_state.p[0], lead->d_state.p, cfg.quad ? lead->d_bins.p : nullptr, lead->stream))) return st;
   } else {
     LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
+    if (cfg.quad) LSR_HIP(hipMemsetAsync(lead->d_bins.p, 0, sizeof(long long) * (size_t)B * NDT_NBANKS * NDT_BANK_WORDS, lead->stream));
   }
   if (lead->profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   int launches = 0;
@@ -407,7 +439,7 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   h->ndt.max_iterations = 35; h->ndt.neighborhood = LSR_DIRECT7; h->ndt.d1_sign = 1;
   // tuning defaults may be preset from the environment (A/B runs without touching the caller)
   if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) h->ndt_threads = v; }
-  if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 2) h->ndt_table_mode = v; }
+  if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 3) h->ndt_table_mode = v; }
   if (const char* e = std::getenv("LSR_NDT_QUAD")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_quad = v; }
   if (const char* e = std::getenv("LSR_WAIT_MODE")) {   // 0 | 1 | 2 or spin | yield | sleep
     const std::string w(e);
@@ -502,7 +534,7 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
       if (v != 0 && v != 64 && v != 128 && v != 256) { set_last_error("NDT workgroup key must be 0 (auto), 64, 128 or 256"); return LSR_ERR_INVALID_ARGUMENT; }
       h->ndt_threads = v; return LSR_OK;
     case LSR_NDT_TABLE_MODE:
-      if (v < -1 || v > 2) { set_last_error("NDT table mode must be -1 (auto), 0 dense, 1 compact, 2 LDS"); return LSR_ERR_INVALID_ARGUMENT; }
+      if (v < -1 || v > 3) { set_last_error("NDT table mode must be -1 (auto), 0 dense, 1 compact, 2 LDS, 3 tile"); return LSR_ERR_INVALID_ARGUMENT; }
       h->ndt_table_mode = v; return LSR_OK;
     case LSR_NDT_QUAD:
       if (v < -1 || v > 1) { set_last_error("NDT quad mode must be -1 (auto), 0 or 1"); return LSR_ERR_INVALID_ARGUMENT; }
@@ -932,6 +964,9 @@ int lsr_get_fitness_score_batch(lsr_handle* handles, int count, double max_range
     if (h->device != handles[0]->device) { set_last_error("batched objects must live on one device"); return LSR_ERR_INVALID_ARGUMENT; }
     if (!h->target || h->target->n == 0) { set_last_error("getFitnessScore before setInputTarget"); return LSR_ERR_NO_TARGET; }
     if (!h->has_source) { set_last_error("getFitnessScore before setInputSource"); return LSR_ERR_NO_SOURCE; }
+    // an object's scratch, mailbox and transform buffer hold ONE reduction in flight
+    for (int a = 0; a < b; a++)
+      if (handles[a] == h) { set_last_error("the same object appears twice in the batch"); return LSR_ERR_INVALID_ARGUMENT; }
   }
   DeviceGuard guard(handles[0]->device);
   if (!guard.ok) { set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
@@ -1122,6 +1157,10 @@ int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, si
     // `h` reports the best candidate like a single registration would (getFinalTransformation / hasConverged)
     std::memcpy(h->final_T, edges[0].final_transformation, sizeof(float) * 16);
     h->converged = results[0].converged;
+    // ... but it holds NO input target afterwards: the k windows lived on the worker objects, and whatever `h` held before
+    // the call has nothing to do with the pose just stored — a later getFitnessScore() / align() on `h` must fail loudly
+    // (LSR_ERR_NO_TARGET) instead of pairing the two.  (The buffers stay with the object for the next setInputTarget.)
+    h->target.reset();
   }
   for (int e = 0; e < k_eval; e++) {
     const int id_min = cand[e].second;
@@ -1214,30 +1253,21 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
   if ((st = h->h_prob.reserve(1))) return st;
   NdtLaunchCfg cfg;
   cfg.neighborhood = h->ndt.neighborhood;
-  cfg.threads = (h->ndt_threads == 128 || h->ndt_threads == 256) ? h->ndt_threads : NDT_THREADS;
   {
-    const VoxelGridDev& g = h->target->grid;
-    cfg.tab = g.lds_bytes > 0 ? NDT_TAB_LDS : (g.dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT);
-    if (h->ndt_table_mode == NDT_TAB_DENSE && g.dense) cfg.tab = NDT_TAB_DENSE;
-    if (h->ndt_table_mode == NDT_TAB_COMPACT) cfg.tab = NDT_TAB_COMPACT;
-    cfg.lds_bytes = (cfg.tab == NDT_TAB_LDS) ? g.lds_bytes : 0;
+    lsr_handle one[1] = {h};
+    choose_table_mode(h, one, 1, cfg);
   }
-  cfg.quad = (h->ndt_quad != 0) ? 1 : 0;
   if (cfg.quad) {
-    cfg.threads = (h->ndt_threads == 64 || h->ndt_threads == 128) ? h->ndt_threads : NDT_QUAD_POINTS;
-    if (cfg.tab == NDT_TAB_LDS && cfg.lds_bytes > NDT_LDS_TABLE_MAX_QUAD) {
-      cfg.tab = h->target->grid.dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT;
-      cfg.lds_bytes = 0;
-    }
     if ((st = h->d_bins.reserve((size_t)NDT_NBANKS * NDT_BANK_WORDS))) return st;
     LSR_HIP(hipMemsetAsync(h->d_bins.p, 0, sizeof(long long) * NDT_NBANKS * NDT_BANK_WORDS, h->stream));
   }
-  int nb = ndt_nblocks(h->source.n, 1, cfg.threads);
+  int nb = ndt_nblocks(h->source.n, 1, cfg.threads, cfg.quad != 0);
   cfg.max_blocks = nb;
   if ((st = h->d_partials.reserve(2 * (size_t)nb * NDT_NRED))) return st;
-  fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p, 1, cfg.threads);
   ndt_fill_diag_state(h->h_state.p[0], p6, T16, compute_hessian, h->ndt, (int)h->source.n);
   h->h_state.p[1] = h->h_state.p[0];
+  if (cfg.tab == NDT_TAB_TILE && (st = ndt_sort_source(h->source, h->h_state.p[0].T, h->target->grid, h->source_sorted, h->scratch, h->stream))) return st;
+  fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p, cfg);
   LSR_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, sizeof(NdtProblem), hipMemcpyHostToDevice, h->stream));
   LSR_HIP(hipMemcpyAsync(h->d_state.p, h->h_state.p, 2 * sizeof(NdtState), hipMemcpyHostToDevice, h->stream));
   // launch 0 evaluates, launch 1 sums the rows into the state (PH_DIAG) -> state buffer (2 & 1) = 0

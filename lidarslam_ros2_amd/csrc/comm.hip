@@ -90,10 +90,12 @@ int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_c
   if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) { lsr::set_last_error("bad communicator arguments"); return LSR_ERR_INVALID_ARGUMENT; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) { lsr::set_last_error("no such HIP device"); return LSR_ERR_NO_DEVICE; }
+  lsr::DeviceGuard guard(device_id);   // the caller's current device is restored on every path out of here
+  if (!guard.ok) { lsr::set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
   lsr_comm c = new (std::nothrow) lsr_comm_s();
   if (!c) return LSR_ERR_HIP;
   c->rank = rank; c->world = world; c->device = device_id;
-  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     lsr::set_last_error("communicator stream could not be created");
     return LSR_ERR_HIP;
@@ -113,7 +115,7 @@ int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_c
 
 int lsr_comm_destroy(lsr_comm c) {
   if (!c) return LSR_OK;
-  (void)hipSetDevice(c->device);
+  lsr::DeviceGuard guard(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) { Rccl* r = rccl(); if (r) (void)r->comm_destroy(c->comm); }
   (void)hipStreamDestroy(c->stream);
@@ -121,63 +123,86 @@ int lsr_comm_destroy(lsr_comm c) {
   return LSR_OK;
 }
 
+// Where a rank's own share fails (an empty or ill-posed candidate, a HIP error), the rank STILL takes part in the all-gather:
+// its records travel flagged invalid (converged = -1, NaN pose / score / fitness) and the error is returned after the
+// collective — the other ranks never wait for a rank that has already left (the C ABI has no timeout or abort).
+static void invalid_record(lsr_shard_record& R) {
+  for (int k = 0; k < 12; k++) R.T[k] = NAN;
+  R.score = NAN; R.iterations = 0.f; R.converged = -1.f; R.fitness = NAN;
+}
+
 int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_count, int global_count, const float* local_guesses,
                             int with_fitness, lsr_shard_record* all_records) {
-  if (!c || global_count <= 0 || !all_records || local_count < 0 || (local_count > 0 && !local_handles)) {
-    lsr::set_last_error("bad sharded-batch arguments");
-    return LSR_ERR_INVALID_ARGUMENT;
-  }
+  if (!c || global_count <= 0 || !all_records) { lsr::set_last_error("bad sharded-batch arguments"); return LSR_ERR_INVALID_ARGUMENT; }
   int first = 0, mine = 0;
   lsr_shard_range(global_count, c->world, c->rank, &first, &mine);
-  if (mine != local_count) { lsr::set_last_error("local_count does not match this rank's share of the batch (lsr_shard_range)"); return LSR_ERR_INVALID_ARGUMENT; }
-  // ---- this rank's share: no collective on the data path
-  std::vector<lsr_shard_record> local((size_t)std::max(local_count, 1));
-  if (local_count > 0) {
+  // ---- this rank's share: no collective on the data path.  Argument errors of THIS rank are local failures too.
+  int local_status = LSR_OK;
+  std::string local_error;
+  std::vector<lsr_shard_record> local((size_t)std::max(mine, 1));
+  for (auto& R : local) invalid_record(R);
+  if (local_count < 0 || (local_count > 0 && !local_handles)) {
+    local_status = LSR_ERR_INVALID_ARGUMENT; local_error = "bad sharded-batch arguments";
+  } else if (mine != local_count) {
+    local_status = LSR_ERR_INVALID_ARGUMENT; local_error = "local_count does not match this rank's share of the batch (lsr_shard_range)";
+  } else if (local_count > 0) {
     std::vector<float> finals((size_t)local_count * 16);
     std::vector<lsr_result> res((size_t)local_count);
     int st = lsr_align_batch(local_handles, local_count, local_guesses, finals.data(), res.data());
-    if (st) return st;
-    for (int b = 0; b < local_count; b++) {
-      lsr_shard_record& R = local[b];
-      const float* M = finals.data() + 16 * b;  // column-major 4x4 -> row-major 3x4
-      for (int r = 0; r < 3; r++) for (int col = 0; col < 4; col++) R.T[r * 4 + col] = M[col * 4 + r];
-      R.score = (float)res[b].score;
-      R.iterations = (float)res[b].iterations;
-      R.converged = res[b].converged ? 1.f : 0.f;
-      R.fitness = NAN;
-    }
-    if (with_fitness) {   // every candidate's search + reduction enqueued before the first result is read
-      std::vector<double> fit((size_t)local_count);
-      if ((st = lsr_get_fitness_score_batch(local_handles, local_count, 1.7976931348623157e308, fit.data()))) return st;
-      for (int b = 0; b < local_count; b++) local[b].fitness = (float)fit[b];
+    std::vector<double> fit((size_t)local_count, (double)NAN);
+    if (!st && with_fitness)   // every candidate's search + reduction enqueued before the first result is read
+      st = lsr_get_fitness_score_batch(local_handles, local_count, 1.7976931348623157e308, fit.data());
+    if (st) {
+      local_status = st; local_error = lsr_last_error();
+    } else {
+      for (int b = 0; b < local_count; b++) {
+        lsr_shard_record& R = local[b];
+        const float* M = finals.data() + 16 * b;  // column-major 4x4 -> row-major 3x4
+        for (int r = 0; r < 3; r++) for (int col = 0; col < 4; col++) R.T[r * 4 + col] = M[col * 4 + r];
+        R.score = (float)res[b].score;
+        R.iterations = (float)res[b].iterations;
+        R.converged = res[b].converged ? 1.f : 0.f;
+        R.fitness = with_fitness ? (float)fit[b] : NAN;
+      }
     }
   }
+  auto finish = [&](int collective_status) {
+    if (local_status) { lsr::set_last_error(local_error); return local_status; }
+    return collective_status;
+  };
   if (c->world == 1 && !c->comm) {
     std::memcpy(all_records, local.data(), sizeof(lsr_shard_record) * (size_t)global_count);
-    return LSR_OK;
+    return finish(LSR_OK);
   }
   // ---- ONE all-gather of fixed-size blocks (padded to the largest share): 64 B x 64 candidates = 4 KiB, latency bound
   Rccl* r = rccl();
   if (!r || !c->comm) { lsr::set_last_error("communicator has no RCCL handle"); return LSR_ERR_NOT_IMPLEMENTED; }
-  if (hipSetDevice(c->device) != hipSuccess) return LSR_ERR_HIP;
+  lsr::DeviceGuard guard(c->device);
+  if (!guard.ok) { lsr::set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
   const int max_count = (global_count + c->world - 1) / c->world;
   int st;
   if ((st = c->d_send.reserve((size_t)max_count))) return st;
   if ((st = c->d_recv.reserve((size_t)max_count * c->world))) return st;
   LSR_HIP(hipMemsetAsync(c->d_send.p, 0, sizeof(lsr_shard_record) * (size_t)max_count, c->stream));
-  if (local_count > 0)
-    LSR_HIP(hipMemcpyAsync(c->d_send.p, local.data(), sizeof(lsr_shard_record) * (size_t)local_count, hipMemcpyHostToDevice, c->stream));
+  if (mine > 0)
+    LSR_HIP(hipMemcpyAsync(c->d_send.p, local.data(), sizeof(lsr_shard_record) * (size_t)mine, hipMemcpyHostToDevice, c->stream));
   const int rc = r->all_gather(c->d_send.p, c->d_recv.p, sizeof(lsr_shard_record) * (size_t)max_count, /*ncclUint8*/ 1, c->comm, c->stream);
   if (rc) return rccl_fail("ncclAllGather", rc);
   std::vector<lsr_shard_record> table((size_t)max_count * c->world);
   LSR_HIP(hipMemcpyAsync(table.data(), c->d_recv.p, sizeof(lsr_shard_record) * table.size(), hipMemcpyDeviceToHost, c->stream));
   LSR_HIP(hipStreamSynchronize(c->stream));
+  bool remote_invalid = false;
   for (int rk = 0; rk < c->world; rk++) {
     int f = 0, n = 0;
     lsr_shard_range(global_count, c->world, rk, &f, &n);
     if (n) std::memcpy(all_records + f, table.data() + (size_t)rk * max_count, sizeof(lsr_shard_record) * (size_t)n);
+    for (int k = 0; k < n; k++) remote_invalid = remote_invalid || (rk != c->rank && all_records[f + k].converged < 0.f);
   }
-  return LSR_OK;
+  if (!local_status && remote_invalid) {   // the table is complete, but some other rank's share failed: say so
+    lsr::set_last_error("another rank's share of the batch failed: its records are flagged converged = -1");
+    return LSR_ERR_HIP;
+  }
+  return finish(LSR_OK);
 }
 
 }  // extern "C"

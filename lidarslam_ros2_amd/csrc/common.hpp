@@ -27,6 +27,21 @@ void set_last_error(const std::string& s);
     }                                                                                                         \
   } while (0)
 
+// Makes `dev` the calling thread's current HIP device for the lifetime of the guard and restores the caller's afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // Growable device allocation (never shrinks; HBM is plentiful: 288 GB per MI355X).
 template <typename T>
 struct DevBuf {

@@ -246,8 +246,11 @@ __global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* _
   const unsigned int off = start[cell];
   const int cnt = (int)(start[cell + 1] - off);
   if (cnt == 0) {
-    if (tid < 4) rec[(size_t)cell * 4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid == 0) { leaf_key[cell] = -1; leaf_n[cell] = 0; cell_slot[cell] = -1; }
+    if (tid == 0) {
+      const double zero[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      leaf_record_dev(zero, zero, 0, false, rec + (size_t)cell * 4);   // NaN pieces: an empty cell answers no lookup
+      leaf_key[cell] = -1; leaf_n[cell] = 0; cell_slot[cell] = -1;
+    }
     return;
   }
   __shared__ double s_w[VG_LEAF_THREADS / 64][9];
@@ -295,11 +298,52 @@ __global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* _
   leaf_n[cell] = n;
   for (int k = 0; k < 3; k++) mean64[(size_t)cell * 3 + k] = mean[k];
   for (int k = 0; k < 9; k++) icov64[(size_t)cell * 9 + k] = icov[k];
-  rec[(size_t)cell * 4 + 0] = make_float4((float)mean[0], (float)mean[1], (float)mean[2], (float)icov[0]);
-  rec[(size_t)cell * 4 + 1] = make_float4((float)icov[1], (float)icov[2], (float)icov[4], (float)icov[5]);
-  rec[(size_t)cell * 4 + 2] = make_float4((float)icov[8], (float)n, 0.f, 0.f);
-  rec[(size_t)cell * 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  leaf_record_dev(mean, icov, n, valid, rec + (size_t)cell * 4);
   cell_slot[cell] = valid ? cell : -1;
+}
+
+
+// ---- source ordering for the tile-staged derivative pass (NDT_TAB_TILE) -------------------------------------------------
+// key of a source point = Morton code of the (2^shift x 2^shift cells) x (all z) column of the target grid its image under
+// the initial guess falls into, clamped to the grid; non-finite points get the sentinel key (sorted last).  The counting
+// sort itself is the grid builder's (vg_scan / vg_cellscan / vg_scatter): stable, deterministic, no host round trip.
+struct SrcSortT { float t[12]; };
+__device__ __forceinline__ unsigned int spread7(unsigned int v) {   // bit i of v -> bit 2 i
+  v = (v | (v << 4)) & 0x0F0Fu;
+  v = (v | (v << 2)) & 0x3333u;
+  v = (v | (v << 1)) & 0x5555u;
+  return v;
+}
+__global__ __launch_bounds__(256) void src_hist_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                       int n, const SrcSortT T, float leaf, int mb0, int mb1, int d0, int d1, int shift, int nkeys,
+                                                       unsigned short* __restrict__ keys, unsigned short* __restrict__ hist) {
+  extern __shared__ unsigned int s_hist[];  // [nkeys + 1]
+  const int C = nkeys + 1, tid = threadIdx.x;
+  for (int k = tid; k < C; k += 256) s_hist[k] = 0u;
+  __syncthreads();
+  const int base = blockIdx.x * VG_CHUNK;
+#pragma unroll 4
+  for (int j = 0; j < VG_CHUNK / 256; j++) {
+    const int i = base + j * 256 + tid;
+    if (i < n) {
+      const float px = x[i], py = y[i], pz = z[i];
+      unsigned int k = (unsigned int)nkeys;
+      if (isfinite(px) && isfinite(py) && isfinite(pz)) {
+        const float tx = fmaf(T.t[0], px, fmaf(T.t[1], py, fmaf(T.t[2], pz, T.t[3])));
+        const float ty = fmaf(T.t[4], px, fmaf(T.t[5], py, fmaf(T.t[6], pz, T.t[7])));
+        const float fx = fminf(fmaxf(floorf(tx / leaf) - (float)mb0, 0.f), (float)(d0 - 1));   // NaN / inf images clamp too
+        const float fy = fminf(fmaxf(floorf(ty / leaf) - (float)mb1, 0.f), (float)(d1 - 1));
+        const unsigned int cx = (unsigned int)(int)fx >> shift, cy = (unsigned int)(int)fy >> shift;
+        k = spread7(cx) | (spread7(cy) << 1);
+        if (k >= (unsigned int)nkeys) k = (unsigned int)nkeys - 1u;
+      }
+      keys[i] = (unsigned short)k;
+      atomicAdd(&s_hist[k], 1u);
+    }
+  }
+  __syncthreads();
+  unsigned short* row = hist + (size_t)blockIdx.x * C;
+  for (int k = tid; k < C; k += 256) row[k] = (unsigned short)s_hist[k];
 }
 
 }  // namespace
@@ -350,6 +394,35 @@ int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
                      grid.mean64.p, grid.icov64.p, grid.leaf_key.p, grid.leaf_n.p, grid.cell_slot.p);
   LSR_HIP(hipGetLastError());
   grid.n_leaves = ncells;  // leaf arrays are indexed by cell; empty cells carry leaf_key = -1
+  return LSR_OK;
+}
+
+int ndt_sort_source(const DeviceCloud& src, const float* T12, const VoxelGridDev& grid, DeviceCloud& out, BuildScratch& sc, hipStream_t stream) {
+  const int n = (int)src.n;
+  int st = out.resize(src.n);
+  if (st) return st;
+  if (n == 0) return LSR_OK;
+  // columns of 2^shift x 2^shift cells, at most 64 x 64 of them: Morton keys below 4096
+  int shift = 0;
+  while (((grid.div_b[0] + (1 << shift) - 1) >> shift) > 64 || ((grid.div_b[1] + (1 << shift) - 1) >> shift) > 64) shift++;
+  const int nkeys = 4096, C = nkeys + 1;
+  const int nblk = (n + VG_CHUNK - 1) / VG_CHUNK;
+  const size_t w_total = (size_t)C, w_start = (size_t)C + 1, w_blkoff = (size_t)nblk * C, w_hist = ((size_t)nblk * C + 1) / 2, w_keys = ((size_t)n + 1) / 2;
+  if ((st = sc.words.reserve(16 + w_total + w_start + w_blkoff + w_hist + w_keys + 16))) return st;
+  unsigned int* total = sc.words.p + 16;
+  unsigned int* start = total + w_total;
+  unsigned int* blkoff = start + w_start;
+  unsigned short* hist = reinterpret_cast<unsigned short*>(blkoff + w_blkoff);
+  unsigned short* keys = reinterpret_cast<unsigned short*>(blkoff + w_blkoff + w_hist);
+  SrcSortT T;
+  for (int k = 0; k < 12; k++) T.t[k] = T12[k];
+  hipLaunchKernelGGL(src_hist_kernel, dim3(nblk), dim3(256), (size_t)C * 4, stream, src.x(), src.y(), src.z(), n, T, grid.leaf, grid.min_b[0],
+                     grid.min_b[1], grid.div_b[0], grid.div_b[1], shift, nkeys, keys, hist);
+  hipLaunchKernelGGL(vg_scan_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, hist, nblk, C, blkoff, total);
+  hipLaunchKernelGGL(vg_cellscan_kernel, dim3(1), dim3(1024), 0, stream, total, C, start);
+  hipLaunchKernelGGL(vg_scatter_kernel, dim3(nblk), dim3(256), (size_t)C * 8, stream, src.x(), src.y(), src.z(), n, keys, blkoff, start, C,
+                     out.x(), out.y(), out.z());
+  LSR_HIP(hipGetLastError());
   return LSR_OK;
 }
 

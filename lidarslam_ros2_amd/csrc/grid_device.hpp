@@ -105,4 +105,21 @@ __device__ inline int leaf_finalize_dev(const double* s, int n, int min_points, 
   return n;
 }
 
+// The 64-byte leaf record the derivative pass reads (ndt_point.hpp: pair_terms): {mean_hi.xyz, c00 | c01 c02 c11 c12 |
+// c22, mean_lo.xyz | n, 0, 0, 0}.  mean = mean_hi + mean_lo as an fp32 head + tail pair: the reference subtracts the DOUBLE mean.
+// A leaf lookups cannot use (n < min_points, invalid covariance) carries NaN in the three 16-byte pieces the pass reads — the
+// pair then drops itself through ndt_omp's own range test — and its point count in the fourth.
+__device__ inline void leaf_record_dev(const double* mean, const double* icov, int n, bool usable, float4* __restrict__ rec) {
+  if (usable) {
+    const float hx = (float)mean[0], hy = (float)mean[1], hz = (float)mean[2];
+    rec[0] = make_float4(hx, hy, hz, (float)icov[0]);
+    rec[1] = make_float4((float)icov[1], (float)icov[2], (float)icov[4], (float)icov[5]);
+    rec[2] = make_float4((float)icov[8], (float)(mean[0] - (double)hx), (float)(mean[1] - (double)hy), (float)(mean[2] - (double)hz));
+  } else {
+    const float qnan = __int_as_float(0x7FC00000);
+    rec[0] = rec[1] = rec[2] = make_float4(qnan, qnan, qnan, qnan);
+  }
+  rec[3] = make_float4((float)n, 0.f, 0.f, 0.f);
+}
+
 }  // namespace lsr

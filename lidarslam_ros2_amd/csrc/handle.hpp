@@ -29,6 +29,7 @@ struct lsr_handle_s {
   std::shared_ptr<TargetData> target;
   std::shared_ptr<TargetData> spare_target;  // recycled by the next setInputTarget when no other handle shares it
   DeviceCloud source;
+  DeviceCloud source_sorted;  // NDT_TAB_TILE: the source ordered by voxel tile of its guess-moved points (rebuilt by every align)
   DeviceCloud raw, filtered;  // N1: unfiltered upload / stand-alone filter result
   bool has_source = false;
   bool source_cov_valid = false;

@@ -19,6 +19,7 @@
 #include <cmath>
 
 #include "grid_device.hpp"
+#include "ndt_point.hpp"
 #include "sort.hpp"
 
 namespace lsr {
@@ -61,29 +62,6 @@ __host__ __device__ inline void angle_tables(const double* p, bool with_hessian,
     hang[42] = (float)(-sx * sz + cx * sy * cz); hang[43] = (float)(-cx * sy * sz - sx * cz); hang[44] = 0.f;
     hang[45] = hang[46] = hang[47] = 0.f;
   }
-}
-
-// fp32 (Translation * Rx * Ry * Rz) exactly as the reference composes Eigen::Affine3f from the
-// float-cast pose vector; T12 row-major 3x4.
-__host__ __device__ inline void pose_to_T12(const double* p, float* T) {
-  float ax = (float)p[3], ay = (float)p[4], az = (float)p[5];
-  float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
-  // A = Rx * Ry
-  float a00 = cy, a01 = 0.f, a02 = sy;
-  float a10 = sx * sy, a11 = cx, a12 = -sx * cy;
-  float a20 = -cx * sy, a21 = sx, a22 = cx * cy;
-  // R = A * Rz
-  T[0] = a00 * cz + a01 * sz; T[1] = -a00 * sz + a01 * cz; T[2] = a02;
-  T[4] = a10 * cz + a11 * sz; T[5] = -a10 * sz + a11 * cz; T[6] = a12;
-  T[8] = a20 * cz + a21 * sz; T[9] = -a20 * sz + a21 * cz; T[10] = a22;
-  T[3] = (float)p[0]; T[7] = (float)p[1]; T[11] = (float)p[2];
-}
-
-__host__ __device__ inline void T12_to_colmajor16(const float* T, float* M) {
-  M[0] = T[0]; M[1] = T[4]; M[2] = T[8];  M[3] = 0.f;
-  M[4] = T[1]; M[5] = T[5]; M[6] = T[9];  M[7] = 0.f;
-  M[8] = T[2]; M[9] = T[6]; M[10] = T[10]; M[11] = 0.f;
-  M[12] = T[3]; M[13] = T[7]; M[14] = T[11]; M[15] = 1.f;
 }
 
 // Eigen 3.4 MatrixBase::eulerAngles(0,1,2) on the fp32 rotation block (host only; used once per align).
@@ -247,129 +225,52 @@ __device__ __forceinline__ bool mt_update_interval(MtInterval& I, double a_t, do
   return true;
 }
 
-// delta = H^{-1} b by Gaussian elimination with partial pivoting, entirely in registers (every loop
-// fully unrolled, row swaps by select).  The reference calls JacobiSVD::solve; for a non-singular 6x6
-// both give H^{-1} b.  A column whose pivot vanishes is dropped = its unknown set to 0, which is the
-// SVD's minimum-norm answer for the degenerate all-zero Hessian of a scan that overlaps no voxel.
-// (A wave-parallel Gauss-Jordan on an LDS matrix was measured slower: +0.9 us per pass on average.)
-// Hu: the 21 values of the upper triangle, row-major (0,0..5) (1,1..5) ... (5,5), read straight from the LDS totals
-// (21 independent ds_reads, one wait).
-// Its own (not inlined) function: with the 6x7 working matrix in registers it needs ~140 VGPRs, which still fits the
-// caller-saved half of the register file — inlined into the Newton half the two together spill to scratch.
-// g: the gradient (the right-hand side is -g); out[0..5] receives delta.
-// Fast path first: near the optimum the Hessian is definite, and an unpivoted LDL^T of the upper triangle (~100 fp64 FMAs
-// and 6 reciprocals on the one lane everybody waits for) is as stable as pivoted elimination there.  It is accepted only
-// when every pivot has the sign of the first one and none is tiny against the matrix scale; anything else (indefinite
-// far from the optimum, rank deficient) takes the pivoted elimination below.
-__device__ __attribute__((noinline)) void solve6(const LdsDouble* Hu, const LdsDouble* g, LdsDouble* out) {
-  double b[6], x[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) b[i] = -g[i];
-  {
-    double a[6][6];  // upper triangle in a[i][j], i <= j
-    double scale = 0;
-    {
-      int k = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = i; j < 6; j++) { a[i][j] = Hu[k]; scale = fmax(scale, fabs(a[i][j])); k++; }
-    }
-    // a[i][j] (i < j) becomes L[j][i] * d[i] during the sweep, then L[j][i]; d[j] replaces a[j][j]
-    double d[6], rd[6];
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      double dj = a[j][j];
-#pragma unroll
-      for (int k = 0; k < j; k++) dj = fma(-a[k][j] * a[k][j], d[k], dj);  // a[k][j] holds L[j][k]
-      d[j] = dj;
-      ok = ok && (dj * d[0] > 0.0) && (fabs(dj) > 1e-13 * scale);
-      rd[j] = mt_div(1.0, dj);
-#pragma unroll
-      for (int i = j + 1; i < 6; i++) {
-        double v = a[j][i];
-#pragma unroll
-        for (int k = 0; k < j; k++) v = fma(-a[k][i] * a[k][j], d[k], v);
-        a[j][i] = v * rd[j];  // L[i][j]
-      }
-    }
-    if (ok) {
-      double y[6];
-#pragma unroll
-      for (int i = 0; i < 6; i++) {  // L y = b
-        double v = b[i];
-#pragma unroll
-        for (int k = 0; k < i; k++) v = fma(-a[k][i], y[k], v);
-        y[i] = v;
-      }
-#pragma unroll
-      for (int i = 5; i >= 0; i--) {  // L^T x = D^-1 y
-        double v = y[i] * rd[i];
-#pragma unroll
-        for (int k = i + 1; k < 6; k++) v = fma(-a[i][k], x[k], v);
-        x[i] = v;
-      }
-#pragma unroll
-      for (int i = 0; i < 6; i++) out[i] = x[i];
-      return;
-    }
+// delta = H^{-1} (-g) by Gauss-Jordan elimination with partial pivoting on ONE WAVE: lane 8 r + c holds element (r, c) of the
+// augmented 6 x 7 matrix [H | -g] in a register, every step is a handful of cross-lane reads.  The reference calls
+// JacobiSVD::solve; for a non-singular 6x6 both give H^{-1} b.  A column whose pivot vanishes is dropped = its unknown set to
+// 0, which is the SVD's minimum-norm answer for the degenerate all-zero Hessian of a scan that overlaps no voxel.
+// Hu: the 21 values of the upper triangle, row-major (0,0..5) (1,1..5) ... (5,5), g: the gradient, out[0..5] receives delta
+// (all three in LDS; the caller fences the wave's LDS traffic around the call).
+// Why a wave and not one lane with the matrix in registers (rounds 1-2: ~166 VGPRs, fully unrolled): the register count of a
+// kernel is the maximum over everything it calls, for EVERY wave — that one-lane solver capped the derivative kernels at two
+// waves per SIMD (one 512-thread workgroup per CU), which is what bounds the passes that have more workgroups than CUs
+// (cfg 5, candidate batches).  Here the solver needs a dozen registers; the kernels fit twice the waves.
+__device__ __forceinline__ void solve6_wave(const LdsDouble* Hu, const LdsDouble* g, LdsDouble* out) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane >> 3, c = lane & 7;
+  double v = 0.0;
+  if (r < 6 && c < 6) {
+    const int i = min(r, c), j = max(r, c);
+    v = Hu[6 * i - (i * (i - 1)) / 2 + (j - i)];   // row i of the upper triangle starts at 6 i - i (i - 1) / 2
+  } else if (r < 6 && c == 6) {
+    v = -g[r];
   }
-  double A[6][7];
-  double scale = 0;
-  {
-    int k = 0;
+  double scale = (r < 6 && c < 6) ? fabs(v) : 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-#pragma unroll
-      for (int j = i; j < 6; j++) {
-        A[i][j] = Hu[k];
-        A[j][i] = Hu[k];
-        scale = fmax(scale, fabs(Hu[k]));
-        k++;
-      }
-      A[i][6] = b[i];
-    }
-  }
+  for (int m = 32; m >= 1; m >>= 1) scale = fmax(scale, __shfl_xor(scale, m, 64));
   unsigned int dropped = 0u;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
-    // pivot search over rows k..5, then bring the pivot row to position k by selects
-    double best = fabs(A[k][k]);
+    // pivot search over rows k..5 of column k (the same answer in every lane)
+    double best = fabs(__shfl(v, k * 8 + k, 64));
     int piv = k;
 #pragma unroll
     for (int i = k + 1; i < 6; i++) {
-      const double v = fabs(A[i][k]);
-      if (v > best) { best = v; piv = i; }
+      const double t = fabs(__shfl(v, i * 8 + k, 64));
+      if (t > best) { best = t; piv = i; }
     }
     if (!(best > scale * 1e-300) || !(best > 0)) { dropped |= (1u << k); continue; }
-#pragma unroll
-    for (int i = k + 1; i < 6; i++) {
-      const bool sw = (piv == i);
-#pragma unroll
-      for (int j = k; j < 7; j++) {
-        const double a = A[k][j], c = A[i][j];
-        A[k][j] = sw ? c : a;
-        A[i][j] = sw ? a : c;
-      }
-    }
-    const double inv = 1.0 / A[k][k];
-#pragma unroll
-    for (int i = k + 1; i < 6; i++) {
-      const double f = A[i][k] * inv;
-#pragma unroll
-      for (int j = k + 1; j < 7; j++) A[i][j] -= f * A[k][j];
-    }
+    // bring the pivot row to position k
+    const double from_piv = __shfl(v, piv * 8 + c, 64), from_k = __shfl(v, k * 8 + c, 64);
+    v = (r == k) ? from_piv : ((r == piv) ? from_k : v);
+    // eliminate column k from every other row
+    const double akk = __shfl(v, k * 8 + k, 64), akj = __shfl(v, k * 8 + c, 64), aik = __shfl(v, r * 8 + k, 64);
+    const double f = aik * (1.0 / akk);
+    if (r != k && r < 6) v -= f * akj;
   }
-#pragma unroll
-  for (int k = 5; k >= 0; k--) {
-    double sacc = A[k][6];
-#pragma unroll
-    for (int j = k + 1; j < 6; j++) sacc -= A[k][j] * x[j];
-    x[k] = (dropped & (1u << k)) ? 0.0 : sacc / A[k][k];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) out[i] = x[i];
+  const int jj = min(lane, 5);
+  const double num = __shfl(v, jj * 8 + 6, 64), den = __shfl(v, jj * 8 + jj, 64);
+  if (lane < 6) out[lane] = ((dropped >> lane) & 1u) ? 0.0 : num / den;
 }
 
 // The angular coefficient tables of eq. 6.19 (jang, 24 entries) and eq. 6.21 (hang, 48 entries) as DATA: every entry is
@@ -487,14 +388,8 @@ __device__ __forceinline__ void build_request(NdtState* S, double* f /*8*/, floa
     if (tid == 0) S->pad1 = 0;
   } else if (tid == THREADS - 1) {
     // fp32 (Translation * Rx * Ry * Rz), as pose_to_T12
-    const float fcx = cs_f[0], fcy = cs_f[1], fcz = cs_f[2], fsx = cs_f[3], fsy = cs_f[4], fsz = cs_f[5];
-    const float a00 = fcy, a02 = fsy;
-    const float a10 = fsx * fsy, a11 = fcx, a12 = -fsx * fcy;
-    const float a20 = -fcx * fsy, a21 = fsx, a22 = fcx * fcy;
     float* T = S->T;
-    T[0] = a00 * fcz; T[1] = -a00 * fsz; T[2] = a02;
-    T[4] = a10 * fcz + a11 * fsz; T[5] = -a10 * fsz + a11 * fcz; T[6] = a12;
-    T[8] = a20 * fcz + a21 * fsz; T[9] = -a20 * fsz + a21 * fcz; T[10] = a22;
+    compose_R12(cs_f[0], cs_f[1], cs_f[2], cs_f[3], cs_f[4], cs_f[5], T);
     T[3] = (float)S->x_t[0]; T[7] = (float)S->x_t[1]; T[11] = (float)S->x_t[2];
     T12_to_colmajor16(T, S->final_T);  // final_transformation_ is assigned before every MT pass
   }
@@ -542,14 +437,8 @@ __device__ __forceinline__ void build_request_wave0(NdtState* S, double* f /*8*/
   if (with_hang && lane < 8) S->hang[40 + lane] = (float)angle_entry_value(ent_b, f);  // entries 64..71
   if (lane == 63) {
     // fp32 (Translation * Rx * Ry * Rz), as pose_to_T12
-    const float fcx = cs_f[0], fcy = cs_f[1], fcz = cs_f[2], fsx = cs_f[3], fsy = cs_f[4], fsz = cs_f[5];
-    const float a00 = fcy, a02 = fsy;
-    const float a10 = fsx * fsy, a11 = fcx, a12 = -fsx * fcy;
-    const float a20 = -fcx * fsy, a21 = fsx, a22 = fcx * fcy;
     float* T = S->T;
-    T[0] = a00 * fcz; T[1] = -a00 * fsz; T[2] = a02;
-    T[4] = a10 * fcz + a11 * fsz; T[5] = -a10 * fsz + a11 * fcz; T[6] = a12;
-    T[8] = a20 * fcz + a21 * fsz; T[9] = -a20 * fsz + a21 * fcz; T[10] = a22;
+    compose_R12(cs_f[0], cs_f[1], cs_f[2], cs_f[3], cs_f[4], cs_f[5], T);
     T[3] = (float)S->x_t[0]; T[7] = (float)S->x_t[1]; T[11] = (float)S->x_t[2];
     T12_to_colmajor16(T, S->final_T);  // final_transformation_ is assigned before every MT pass
   }
@@ -757,18 +646,28 @@ __device__ __forceinline__ int ndt_newton_begin(LdsState* S, const LdsDouble* de
   return CTL_DONE;
 }
 
-__device__ __forceinline__ void ndt_controller(LdsState* S, const LdsDouble* sums) {
-  int next = ndt_controller_mt(S, sums);
+// The controller step, executed by the 64 lanes of wave 0 (threadIdx.x < 64): the scalar pieces run on lane 0, the 6x6 solve
+// on the whole wave; `next` travels through an SGPR, the wave's own LDS traffic is ordered by wave_lds_fence().
+__device__ __forceinline__ void ndt_controller_wave0(LdsState* S, const LdsDouble* sums) {
+  const bool lead = (threadIdx.x == 0);
+  int next = 0;
+  if (lead) next = ndt_controller_mt(S, sums);
+  next = __builtin_amdgcn_readfirstlane(next);
   LdsDouble* scratch = const_cast<LdsDouble*>(sums);  // sums[0..7] are consumed by now: delta lands in sums[0..5]
   for (int guard = 0; guard < 8 && next != CTL_DONE; guard++) {
     if (next == CTL_NEWTON_END) {
-      next = ndt_newton_end(S);
+      if (lead) next = ndt_newton_end(S);
     } else {
-      solve6(sums + 8, S->g, scratch);  // the Hessian in use is always the one of the pass that just finished
-      next = ndt_newton_begin(S, scratch);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      solve6_wave(sums + 8, S->g, scratch);  // the Hessian in use is always the one of the pass that just finished
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lead) next = ndt_newton_begin(S, scratch);
     }
+    next = __builtin_amdgcn_readfirstlane(next);
   }
-  if (next != CTL_DONE) {  // unreachable in practice (the a_t == 0 path converges after two rounds)
+  if (lead && next != CTL_DONE) {  // unreachable in practice (the a_t == 0 path converges after two rounds)
     S->trans_probability = S->score / (double)S->n_points;
     S->done = 1;
   }
@@ -874,97 +773,6 @@ struct Offsets<27> {
     dz = o % 3 - 1;
   }
 };
-
-// One (point, voxel) pair of eq. 6.9-6.13 in the factorised form: the point Jacobian and second derivatives
-// do not depend on the voxel, so a pair only adds to A = sum w C q and E = sum w (C - d2 Cq Cq^T); fp32 per pair with
-// ndt_omp's precision recipe: the weight is scaled by the DOUBLE gauss_d1 and rounded back to float.
-__device__ __forceinline__ void pair_terms(const bool leaf_ok, const bool hess, const float tx, const float ty, const float tz,
-                                           const float4 r0, const float4 r1, const float c22, const float d2, const double d1d,
-                                           float& score, float& npairs, float& A0, float& A1, float& A2, float& E00, float& E01,
-                                           float& E02, float& E11, float& E12, float& E22) {
-  const float q0 = tx - r0.x, q1 = ty - r0.y, q2 = tz - r0.z;
-  const float c00 = r0.w, c01 = r1.x, c02 = r1.y, c11 = r1.z, c12 = r1.w;
-  const float Cq0 = fmaf(c00, q0, fmaf(c01, q1, c02 * q2));
-  const float Cq1 = fmaf(c01, q0, fmaf(c11, q1, c12 * q2));
-  const float Cq2 = fmaf(c02, q0, fmaf(c12, q1, c22 * q2));
-  const float qCq = fmaf(q0, Cq0, fmaf(q1, Cq1, q2 * Cq2));
-  const float e = expf(-d2 * qCq * 0.5f);
-  const float w0 = d2 * e;
-  // ndt_omp drops the whole pair (score included) when d2*e is outside [0,1] or NaN
-  const bool ok = leaf_ok & (w0 <= 1.f) & (w0 >= 0.f);
-  score += ok ? (float)(-d1d * (double)e) : 0.f;
-  npairs += ok ? 1.f : 0.f;
-  const float w = (float)((double)w0 * d1d);
-  A0 = ok ? fmaf(w, Cq0, A0) : A0;
-  A1 = ok ? fmaf(w, Cq1, A1) : A1;
-  A2 = ok ? fmaf(w, Cq2, A2) : A2;
-  if (hess) {
-    const float wd = -w * d2;
-    E00 = ok ? E00 + fmaf(wd * Cq0, Cq0, w * c00) : E00;
-    E01 = ok ? E01 + fmaf(wd * Cq0, Cq1, w * c01) : E01;
-    E02 = ok ? E02 + fmaf(wd * Cq0, Cq2, w * c02) : E02;
-    E11 = ok ? E11 + fmaf(wd * Cq1, Cq1, w * c11) : E11;
-    E12 = ok ? E12 + fmaf(wd * Cq1, Cq2, w * c12) : E12;
-    E22 = ok ? E22 + fmaf(wd * Cq2, Cq2, w * c22) : E22;
-  }
-}
-
-// The 29 per-point terms (score, 3 + 3 gradient, #pairs, 21 Hessian upper triangle) from the point's A / E sums, the point
-// Jacobian J = [I | J3 J4 J5] (eq. 6.18/6.19) and the second-derivative vectors (eq. 6.20/6.21) of the UNTRANSFORMED point.
-// o[8..28] are only written when hess.
-__device__ __forceinline__ void point_terms(const bool hess, const float px, const float py, const float pz, const float score,
-                                            const float npairs, const float A0, const float A1, const float A2, const float E00,
-                                            const float E01, const float E02, const float E11, const float E12, const float E22,
-                                            const LdsState* L, float* __restrict__ o) {
-  const __attribute__((address_space(3))) float* ja = L->jang;
-  const float j_a = fmaf(ja[0], px, fmaf(ja[1], py, ja[2] * pz));
-  const float j_b = fmaf(ja[3], px, fmaf(ja[4], py, ja[5] * pz));
-  const float j_c = fmaf(ja[6], px, fmaf(ja[7], py, ja[8] * pz));
-  const float j_d = fmaf(ja[9], px, fmaf(ja[10], py, ja[11] * pz));
-  const float j_e = fmaf(ja[12], px, fmaf(ja[13], py, ja[14] * pz));
-  const float j_f = fmaf(ja[15], px, ja[16] * py);
-  const float j_g = fmaf(ja[18], px, ja[19] * py);
-  const float j_h = fmaf(ja[21], px, ja[22] * py);
-  // J3 = (0, a, b), J4 = (c, d, e), J5 = (f, g, h)
-  o[0] = score;
-  o[1] = A0;
-  o[2] = A1;
-  o[3] = A2;
-  o[4] = fmaf(A1, j_a, A2 * j_b);
-  o[5] = fmaf(A0, j_c, fmaf(A1, j_d, A2 * j_e));
-  o[6] = fmaf(A0, j_f, fmaf(A1, j_g, A2 * j_h));
-  o[7] = npairs;
-  if (hess) {
-    // E J_k for k = 3,4,5
-    const float e3x = fmaf(E01, j_a, E02 * j_b), e3y = fmaf(E11, j_a, E12 * j_b), e3z = fmaf(E12, j_a, E22 * j_b);
-    const float e4x = fmaf(E00, j_c, fmaf(E01, j_d, E02 * j_e)), e4y = fmaf(E01, j_c, fmaf(E11, j_d, E12 * j_e)),
-                e4z = fmaf(E02, j_c, fmaf(E12, j_d, E22 * j_e));
-    const float e5x = fmaf(E00, j_f, fmaf(E01, j_g, E02 * j_h)), e5y = fmaf(E01, j_f, fmaf(E11, j_g, E12 * j_h)),
-                e5z = fmaf(E02, j_f, fmaf(E12, j_g, E22 * j_h));
-    const __attribute__((address_space(3))) float* ha = L->hang;
-    // second-derivative vectors (eq. 6.20/6.21) dotted with A = sum w C q
-    const float ha2 = fmaf(ha[0], px, fmaf(ha[1], py, ha[2] * pz)), ha3 = fmaf(ha[3], px, fmaf(ha[4], py, ha[5] * pz));
-    const float hb2 = fmaf(ha[6], px, fmaf(ha[7], py, ha[8] * pz)), hb3 = fmaf(ha[9], px, fmaf(ha[10], py, ha[11] * pz));
-    const float hc2 = fmaf(ha[12], px, ha[13] * py), hc3 = fmaf(ha[15], px, ha[16] * py);
-    const float hd1 = fmaf(ha[18], px, fmaf(ha[19], py, ha[20] * pz)), hd2 = fmaf(ha[21], px, fmaf(ha[22], py, ha[23] * pz)),
-                hd3 = fmaf(ha[24], px, fmaf(ha[25], py, ha[26] * pz));
-    const float he1 = fmaf(ha[27], px, ha[28] * py), he2 = fmaf(ha[30], px, ha[31] * py), he3 = fmaf(ha[33], px, ha[34] * py);
-    const float hf1 = fmaf(ha[36], px, ha[37] * py), hf2 = fmaf(ha[39], px, ha[40] * py), hf3 = fmaf(ha[42], px, ha[43] * py);
-    // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
-    o[8] = E00;  o[9] = E01;  o[10] = E02;
-    o[11] = e3x; o[12] = e4x; o[13] = e5x;
-    o[14] = E11; o[15] = E12;
-    o[16] = e3y; o[17] = e4y; o[18] = e5y;
-    o[19] = E22;
-    o[20] = e3z; o[21] = e4z; o[22] = e5z;
-    o[23] = fmaf(j_a, e3y, j_b * e3z) + fmaf(A1, ha2, A2 * ha3);                       // (3,3)
-    o[24] = fmaf(j_a, e4y, j_b * e4z) + fmaf(A1, hb2, A2 * hb3);                       // (3,4)
-    o[25] = fmaf(j_a, e5y, j_b * e5z) + fmaf(A1, hc2, A2 * hc3);                       // (3,5)
-    o[26] = fmaf(j_c, e4x, fmaf(j_d, e4y, j_e * e4z)) + fmaf(A0, hd1, fmaf(A1, hd2, A2 * hd3));  // (4,4)
-    o[27] = fmaf(j_c, e5x, fmaf(j_d, e5y, j_e * e5z)) + fmaf(A0, he1, fmaf(A1, he2, A2 * he3));  // (4,5)
-    o[28] = fmaf(j_f, e5x, fmaf(j_g, e5y, j_h * e5z)) + fmaf(A0, hf1, fmaf(A1, hf2, A2 * hf3));  // (5,5)
-  }
-}
 
 // One derivative pass (K3) preceded by the controller step (K4) that consumes the PREVIOUS pass.
 //
@@ -1093,7 +901,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
     barrier_lds_only();
     LSR_STAMP(6)
     LSR_CTL_BEGIN(L)
-    if (tid == 0) ndt_controller(L, (const LdsDouble*)s_sum);
+    if (tid < 64) ndt_controller_wave0(L, (const LdsDouble*)s_sum);
     barrier_lds_only();
     LSR_CTL_END(0)
     LSR_STAMP(5)
@@ -1142,9 +950,9 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
   for (int k = 0; k < 29; k++) acc[k] = 0.0;
 
   while (i < P.n) {
-    const float tx = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
-    const float ty = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
-    const float tz = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
+    const float tx = xform_ref(T[0], T[1], T[2], T[3], x, y, z);
+    const float ty = xform_ref(T[4], T[5], T[6], T[7], x, y, z);
+    const float tz = xform_ref(T[8], T[9], T[10], T[11], x, y, z);
     // DIRECT-N neighbourhood of the TRANSFORMED point: floor(x'/leaf) in fp32.
     const float fx = floorf(tx / leaf), fy = floorf(ty / leaf), fz = floorf(tz / leaf);
     // NaN / far-out-of-range points land outside the grid and contribute nothing.
@@ -1165,8 +973,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
       valid[o] = in;
       cellv[o] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
     }
-    float4 r0[NOFF], r1[NOFF];
-    float c22v[NOFF];
+    float4 r0[NOFF], r1[NOFF], r2[NOFF];
     if (TAB == NDT_TAB_LDS) {
       int slot[NOFF];
 #pragma unroll
@@ -1179,7 +986,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
       for (int o = 0; o < NOFF; o++) {
         r0[o] = s_rec[slot[o] * 3 + 0];
         r1[o] = s_rec[slot[o] * 3 + 1];
-        c22v[o] = reinterpret_cast<const float*>(s_rec + slot[o] * 3 + 2)[0];
+        r2[o] = s_rec[slot[o] * 3 + 2];
       }
     } else {
       size_t ridx[NOFF];
@@ -1194,12 +1001,10 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
         }
       }
 #pragma unroll
-      for (int o = 0; o < NOFF; o++) {
+      for (int o = 0; o < NOFF; o++) {   // empty / under-populated / invalidated cells hold NaN records: the pair drops itself
         r0[o] = P.rec[ridx[o] * 4 + 0];
         r1[o] = P.rec[ridx[o] * 4 + 1];
-        const float4 r2 = P.rec[ridx[o] * 4 + 2];
-        c22v[o] = r2.x;
-        valid[o] = valid[o] & (r2.y >= 6.f);  // empty / under-populated / invalidated cells carry n < 6
+        r2[o] = P.rec[ridx[o] * 4 + 2];
       }
     }
 
@@ -1208,13 +1013,13 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, 
     float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;  // sum w * (C - d2 Cq Cq^T)
 #pragma unroll
     for (int o = 0; o < NOFF; o++)
-      pair_terms(valid[o], hess, tx, ty, tz, r0[o], r1[o], c22v[o], d2, d1d, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22);
+      pair_terms(valid[o], hess, tx, ty, tz, r0[o], r1[o], r2[o], d2, d1d, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22);
     const float px = x, py = y, pz = z;
     i += stride;
     if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }   // next point's loads fly under the maths below
     if (npairs == 0.f) continue;
     float ot[29];
-    point_terms(hess, px, py, pz, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22, L, ot);
+    point_terms(hess, px, py, pz, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22, L->jang, L->hang, ot);
     if (hess) {
 #pragma unroll
       for (int k = 0; k < 29; k++) acc[k] += (double)ot[k];
@@ -1284,8 +1089,34 @@ __device__ __forceinline__ float dpp_quad_sum(float v) {
   return v;
 }
 
-template <int NOFF, int TAB, int PTS>
-__global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem P, const int seq) {
+// min / max over the lanes of a wave (every lane receives the result)
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int m = 4; m <= 32; m <<= 1) v = min(v, __shfl_xor(v, m, 64));   // the four lanes of a quad hold the same value
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int m = 4; m <= 32; m <<= 1) v = max(v, __shfl_xor(v, m, 64));
+  return v;
+}
+// n / d for small n through a precomputed magic number m = 2^32 / d + 1 (exact for n, d < 65536; d = 1 has no such m)
+__device__ __forceinline__ unsigned int div_magic(unsigned int d) { return 0xFFFFFFFFu / d + 1u; }
+__device__ __forceinline__ unsigned int div_small(unsigned int n, unsigned int d, unsigned int m) { return d == 1u ? n : __umulhi(n, m); }
+
+// TAB (NdtTableMode) of the quad kernel:
+//  NDT_TAB_LDS   the whole valid-voxel table staged into LDS at the head of the launch (tables that fit: res 5.0);
+//  NDT_TAB_TILE  per workgroup and per pass, the BOX of grid cells its points touch (bounding box of their centre cells + the
+//                one-cell halo of the neighbourhood) is gathered from the dense global table into LDS with global->LDS DMA
+//                (48 of the 64 bytes of every record, one 16-byte piece per lane), and the 7 x 3 dependent gathers of a point
+//                become ds_read_b128.  The source is ordered by voxel tile at the start of the align (ndt_sort_source), so a
+//                workgroup's 128 points are neighbours in space — and stay neighbours under any rigid motion the line search
+//                applies — and their box is a few dozen cells.  A box beyond the tile buffer (scattered points) makes that
+//                workgroup read the global table directly for that pass, as NDT_TAB_DENSE does for all.
+//  NDT_TAB_DENSE / NDT_TAB_COMPACT  records gathered from global memory.
+// BYVAL: the problem travels in the kernel arguments (single registrations); otherwise probs[blockIdx.y] (batches).
+template <int NOFF, int TAB, int PTS, bool BYVAL>
+__global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq) {
   constexpr int THREADS = 4 * PTS;
   // floats per row of the per-point buffers, chosen against the 32-lane groups of ds_*_b32: phase A writes rows
   // ql + 4m at columns pq (4 rows x 8 columns per group): pitch = 8 (mod 32) spreads them over all 32 banks; phase C reads
@@ -1293,6 +1124,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   constexpr int PITCH_PT = PTS + 8, PITCH_O = PTS + 16;
   constexpr int SEGS = THREADS / 32;       // interleaved segments per value in the workgroup sum
   constexpr int NT = (NOFF + 3) / 4;       // neighbours per lane
+  const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
   if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x, ql = tid & 3, pq = tid >> 2;
   LSR_STAMP(0)
@@ -1305,6 +1137,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   __shared__ double s_bin[NDT_NBINS][32];
   __shared__ double s_sum[NDT_NRED];
   __shared__ double s_lu[8][2];
+  __shared__ int s_box[8];               // NDT_TAB_TILE: min (0..2) / max (3..5) centre cell of this workgroup's points
   constexpr int STATE_Q = (int)(sizeof(NdtState) / 16);
   __shared__ uint4 s_state_q[STATE_Q];
   unsigned int* s_state = reinterpret_cast<unsigned int*>(s_state_q);
@@ -1337,6 +1170,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
       s_bin[k][tid & 31] = (double)msum * q;
     }
     if (tid < STATE_Q) s_state_q[tid] = stq;
+    if (TAB == NDT_TAB_TILE && tid >= THREADS - 6) s_box[THREADS - 1 - tid] = (THREADS - 1 - tid < 3) ? INT_MAX : INT_MIN;
     // issued after the shared lines have landed, on purpose (see the one-lane kernel): these fly across the head's barriers
     if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
     if (tid < 64) ang_entry = k_angle_entries[tid];
@@ -1383,7 +1217,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
       wave_lds_fence();
       LSR_STAMP(6)
       LSR_CTL_BEGIN(L)
-      if (tid == 0) ndt_controller(L, (const LdsDouble*)s_sum);
+      ndt_controller_wave0(L, (const LdsDouble*)s_sum);
       wave_lds_fence();
       LSR_CTL_END(0)
       LSR_STAMP(5)
@@ -1433,23 +1267,79 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
 
   const unsigned short* s_map = reinterpret_cast<const unsigned short*>(s_table);
   const float4* s_rec = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(s_table) + P.lds_map_bytes);
+  const float4* s_tile = reinterpret_cast<const float4*>(s_table);
 
-  // Three phases per batch of PTS points, so that no instruction is issued for more lanes than it has work for:
-  //  A (all 4 PTS lanes, four per point): transform, neighbourhood, pair terms, quad combine -> 14 floats per point in LDS
-  //  B (PTS lanes, one per point): the 29 Jacobian / Hessian terms of the point -> LDS
-  //  C (all lanes): fp64 sum over the points, SEGS segments per value
+  // Per batch of PTS points:
+  //  A (all 4 PTS lanes, four per point): transform, neighbourhood, pair terms, quad combine;
+  //  B the 29 Jacobian / Hessian terms of the point.  With Hessian: the 14 per-point sums go through LDS to ONE lane per point
+  //    (two full waves instead of eight quarter-full ones: ~150 instructions per wave); gradient-only passes (three in four)
+  //    form their 8 terms right where the sums are, in every lane of the quad — ~30 instructions, no barrier, no LDS round trip;
+  //  C (all lanes): fp64 sum over the points, SEGS segments per value.
   const int nred = hess ? 29 : NDT_NRED_GRAD;
   const int cv = tid / SEGS, cseg = tid % SEGS;
   double csum = 0.0;
   for (int base = blockIdx.x * PTS; base < P.n; base += stride) {  // uniform across the workgroup
     // ---- phase A
     {
-      const float tx = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
-      const float ty = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
-      const float tz = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
+      const float tx = xform_ref(T[0], T[1], T[2], T[3], x, y, z);
+      const float ty = xform_ref(T[4], T[5], T[6], T[7], x, y, z);
+      const float tz = xform_ref(T[8], T[9], T[10], T[11], x, y, z);
       const float fx = floorf(tx / leaf), fy = floorf(ty / leaf), fz = floorf(tz / leaf);
       const bool finite_ok = (i < P.n) && (fabsf(fx) < 1.0e9f) && (fabsf(fy) < 1.0e9f) && (fabsf(fz) < 1.0e9f);
       const int ci = finite_ok ? (int)fx : INT_MIN / 2, cj = finite_ok ? (int)fy : INT_MIN / 2, ck = finite_ok ? (int)fz : INT_MIN / 2;
+
+      // ---- NDT_TAB_TILE: the box of cells this batch touches -> LDS
+      bool use_tile = false;
+      int lo0 = 0, lo1 = 0, lo2 = 0, tdx = 1, tdxy = 1;
+      if (TAB == NDT_TAB_TILE) {
+        // centre cells that can have a neighbour inside the grid: within one cell of it
+        const bool near = (ci >= P.min_b[0] - 1) & (ci <= P.max_b[0] + 1) & (cj >= P.min_b[1] - 1) & (cj <= P.max_b[1] + 1) &
+                          (ck >= P.min_b[2] - 1) & (ck <= P.max_b[2] + 1);
+        const int mn0 = wave_min_i(near ? ci : INT_MAX), mn1 = wave_min_i(near ? cj : INT_MAX), mn2 = wave_min_i(near ? ck : INT_MAX);
+        const int mx0 = wave_max_i(near ? ci : INT_MIN), mx1 = wave_max_i(near ? cj : INT_MIN), mx2 = wave_max_i(near ? ck : INT_MIN);
+        if ((tid & 63) == 0 && mn0 != INT_MAX) {
+          atomicMin(&s_box[0], mn0); atomicMin(&s_box[1], mn1); atomicMin(&s_box[2], mn2);
+          atomicMax(&s_box[3], mx0); atomicMax(&s_box[4], mx1); atomicMax(&s_box[5], mx2);
+        }
+        barrier_lds_only();
+        const int b0 = uniform_i(s_box[0]), b1 = uniform_i(s_box[1]), b2 = uniform_i(s_box[2]);
+        const int b3 = uniform_i(s_box[3]), b4 = uniform_i(s_box[4]), b5 = uniform_i(s_box[5]);
+        if (b0 == INT_MAX) {
+          use_tile = true;   // no point of this batch is near the grid: every neighbour fails the bounds test, nothing is read
+        } else {
+          lo0 = max(b0 - 1, P.min_b[0]); lo1 = max(b1 - 1, P.min_b[1]); lo2 = max(b2 - 1, P.min_b[2]);
+          const int hi0 = min(b3 + 1, P.max_b[0]), hi1 = min(b4 + 1, P.max_b[1]), hi2 = min(b5 + 1, P.max_b[2]);
+          const int tdy = hi1 - lo1 + 1, tdz = hi2 - lo2 + 1;
+          tdx = hi0 - lo0 + 1;
+          tdxy = tdx * tdy;
+          const long long ncell = (long long)tdxy * tdz;
+          use_tile = ncell * NDT_LDS_REC_BYTES <= (long long)P.tile_bytes;
+          if (use_tile) {
+            // one 16-byte piece per lane and DMA instruction: piece q = 3 * (cell of the box) + part, LDS address 16 q
+            const unsigned int npieces = 3u * (unsigned int)ncell;
+            const unsigned int mxy = div_magic((unsigned int)tdxy), mx = div_magic((unsigned int)tdx);
+            const unsigned char* recb = reinterpret_cast<const unsigned char*>(P.rec);
+            unsigned char* dst = reinterpret_cast<unsigned char*>(s_table);
+            for (unsigned int q0 = (unsigned int)(tid & ~63); q0 < npieces; q0 += THREADS) {   // q0: wave-uniform
+              const unsigned int q = q0 + (unsigned int)(tid & 63);
+              if (q < npieces) {
+                const unsigned int cell = (q * 21846u) >> 16;          // q / 3 for q < 32768
+                const unsigned int part = q - 3u * cell;
+                const unsigned int c = div_small(cell, (unsigned int)tdxy, mxy);
+                const unsigned int rem = cell - c * (unsigned int)tdxy;
+                const unsigned int b = div_small(rem, (unsigned int)tdx, mx);
+                const unsigned int a = rem - b * (unsigned int)tdx;
+                const size_t gcell = (size_t)(lo0 - P.min_b[0] + (int)a) + (size_t)(lo1 - P.min_b[1] + (int)b) * P.mul1 +
+                                     (size_t)(lo2 - P.min_b[2] + (int)c) * P.mul2;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(recb + gcell * 64 + part * 16),
+                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)q0 * 16), 16, 0, 0);
+              }
+            }
+          }
+        }
+        __syncthreads();   // the tile has landed (vmcnt(0) + barrier); s_box may be reset for the next batch
+        if (tid >= THREADS - 6) s_box[THREADS - 1 - tid] = (THREADS - 1 - tid < 3) ? INT_MAX : INT_MIN;
+      }
 
       bool valid[NT];
       int cellv[NT];
@@ -1462,10 +1352,10 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
         const bool in = (o < NOFF) & (a >= P.min_b[0]) & (a <= P.max_b[0]) & (b >= P.min_b[1]) & (b <= P.max_b[1]) &
                         (c >= P.min_b[2]) & (c <= P.max_b[2]);
         valid[t] = in;
-        cellv[t] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
+        if (TAB == NDT_TAB_TILE && use_tile) cellv[t] = in ? ((a - lo0) + (b - lo1) * tdx + (c - lo2) * tdxy) : 0;
+        else cellv[t] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
       }
-      float4 r0[NT], r1[NT];
-      float c22v[NT];
+      float4 r0[NT], r1[NT], r2[NT];
       if (TAB == NDT_TAB_LDS) {
         int slot[NT];
 #pragma unroll
@@ -1478,13 +1368,20 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
         for (int t = 0; t < NT; t++) {
           r0[t] = s_rec[slot[t] * 3 + 0];
           r1[t] = s_rec[slot[t] * 3 + 1];
-          c22v[t] = reinterpret_cast<const float*>(s_rec + slot[t] * 3 + 2)[0];
+          r2[t] = s_rec[slot[t] * 3 + 2];
+        }
+      } else if (TAB == NDT_TAB_TILE && use_tile) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {   // unusable cells of the box hold NaN records: the pair drops itself
+          r0[t] = s_tile[cellv[t] * 3 + 0];
+          r1[t] = s_tile[cellv[t] * 3 + 1];
+          r2[t] = s_tile[cellv[t] * 3 + 2];
         }
       } else {
         size_t ridx[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-          if (TAB == NDT_TAB_DENSE) {
+          if (TAB != NDT_TAB_COMPACT) {
             ridx[t] = (size_t)cellv[t];
           } else {
             const int sl = P.cell_slot[cellv[t]];
@@ -1496,9 +1393,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
         for (int t = 0; t < NT; t++) {
           r0[t] = P.rec[ridx[t] * 4 + 0];
           r1[t] = P.rec[ridx[t] * 4 + 1];
-          const float4 r2 = P.rec[ridx[t] * 4 + 2];
-          c22v[t] = r2.x;
-          valid[t] = valid[t] & (r2.y >= 6.f);
+          r2[t] = P.rec[ridx[t] * 4 + 2];
         }
       }
 
@@ -1507,56 +1402,67 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
       float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; t++)
-        pair_terms(valid[t], hess, tx, ty, tz, r0[t], r1[t], c22v[t], d2, d1d, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22);
+        pair_terms(valid[t], hess, tx, ty, tz, r0[t], r1[t], r2[t], d2, d1d, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22);
       // the quad's four partial sums -> every lane of the quad (fp32, as the reference sums a point's voxels in float)
       score = dpp_quad_sum(score); npairs = dpp_quad_sum(npairs);
       A0 = dpp_quad_sum(A0); A1 = dpp_quad_sum(A1); A2 = dpp_quad_sum(A2);
       if (hess) {
         E00 = dpp_quad_sum(E00); E01 = dpp_quad_sum(E01); E02 = dpp_quad_sum(E02);
         E11 = dpp_quad_sum(E11); E12 = dpp_quad_sum(E12); E22 = dpp_quad_sum(E22);
+        // lane l of the quad stores rows l, l + 4, l + 8, (l + 12) of the point's record: one to four stores per lane
+        const float row0 = (ql == 0) ? score : (ql == 1) ? npairs : (ql == 2) ? A0 : A1;
+        const float row1 = (ql == 0) ? A2 : (ql == 1) ? E00 : (ql == 2) ? E01 : E02;
+        const float row2 = (ql == 0) ? E11 : (ql == 1) ? E12 : (ql == 2) ? E22 : x;
+        s_pt[ql][pq] = row0;
+        s_pt[4 + ql][pq] = row1;
+        s_pt[8 + ql][pq] = row2;
+        if (ql < 2) s_pt[12 + ql][pq] = (ql == 0) ? y : z;
+      } else {
+        // gradient-only pass: the 8 terms of the point, formed by every lane of the quad (identical values); lane l stores
+        // rows l and l + 4
+        float o[29];
+        if (npairs != 0.f) {
+          point_terms(false, x, y, z, score, npairs, A0, A1, A2, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, L->jang, L->hang, o);
+        } else {
+#pragma unroll
+          for (int k = 0; k < NDT_NRED_GRAD; k++) o[k] = 0.f;
+        }
+        s_o[ql][pq] = (ql == 0) ? o[0] : (ql == 1) ? o[1] : (ql == 2) ? o[2] : o[3];
+        s_o[4 + ql][pq] = (ql == 0) ? o[4] : (ql == 1) ? o[5] : (ql == 2) ? o[6] : o[7];
       }
-      // lane l of the quad stores rows l, l + 4, l + 8, (l + 12) of the point's record: one to four stores per lane
-      const float row0 = (ql == 0) ? score : (ql == 1) ? npairs : (ql == 2) ? A0 : A1;
-      const float row1 = (ql == 0) ? A2 : (ql == 1) ? E00 : (ql == 2) ? E01 : E02;
-      const float row2 = (ql == 0) ? E11 : (ql == 1) ? E12 : (ql == 2) ? E22 : x;
-      s_pt[ql][pq] = row0;
-      s_pt[4 + ql][pq] = row1;
-      s_pt[8 + ql][pq] = row2;
-      if (ql < 2) s_pt[12 + ql][pq] = (ql == 0) ? y : z;
       i += stride;
       x = 0.f; y = 0.f; z = 0.f;
       if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }   // next batch's loads fly under phases B and C
     }
     LSR_STAMP(12)
     barrier_lds_only();
-    // ---- phase B
-    if (tid < PTS) {
-      const float npairs = s_pt[1][tid];
-      float o[29];
-      if (npairs != 0.f) {
-        point_terms(hess, s_pt[11][tid], s_pt[12][tid], s_pt[13][tid], s_pt[0][tid], npairs, s_pt[2][tid], s_pt[3][tid], s_pt[4][tid],
-                    s_pt[5][tid], s_pt[6][tid], s_pt[7][tid], s_pt[8][tid], s_pt[9][tid], s_pt[10][tid], L, o);
-      } else {
+    // ---- phase B (passes with Hessian)
+    if (hess) {
+      if (tid < PTS) {
+        const float npairs = s_pt[1][tid];
+        float o[29];
+        if (npairs != 0.f) {
+          point_terms(true, s_pt[11][tid], s_pt[12][tid], s_pt[13][tid], s_pt[0][tid], npairs, s_pt[2][tid], s_pt[3][tid], s_pt[4][tid],
+                      s_pt[5][tid], s_pt[6][tid], s_pt[7][tid], s_pt[8][tid], s_pt[9][tid], s_pt[10][tid], L->jang, L->hang, o);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 29; k++) o[k] = 0.f;
-      }
-      if (hess) {
+          for (int k = 0; k < 29; k++) o[k] = 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < 29; k++) s_o[k][tid] = o[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < NDT_NRED_GRAD; k++) s_o[k][tid] = o[k];
       }
+      LSR_STAMP(13)
+      barrier_lds_only();
     }
-    LSR_STAMP(13)
-    barrier_lds_only();
     LSR_STAMP(14)
     // ---- phase C: the float terms of the reference's per-point sums, accumulated in double
     if (cv < nred) {
 #pragma unroll
       for (int k = 0; k < PTS / SEGS; k++) csum += (double)s_o[cv][cseg + SEGS * k];
     }
-    // (the next batch overwrites s_pt only: phase C of this batch reads s_o, phase B of the next one is behind a barrier)
+    // the next batch writes s_pt / s_o again: with Hessian (and in tile mode) its writes are behind a barrier of the next round;
+    // a gradient-only round without the tile barriers writes s_o straight away
+    if (!hess && TAB != NDT_TAB_TILE && base + stride < P.n) barrier_lds_only();
   }
 
   LSR_STAMP(2)
@@ -1687,35 +1593,38 @@ int ndt_init_single(const NdtState& st, NdtState* d_state2, long long* d_bins, h
 }
 
 template <int NOFF, int TAB, int PTS>
-static int launch_quad_variant(dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, int seq) {
-  static bool allowed[64] = {};
+static int launch_quad_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq) {
+  static bool allowed[2][64] = {};
   if (dyn_lds > 32 * 1024) {
     int dev = 0;
     LSR_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !allowed[dev]) {
-      LSR_HIP(hipFuncSetAttribute((const void*)ndt_eval_quad_kernel<NOFF, TAB, PTS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)NDT_LDS_TABLE_MAX_QUAD));
-      allowed[dev] = true;
+    if (dev >= 0 && dev < 64 && !allowed[byval ? 1 : 0][dev]) {
+      const void* fn = byval ? (const void*)ndt_eval_quad_kernel<NOFF, TAB, PTS, true> : (const void*)ndt_eval_quad_kernel<NOFF, TAB, PTS, false>;
+      LSR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NDT_LDS_TABLE_MAX_QUAD));
+      allowed[byval ? 1 : 0][dev] = true;
     }
   }
-  hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB, PTS>), grid, dim3(4 * PTS), dyn_lds, stream, pv, seq);
+  if (byval) hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB, PTS, true>), grid, dim3(4 * PTS), dyn_lds, stream, pv, d_probs, seq);
+  else hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB, PTS, false>), grid, dim3(4 * PTS), dyn_lds, stream, pv, d_probs, seq);
   return LSR_OK;
 }
 
 template <int NOFF>
-static int launch_quad(const NdtLaunchCfg& cfg, dim3 grid, hipStream_t stream, const NdtProblem& pv, int seq) {
-  const size_t dyn = (cfg.tab == NDT_TAB_LDS) ? (size_t)cfg.lds_bytes : 0;
+static int launch_quad(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq) {
+  const size_t dyn = (cfg.tab == NDT_TAB_LDS || cfg.tab == NDT_TAB_TILE) ? (size_t)cfg.lds_bytes : 0;
   if (cfg.threads == 64) {  // points per workgroup
     switch (cfg.tab) {
-      case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 64>(grid, dyn, stream, pv, seq);
-      case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 64>(grid, dyn, stream, pv, seq);
-      default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 64>(grid, dyn, stream, pv, seq);
+      case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 64>(byval, grid, dyn, stream, pv, d_probs, seq);
+      case NDT_TAB_TILE: return launch_quad_variant<NOFF, NDT_TAB_TILE, 64>(byval, grid, dyn, stream, pv, d_probs, seq);
+      case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 64>(byval, grid, dyn, stream, pv, d_probs, seq);
+      default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 64>(byval, grid, dyn, stream, pv, d_probs, seq);
     }
   }
   switch (cfg.tab) {
-    case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 128>(grid, dyn, stream, pv, seq);
-    case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 128>(grid, dyn, stream, pv, seq);
-    default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 128>(grid, dyn, stream, pv, seq);
+    case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
+    case NDT_TAB_TILE: return launch_quad_variant<NOFF, NDT_TAB_TILE, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
+    case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
+    default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
   }
 }
 
@@ -1723,14 +1632,17 @@ static int launch_quad(const NdtLaunchCfg& cfg, dim3 grid, hipStream_t stream, c
 int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, const NdtLaunchCfg& cfg, int seq0, int count,
                      hipStream_t stream) {
   if (cfg.quad) {
-    if (cfg.batch != 1 || !h_single || !h_single->bins) { set_last_error("the quad kernel runs single registrations"); return LSR_ERR_INVALID_ARGUMENT; }
-    dim3 qgrid(cfg.max_blocks, 1);
+    const bool qbyval = (cfg.batch == 1 && h_single != nullptr);
+    if (qbyval ? !h_single->bins : !d_probs) { set_last_error("the quad kernel needs its accumulator banks / problem array"); return LSR_ERR_INVALID_ARGUMENT; }
+    dim3 qgrid(cfg.max_blocks, cfg.batch);
+    NdtProblem qpv;
+    if (qbyval) qpv = *h_single; else std::memset(&qpv, 0, sizeof(qpv));
     for (int i = 0; i < count; i++) {
       int st;
       switch (cfg.neighborhood) {
-        case LSR_DIRECT1: st = launch_quad<1>(cfg, qgrid, stream, *h_single, seq0 + i); break;
-        case LSR_DIRECT26: st = launch_quad<27>(cfg, qgrid, stream, *h_single, seq0 + i); break;
-        default: st = launch_quad<7>(cfg, qgrid, stream, *h_single, seq0 + i); break;
+        case LSR_DIRECT1: st = launch_quad<1>(cfg, qbyval, qgrid, stream, qpv, d_probs, seq0 + i); break;
+        case LSR_DIRECT26: st = launch_quad<27>(cfg, qbyval, qgrid, stream, qpv, d_probs, seq0 + i); break;
+        default: st = launch_quad<7>(cfg, qbyval, qgrid, stream, qpv, d_probs, seq0 + i); break;
       }
       if (st) return st;
     }
@@ -1888,10 +1800,7 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __rest
   for (int k = 0; k < 3; k++) mean64[(size_t)r * 3 + k] = mean[k];
   for (int k = 0; k < 9; k++) icov64[(size_t)r * 9 + k] = icov[k];
   const size_t ri = dense ? (size_t)key : (size_t)r;  // dense: record lives at its cell index
-  rec[ri * 4 + 0] = make_float4((float)mean[0], (float)mean[1], (float)mean[2], (float)icov[0]);
-  rec[ri * 4 + 1] = make_float4((float)icov[1], (float)icov[2], (float)icov[4], (float)icov[5]);
-  rec[ri * 4 + 2] = make_float4((float)icov[8], (float)n, 0.f, 0.f);
-  rec[ri * 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  leaf_record_dev(mean, icov, n, valid, rec + ri * 4);
   cell_slot[key] = valid ? (int)ri : -1;
   if (valid) atomicAdd(n_valid, 1);
 }
@@ -2208,7 +2117,7 @@ __global__ __launch_bounds__(1024) void lds_pack_kernel(const int* __restrict__ 
         const float4 a = rec[(size_t)ri * 4 + 0], b = rec[(size_t)ri * 4 + 1], d = rec[(size_t)ri * 4 + 2];
         out[(size_t)slot * 3 + 0] = a;
         out[(size_t)slot * 3 + 1] = b;
-        out[(size_t)slot * 3 + 2] = make_float4(d.x, 0.f, 0.f, 0.f);
+        out[(size_t)slot * 3 + 2] = d;   // {c22, mean_lo.xyz}
         map[c] = (unsigned short)slot;
         slot++;
       } else {
@@ -2354,7 +2263,7 @@ int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
   grid.dense = grid.ncells <= ((size_t)4 << 20);
   if (grid.dense) {
     if ((st = grid.rec.reserve(grid.ncells * 4))) return st;
-    LSR_HIP(hipMemsetAsync(grid.rec.p, 0, grid.ncells * 4 * sizeof(float4), stream));
+    LSR_HIP(hipMemsetAsync(grid.rec.p, 0xFF, grid.ncells * 4 * sizeof(float4), stream));   // all-ones words are NaN: empty cells answer no lookup
   } else {
     if ((st = grid.rec.reserve((size_t)n_runs * 4))) return st;
   }

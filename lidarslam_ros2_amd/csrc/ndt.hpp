@@ -42,9 +42,12 @@ constexpr int NDT_NBANKS = 3;                                    // launch seq a
 enum NdtTableMode : int {
   NDT_TAB_DENSE = 0,    // 64-byte records per grid cell in global memory (no cell->slot indirection)
   NDT_TAB_COMPACT = 1,  // cell_slot[] -> compact 64-byte records in global memory (huge grids)
-  NDT_TAB_LDS = 2       // the whole valid-voxel table (uint16 cell->slot map + 48-byte records) staged into LDS at the
+  NDT_TAB_LDS = 2,      // the whole valid-voxel table (uint16 cell->slot map + 48-byte records) staged into LDS at the
                         // head of every launch, in the shadow of the controller: gathers become ds_read_b128
+  NDT_TAB_TILE = 3      // tables that do not fit LDS (ndt_resolution <= 2 m on a 20-frame submap): per workgroup and pass the box
+                        // of dense-table cells its (tile-ordered) points touch is staged into LDS; quad kernel only
 };
+constexpr int NDT_TILE_BYTES = 32 * 1024;  // tile buffer per workgroup: 682 cells of 48 bytes
 
 struct NdtState {
   // ---- evaluation request, read by every workgroup of the next launch
@@ -101,7 +104,7 @@ struct NdtProblem {
   int lds_map_bytes;        // NDT_TAB_LDS: bytes of the uint16 cell->slot map at the start of lds_image (multiple of 16)
   const uint4* lds_image;   // NDT_TAB_LDS: [map | records], padded to a multiple of 1 KiB (one wave-wide 16-byte DMA)
   int lds_bytes;
-  int pad;
+  int tile_bytes;           // NDT_TAB_TILE: capacity of the per-workgroup LDS tile buffer (dynamic LDS of the launch)
   long long* bins;          // quad kernel: [NDT_NBANKS][NDT_NSHARDS][NDT_NBINS][32] int64 accumulators (zeroed by the host before launch 0)
   NdtState* st;             // [2] double buffered by launch parity
   double* partials;         // [2][nblocks][NDT_NRED]
@@ -137,7 +140,8 @@ struct NdtLaunchCfg {
   int threads = NDT_THREADS;
   int lds_bytes = 0;       // dynamic LDS (largest lds_bytes of the batch) when tab == NDT_TAB_LDS
   int quad = 0;            // 1: four lanes per source point, 512-thread workgroups, binned integer accumulation (single
-                           // registrations: spreads a 30k-point scan over every CU); 0: one lane per point, partial rows
+                           // registrations: spreads a 30k-point scan over every CU; batches whose tables need NDT_TAB_TILE);
+                           // 0: one lane per point, partial rows
 };
 constexpr int NDT_QUAD_THREADS = 512;
 constexpr int NDT_QUAD_POINTS = NDT_QUAD_THREADS / 4;  // source points per workgroup pass
@@ -152,6 +156,10 @@ int ndt_pack_lds_table(VoxelGridDev& grid, BuildScratch& sc, bool per_cell_leaf_
 // round trip.  grid.min_b / div_b / ncells must be set.
 constexpr int VG_DENSE_MAX_CELLS = 16383;
 int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
+// Order the source cloud by voxel tile (NDT_TAB_TILE): counting sort of the points by the Morton code of the 2^shift x 2^shift
+// column of grid cells their guess-moved image falls into (grid_dense.hip).  Consecutive points of `out` are neighbours in
+// space, so the cells a workgroup of the derivative pass touches form a small box.  T12: row-major 3x4 guess (host memory).
+int ndt_sort_source(const DeviceCloud& src, const float* T12, const VoxelGridDev& grid, DeviceCloud& out, BuildScratch& sc, hipStream_t stream);
 // One small launch that writes the initial state (passed in the kernel arguments) into both state buffers and clears the
 // quad kernel's accumulator banks (d_bins nullable).
 int ndt_init_single(const NdtState& st, NdtState* d_state2, long long* d_bins, hipStream_t stream);

@@ -60,7 +60,7 @@ def search_loop(registration: Registration, submaps: Sequence[SubMap], params: L
     keep = []
     on_device, stride = None, None
     for i, sm in enumerate(submaps):
-        ptr, st, cnt, dev, holder = _cloud_args(sm.cloud)
+        ptr, st, cnt, dev, holder = _cloud_args(sm.cloud, registration)
         keep.append(holder)
         if on_device is None:
             on_device, stride = dev, st

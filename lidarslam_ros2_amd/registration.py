@@ -26,8 +26,10 @@ def _is_torch_cuda(x) -> bool:
     return hasattr(x, "is_cuda") and bool(x.is_cuda)
 
 
-def _cloud_args(cloud):
-    """-> (pointer, stride_bytes, n, on_device, keepalive)"""
+def _cloud_args(cloud, reg=None):
+    """-> (pointer, stride_bytes, n, on_device, keepalive).  reg: the registration object that is going to read the cloud —
+    for a CUDA tensor its stream is ordered after torch's current stream AFTER any .contiguous() copy has been enqueued there
+    (the copy is the buffer the core reads; an event recorded before it would not cover it)."""
     if _is_torch_cuda(cloud):
         import torch
 
@@ -36,6 +38,8 @@ def _cloud_args(cloud):
             raise ValueError("device cloud must be float32 of shape (n, c>=3)")
         if not t.is_contiguous():
             t = t.contiguous()
+        if reg is not None:
+            _order_after_torch(reg, t)
         return C.c_void_p(t.data_ptr()), t.shape[1] * 4, t.shape[0], True, t
     a = np.asarray(cloud)
     if a.ndim != 2 or a.shape[1] < 3:
@@ -131,8 +135,7 @@ class Registration:
 
     # -- clouds ------------------------------------------------------------------------------
     def setInputTarget(self, cloud):  # scanmatcher_component.cpp:275,307,315; graph_based_slam_component.cpp:227
-        _order_after_torch(self, cloud)
-        p, stride, n, dev, keep = _cloud_args(cloud)
+        p, stride, n, dev, keep = _cloud_args(cloud, self)
         fn = self._lib.lsr_set_input_target_device if dev else self._lib.lsr_set_input_target
         capi.check(fn(self._h, p, stride, n), "setInputTarget")
         self._keep["target"] = None  # the core keeps its own SoA copy in HBM
@@ -140,9 +143,7 @@ class Registration:
     def setInputTargetFrames(self, frames, poses):
         """Submap assembly on the device: frame f transformed by poses[f] (4x4), concatenated, then
         setInputTarget (scanmatcher_component.cpp:449-464,307).  Frames: host arrays or CUDA tensors, same layout."""
-        for f in frames:
-            _order_after_torch(self, f)
-        args = [_cloud_args(f) for f in frames]
+        args = [_cloud_args(f, self) for f in frames]
         dev = args[0][3]
         if any(a[3] != dev for a in args) or any(a[1] != args[0][1] for a in args):
             raise ValueError("frames must all be host or all device, with one record stride")
@@ -156,8 +157,7 @@ class Registration:
         self._n_target = int(sum(a[2] for a in args))
 
     def setInputSource(self, cloud):  # scanmatcher_component.cpp:329; graph_based_slam_component.cpp:181
-        _order_after_torch(self, cloud)
-        p, stride, n, dev, keep = _cloud_args(cloud)
+        p, stride, n, dev, keep = _cloud_args(cloud, self)
         fn = self._lib.lsr_set_input_source_device if dev else self._lib.lsr_set_input_source
         capi.check(fn(self._h, p, stride, n), "setInputSource")
         self._n_source = n
@@ -166,8 +166,7 @@ class Registration:
     def setInputSourceFiltered(self, cloud, leaf: float) -> int:
         """pcl::VoxelGrid(leaf).filter + setInputSource on the device (scanmatcher_component.cpp:324-329);
         returns the number of points kept."""
-        _order_after_torch(self, cloud)
-        p, stride, n, dev, keep = _cloud_args(cloud)
+        p, stride, n, dev, keep = _cloud_args(cloud, self)
         n_out = C.c_size_t()
         capi.check(self._lib.lsr_set_input_source_filtered(self._h, p, stride, n, C.c_float(leaf), 1 if dev else 0,
                                                            C.byref(n_out)), "setInputSourceFiltered")
@@ -177,8 +176,7 @@ class Registration:
     def setInputSourceFrontend(self, cloud, scan_min_range: float, scan_max_range: float, vg_size_for_input: float) -> int:
         """Range filter (scanmatcher_component.cpp:210-218) + VoxelGrid (:324-328) + setInputSource (:329) on the
         device; returns the number of points kept."""
-        _order_after_torch(self, cloud)
-        p, stride, n, dev, keep = _cloud_args(cloud)
+        p, stride, n, dev, keep = _cloud_args(cloud, self)
         n_out = C.c_size_t()
         capi.check(self._lib.lsr_set_input_source_frontend(self._h, p, stride, n, float(scan_min_range), float(scan_max_range),
                                                            C.c_float(vg_size_for_input), 1 if dev else 0, C.byref(n_out)),
@@ -411,7 +409,7 @@ class GeneralizedIterativeClosestPoint(Registration):
 
     def setInputTarget(self, cloud):
         super().setInputTarget(cloud)
-        self._n_target = _cloud_args(cloud)[2]
+        self._n_target = int(np.shape(cloud)[0]) if not _is_torch_cuda(cloud) else int(cloud.shape[0])
 
 
 def set_input_target_batch(regs: Sequence[Registration], clouds):
@@ -421,9 +419,7 @@ def set_input_target_batch(regs: Sequence[Registration], clouds):
     B = len(regs)
     if len(clouds) != B:
         raise ValueError("one cloud per registration object")
-    for r, c in zip(regs, clouds):
-        _order_after_torch(r, c)
-    args = [_cloud_args(c) for c in clouds]
+    args = [_cloud_args(c, r) for r, c in zip(regs, clouds)]
     if B and (any(a[3] != args[0][3] for a in args) or any(a[1] != args[0][1] for a in args)):
         raise ValueError("clouds must all be host or all device, with one record stride")
     hs = (C.c_void_p * B)(*[r._h for r in regs])

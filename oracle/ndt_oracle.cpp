@@ -311,7 +311,17 @@ struct NdtResult {
   int n_hessian_recompute;
 };
 
+// Test hook (tests/ndt_host_emu.py): the Newton / More-Thuente loop below driven by a DIFFERENT derivative evaluation — the GPU
+// kernels' own fp32 operation order compiled for the host (tools/ndt_host_emu) — to measure on the CPU what that operation
+// order alone does to a registration.  mode: 3 = first pass of align() (point transform = T16 as given), 1 = pass with
+// Hessian at p (refresh j_ang and h_ang), 0 = gradient-only pass at p (refresh j_ang only), 2 = computeHessian at the pose of
+// the last pass (current j_ang, h_ang as left by the last mode-1/3 pass; only hess is written).  Returns the score.
+typedef double (*DerivCb)(void* user, const double* p, const float* T16, int mode, double* grad, double* hess);
+
 struct Ndt {
+  DerivCb cb = nullptr;
+  void* cb_user = nullptr;
+  bool cb_first = true;
   const Grid* g;
   const float* src;
   size_t stride_f, n;
@@ -334,6 +344,7 @@ void gauss_constants(double res, double outlier, double* d1, double* d2, double*
 }
 
 void transform_cloud(Ndt& S, const float* M) {
+  if (S.cb) return;   // the hook transforms the points itself
   S.trans.resize(S.n * 3);
 #pragma omp parallel for schedule(static) num_threads(S.prm.num_threads > 0 ? S.prm.num_threads : omp_get_max_threads())
   for (long i = 0; i < (long)S.n; i++) transform_point_f(M, P(S.src, S.stride_f, i), &S.trans[3 * i]);
@@ -342,6 +353,12 @@ void transform_cloud(Ndt& S, const float* M) {
 // computeDerivatives + updateDerivatives restatement: per-pair fp32,
 // per-point fp64 accumulators, final sum sequential in index order.
 double compute_derivatives(Ndt& S, const double* p, bool compute_hessian, double* grad, double* hess) {
+  if (S.cb) {
+    for (int a = 0; a < 36; a++) hess[a] = 0;
+    const int mode = S.cb_first ? 3 : (compute_hessian ? 1 : 0);
+    S.cb_first = false;
+    return S.cb(S.cb_user, p, S.res->final_transformation, mode, grad, hess);
+  }
   compute_angle_derivatives(p, compute_hessian, S.prm.d1_sign, S.ang);
   const size_t n = S.n;
   std::vector<double>&sc = S.sc, &gr = S.gr, &he = S.he;
@@ -433,6 +450,11 @@ double compute_derivatives(Ndt& S, const double* p, bool compute_hessian, double
 // computeHessian + updateHessian restatement: fp64 per pair, sequential; uses the CURRENT
 // j_ang and whatever h_ang the last compute_hessian=true call left behind.
 void compute_hessian_only(Ndt& S, double* hess) {
+  if (S.cb) {
+    double g_unused[6];
+    S.cb(S.cb_user, nullptr, S.res->final_transformation, 2, g_unused, hess);
+    return;
+  }
   for (int a = 0; a < 36; a++) hess[a] = 0;
   for (size_t idx = 0; idx < S.n; idx++) {
     const float* xs = P(S.src, S.stride_f, idx);
@@ -690,9 +712,10 @@ double orc_ndt_derivatives(void* gp, const float* src, size_t stride_floats, siz
 
 // pcl::Registration::align + NDT::computeTransformation restatement.
 // trace (nullable): per Newton iteration 9 doubles {p[6], score, step_length, n_evals_so_far}.
-int orc_ndt_align(void* gp, const float* src, size_t stride_floats, size_t n, const float* guess16,
-                  const NdtParams* prm, NdtResult* R, double* trace, int trace_cap) {
+static int ndt_align_impl(void* gp, const float* src, size_t stride_floats, size_t n, const float* guess16,
+                          const NdtParams* prm, NdtResult* R, double* trace, int trace_cap, DerivCb cb, void* cb_user) {
   Ndt S;
+  S.cb = cb; S.cb_user = cb_user;
   std::memset(R, 0, sizeof(*R));
   S.g = (Grid*)gp; S.src = src; S.stride_f = stride_floats; S.n = n; S.res = R; S.prm = *prm;
   double d3;
@@ -745,6 +768,16 @@ int orc_ndt_align(void* gp, const float* src, size_t stride_floats, size_t n, co
   R->iterations = nr_iterations;
   for (int i = 0; i < 6; i++) R->final_p[i] = p[i];
   return 0;
+}
+
+int orc_ndt_align(void* gp, const float* src, size_t stride_floats, size_t n, const float* guess16,
+                  const NdtParams* prm, NdtResult* R, double* trace, int trace_cap) {
+  return ndt_align_impl(gp, src, stride_floats, n, guess16, prm, R, trace, trace_cap, nullptr, nullptr);
+}
+// the same loop with the derivative evaluation replaced by `cb` (see DerivCb)
+int orc_ndt_align_cb(void* gp, const float* src, size_t stride_floats, size_t n, const float* guess16,
+                     const NdtParams* prm, NdtResult* R, double* trace, int trace_cap, DerivCb cb, void* cb_user) {
+  return ndt_align_impl(gp, src, stride_floats, n, guess16, prm, R, trace, trace_cap, cb, cb_user);
 }
 
 // pcl::VoxelGrid<PointT>::applyFilter restatement (PCL 1.12 voxel_grid.hpp; call sites

@@ -67,6 +67,9 @@ def lib():
         L.orc_ndt_align.restype = C.c_int
         L.orc_ndt_align.argtypes = [vp, fp, C.c_size_t, C.c_size_t, fp, C.POINTER(NdtParams), C.POINTER(NdtResult),
                                     dp, C.c_int]
+        L.orc_ndt_align_cb.restype = C.c_int
+        L.orc_ndt_align_cb.argtypes = [vp, fp, C.c_size_t, C.c_size_t, fp, C.POINTER(NdtParams), C.POINTER(NdtResult),
+                                       dp, C.c_int, vp, vp]
         L.orc_max_threads.restype = C.c_int
         L.orc_voxel_grid_filter.restype = C.c_int
         L.orc_voxel_grid_filter.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_float, fp]
@@ -192,7 +195,9 @@ def ndt_derivatives(grid: VoxelGridCovariance, src: np.ndarray, p, *, T=None, co
 
 def ndt_align(grid: VoxelGridCovariance, src: np.ndarray, guess=None, *, resolution=None, step_size=0.1,
               outlier_ratio=0.55, trans_eps=0.01, max_iterations=35, search=7, d1_sign=1, num_threads=0,
-              trace=False):
+              trace=False, deriv_cb=None):
+    """deriv_cb = (function address, user pointer): run the same Newton / More-Thuente loop on another derivative evaluation
+    (ndt_oracle.cpp DerivCb; tests/ndt_host_emu.py plugs the GPU kernels' arithmetic compiled for the host in here)."""
     s, sp = _f32(src)
     prm = NdtParams(resolution or grid.leaf, step_size, outlier_ratio, trans_eps, max_iterations, search, d1_sign,
                     num_threads)
@@ -203,7 +208,11 @@ def ndt_align(grid: VoxelGridCovariance, src: np.ndarray, guess=None, *, resolut
         gp = gc.ctypes.data_as(C.POINTER(C.c_float))
     cap = max_iterations + 4
     tr = np.zeros((cap, 9))
-    lib().orc_ndt_align(grid.h, sp, s.shape[1], s.shape[0], gp, C.byref(prm), C.byref(res), _f64p(tr), cap)
+    if deriv_cb is None:
+        lib().orc_ndt_align(grid.h, sp, s.shape[1], s.shape[0], gp, C.byref(prm), C.byref(res), _f64p(tr), cap)
+    else:
+        lib().orc_ndt_align_cb(grid.h, sp, s.shape[1], s.shape[0], gp, C.byref(prm), C.byref(res), _f64p(tr), cap,
+                               C.c_void_p(deriv_cb[0]), C.c_void_p(deriv_cb[1]))
     out = dict(final=np.array(res.final_transformation, np.float32).reshape(4, 4).T.copy(),
                converged=bool(res.converged), iterations=int(res.iterations),
                trans_probability=float(res.trans_probability), p=np.array(res.final_p),

@@ -303,3 +303,67 @@ def test_cfg4_fixture_is_well_formed():
     assert np.abs(R @ np.transpose(R, (0, 2, 1)) - np.eye(3)).max() < 1e-5      # fp32-composed rotations
     assert np.all(fx["converged"]) and fx["iterations"].min() >= 1 and fx["iterations"].max() <= 100
     assert np.all(fx["fitness"] > 0) and np.all(np.isfinite(fx["fitness"]))
+
+
+def _snippets(path):
+    """{name: text} of the blocks between '[snippet: NAME]' and '[end snippet]' marker lines (markers excluded; leading
+    indentation and trailing blanks normalised)."""
+    import re
+    import textwrap
+
+    out, name, buf = {}, None, []
+    for line in open(path).read().splitlines():
+        m = re.search(r"\[snippet: (\w+)\]", line)
+        if m:
+            name, buf = m.group(1), []
+        elif "[end snippet]" in line and name:
+            out[name] = textwrap.dedent("\n".join(buf)).strip("\n")
+            name = None
+        elif name:
+            buf.append(line.rstrip())
+    return out
+
+
+def test_integration_md_snippets_compile_against_the_header(tmp_path):
+    """Every code block of INTEGRATION.md that touches the C ABI lives verbatim in a file this test COMPILES and LINKS against
+    include/lidarslam_reg.h + liblidarslam_reg.so: the pcl::Registration binding (include/lidarslam_reg/gfx950_registration.hpp,
+    against tests/cpp/mock/pcl — virtual setInput*, non-virtual getFitnessScore, as in PCL 1.12) and tests/cpp/integration_snippets.cpp
+    (construction sites, searchLoop in one call, PointCloud2 codec, sharded candidate set)."""
+    import subprocess
+
+    libdir = os.path.join(ROOT, "lidarslam_ros2_amd")
+    exe = str(tmp_path / "integration_snippets")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "tests", "cpp", "mock"), os.path.join(ROOT, "tests", "cpp", "integration_snippets.cpp"),
+                           "-o", exe, "-L" + libdir, "-llidarslam_reg", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    doc = _snippets(os.path.join(ROOT, "INTEGRATION.md"))
+    src = {}
+    src.update(_snippets(os.path.join(ROOT, "include", "lidarslam_reg", "gfx950_registration.hpp")))
+    src.update(_snippets(os.path.join(ROOT, "tests", "cpp", "integration_snippets.cpp")))
+    assert set(src) == {"binding", "construction", "fitness", "search_loop", "pc2", "sharded"}
+    assert set(doc) == set(src), (sorted(doc), sorted(src))
+    for name in src:
+        assert doc[name] == src[name], f"INTEGRATION.md block '{name}' differs from the compiled source"
+
+
+def test_cfg4_tight_fixture_is_well_formed():
+    """tests/golden/cfg4_candidates_oracle_tight.npz (make_cfg4_tight_fixture.py): tight-epsilon results and the CPU-vs-CPU
+    spread of the eps-0.01 schedule under fp32-ulp perturbations.  The perturbed CPU runs take the same number of Newton
+    iterations as the committed result on every candidate; only a short list of candidates moves by more than half the
+    north_star bar — the list the GPU test bounds by its spread instead of the bar."""
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    fx = np.load(os.path.join(here, "golden", "cfg4_candidates_oracle.npz"))
+    fxt = np.load(os.path.join(here, "golden", "cfg4_candidates_oracle_tight.npz"))
+    assert fxt["final_tight"].shape == (64, 4, 4) and fxt["final_fma"].shape == (64, 4, 4) and fxt["final_jitter"].shape[:2] == (64, 4)
+    assert np.all(fxt["converged_tight"]) and fxt["iterations_tight"].max() <= 102
+    assert np.array_equal(fxt["iterations_fma"], fx["iterations"])
+    sp_t, sp_r = fxt["cpu_spread_translation_m"], fxt["cpu_spread_rotation_rad"]
+    sensitive = [c for c in range(64) if sp_t[c] > 5e-4 or sp_r[c] > 5e-5]
+    assert 1 <= len(sensitive) <= 6 and 34 in sensitive, sensitive
+    from lidarslam_ros2_amd.posemath import pose_delta
+
+    # where the eps-0.01 schedule stops short of the optimum (up to the 0.01 m termination tolerance) the two fixtures differ
+    d = np.array([pose_delta(fx["final"][c], fxt["final_tight"][c])[0] for c in range(64)])
+    assert np.median(d) < 0.02 and d.max() < 1.5
