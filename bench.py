@@ -583,6 +583,8 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
 
     tptr = (C.c_void_p * max(nloc, 1))(*[C.c_void_p(t.data_ptr()) for t in tgts])
     tcnt = (C.c_size_t * max(nloc, 1))(*[int(t.shape[0]) for t in tgts])
+    sptr = (C.c_void_p * max(nloc, 1))(*[C.c_void_p(t.data_ptr()) for t in srcs])
+    scnt = (C.c_size_t * max(nloc, 1))(*[int(t.shape[0]) for t in srcs])
 
     def one_round(batched: bool):
         """-> seconds for this rank's share; fills recs.  batched: the staged C-ABI entries (lsr_set_input_target_batch, the
@@ -591,10 +593,11 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
         t0 = time.perf_counter()
         if batched and nloc:
             _capi.check(lib.lsr_set_input_target_batch(hs, nloc, tptr, tcnt, 32, 1), "lsr_set_input_target_batch")
+            _capi.check(lib.lsr_set_input_source_batch(hs, nloc, sptr, scnt, 32, 1), "lsr_set_input_source_batch")
         for b, (r, t, s) in enumerate(zip(regs, tgts, srcs)):
             if not batched:
                 _capi.check(lib.lsr_set_input_target_device(r._h, C.c_void_p(t.data_ptr()), 32, int(t.shape[0])), "setInputTarget")
-            _capi.check(lib.lsr_set_input_source_device(r._h, C.c_void_p(s.data_ptr()), 32, int(s.shape[0])), "setInputSource")
+                _capi.check(lib.lsr_set_input_source_device(r._h, C.c_void_p(s.data_ptr()), 32, int(s.shape[0])), "setInputSource")
             if not batched:
                 fin = np.zeros(16, np.float32)
                 _capi.check(lib.lsr_align(r._h, guesses[b].ctypes.data_as(fptr), fin.ctypes.data_as(fptr), C.byref(r._last), None, 0), "align")

@@ -73,7 +73,9 @@ typedef enum lsr_key {
   LSR_NDT_WORKGROUP = 40,             /* one-lane kernel: threads per workgroup (128, 256); quad kernel: source points per
                                          workgroup (64, 128; four lanes each); 0 = automatic */
   LSR_NDT_TABLE_MODE = 41,            /* where the pass reads leaf records: -1 = automatic, 0 = dense global table,
-                                         1 = compact global table, 2 = whole table staged in LDS (when it fits) */
+                                         1 = compact global table, 2 = whole table staged in LDS (when it fits), 3 = per
+                                         workgroup the box of cells its tile-ordered points touch staged in LDS (dense tables
+                                         that do not fit LDS: ndt_resolution <= 2 m on a 20-frame submap) */
   LSR_GRID_BUILDER = 42,              /* 0 = automatic (counting sort for <= 16383 grid cells, radix sort beyond), 1 = always
                                          the radix-sort builder */
   LSR_WAIT_MODE = 43,                 /* how the calling thread waits for the device inside align() / setInputTarget():
@@ -81,8 +83,11 @@ typedef enum lsr_key {
                                          polls, 2 = sleep 20 us between polls (a ROS2 MultiThreadedExecutor runs two
                                          registration objects side by side, lidarslam/src/lidarslam.cpp:12-17).
                                          Environment preset: LSR_WAIT_MODE=spin|yield|sleep (or 0|1|2) */
-  LSR_NDT_QUAD = 44                   /* single NDT registrations: 1 = four lanes per source point on every CU with exact
+  LSR_NDT_QUAD = 44,                  /* single NDT registrations: 1 = four lanes per source point on every CU with exact
                                          integer-binned accumulation, 0 = one lane per point with partial rows, -1 = automatic */
+  LSR_NDT_SORT = 45                   /* order the source by voxel tile of its guess-moved points at the start of align():
+                                         -1 = automatic (tile table mode only), 0 = never (the tile mode then falls back to the
+                                         global table), 1 = also when the records are gathered from the global table */
 } lsr_key;
 /* Environment presets read when an object is created: LSR_NDT_WORKGROUP, LSR_NDT_TABLE_MODE, LSR_NDT_QUAD, LSR_GRID_BUILDER,
  * LSR_WAIT_MODE (the keys above).  Diagnostic A/B switches read once per process, all with bit-identical results
@@ -157,6 +162,11 @@ int lsr_set_input_target_frames(lsr_handle h, int n_frames, const void* const* f
 /* registration_->setInputSource(cloud)   scanmatcher_component.cpp:329; graph_based_slam_component.cpp:181 */
 int lsr_set_input_source(lsr_handle h, const void* pts, size_t stride_bytes, size_t n);
 int lsr_set_input_source_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n);
+/* The same for a SET of candidates (graph_based_slam_component.cpp:181 inside the candidate loop): handles[b] receives clouds[b];
+ * all host or all device pointers; the uploads share launches.  Device inputs follow the lifetime rule of
+ * lsr_set_input_source_device. */
+int lsr_set_input_source_batch(lsr_handle* handles, int count, const void* const* clouds, const size_t* counts,
+                               size_t stride_bytes, int on_device);
 /* pcl::VoxelGrid<PointXYZI>::filter (centroid per occupied leaf, output ordered by leaf index) fused with
  * setInputSource: the frontend's per-scan `voxel_grid.filter(*filtered); registration_->setInputSource(filtered)`
  * (scanmatcher_component.cpp:324-329) without the filtered cloud ever leaving HBM.  on_device != 0: `pts` is a

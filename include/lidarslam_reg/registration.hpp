@@ -117,6 +117,21 @@ class Registration {
     if (st != LSR_OK) std::fprintf(stderr, "[lidarslam_reg::setInputTargets] %s: %s\n", lsr_status_string(st), lsr_last_error());
     return st == LSR_OK;
   }
+  static bool setInputSources(const std::vector<Registration*>& regs, const std::vector<PointCloudSourceConstPtr>& clouds) {
+    if (regs.size() != clouds.size()) return false;
+    std::vector<lsr_handle> hs;
+    std::vector<const void*> ptrs;
+    std::vector<size_t> counts;
+    for (size_t b = 0; b < regs.size(); b++) {
+      regs[b]->input_ = clouds[b];
+      hs.push_back(regs[b]->h_);
+      ptrs.push_back(clouds[b]->points.data());
+      counts.push_back(clouds[b]->points.size());
+    }
+    const int st = lsr_set_input_source_batch(hs.data(), (int)hs.size(), ptrs.data(), counts.data(), sizeof(PointSource), 0);
+    if (st != LSR_OK) std::fprintf(stderr, "[lidarslam_reg::setInputSources] %s: %s\n", lsr_status_string(st), lsr_last_error());
+    return st == LSR_OK;
+  }
   // one shared launch chain for all members (NDT; GICP members are registered one after the other); `output` clouds are not
   // materialised (both reference callers discard them)
   static bool alignBatch(const std::vector<Registration*>& regs, const std::vector<Matrix4f>& guesses) {

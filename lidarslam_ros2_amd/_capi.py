@@ -19,7 +19,7 @@ KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
 (RESOLUTION, TRANSFORMATION_EPSILON, STEP_SIZE, OUTLIER_RATIO, MAX_CORRESPONDENCE_DISTANCE, ROTATION_EPSILON,
  EUCLIDEAN_FITNESS_EPSILON, GICP_EPSILON) = range(8)
 (MAX_ITERATIONS, NEIGHBORHOOD, NUM_THREADS, K_CORRESPONDENCES, MAX_INNER_ITERATIONS, RANSAC_ITERATIONS,
- HESSIAN_D1_SIGN, PROFILE, NDT_WORKGROUP, NDT_TABLE_MODE, GRID_BUILDER, WAIT_MODE, NDT_QUAD) = range(32, 45)
+ HESSIAN_D1_SIGN, PROFILE, NDT_WORKGROUP, NDT_TABLE_MODE, GRID_BUILDER, WAIT_MODE, NDT_QUAD, NDT_SORT) = range(32, 46)
 
 EXPORTED_SYMBOLS = [
     "lsr_version", "lsr_status_string", "lsr_last_error", "lsr_device_count", "lsr_create", "lsr_destroy",
@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_search_loop", "lsr_ndt_grid_info",
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
     "lsr_debug_angle_tables", "lsr_set_input_source_pc2", "lsr_get_source_pc2", "lsr_voxel_grid_filter_pc2", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
-    "lsr_set_input_target_batch", "lsr_get_fitness_score_batch",
+    "lsr_set_input_target_batch", "lsr_set_input_source_batch", "lsr_get_fitness_score_batch",
 ]
 
 
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
     L.lsr_get_fitness_score.argtypes = [vp, C.c_double, dp]
     L.lsr_get_fitness_score_batch.argtypes = [C.POINTER(vp), C.c_int, C.c_double, dp]
     L.lsr_set_input_target_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.c_int]
+    L.lsr_set_input_source_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.c_int]
     L.lsr_search_loop.argtypes = [vp, C.POINTER(SubMap), C.c_int, C.c_size_t, C.c_int, C.POINTER(LoopParams),
                                   C.POINTER(LoopEdge), C.c_int, ip]
     L.lsr_ndt_grid_info.argtypes = [vp, ip]

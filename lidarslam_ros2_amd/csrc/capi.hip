@@ -57,13 +57,27 @@ int upload_cloud(lsr_handle h, const void* pts, size_t stride, size_t n, bool on
 // Workgroups per registration.  A single registration spreads one point per thread over as many CUs as
 // it can (latency); a batch wants ~4 resident workgroups per CU in total and lets every thread stride
 // over several points, which amortises the reduction and the partial-row traffic (throughput).
-int ndt_nblocks(size_t n, int batch = 1, int threads = NDT_THREADS, bool quad = false) {
+// Compute units of the device (256 on MI355X).
+int device_cus(int device) {
+  static int cached[64] = {};
+  if (device >= 0 && device < 64 && cached[device] > 0) return cached[device];
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 256;
+  if (device >= 0 && device < 64) cached[device] = v;
+  return v;
+}
+
+// Workgroups per registration.  Every workgroup of a pass pays the fixed head of the launch (totals of the previous pass,
+// controller step, next request: 2.5-4 us) before it evaluates a point, so a pass never launches more workgroups than the
+// chip holds at once — two per CU for both kernels (quad kernel: 8 waves of <= 128 VGPRs; one-lane kernel: 4 waves of <= 256)
+// — and lets each of them walk several batches of points instead.  (Round 2 launched ceil(n / 128) workgroups: at cfg 5 that
+// was 938 of them taking turns on 256 CUs, each turn with its own head.)
+constexpr int NDT_WGS_PER_CU = 2;
+int ndt_nblocks(size_t n, int device, int batch = 1, int threads = NDT_THREADS) {
   int nb = (int)((n + threads - 1) / threads);
-  nb = std::max(1, std::min(nb, NDT_MAX_BLOCKS));
-  if (batch > 1 && !quad) {
-    int per = std::max(4, (4 * 256 + batch - 1) / batch);  // the batch kernel runs 4 workgroups per CU
-    nb = std::min(nb, per);
-  }
+  const int resident = device_cus(device) * NDT_WGS_PER_CU;
+  const int share = std::max(1, resident / std::max(1, batch));
+  nb = std::max(1, std::min(nb, std::min(share, NDT_MAX_BLOCKS)));
   return nb;
 }
 
@@ -87,10 +101,10 @@ constexpr int NDT_ROW_STATIC_LDS = 12 * 1024;    // ... of the one-lane kernel (
 
 void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_partials, const NdtLaunchCfg& cfg) {
   const VoxelGridDev& g = h->target->grid;
-  const DeviceCloud& src = (cfg.tab == NDT_TAB_TILE) ? h->source_sorted : h->source;   // tile mode reads the tile-ordered copy
+  const DeviceCloud& src = cfg.sorted ? h->source_sorted : h->source;   // the tile-ordered copy (always in tile mode)
   P.sx = src.x(); P.sy = src.y(); P.sz = src.z();
   P.n = (int)h->source.n;
-  P.nblocks = ndt_nblocks(h->source.n, cfg.batch, cfg.threads, cfg.quad != 0);
+  P.nblocks = ndt_nblocks(h->source.n, h->device, cfg.batch, cfg.threads);
   P.lds_image = g.lds_image.p;
   P.lds_map_bytes = g.lds_map_bytes;
   P.lds_bytes = g.lds_bytes;
@@ -109,7 +123,8 @@ void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_part
 
 // Where the derivative pass reads the leaf records, and with which kernel.  grids: the batch's targets.
 //  every table fits LDS            -> NDT_TAB_LDS   (quad kernel for one registration, one-lane kernel for a batch)
-//  dense tables that do not fit    -> NDT_TAB_TILE  (quad kernel, also for batches; source ordered by voxel tile per align)
+//  dense tables that do not fit    -> NDT_TAB_DENSE (global gathers; L2 resident at the reference's resolutions), or on request
+//                                     NDT_TAB_TILE  (quad kernel, also for batches; source ordered by voxel tile per align)
 //  tables beyond 4 Mi cells        -> NDT_TAB_COMPACT (global gathers through cell_slot)
 // table_mode: the lead object's LSR_NDT_TABLE_MODE override (-1 automatic).
 void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg) {
@@ -127,20 +142,23 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   const int static_lds = want_quad_single ? NDT_QUAD_STATIC_LDS : NDT_ROW_STATIC_LDS;
   const int table_cap = std::min(want_quad_single ? NDT_LDS_TABLE_MAX_QUAD : NDT_LDS_TABLE_MAX, lds_cap - static_lds);
   const bool lds_ok = all_lds && lds_max <= table_cap;
-  const bool tile_ok = all_dense && lead->ndt_quad != 0 && NDT_TILE_BYTES + NDT_QUAD_STATIC_LDS <= lds_cap;
+  const bool tile_ok = all_dense && lead->ndt_quad != 0 && lead->ndt_sort != 0 && NDT_TILE_BYTES + NDT_QUAD_STATIC_LDS <= lds_cap;
   int tab;
   if (override_mode == NDT_TAB_COMPACT) tab = NDT_TAB_COMPACT;
   else if (override_mode == NDT_TAB_DENSE && all_dense) tab = NDT_TAB_DENSE;
   else if (override_mode == NDT_TAB_TILE && tile_ok) tab = NDT_TAB_TILE;
   else if (override_mode == NDT_TAB_LDS && lds_ok) tab = NDT_TAB_LDS;
   else if (lds_ok) tab = NDT_TAB_LDS;
-  else if (tile_ok) tab = NDT_TAB_TILE;
-  else tab = all_dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT;
+  else tab = all_dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT;   // measured: the pass is not gather bound, the tile mode's
+                                                            // extra barriers cost more than its LDS gathers save — on request only
   cfg.tab = tab;
   cfg.quad = (want_quad_single || tab == NDT_TAB_TILE) ? 1 : 0;
   cfg.lds_bytes = (tab == NDT_TAB_LDS) ? lds_max : (tab == NDT_TAB_TILE ? NDT_TILE_BYTES : 0);
   if (cfg.quad) cfg.threads = (lead->ndt_threads == 64 || lead->ndt_threads == 128) ? lead->ndt_threads : NDT_QUAD_POINTS;  // POINTS per workgroup
   else cfg.threads = (lead->ndt_threads == 128 || lead->ndt_threads == 256) ? lead->ndt_threads : NDT_THREADS;
+  // source ordered by voxel tile: always for the tile mode (its boxes are small only then); for global-table gathers on request
+  // (LSR_NDT_SORT = 1): neighbouring lanes then read neighbouring records
+  cfg.sorted = (tab == NDT_TAB_TILE) || (lead->ndt_sort == 1 && tab != NDT_TAB_LDS);
 }
 
 // A fresh target object — or the handle's current one recycled when nobody else holds it (lsr_share_target): its device
@@ -182,11 +200,25 @@ int ensure_ndt_grid(lsr_handle h) {
   return LSR_OK;
 }
 
+// An NDT target whose voxel grid was built by the counting-sort builder keeps its points in voxel order: the neighbour grid is
+// a refinement of that order (one launch, nn_build_hash_from_grids) instead of a second sort of the cloud.
+bool hash_from_grid_possible(lsr_handle h) {
+  const TargetData& t = *h->target;
+  return h->method == LSR_METHOD_NDT && t.has_grid && t.grid.has_sorted && t.grid.ncells > 0 && t.grid.sorted_n == t.cloud.n;
+}
+
 int ensure_target_hash(lsr_handle h) {
   TargetData& t = *h->target;
   std::lock_guard<std::mutex> lock(t.build_mutex);
   if (t.has_hash) return LSR_OK;
-  int st = nn_build_hash(t.cloud, nn_pick_cell(t.cloud.n, h), t.hash, h->scratch, h->stream);
+  int st;
+  if (hash_from_grid_possible(h)) {
+    const VoxelGridDev* vg[1] = {&t.grid};
+    HashGridDev* hg[1] = {&t.hash};
+    st = nn_build_hash_from_grids(vg, hg, 1, h->stream);
+  } else {
+    st = nn_build_hash(t.cloud, nn_pick_cell(t.cloud.n, h), t.hash, h->scratch, h->stream);
+  }
   if (st) return st;
   t.has_hash = true;
   return LSR_OK;
@@ -298,7 +330,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   size_t tot_blocks = 0;
   int max_blocks = 1;
   for (int b = 0; b < B; b++) {
-    int nb = ndt_nblocks(hs[b]->source.n, B, cfg.threads, cfg.quad != 0);
+    int nb = ndt_nblocks(hs[b]->source.n, lead->device, B, cfg.threads);
     tot_blocks += nb;
     max_blocks = std::max(max_blocks, nb);
   }
@@ -311,7 +343,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     lsr_handle h = hs[b];
     ndt_fill_initial_state(lead->h_state.p[2 * b], guesses ? guesses + 16 * b : nullptr, h->ndt, (int)h->source.n);
     lead->h_state.p[2 * b + 1] = lead->h_state.p[2 * b];
-    if (cfg.tab == NDT_TAB_TILE) {
+    if (cfg.sorted) {
       // order this member's source by voxel tile of its guess-moved points (4 launches on the chain's stream)
       if ((st = ndt_sort_source(h->source, lead->h_state.p[2 * b].T, h->target->grid, h->source_sorted, h->scratch, lead->stream))) return st;
     }
@@ -441,6 +473,7 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) h->ndt_threads = v; }
   if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 3) h->ndt_table_mode = v; }
   if (const char* e = std::getenv("LSR_NDT_QUAD")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_quad = v; }
+  if (const char* e = std::getenv("LSR_NDT_SORT")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_sort = v; }
   if (const char* e = std::getenv("LSR_WAIT_MODE")) {   // 0 | 1 | 2 or spin | yield | sleep
     const std::string w(e);
     const int v = (w == "spin") ? 0 : (w == "yield") ? 1 : (w == "sleep") ? 2 : (w.size() == 1 && w[0] >= '0' && w[0] <= '2') ? w[0] - '0' : -1;
@@ -539,6 +572,9 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
     case LSR_NDT_QUAD:
       if (v < -1 || v > 1) { set_last_error("NDT quad mode must be -1 (auto), 0 or 1"); return LSR_ERR_INVALID_ARGUMENT; }
       h->ndt_quad = v; return LSR_OK;
+    case LSR_NDT_SORT:
+      if (v < -1 || v > 1) { set_last_error("NDT source ordering must be -1 (auto), 0 or 1"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->ndt_sort = v; return LSR_OK;
     case LSR_GRID_BUILDER:
       if (v < 0 || v > 1) { set_last_error("grid builder must be 0 (auto) or 1 (radix-sort builder)"); return LSR_ERR_INVALID_ARGUMENT; }
       h->scratch.force_sort_path = (v == 1);
@@ -566,6 +602,7 @@ int lsr_get_i32(lsr_handle h, int key, int* v) {
     case LSR_NDT_WORKGROUP: *v = h->ndt_threads; return LSR_OK;
     case LSR_NDT_TABLE_MODE: *v = h->ndt_table_mode; return LSR_OK;
     case LSR_NDT_QUAD: *v = h->ndt_quad; return LSR_OK;
+    case LSR_NDT_SORT: *v = h->ndt_sort; return LSR_OK;
     case LSR_GRID_BUILDER: *v = h->scratch.force_sort_path ? 1 : 0; return LSR_OK;
     case LSR_WAIT_MODE: *v = h->scratch.wait_mode; return LSR_OK;
     default: set_last_error("unknown i32 key"); return LSR_ERR_INVALID_ARGUMENT;
@@ -674,33 +711,52 @@ int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const
     return st;
   };
   int st;
-  for (int b = 0; b < count; b++) {   // stage 0: uploads + bounding boxes
+  if (stride_bytes < 12 || (stride_bytes % 4) != 0) { set_last_error("stride_bytes must be a multiple of 4 and >= 12"); return LSR_ERR_INVALID_ARGUMENT; }
+  // NDT members are built by GROUP launches on the first member's stream (one launch per stage for up to 16 members: a
+  // candidate set is bound by the host's launch rate otherwise); GICP members keep their own path and stream.
+  hipStream_t lead_stream = handles[0]->stream;
+  std::vector<TargetBuildJob> jobs;
+  std::vector<int> job_of((size_t)count, -1);
+  for (int b = 0; b < count; b++) {   // stage 0: uploads (+ de-interleave and bounding boxes of the NDT members in group launches)
     lsr_handle h = handles[b];
+    if (counts[b] > 0 && !clouds[b]) { set_last_error("null point pointer"); return fail(LSR_ERR_INVALID_ARGUMENT); }
+    if (counts[b] > (size_t)INT32_MAX / 2) { set_last_error("cloud too large"); return fail(LSR_ERR_INVALID_ARGUMENT); }
     auto t = fresh_target(h);
-    if ((st = upload_cloud(h, clouds[b], stride_bytes, counts[b], on_device != 0, t->cloud))) return fail(st);
     t->n = counts[b];
     h->target = t;
-    if ((st = cloud_bbox_begin(t->cloud, h->scratch, h->stream))) return fail(st);
-  }
-  for (int b = 0; b < count; b++) {   // stage 1: the rest of every build
-    lsr_handle h = handles[b];
-    TargetData& t = *h->target;
-    if (h->method == LSR_METHOD_NDT) {
-      if ((st = ndt_build_grid_begin(t.cloud, (float)h->ndt.resolution, t.grid, h->scratch, h->stream))) return fail(st);
-    } else {
-      if ((st = ensure_target_hash(h))) return fail(st);
+    if (h->method != LSR_METHOD_NDT) {
+      if ((st = upload_cloud(h, clouds[b], stride_bytes, counts[b], on_device != 0, t->cloud))) return fail(st);
+      if ((st = cloud_bbox_begin(t->cloud, h->scratch, h->stream))) return fail(st);
+      continue;
     }
+    if (h->stream != lead_stream) {   // whatever this member still has in flight on its own stream comes first
+      if (hipEventRecord(h->ev1, h->stream) != hipSuccess || hipStreamWaitEvent(lead_stream, h->ev1, 0) != hipSuccess) return fail(LSR_ERR_HIP);
+    }
+    const void* d_aos = clouds[b];
+    if (!on_device && counts[b] > 0) {
+      if ((st = h->staging.reserve(counts[b] * stride_bytes))) return fail(st);
+      if (hipMemcpyAsync(h->staging.p, clouds[b], counts[b] * stride_bytes, hipMemcpyHostToDevice, lead_stream) != hipSuccess) return fail(LSR_ERR_HIP);
+      d_aos = h->staging.p;
+    }
+    job_of[b] = (int)jobs.size();
+    jobs.push_back(TargetBuildJob{d_aos, stride_bytes, counts[b], &t->cloud, (float)h->ndt.resolution, &t->grid, &h->scratch, 0});
   }
+  if (!jobs.empty() && (st = ndt_targets_ingest(jobs.data(), (int)jobs.size(), lead_stream))) return fail(st);
+  // stage 1: the rest of every build
+  if (!jobs.empty() && (st = ndt_targets_build_begin(jobs.data(), (int)jobs.size(), lead_stream))) return fail(st);
+  for (int b = 0; b < count; b++)
+    if (handles[b]->method != LSR_METHOD_NDT && (st = ensure_target_hash(handles[b]))) return fail(st);
   for (int b = 0; b < count; b++) {   // stage 2: results
     lsr_handle h = handles[b];
     TargetData& t = *h->target;
     if (h->method == LSR_METHOD_NDT) {
-      if ((st = ndt_build_grid_end(t.grid, h->scratch, h->stream))) return fail(st);
+      if ((st = ndt_build_grid_end(t.grid, h->scratch, lead_stream))) return fail(st);
       t.has_grid = true;
       t.grid_leaf = (float)h->ndt.resolution;
     }
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_last_error("stream error in the target batch"); return fail(LSR_ERR_HIP); }
   }
+  if (hipStreamSynchronize(lead_stream) != hipSuccess) { set_last_error("stream error in the target batch"); return fail(LSR_ERR_HIP); }
   return LSR_OK;
 }
 int lsr_set_input_target_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n) {
@@ -722,6 +778,51 @@ int lsr_set_input_source(lsr_handle h, const void* pts, size_t stride_bytes, siz
 }
 int lsr_set_input_source_device(lsr_handle h, const void* dev_pts, size_t stride_bytes, size_t n) {
   return set_source_impl(h, dev_pts, stride_bytes, n, true);
+}
+
+// setInputSource of every candidate of a set (graph_based_slam_component.cpp:181 per candidate): the de-interleaves of up to 16
+// members share one launch on the first member's stream.
+int lsr_set_input_source_batch(lsr_handle* handles, int count, const void* const* clouds, const size_t* counts, size_t stride_bytes,
+                               int on_device) {
+  if (count < 0 || (count > 0 && (!handles || !clouds || !counts))) { set_last_error("bad batch arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (count == 0) return LSR_OK;
+  if (stride_bytes < 12 || (stride_bytes % 4) != 0) { set_last_error("stride_bytes must be a multiple of 4 and >= 12"); return LSR_ERR_INVALID_ARGUMENT; }
+  for (int b = 0; b < count; b++) {
+    if (!handles[b]) { set_last_error("null handle"); return LSR_ERR_INVALID_ARGUMENT; }
+    if (handles[b]->device != handles[0]->device) { set_last_error("batched objects must live on one device"); return LSR_ERR_INVALID_ARGUMENT; }
+    if (counts[b] > 0 && !clouds[b]) { set_last_error("null point pointer"); return LSR_ERR_INVALID_ARGUMENT; }
+    if (counts[b] > (size_t)INT32_MAX / 2) { set_last_error("cloud too large"); return LSR_ERR_INVALID_ARGUMENT; }
+    for (int a = 0; a < b; a++)
+      if (handles[a] == handles[b]) { set_last_error("the same object appears twice in the batch"); return LSR_ERR_INVALID_ARGUMENT; }
+  }
+  DeviceGuard guard(handles[0]->device);
+  if (!guard.ok) { set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
+  hipStream_t lead_stream = handles[0]->stream;
+  std::vector<DeinterleaveJob> jobs((size_t)count);
+  int st;
+  for (int b = 0; b < count; b++) {
+    lsr_handle h = handles[b];
+    if (h->stream != lead_stream) {
+      LSR_HIP(hipEventRecord(h->ev1, h->stream));
+      LSR_HIP(hipStreamWaitEvent(lead_stream, h->ev1, 0));
+    }
+    const void* d_aos = clouds[b];
+    if (!on_device && counts[b] > 0) {
+      if ((st = h->staging.reserve(counts[b] * stride_bytes))) return st;
+      LSR_HIP(hipMemcpyAsync(h->staging.p, clouds[b], counts[b] * stride_bytes, hipMemcpyHostToDevice, lead_stream));
+      d_aos = h->staging.p;
+    }
+    jobs[b] = DeinterleaveJob{d_aos, stride_bytes, counts[b], &h->source};
+    h->has_source = true;
+    h->source_cov_valid = false;
+  }
+  if ((st = deinterleave_group(jobs.data(), count, lead_stream))) return st;
+  // every member's own stream continues after the shared launch (its next align / fitness call runs there)
+  LSR_HIP(hipEventRecord(handles[0]->ev0, lead_stream));
+  for (int b = 1; b < count; b++)
+    if (handles[b]->stream != lead_stream) LSR_HIP(hipStreamWaitEvent(handles[b]->stream, handles[0]->ev0, 0));
+  if (!on_device) LSR_HIP(hipStreamSynchronize(lead_stream));  // the callers may reuse their host buffers
+  return LSR_OK;
 }
 
 // pcl::VoxelGrid::filter + registration_->setInputSource, without the cloud leaving HBM
@@ -970,14 +1071,51 @@ int lsr_get_fitness_score_batch(lsr_handle* handles, int count, double max_range
   }
   DeviceGuard guard(handles[0]->device);
   if (!guard.ok) { set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
+  // Members whose neighbour grid can be refined from their voxel grid (NDT, counting-sort builder) are served by GROUP launches
+  // on the first member's stream: one launch for the grids, three per group for search + reduction.  The others keep the
+  // staged per-member path on their own streams.
+  hipStream_t lead_stream = handles[0]->stream;
+  std::vector<int> grouped, single;
+  std::vector<const VoxelGridDev*> vgs;
+  std::vector<HashGridDev*> hgs;
+  for (int b = 0; b < count; b++) {
+    lsr_handle h = handles[b];
+    if (hash_from_grid_possible(h) && !target_is_shared(h)) {
+      grouped.push_back(b);
+      if (!h->target->has_hash) { vgs.push_back(&h->target->grid); hgs.push_back(&h->target->hash); }
+      if (h->stream != lead_stream) {   // the member's source upload / anything else in flight on its own stream comes first
+        LSR_HIP(hipEventRecord(h->ev1, h->stream));
+        LSR_HIP(hipStreamWaitEvent(lead_stream, h->ev1, 0));
+      }
+    } else {
+      single.push_back(b);
+    }
+  }
+  int first_error = LSR_OK;
+  if (!vgs.empty()) {
+    if ((st = nn_build_hash_from_grids(vgs.data(), hgs.data(), (int)vgs.size(), lead_stream))) return st;
+    for (int b : grouped) handles[b]->target->has_hash = true;
+  }
+  if (!grouped.empty()) {
+    std::vector<FitJob> jobs;
+    for (int b : grouped) jobs.push_back(FitJob{&handles[b]->source, handles[b]->final_T, &handles[b]->target->hash, max_range, &handles[b]->scratch});
+    if ((st = nn_fitness_begin_group(jobs.data(), (int)jobs.size(), lead_stream))) return st;
+  }
   int begun = 0;
-  for (; begun < count; begun++) {
-    lsr_handle h = handles[begun];
+  for (; begun < (int)single.size(); begun++) {
+    lsr_handle h = handles[single[begun]];
     if ((st = ensure_target_hash(h))) break;
     if ((st = nn_fitness_begin(h->source, h->final_T, h->target->hash, max_range, h->scratch, h->d_T16, h->stream))) break;
   }
-  int first_error = (begun < count) ? st : LSR_OK;
-  for (int b = 0; b < begun; b++) {   // collect what was enqueued even after an error: no reduction stays in flight
+  if (begun < (int)single.size()) first_error = st;
+  for (int b : grouped) {   // collect what was enqueued even after an error: no reduction stays in flight
+    double v = 0;
+    st = nn_fitness_end(handles[b]->scratch, lead_stream, &v);
+    if (st && !first_error) first_error = st;
+    out[b] = v;
+  }
+  for (int k = 0; k < begun; k++) {
+    const int b = single[k];
     double v = 0;
     st = nn_fitness_end(handles[b]->scratch, handles[b]->stream, &v);
     if (st && !first_error) first_error = st;
@@ -1076,7 +1214,7 @@ int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, si
     for (int e = 0; e < k_eval; e++) {
       lsr_handle a = h->aux[e].get();
       a->ndt = h->ndt; a->gicp = h->gicp;
-      a->ndt_threads = h->ndt_threads; a->ndt_table_mode = h->ndt_table_mode; a->ndt_quad = h->ndt_quad;
+      a->ndt_threads = h->ndt_threads; a->ndt_table_mode = h->ndt_table_mode; a->ndt_quad = h->ndt_quad; a->ndt_sort = h->ndt_sort;
       a->scratch.wait_mode = h->scratch.wait_mode; a->scratch.force_sort_path = h->scratch.force_sort_path;
       int st = a->source.resize(h->source.n);
       if (st) return st;
@@ -1261,12 +1399,12 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
     if ((st = h->d_bins.reserve((size_t)NDT_NBANKS * NDT_BANK_WORDS))) return st;
     LSR_HIP(hipMemsetAsync(h->d_bins.p, 0, sizeof(long long) * NDT_NBANKS * NDT_BANK_WORDS, h->stream));
   }
-  int nb = ndt_nblocks(h->source.n, 1, cfg.threads, cfg.quad != 0);
+  int nb = ndt_nblocks(h->source.n, h->device, 1, cfg.threads);
   cfg.max_blocks = nb;
   if ((st = h->d_partials.reserve(2 * (size_t)nb * NDT_NRED))) return st;
   ndt_fill_diag_state(h->h_state.p[0], p6, T16, compute_hessian, h->ndt, (int)h->source.n);
   h->h_state.p[1] = h->h_state.p[0];
-  if (cfg.tab == NDT_TAB_TILE && (st = ndt_sort_source(h->source, h->h_state.p[0].T, h->target->grid, h->source_sorted, h->scratch, h->stream))) return st;
+  if (cfg.sorted && (st = ndt_sort_source(h->source, h->h_state.p[0].T, h->target->grid, h->source_sorted, h->scratch, h->stream))) return st;
   fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p, cfg);
   LSR_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, sizeof(NdtProblem), hipMemcpyHostToDevice, h->stream));
   LSR_HIP(hipMemcpyAsync(h->d_state.p, h->h_state.p, 2 * sizeof(NdtState), hipMemcpyHostToDevice, h->stream));

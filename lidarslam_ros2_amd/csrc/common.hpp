@@ -133,6 +133,15 @@ struct VoxelGridDev {
   // fp64 copies for inspection/parity (mean 3, icov 9 row-major) + key + count per leaf
   DevBuf<double> mean64, icov64;
   DevBuf<int> leaf_key, leaf_n;
+  // what the counting-sort builder leaves behind (dense key spaces): the target's points in cell order (x | y | z planes of
+  // `sorted_pitch` floats), their original indices, the start of every cell (ncells + 2 entries: [ncells] = first non-finite
+  // point, [ncells + 1] = n) and the rank of every cell among the occupied ones.  getFitnessScore's neighbour grid is a
+  // refinement of exactly this ordering (nn_build_hash_from_grid), so it never sorts the target a second time.
+  bool has_sorted = false;
+  size_t sorted_pitch = 0, sorted_n = 0;
+  DevBuf<float> sorted;
+  DevBuf<int> sorted_idx;
+  DevBuf<unsigned int> cell_start, cell_rank;
 };
 
 // ---- NN grid over a cloud (fitness score, GICP): two-level blocked voxel grid ------------------

@@ -82,14 +82,14 @@ __device__ __forceinline__ double wave_sum64(double v) {
 
 // key = linear leaf index exactly as VoxelGridCovariance computes it; non-finite points get the
 // sentinel bin `ncells` (sorted last, never a leaf)
-__global__ __launch_bounds__(256) void vg_hist_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+__device__ __forceinline__ void vg_hist_kernel_body(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                       int n, float inv_leaf, int mb0, int mb1, int mb2, int mul1, int mul2, int ncells,
-                                                      unsigned short* __restrict__ keys, unsigned short* __restrict__ hist) {
+                                                      unsigned short* __restrict__ keys, unsigned short* __restrict__ hist, const int blk_x) {
   extern __shared__ unsigned int s_hist[];  // [ncells + 1]
   const int C = ncells + 1, tid = threadIdx.x;
   for (int k = tid; k < C; k += 256) s_hist[k] = 0u;
   __syncthreads();
-  const int base = blockIdx.x * VG_CHUNK;
+  const int base = blk_x * VG_CHUNK;
   float px[VG_CHUNK / 256], py[VG_CHUNK / 256], pz[VG_CHUNK / 256];
 #pragma unroll
   for (int j = 0; j < VG_CHUNK / 256; j++) {  // every load of the chunk in flight at once
@@ -114,18 +114,23 @@ __global__ __launch_bounds__(256) void vg_hist_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
-  unsigned short* row = hist + (size_t)blockIdx.x * C;
+  unsigned short* row = hist + (size_t)blk_x * C;
   for (int k = tid; k < C; k += 256) row[k] = (unsigned short)s_hist[k];  // <= VG_CHUNK = 4096
+}
+__global__ __launch_bounds__(256) void vg_hist_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                      int n, float inv_leaf, int mb0, int mb1, int mb2, int mul1, int mul2, int ncells,
+                                                      unsigned short* __restrict__ keys, unsigned short* __restrict__ hist) {
+  vg_hist_kernel_body(x, y, z, n, inv_leaf, mb0, mb1, mb2, mul1, mul2, ncells, keys, hist, (int)blockIdx.x);
 }
 
 // per cell: exclusive scan of the block histograms (offset of this block's points inside the cell) + cell total.
 // 256 threads = 32 cells x 8 segments of the block range: eight times the loads in flight of a thread-per-cell loop.
 constexpr int VG_SCAN_SEGS = 8;
-__global__ __launch_bounds__(256) void vg_scan_kernel(const unsigned short* __restrict__ hist, int nblk, int C,
-                                                      unsigned int* __restrict__ blkoff, unsigned int* __restrict__ total) {
+__device__ __forceinline__ void vg_scan_kernel_body(const unsigned short* __restrict__ hist, int nblk, int C,
+                                                      unsigned int* __restrict__ blkoff, unsigned int* __restrict__ total, const int blk_x) {
   __shared__ unsigned int s_seg[VG_SCAN_SEGS][32];
   const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + cl;
+  const int k = blk_x * 32 + cl;
   const int per = (nblk + VG_SCAN_SEGS - 1) / VG_SCAN_SEGS;
   const int b0 = seg * per, b1 = min(nblk, b0 + per);
   unsigned int sum = 0u;
@@ -157,40 +162,56 @@ __global__ __launch_bounds__(256) void vg_scan_kernel(const unsigned short* __re
     if (seg == VG_SCAN_SEGS - 1) total[k] = run;
   }
 }
+__global__ __launch_bounds__(256) void vg_scan_kernel(const unsigned short* __restrict__ hist, int nblk, int C,
+                                                      unsigned int* __restrict__ blkoff, unsigned int* __restrict__ total) {
+  vg_scan_kernel_body(hist, nblk, C, blkoff, total, (int)blockIdx.x);
+}
 
 // one workgroup: exclusive scan over the cells -> start[0..C] (start[C] = n)
-__global__ __launch_bounds__(1024) void vg_cellscan_kernel(const unsigned int* __restrict__ total, int C, unsigned int* __restrict__ start) {
-  __shared__ unsigned int s_s[1024];
+__device__ __forceinline__ void vg_cellscan_kernel_body(const unsigned int* __restrict__ total, int C, unsigned int* __restrict__ start,
+                                                        unsigned int* __restrict__ rank /*nullable*/, const int blk_x) {
+  __shared__ unsigned int s_s[1024], s_o[1024];
   const int tid = threadIdx.x;
   const int per = (C + 1023) / 1024;
   const int c0 = tid * per, c1 = min(C, c0 + per);
-  unsigned int cnt = 0u;
-  for (int c = c0; c < c1; c++) cnt += total[c];
+  unsigned int cnt = 0u, occ = 0u;
+  for (int c = c0; c < c1; c++) { const unsigned int t = total[c]; cnt += t; occ += (t != 0u); }
   s_s[tid] = cnt;
+  s_o[tid] = occ;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    const unsigned int v = (tid >= off) ? s_s[tid - off] : 0u;
+    const unsigned int v = (tid >= off) ? s_s[tid - off] : 0u, w = (tid >= off) ? s_o[tid - off] : 0u;
     __syncthreads();
     s_s[tid] += v;
+    s_o[tid] += w;
     __syncthreads();
   }
-  unsigned int run = s_s[tid] - cnt;
-  for (int c = c0; c < c1; c++) { start[c] = run; run += total[c]; }
+  unsigned int run = s_s[tid] - cnt, rrun = s_o[tid] - occ;
+  for (int c = c0; c < c1; c++) {
+    const unsigned int t = total[c];
+    start[c] = run; run += t;
+    if (rank) { rank[c] = rrun; rrun += (t != 0u); }   // rank of the cell among the cells that hold points (the sentinel bin counts too: it is last)
+  }
   if (tid == 1023) start[C] = s_s[1023];
+}
+__global__ __launch_bounds__(1024) void vg_cellscan_kernel(const unsigned int* __restrict__ total, int C, unsigned int* __restrict__ start,
+                                                           unsigned int* __restrict__ rank) {
+  vg_cellscan_kernel_body(total, C, start, rank, (int)blockIdx.x);
 }
 
 // Scatter into cell order.  Wave w of block b owns points [b*4096 + w*1024, +1024) and walks them in 16 steps of
 // 64 consecutive points.  s_c[k] packs four 16-bit counters (one per wave): first the per-wave counts of key k, then
 // their exclusive prefix over the waves, then — advanced by ds_add_rtn_u64 — the running offset of each wave: blocks,
 // waves and steps are in point order, lanes of one step are ranked by the returning atomic.
-__global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+__device__ __forceinline__ void vg_scatter_kernel_body(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                          int n, const unsigned short* __restrict__ keys, const unsigned int* __restrict__ blkoff,
                                                          const unsigned int* __restrict__ start, int C, float* __restrict__ ox,
-                                                         float* __restrict__ oy, float* __restrict__ oz) {
+                                                         float* __restrict__ oy, float* __restrict__ oz, int* __restrict__ oidx /*nullable*/,
+                                                         const int blk_x) {
   extern __shared__ unsigned long long s_c[];  // [C]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   for (int k = tid; k < C; k += 256) s_c[k] = 0ull;
-  const int base_i = blockIdx.x * VG_CHUNK + w * (VG_CHUNK / 4) + lane;
+  const int base_i = blk_x * VG_CHUNK + w * (VG_CHUNK / 4) + lane;
   unsigned int key[VG_STEPS];
   float px[VG_STEPS], py[VG_STEPS], pz[VG_STEPS];
 #pragma unroll
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict
   }
   // absolute position of this block's first point of every key this lane holds (one round trip for all 16 steps)
   unsigned int absb[VG_STEPS];
-  const unsigned int* boff = blkoff + (size_t)blockIdx.x * C;
+  const unsigned int* boff = blkoff + (size_t)blk_x * C;
 #pragma unroll
   for (int j = 0; j < VG_STEPS; j++) absb[j] = (key[j] != 0xFFFFu) ? (start[key[j]] + boff[key[j]]) : 0u;
   __syncthreads();
@@ -228,21 +249,28 @@ __global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict
       const unsigned long long old = atomicAdd(&s_c[k], 1ull << sh);
       const unsigned int pos = absb[j] + ((unsigned int)(old >> sh) & 0xFFFFu);
       ox[pos] = px[j]; oy[pos] = py[j]; oz[pos] = pz[j];
+      if (oidx) oidx[pos] = base_i + j * 64;
     }
   }
+}
+__global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                         int n, const unsigned short* __restrict__ keys, const unsigned int* __restrict__ blkoff,
+                                                         const unsigned int* __restrict__ start, int C, float* __restrict__ ox,
+                                                         float* __restrict__ oy, float* __restrict__ oz, int* __restrict__ oidx) {
+  vg_scatter_kernel_body(x, y, z, n, keys, blkoff, start, C, ox, oy, oz, oidx, (int)blockIdx.x);
 }
 
 // K1 + K2, one workgroup (4 waves) per grid cell: wave v sums the cell's points v*64 + lane + 256*t (cell order = point
 // order), waves are combined in wave order, thread 0 finalises the leaf (leaf_finalize_dev).  Dense record layout
 // (record of cell c at rec[4c]); empty cells are written as zero records.
 constexpr int VG_LEAF_THREADS = 256;
-__global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
+__device__ __forceinline__ void vg_leaf_kernel_body(const float* __restrict__ sx, const float* __restrict__ sy,
                                                                   const float* __restrict__ sz, const unsigned int* __restrict__ start,
                                                                   int ncells, int min_points, double eig_mult, float4* __restrict__ rec,
                                                                   double* __restrict__ mean64, double* __restrict__ icov64,
                                                                   int* __restrict__ leaf_key, int* __restrict__ leaf_n,
-                                                                  int* __restrict__ cell_slot) {
-  const int cell = blockIdx.x, tid = threadIdx.x;
+                                                                  int* __restrict__ cell_slot, const int blk_x) {
+  const int cell = blk_x, tid = threadIdx.x;
   const unsigned int off = start[cell];
   const int cnt = (int)(start[cell + 1] - off);
   if (cnt == 0) {
@@ -301,7 +329,113 @@ __global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* _
   leaf_record_dev(mean, icov, n, valid, rec + (size_t)cell * 4);
   cell_slot[cell] = valid ? cell : -1;
 }
+__global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                                  const float* __restrict__ sz, const unsigned int* __restrict__ start,
+                                                                  int ncells, int min_points, double eig_mult, float4* __restrict__ rec,
+                                                                  double* __restrict__ mean64, double* __restrict__ icov64,
+                                                                  int* __restrict__ leaf_key, int* __restrict__ leaf_n,
+                                                                  int* __restrict__ cell_slot) {
+  vg_leaf_kernel_body(sx, sy, sz, start, ncells, min_points, eig_mult, rec, mean64, icov64, leaf_key, leaf_n, cell_slot, (int)blockIdx.x);
+}
 
+
+// ---- the same builders over a GROUP of targets: blockIdx.y selects the member, whose parameters travel in the kernel arguments ----
+struct VgMember {
+  const unsigned char* aos; size_t stride;        // ingest: strided xyz records in device memory
+  float *x, *y, *z;                               // SoA planes of the target cloud
+  int n, nblk, ingest_blocks;                     // points, counting-sort chunks, workgroups of the ingest pass
+  float inv_leaf; int mb0, mb1, mb2, mul1, mul2, ncells;
+  unsigned short *keys, *hist; unsigned int *blkoff, *total, *start, *rank;
+  float *sx, *sy, *sz; int* sidx;
+  float4* rec; double *mean64, *icov64; int *leaf_key, *leaf_n, *cell_slot;
+  BuildMailbox* mb; unsigned int bbox_token;
+};
+struct VgGroup { VgMember m[LSR_GROUP]; };
+static_assert(sizeof(VgGroup) <= 3800, "a group's parameters must fit the kernel argument segment");
+
+// ingest = de-interleave + bounding box in ONE pass over the strided records (a single target runs them as two kernels):
+// workgroup b of a member walks points b*256 + tid + k * ingest_blocks*256, writes the SoA planes and leaves one BboxPart
+// record in the member's host mailbox (same record, same host-side fold as bbox_kernel's)
+__global__ __launch_bounds__(256) void vg_ingest_group_kernel(const VgGroup g) {
+  const VgMember& M = g.m[blockIdx.y];
+  if ((int)blockIdx.x >= M.ingest_blocks) return;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  unsigned int cnt = 0;
+  const int step = M.ingest_blocks * 256;
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < M.n; i0 += 4 * step) {
+    float p[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * step;
+      if (i < M.n) {
+        const float* q = reinterpret_cast<const float*>(M.aos + (size_t)i * M.stride);
+        p[u][0] = q[0]; p[u][1] = q[1]; p[u][2] = q[2];
+      } else {
+        p[u][0] = p[u][1] = p[u][2] = NAN;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * step;
+      if (i < M.n) { M.x[i] = p[u][0]; M.y[i] = p[u][1]; M.z[i] = p[u][2]; }
+      if (!(isfinite(p[u][0]) && isfinite(p[u][1]) && isfinite(p[u][2]))) continue;
+      cnt++;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], p[u][k]); mx[k] = fmaxf(mx[k], p[u][k]); }
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      mn[k] = fminf(mn[k], __shfl_xor(mn[k], m, 64));
+      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], m, 64));
+    }
+    cnt += __shfl_xor(cnt, m, 64);
+  }
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  __shared__ unsigned int s_cnt[4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 3; k++) { s_mn[w][k] = mn[k]; s_mx[w][k] = mx[k]; }
+    s_cnt[w] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    BboxPart* P = &M.mb->part[blockIdx.x];
+    for (int k = 0; k < 3; k++) {
+      P->mn[k] = fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k]));
+      P->mx[k] = fmaxf(fmaxf(s_mx[0][k], s_mx[1][k]), fmaxf(s_mx[2][k], s_mx[3][k]));
+    }
+    P->n_finite = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __threadfence_system();
+    __hip_atomic_store(&P->token, M.bbox_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ __launch_bounds__(256) void vg_hist_group_kernel(const VgGroup g) {
+  const VgMember& M = g.m[blockIdx.y];
+  if ((int)blockIdx.x >= M.nblk) return;
+  vg_hist_kernel_body(M.x, M.y, M.z, M.n, M.inv_leaf, M.mb0, M.mb1, M.mb2, M.mul1, M.mul2, M.ncells, M.keys, M.hist, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void vg_scan_group_kernel(const VgGroup g) {
+  const VgMember& M = g.m[blockIdx.y];
+  if ((int)blockIdx.x >= (M.ncells + 1 + 31) / 32) return;
+  vg_scan_kernel_body(M.hist, M.nblk, M.ncells + 1, M.blkoff, M.total, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(1024) void vg_cellscan_group_kernel(const VgGroup g) {
+  const VgMember& M = g.m[blockIdx.x];
+  vg_cellscan_kernel_body(M.total, M.ncells + 1, M.start, M.rank, 0);
+}
+__global__ __launch_bounds__(256) void vg_scatter_group_kernel(const VgGroup g) {
+  const VgMember& M = g.m[blockIdx.y];
+  if ((int)blockIdx.x >= M.nblk) return;
+  vg_scatter_kernel_body(M.x, M.y, M.z, M.n, M.keys, M.blkoff, M.start, M.ncells + 1, M.sx, M.sy, M.sz, M.sidx, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_group_kernel(const VgGroup g) {
+  const VgMember& M = g.m[blockIdx.y];
+  if ((int)blockIdx.x >= M.ncells) return;
+  vg_leaf_kernel_body(M.sx, M.sy, M.sz, M.start, M.ncells, 6, 0.01, M.rec, M.mean64, M.icov64, M.leaf_key, M.leaf_n, M.cell_slot, (int)blockIdx.x);
+}
 
 // ---- source ordering for the tile-staged derivative pass (NDT_TAB_TILE) -------------------------------------------------
 // key of a source point = Morton code of the (2^shift x 2^shift cells) x (all z) column of the target grid its image under
@@ -355,18 +489,22 @@ int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
   const int nblk = (n + VG_CHUNK - 1) / VG_CHUNK;
   const float inv_leaf = 1.0f / leaf;
   int st;
-  // scratch words: total[C] | start[C+1] | blkoff[nblk*C] | hist(u16)[nblk*C] | keys(u16)[n]
-  const size_t w_total = (size_t)C, w_start = (size_t)C + 1, w_blkoff = (size_t)nblk * C, w_hist = ((size_t)nblk * C + 1) / 2,
-               w_keys = ((size_t)n + 1) / 2;
-  if ((st = sc.words.reserve(16 + w_total + w_start + w_blkoff + w_hist + w_keys + 16))) return st;
+  // scratch words: total[C] | blkoff[nblk*C] | hist(u16)[nblk*C] | keys(u16)[n]; the cell-ordered points, their indices, the cell
+  // starts and ranks stay with the grid (the neighbour grid of getFitnessScore refines them)
+  const size_t w_total = (size_t)C, w_blkoff = (size_t)nblk * C, w_hist = ((size_t)nblk * C + 1) / 2, w_keys = ((size_t)n + 1) / 2;
+  if ((st = sc.words.reserve(16 + w_total + w_blkoff + w_hist + w_keys + 16))) return st;
   unsigned int* total = sc.words.p + 16;
-  unsigned int* start = total + w_total;
-  unsigned int* blkoff = start + w_start;
+  unsigned int* blkoff = total + w_total;
   unsigned short* hist = reinterpret_cast<unsigned short*>(blkoff + w_blkoff);
   unsigned short* keys = reinterpret_cast<unsigned short*>(blkoff + w_blkoff + w_hist);
   const size_t pitch = ((size_t)n + 63) & ~(size_t)63;
-  if ((st = sc.sorted.reserve(3 * pitch))) return st;
-  float* sx = sc.sorted.p; float* sy = sx + pitch; float* sz = sy + pitch;
+  if ((st = grid.sorted.reserve(3 * pitch))) return st;
+  if ((st = grid.sorted_idx.reserve(pitch))) return st;
+  if ((st = grid.cell_start.reserve((size_t)C + 1))) return st;
+  if ((st = grid.cell_rank.reserve((size_t)C))) return st;
+  grid.sorted_pitch = pitch; grid.sorted_n = (size_t)n; grid.has_sorted = true;
+  unsigned int* start = grid.cell_start.p;
+  float* sx = grid.sorted.p; float* sy = sx + pitch; float* sz = sy + pitch;
   if ((st = grid.cell_slot.reserve(grid.ncells))) return st;
   if ((st = grid.rec.reserve(grid.ncells * 4))) return st;
   if ((st = grid.mean64.reserve(grid.ncells * 3))) return st;
@@ -387,9 +525,9 @@ int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
   hipLaunchKernelGGL(vg_hist_kernel, dim3(nblk), dim3(256), (size_t)C * 4, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
                      grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, ncells, keys, hist);
   hipLaunchKernelGGL(vg_scan_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, hist, nblk, C, blkoff, total);
-  hipLaunchKernelGGL(vg_cellscan_kernel, dim3(1), dim3(1024), 0, stream, total, C, start);
+  hipLaunchKernelGGL(vg_cellscan_kernel, dim3(1), dim3(1024), 0, stream, total, C, start, grid.cell_rank.p);
   hipLaunchKernelGGL(vg_scatter_kernel, dim3(nblk), dim3(256), (size_t)C * 8, stream, cloud.x(), cloud.y(), cloud.z(), n, keys, blkoff,
-                     start, C, sx, sy, sz);
+                     start, C, sx, sy, sz, grid.sorted_idx.p);
   hipLaunchKernelGGL(vg_leaf_kernel, dim3(ncells), dim3(VG_LEAF_THREADS), 0, stream, sx, sy, sz, start, ncells, 6, 0.01, grid.rec.p,
                      grid.mean64.p, grid.icov64.p, grid.leaf_key.p, grid.leaf_n.p, grid.cell_slot.p);
   LSR_HIP(hipGetLastError());
@@ -419,9 +557,110 @@ int ndt_sort_source(const DeviceCloud& src, const float* T12, const VoxelGridDev
   hipLaunchKernelGGL(src_hist_kernel, dim3(nblk), dim3(256), (size_t)C * 4, stream, src.x(), src.y(), src.z(), n, T, grid.leaf, grid.min_b[0],
                      grid.min_b[1], grid.div_b[0], grid.div_b[1], shift, nkeys, keys, hist);
   hipLaunchKernelGGL(vg_scan_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, hist, nblk, C, blkoff, total);
-  hipLaunchKernelGGL(vg_cellscan_kernel, dim3(1), dim3(1024), 0, stream, total, C, start);
+  hipLaunchKernelGGL(vg_cellscan_kernel, dim3(1), dim3(1024), 0, stream, total, C, start, (unsigned int*)nullptr);
   hipLaunchKernelGGL(vg_scatter_kernel, dim3(nblk), dim3(256), (size_t)C * 8, stream, src.x(), src.y(), src.z(), n, keys, blkoff, start, C,
-                     out.x(), out.y(), out.z());
+                     out.x(), out.y(), out.z(), (int*)nullptr);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+// ---- host side of the group kernels -----------------------------------------------------------------------------------
+int ndt_targets_ingest(TargetBuildJob* jobs, int count, hipStream_t stream) {
+  int st;
+  for (int g0 = 0; g0 < count; g0 += LSR_GROUP) {
+    VgGroup grp;
+    std::memset(&grp, 0, sizeof(grp));
+    const int ng = std::min(LSR_GROUP, count - g0);
+    int max_blocks = 0;
+    for (int k = 0; k < ng; k++) {
+      TargetBuildJob& J = jobs[g0 + k];
+      if ((st = J.cloud->resize(J.n))) return st;
+      J.sc->bbox_parts = 0;
+      VgMember& M = grp.m[k];
+      M.n = (int)J.n;
+      if (J.n == 0) continue;
+      if ((st = J.sc->ensure_mailbox())) return st;
+      unsigned int token = ++J.sc->token;
+      if (token == 0) token = ++J.sc->token;
+      M.aos = static_cast<const unsigned char*>(J.d_aos); M.stride = J.stride;
+      M.x = J.cloud->x(); M.y = J.cloud->y(); M.z = J.cloud->z();
+      M.ingest_blocks = std::max(1, std::min((int)((J.n + 1023) / 1024), BBOX_MAX_PARTS));
+      M.mb = J.sc->d_mb; M.bbox_token = token;
+      J.sc->bbox_parts = M.ingest_blocks;
+      J.sc->bbox_token = token;
+      max_blocks = std::max(max_blocks, M.ingest_blocks);
+    }
+    if (max_blocks > 0) hipLaunchKernelGGL(vg_ingest_group_kernel, dim3(max_blocks, ng), dim3(256), 0, stream, grp);
+  }
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+// counting sort + leaf sums + finalisation of `count` targets with dense key spaces (geometry set), five launches per group
+int ndt_build_grids_dense_group(TargetBuildJob* const* jobs, int count, hipStream_t stream) {
+  static bool attr_done[64] = {};
+  int dev = 0;
+  LSR_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    LSR_HIP(hipFuncSetAttribute((const void*)vg_hist_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VG_DENSE_MAX_CELLS * 4 + 4));
+    LSR_HIP(hipFuncSetAttribute((const void*)vg_scatter_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VG_DENSE_MAX_CELLS * 8 + 8));
+    attr_done[dev] = true;
+  }
+  int st;
+  for (int g0 = 0; g0 < count; g0 += LSR_GROUP) {
+    VgGroup grp;
+    std::memset(&grp, 0, sizeof(grp));
+    const int ng = std::min(LSR_GROUP, count - g0);
+    int max_nblk = 0, max_cells = 0;
+    for (int k = 0; k < ng; k++) {
+      const TargetBuildJob& J = *jobs[g0 + k];
+      VoxelGridDev& grid = *J.grid;
+      BuildScratch& sc = *J.sc;
+      const DeviceCloud& cloud = *J.cloud;
+      const int n = (int)cloud.n;
+      const int ncells = (int)grid.ncells, C = ncells + 1;
+      const int nblk = (n + VG_CHUNK - 1) / VG_CHUNK;
+      // the same scratch layout as the single-target builder
+      const size_t w_total = (size_t)C, w_blkoff = (size_t)nblk * C, w_hist = ((size_t)nblk * C + 1) / 2, w_keys = ((size_t)n + 1) / 2;
+      if ((st = sc.words.reserve(16 + w_total + w_blkoff + w_hist + w_keys + 16))) return st;
+      const size_t pitch = ((size_t)n + 63) & ~(size_t)63;
+      if ((st = grid.sorted.reserve(3 * pitch))) return st;
+      if ((st = grid.sorted_idx.reserve(pitch))) return st;
+      if ((st = grid.cell_start.reserve((size_t)C + 1))) return st;
+      if ((st = grid.cell_rank.reserve((size_t)C))) return st;
+      grid.sorted_pitch = pitch; grid.sorted_n = (size_t)n; grid.has_sorted = true;
+      if ((st = grid.cell_slot.reserve(grid.ncells))) return st;
+      if ((st = grid.rec.reserve(grid.ncells * 4))) return st;
+      if ((st = grid.mean64.reserve(grid.ncells * 3))) return st;
+      if ((st = grid.icov64.reserve(grid.ncells * 9))) return st;
+      if ((st = grid.leaf_key.reserve(grid.ncells))) return st;
+      if ((st = grid.leaf_n.reserve(grid.ncells))) return st;
+      grid.dense = true;
+      grid.n_leaves = ncells;
+      VgMember& M = grp.m[k];
+      M.x = cloud.x(); M.y = cloud.y(); M.z = cloud.z();
+      M.n = n; M.nblk = nblk;
+      M.inv_leaf = 1.0f / J.leaf;
+      M.mb0 = grid.min_b[0]; M.mb1 = grid.min_b[1]; M.mb2 = grid.min_b[2];
+      M.mul1 = grid.div_b[0]; M.mul2 = grid.div_b[0] * grid.div_b[1]; M.ncells = ncells;
+      M.total = sc.words.p + 16;
+      M.blkoff = M.total + w_total;
+      M.hist = reinterpret_cast<unsigned short*>(M.blkoff + w_blkoff);
+      M.keys = reinterpret_cast<unsigned short*>(M.blkoff + w_blkoff + w_hist);
+      M.start = grid.cell_start.p; M.rank = grid.cell_rank.p;
+      M.sx = grid.sorted.p; M.sy = M.sx + pitch; M.sz = M.sy + pitch; M.sidx = grid.sorted_idx.p;
+      M.rec = grid.rec.p; M.mean64 = grid.mean64.p; M.icov64 = grid.icov64.p;
+      M.leaf_key = grid.leaf_key.p; M.leaf_n = grid.leaf_n.p; M.cell_slot = grid.cell_slot.p;
+      max_nblk = std::max(max_nblk, nblk);
+      max_cells = std::max(max_cells, ncells);
+    }
+    const int maxC = max_cells + 1;
+    hipLaunchKernelGGL(vg_hist_group_kernel, dim3(max_nblk, ng), dim3(256), (size_t)maxC * 4, stream, grp);
+    hipLaunchKernelGGL(vg_scan_group_kernel, dim3((maxC + 31) / 32, ng), dim3(256), 0, stream, grp);
+    hipLaunchKernelGGL(vg_cellscan_group_kernel, dim3(ng), dim3(1024), 0, stream, grp);
+    hipLaunchKernelGGL(vg_scatter_group_kernel, dim3(max_nblk, ng), dim3(256), (size_t)maxC * 8, stream, grp);
+    hipLaunchKernelGGL(vg_leaf_group_kernel, dim3(max_cells, ng), dim3(VG_LEAF_THREADS), 0, stream, grp);
+  }
   LSR_HIP(hipGetLastError());
   return LSR_OK;
 }

@@ -25,6 +25,7 @@ struct lsr_handle_s {
   int ndt_threads = 0;       // LSR_NDT_WORKGROUP: 0 = automatic, 128 / 256
   int ndt_table_mode = -1;   // LSR_NDT_TABLE_MODE: -1 = automatic, else lsr::NdtTableMode
   int ndt_quad = -1;         // LSR_NDT_QUAD: -1 = automatic (single registrations), 0 = one lane per point, 1 = four
+  int ndt_sort = -1;         // LSR_NDT_SORT: -1 = automatic (tile mode only), 0 = never, 1 = also for global-table gathers
 
   std::shared_ptr<TargetData> target;
   std::shared_ptr<TargetData> spare_target;  // recycled by the next setInputTarget when no other handle shares it

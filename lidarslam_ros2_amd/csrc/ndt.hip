@@ -1813,6 +1813,16 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const unsigned char* 
   x[i] = p[0]; y[i] = p[1]; z[i] = p[2];
 }
 
+struct DeintMember { const unsigned char* aos; size_t stride; int n; float *x, *y, *z; };
+struct DeintGroup { DeintMember m[LSR_GROUP]; };
+__global__ __launch_bounds__(256) void deinterleave_group_kernel(const DeintGroup g) {
+  const DeintMember& M = g.m[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M.n) return;
+  const float* p = (const float*)(M.aos + (size_t)i * M.stride);
+  M.x[i] = p[0]; M.y[i] = p[1]; M.z[i] = p[2];
+}
+
 __global__ __launch_bounds__(256) void transform_strided_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                 const float* __restrict__ z, int n, const float* __restrict__ Tdev,
                                                                 unsigned char* __restrict__ out, size_t stride) {
@@ -1833,6 +1843,25 @@ int deinterleave(const void* d_aos, size_t stride_bytes, size_t n, DeviceCloud& 
   if (n == 0) return LSR_OK;
   hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                      (const unsigned char*)d_aos, stride_bytes, (int)n, out.x(), out.y(), out.z());
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+int deinterleave_group(const DeinterleaveJob* jobs, int count, hipStream_t stream) {
+  int st;
+  for (int g0 = 0; g0 < count; g0 += LSR_GROUP) {
+    DeintGroup grp;
+    std::memset(&grp, 0, sizeof(grp));
+    const int ng = std::min(LSR_GROUP, count - g0);
+    size_t nmax = 0;
+    for (int k = 0; k < ng; k++) {
+      const DeinterleaveJob& J = jobs[g0 + k];
+      if ((st = J.out->resize(J.n))) return st;
+      grp.m[k] = DeintMember{static_cast<const unsigned char*>(J.d_aos), J.stride, (int)J.n, J.out->x(), J.out->y(), J.out->z()};
+      nmax = std::max(nmax, J.n);
+    }
+    if (nmax > 0) hipLaunchKernelGGL(deinterleave_group_kernel, dim3((unsigned)((nmax + 255) / 256), ng), dim3(256), 0, stream, grp);
+  }
   LSR_HIP(hipGetLastError());
   return LSR_OK;
 }
@@ -2079,10 +2108,10 @@ int pc2_write(const DeviceCloud& in, void* d_data, int step, int ox, int oy, int
 // only written when it fits image_cap bytes.  The counts go to the host mailbox (n_valid, n_occupied, lds bytes), then
 // the done token: the host learns the outcome of the whole grid build by polling one word.
 namespace {
-__global__ __launch_bounds__(1024) void lds_pack_kernel(const int* __restrict__ cell_slot, const float4* __restrict__ rec,
-                                                        const int* __restrict__ leaf_n /*nullable: per cell*/, int ncells, int map_bytes,
-                                                        int image_cap, unsigned char* __restrict__ image, BuildMailbox* __restrict__ mb,
-                                                        unsigned int token) {
+__device__ __forceinline__ void lds_pack_body(const int* __restrict__ cell_slot, const float4* __restrict__ rec,
+                                              const int* __restrict__ leaf_n /*nullable: per cell*/, int ncells, int map_bytes,
+                                              int image_cap, unsigned char* __restrict__ image, BuildMailbox* __restrict__ mb,
+                                              unsigned int token) {
   __shared__ int s_cnt[1024];
   __shared__ int s_occ[16];
   const int tid = threadIdx.x;
@@ -2144,7 +2173,41 @@ __global__ __launch_bounds__(1024) void lds_pack_kernel(const int* __restrict__ 
     __hip_atomic_store(&mb->done_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+__global__ __launch_bounds__(1024) void lds_pack_kernel(const int* __restrict__ cell_slot, const float4* __restrict__ rec,
+                                                        const int* __restrict__ leaf_n, int ncells, int map_bytes, int image_cap,
+                                                        unsigned char* __restrict__ image, BuildMailbox* __restrict__ mb, unsigned int token) {
+  lds_pack_body(cell_slot, rec, leaf_n, ncells, map_bytes, image_cap, image, mb, token);
+}
+// one workgroup per member of a group of targets (batched builds, grid_dense.hip)
+__global__ __launch_bounds__(1024) void lds_pack_group_kernel(const PackGroup g) {
+  const PackMember& M = g.m[blockIdx.x];
+  lds_pack_body(M.cell_slot, M.rec, M.leaf_n, M.ncells, M.map_bytes, M.image_cap, M.image, M.mb, M.token);
+}
 }  // namespace
+
+int ndt_pack_lds_tables(VoxelGridDev* const* grids, BuildScratch* const* scs, const unsigned int* tokens, int count, hipStream_t stream) {
+  for (int g0 = 0; g0 < count; g0 += LSR_GROUP) {
+    PackGroup grp;
+    const int ng = std::min(LSR_GROUP, count - g0);
+    for (int k = 0; k < ng; k++) {
+      VoxelGridDev& grid = *grids[g0 + k];
+      BuildScratch& sc = *scs[g0 + k];
+      grid.lds_bytes = grid.lds_map_bytes = 0;
+      int st = sc.ensure_mailbox();
+      if (st) return st;
+      const bool may_fit = grid.ncells > 0 && grid.ncells * 2 + 16 + NDT_LDS_REC_BYTES <= (size_t)NDT_LDS_TABLE_MAX;
+      if (may_fit && (st = grid.lds_image.reserve(NDT_LDS_TABLE_MAX / 16))) return st;
+      PackMember& M = grp.m[k];
+      M.cell_slot = grid.cell_slot.p; M.rec = grid.rec.p; M.leaf_n = grid.leaf_n.p; M.ncells = (int)grid.ncells;
+      M.map_bytes = (int)((grid.ncells * 2 + 15) & ~(size_t)15); M.image_cap = (int)NDT_LDS_TABLE_MAX;
+      M.image = may_fit ? reinterpret_cast<unsigned char*>(grid.lds_image.p) : (unsigned char*)nullptr;
+      M.mb = sc.d_mb; M.token = tokens[g0 + k];
+    }
+    hipLaunchKernelGGL(lds_pack_group_kernel, dim3(ng), dim3(1024), 0, stream, grp);
+  }
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
 
 // Enqueue the pack; the outcome is read from the host mailbox by ndt_finish_grid().
 int ndt_pack_lds_table(VoxelGridDev& grid, BuildScratch& sc, bool per_cell_leaf_n, unsigned int token, hipStream_t stream) {
@@ -2180,22 +2243,21 @@ int ndt_build_grid_end(VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream)
   return LSR_OK;
 }
 
-// Everything up to the last enqueue; the bounding-box pass must have been enqueued (cloud_bbox_begin) or be cached.
-// Dense key spaces leave the build pending (sc.grid_pending): ndt_build_grid_end() collects it.
-int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+// Geometry of the voxel grid from the cloud's bounding box (host poll #1; the bounding-box pass must have been enqueued —
+// cloud_bbox_begin / the batched ingest — or be cached).  *path: 0 = no finite point (empty grid), 1 = dense key space
+// (counting-sort builder, grid_dense.hip), 2 = general key space (radix sort).
+int ndt_grid_geometry(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream, int* path) {
+  *path = 0;
   sc.grid_pending = false;
-  DevBuf<char>& temp = sc.temp;
-  DevBuf<unsigned int>& scratch = sc.words;
-  DevBuf<double>& sums = sc.sums;
   const int n = (int)cloud.n;
   grid.leaf = leaf;
   grid.n_leaves = grid.n_valid = 0;
   grid.ncells = 0;
   grid.lds_bytes = grid.lds_map_bytes = 0;
+  grid.has_sorted = false;
   for (int k = 0; k < 3; k++) { grid.min_b[k] = 0; grid.max_b[k] = -1; grid.div_b[k] = 0; }
   if (n == 0) return LSR_OK;
   const float inv_leaf = 1.0f / leaf;
-
   float mn[3], mx[3];
   unsigned int n_finite = 0;
   int st = cloud_bbox_end(cloud, mn, mx, &n_finite, sc, stream);   // host poll #1
@@ -2212,22 +2274,27 @@ int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
     grid.max_b[k] = (int)floorf(mx[k] * inv_leaf);
     grid.div_b[k] = grid.max_b[k] - grid.min_b[k] + 1;
   }
-  const int mul1 = grid.div_b[0], mul2 = grid.div_b[0] * grid.div_b[1];
   grid.ncells = (size_t)grid.div_b[0] * grid.div_b[1] * grid.div_b[2];
+  *path = (grid.ncells <= (size_t)VG_DENSE_MAX_CELLS && !sc.force_sort_path) ? 1 : 2;
+  return LSR_OK;
+}
+
+static unsigned int next_token(BuildScratch& sc) {
   unsigned int token = ++sc.token;
   if (token == 0) token = ++sc.token;
+  return token;
+}
 
-  if (grid.ncells <= (size_t)VG_DENSE_MAX_CELLS && !sc.force_sort_path) {
-    // dense key space: hand-written counting sort, no further host round trip until the final poll (grid_dense.hip)
-    if ((st = ndt_build_grid_dense(cloud, leaf, grid, sc, stream))) return st;
-    if ((st = ndt_pack_lds_table(grid, sc, true, token, stream))) return st;
-    sc.grid_pending = true;
-    sc.grid_token = token;
-    return LSR_OK;
-  }
-
-  // ---- general key space: stable radix sort (rocPRIM) + run-length encoding
-  st = grid.cell_slot.reserve(grid.ncells);
+// general key space: stable radix sort (rocPRIM) + run-length encoding; returns with the grid complete
+static int ndt_build_grid_general(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  DevBuf<char>& temp = sc.temp;
+  DevBuf<unsigned int>& scratch = sc.words;
+  DevBuf<double>& sums = sc.sums;
+  const int n = (int)cloud.n;
+  const float inv_leaf = 1.0f / leaf;
+  const int mul1 = grid.div_b[0], mul2 = grid.div_b[0] * grid.div_b[1];
+  const unsigned int token = next_token(sc);
+  int st = grid.cell_slot.reserve(grid.ncells);
   if (st) return st;
   LSR_HIP(hipMemsetAsync(grid.cell_slot.p, 0xFF, grid.ncells * sizeof(int), stream));
   const unsigned int sentinel = (unsigned int)grid.ncells;  // non-finite points: one past the last leaf index
@@ -2284,6 +2351,50 @@ int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
   grid.n_valid = sc.mb.p->n_valid;
   grid.lds_bytes = sc.mb.p->lds_bytes;
   grid.lds_map_bytes = sc.mb.p->lds_map_bytes;
+  return LSR_OK;
+}
+
+// Everything up to the last enqueue.  Dense key spaces leave the build pending (sc.grid_pending): ndt_build_grid_end() collects it.
+int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  int path = 0;
+  int st = ndt_grid_geometry(cloud, leaf, grid, sc, stream, &path);
+  if (st || path == 0) return st;
+  if (path == 2) return ndt_build_grid_general(cloud, leaf, grid, sc, stream);
+  // dense key space: hand-written counting sort, no further host round trip until the final poll (grid_dense.hip)
+  const unsigned int token = next_token(sc);
+  if ((st = ndt_build_grid_dense(cloud, leaf, grid, sc, stream))) return st;
+  if ((st = ndt_pack_lds_table(grid, sc, true, token, stream))) return st;
+  sc.grid_pending = true;
+  sc.grid_token = token;
+  return LSR_OK;
+}
+
+// A SET of targets (candidate windows): every member's bounding box has been enqueued (ndt_targets_ingest / cloud_bbox_begin).
+// Members with a dense key space are built by the GROUP kernels of grid_dense.hip — one launch per stage for up to LSR_GROUP
+// members — and left pending; the others are built one by one right here.
+int ndt_targets_build_begin(TargetBuildJob* jobs, int count, hipStream_t stream) {
+  std::vector<TargetBuildJob*> dense;
+  int st;
+  for (int b = 0; b < count; b++) {
+    TargetBuildJob& J = jobs[b];
+    if ((st = ndt_grid_geometry(*J.cloud, J.leaf, *J.grid, *J.sc, stream, &J.path))) return st;
+    if (J.path == 1) dense.push_back(&J);
+  }
+  if (!dense.empty()) {
+    std::vector<VoxelGridDev*> grids;
+    std::vector<BuildScratch*> scs;
+    std::vector<unsigned int> tokens;
+    for (TargetBuildJob* J : dense) {
+      grids.push_back(J->grid);
+      scs.push_back(J->sc);
+      tokens.push_back(next_token(*J->sc));
+    }
+    if ((st = ndt_build_grids_dense_group(dense.data(), (int)dense.size(), stream))) return st;
+    if ((st = ndt_pack_lds_tables(grids.data(), scs.data(), tokens.data(), (int)dense.size(), stream))) return st;
+    for (size_t k = 0; k < dense.size(); k++) { dense[k]->sc->grid_pending = true; dense[k]->sc->grid_token = tokens[k]; }
+  }
+  for (int b = 0; b < count; b++)
+    if (jobs[b].path == 2 && (st = ndt_build_grid_general(*jobs[b].cloud, jobs[b].leaf, *jobs[b].grid, *jobs[b].sc, stream))) return st;
   return LSR_OK;
 }
 

@@ -139,6 +139,7 @@ struct NdtLaunchCfg {
   int tab = NDT_TAB_DENSE; // NdtTableMode
   int threads = NDT_THREADS;
   int lds_bytes = 0;       // dynamic LDS (largest lds_bytes of the batch) when tab == NDT_TAB_LDS
+  int sorted = 0;          // 1: the problems read the tile-ordered copy of the source (ndt_sort_source)
   int quad = 0;            // 1: four lanes per source point, 512-thread workgroups, binned integer accumulation (single
                            // registrations: spreads a 30k-point scan over every CU; batches whose tables need NDT_TAB_TILE);
                            // 0: one lane per point, partial rows
@@ -152,6 +153,31 @@ int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, cons
 // Enqueue the LDS image of the valid-voxel table (grid.lds_image) after the leaf records exist; the kernel publishes
 // n_valid / lds_bytes (0 when the table does not fit NDT_LDS_TABLE_MAX) and the `token` into the host mailbox.
 int ndt_pack_lds_table(VoxelGridDev& grid, BuildScratch& sc, bool per_cell_leaf_n, unsigned int token, hipStream_t stream);
+// ---- batched builds (candidate sets, graph_based_slam_component.cpp:181-231 generalised): the per-member parameters of up to
+// LSR_GROUP members travel in the kernel arguments of ONE launch whose grid's y (or x) index selects the member.
+constexpr int LSR_GROUP = 16;
+struct PackMember {
+  const int* cell_slot; const float4* rec; const int* leaf_n; int ncells, map_bytes, image_cap; unsigned int token;
+  unsigned char* image; BuildMailbox* mb;
+};
+struct PackGroup { PackMember m[LSR_GROUP]; };
+// lds_pack for `count` dense grids (leaf_n per cell) in ceil(count / LSR_GROUP) launches
+int ndt_pack_lds_tables(VoxelGridDev* const* grids, BuildScratch* const* scs, const unsigned int* tokens, int count, hipStream_t stream);
+
+// One target of a batched build: device-resident strided records in, SoA cloud + voxel grid out (each member keeps its own
+// scratch and host mailbox).
+struct TargetBuildJob {
+  const void* d_aos; size_t stride; size_t n;
+  DeviceCloud* cloud; float leaf; VoxelGridDev* grid; BuildScratch* sc;
+  int path;   // set by ndt_targets_build_begin: 0 empty, 1 dense key space, 2 general
+};
+// de-interleave + bounding box of every member in ceil(count / LSR_GROUP) launches (the boxes arrive in the members' mailboxes)
+int ndt_targets_ingest(TargetBuildJob* jobs, int count, hipStream_t stream);
+// grid builds of every member, dense key spaces through the group kernels; ndt_build_grid_end() per member collects them
+int ndt_targets_build_begin(TargetBuildJob* jobs, int count, hipStream_t stream);
+int ndt_build_grids_dense_group(TargetBuildJob* const* jobs, int count, hipStream_t stream);
+int ndt_grid_geometry(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream, int* path);
+
 // K1/K2 for dense key spaces (grid_dense.hip): counting sort + per-cell sums + finalisation, everything enqueued, no host
 // round trip.  grid.min_b / div_b / ncells must be set.
 constexpr int VG_DENSE_MAX_CELLS = 16383;
@@ -187,5 +213,8 @@ int interleave(const DeviceCloud& in, void* d_out, size_t stride_bytes, hipStrea
 int transform_to_strided(const DeviceCloud& src, const float* T16_host, void* d_out, size_t stride_bytes, hipStream_t stream);
 // AoS (strided xyz) -> SoA planes, device to device.
 int deinterleave(const void* d_aos, size_t stride_bytes, size_t n, DeviceCloud& out, hipStream_t stream);
+// the same for a set of clouds, LSR_GROUP per launch
+struct DeinterleaveJob { const void* d_aos; size_t stride; size_t n; DeviceCloud* out; };
+int deinterleave_group(const DeinterleaveJob* jobs, int count, hipStream_t stream);
 
 }  // namespace lsr

@@ -144,6 +144,75 @@ __global__ __launch_bounds__(256) void nnb_table_kernel(const int* __restrict__ 
   for (int f = lane; f <= FINE_PER_BLOCK; f += 64) fine_start[(size_t)b * FINE_STRIDE + f] = st[f];
 }
 
+
+// ---- neighbour grid as a REFINEMENT of the NDT voxel grid ------------------------------------------------------------------
+// An NDT target built by the counting-sort builder (grid_dense.hip) already holds its points in voxel order.  With the fine
+// cell edge = leaf / 8 and the origin = 8 * min_b the coarse cells of the neighbour grid ARE the NDT voxels — floor(p * (8 /
+// leaf)) >> 3 == floor(p / leaf) exactly, scaling by 8 is exact in binary floating point — so the grid only has to order the
+// points of every voxel by their fine cell: one workgroup per voxel, an LDS histogram over the 512 fine cells, no global
+// histogram, no device-wide scan, no second pass over the unsorted cloud (round 2 built a fresh grid over the 661k-point
+// window of every loop-closure candidate: ~125 us of kernels to answer one 30k-query fitness search).
+struct RefineMember {
+  const float *sx, *sy, *sz; const int* sidx; const unsigned int *start, *rank;
+  int ncells; float inv_cell; int o0, o1, o2;
+  int *coarse_block, *block_off, *fine_start; float4* packed; int* order;
+};
+struct RefineGroup { RefineMember m[LSR_GROUP]; };
+__device__ __forceinline__ void nn_refine_body(const RefineMember& M, const int cell) {
+  __shared__ unsigned int s_cnt[FINE_PER_BLOCK], s_off[FINE_PER_BLOCK + 1], s_part[256];
+  const int tid = threadIdx.x;
+  const unsigned int beg = M.start[cell], end = M.start[cell + 1];
+  if (end == beg) {
+    if (tid == 0) M.coarse_block[cell] = -1;
+    return;
+  }
+  const int b = (int)M.rank[cell];
+  for (int k = tid; k < FINE_PER_BLOCK; k += 256) s_cnt[k] = 0u;
+  __syncthreads();
+  for (unsigned int j = beg + tid; j < end; j += 256) {
+    const int fx = (int)floorf(M.sx[j] * M.inv_cell) - M.o0, fy = (int)floorf(M.sy[j] * M.inv_cell) - M.o1, fz = (int)floorf(M.sz[j] * M.inv_cell) - M.o2;
+    atomicAdd(&s_cnt[(fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6)], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the 512 counts: two per thread + Hillis-Steele over the 256 pair sums
+  const unsigned int c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+  s_part[tid] = c0 + c1;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const unsigned int v = (tid >= off) ? s_part[tid - off] : 0u;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  const unsigned int base = s_part[tid] - (c0 + c1);
+  s_off[2 * tid] = base;
+  s_off[2 * tid + 1] = base + c0;
+  if (tid == 255) s_off[FINE_PER_BLOCK] = s_part[255];
+  s_cnt[2 * tid] = 0u;       // becomes the cursor of the scatter
+  s_cnt[2 * tid + 1] = 0u;
+  __syncthreads();
+  for (int f = tid; f <= FINE_PER_BLOCK; f += 256) M.fine_start[(size_t)b * FINE_STRIDE + f] = (int)(beg + s_off[f]);
+  if (tid == 0) {
+    M.coarse_block[cell] = b;
+    M.block_off[b] = (int)beg;
+    M.block_off[b + 1] = (int)end;  // the next occupied voxel (if any) rewrites the same value
+  }
+  for (unsigned int j = beg + tid; j < end; j += 256) {
+    const float px = M.sx[j], py = M.sy[j], pz = M.sz[j];
+    const int fx = (int)floorf(px * M.inv_cell) - M.o0, fy = (int)floorf(py * M.inv_cell) - M.o1, fz = (int)floorf(pz * M.inv_cell) - M.o2;
+    const int fine = (fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6);
+    const unsigned int pos = beg + s_off[fine] + atomicAdd(&s_cnt[fine], 1u);
+    const int oi = M.sidx[j];
+    M.packed[pos] = make_float4(px, py, pz, __int_as_float(oi));
+    M.order[pos] = oi;
+  }
+}
+__global__ __launch_bounds__(256) void nn_refine_group_kernel(const RefineGroup g) {
+  const RefineMember& M = g.m[blockIdx.y];
+  if ((int)blockIdx.x >= M.ncells) return;
+  nn_refine_body(M, (int)blockIdx.x);
+}
+
 // ---- query kernels -------------------------------------------------------------------------------
 // One thread per query walks fine shells 0..ring_cap; a query not proven by then (far-range scan points whose nearest
 // target point is metres away) goes to `work` ([0] = count, [1..] = query indices) and is finished by nn1_coop_kernel,
@@ -202,10 +271,9 @@ __global__ __launch_bounds__(NN_THREADS) void nn1_quad_kernel(NNGridView G, cons
 }
 
 // One wave per query (coop_search over the fine grid, coarse cells when needed): the form used for scan-sized query sets.
-__global__ __launch_bounds__(256) void nn1_wave_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
-                                                       const float* __restrict__ qz, int n, const float* __restrict__ T16, int fine_rings,
-                                                       float max_d2, int* __restrict__ idx, float* __restrict__ d2) {
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+__device__ __forceinline__ void nn1_wave_body(const NNGridView& G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                              const float* __restrict__ qz, int n, const float* __restrict__ T16, int fine_rings,
+                                              float max_d2, int* __restrict__ idx, float* __restrict__ d2, const int wave, const int n_waves) {
   const int lane = threadIdx.x & 63;
   for (int i = wave; i < n; i += n_waves) {
     const float x = qx[i], y = qy[i], z = qz[i];
@@ -225,6 +293,30 @@ __global__ __launch_bounds__(256) void nn1_wave_kernel(NNGridView G, const float
       d2[i] = found ? mine.d : INFINITY;
     }
   }
+}
+__global__ __launch_bounds__(256) void nn1_wave_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                       const float* __restrict__ qz, int n, const float* __restrict__ T16, int fine_rings,
+                                                       float max_d2, int* __restrict__ idx, float* __restrict__ d2) {
+  nn1_wave_body(G, qx, qy, qz, n, T16, fine_rings, max_d2, idx, d2, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6);
+}
+
+// getFitnessScore of a GROUP of candidates: blockIdx.y selects the member, whose grid view, clouds and final transformation
+// travel in the kernel arguments (no per-member upload of the 4x4)
+struct FitMember {
+  NNGridView G;
+  const float *qx, *qy, *qz; int n, blocks;
+  float T16[16];
+  float max_d2; double max_range;
+  int* idx; float* d2; double* part;
+  BuildMailbox* mb; unsigned int token; int empty;
+};
+constexpr int FIT_GROUP = 12;
+struct FitGroup { FitMember m[FIT_GROUP]; };
+static_assert(sizeof(FitGroup) <= 3800, "a group's parameters must fit the kernel argument segment");
+__global__ __launch_bounds__(256) void nn1_wave_group_kernel(const FitGroup g) {
+  const FitMember& M = g.m[blockIdx.y];
+  if ((int)blockIdx.x >= M.blocks || M.empty) return;
+  nn1_wave_body(M.G, M.qx, M.qy, M.qz, M.n, M.T16, 1, M.max_d2, M.idx, M.d2, (blockIdx.x * 256 + threadIdx.x) >> 6, (M.blocks * 256) >> 6);
 }
 
 // tail of nn1_kernel: one wave per deferred query; same (distance, index) order, same fp32 distances => same answer
@@ -271,11 +363,11 @@ __global__ __launch_bounds__(NN_THREADS) void knn_kernel(NNGridView G, const flo
 }
 
 // deterministic two-stage reduction of {sum d2, count} over pairs with d2 <= max_range
-__global__ __launch_bounds__(256) void fitness_partial_kernel(const int* __restrict__ idx, const float* __restrict__ d2, int n,
-                                                              double max_range, double* __restrict__ part) {
+__device__ __forceinline__ void fitness_partial_body(const int* __restrict__ idx, const float* __restrict__ d2, int n, double max_range,
+                                                     double* __restrict__ part, const int blk, const int nblk) {
   __shared__ double s_sum[256], s_cnt[256];
   double sum = 0, cnt = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  for (int i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) {
     if (idx[i] >= 0 && (double)d2[i] <= max_range) { sum += (double)d2[i]; cnt += 1.0; }
   }
   s_sum[threadIdx.x] = sum;
@@ -285,11 +377,15 @@ __global__ __launch_bounds__(256) void fitness_partial_kernel(const int* __restr
     if ((int)threadIdx.x < s) { s_sum[threadIdx.x] += s_sum[threadIdx.x + s]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + s]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s_sum[0]; part[2 * blockIdx.x + 1] = s_cnt[0]; }
+  if (threadIdx.x == 0) { part[2 * blk] = s_sum[0]; part[2 * blk + 1] = s_cnt[0]; }
+}
+__global__ __launch_bounds__(256) void fitness_partial_kernel(const int* __restrict__ idx, const float* __restrict__ d2, int n,
+                                                              double max_range, double* __restrict__ part) {
+  fitness_partial_body(idx, d2, n, max_range, part, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // second stage (one workgroup, fixed order): {sum, count} of the 256 partials straight into the host mailbox
-__global__ __launch_bounds__(256) void fitness_final_kernel(const double* __restrict__ part, BuildMailbox* __restrict__ mb, unsigned int token) {
+__device__ __forceinline__ void fitness_final_body(const double* __restrict__ part, BuildMailbox* __restrict__ mb, unsigned int token) {
   __shared__ double s_sum[256], s_cnt[256];
   s_sum[threadIdx.x] = part[2 * threadIdx.x];
   s_cnt[threadIdx.x] = part[2 * threadIdx.x + 1];
@@ -303,7 +399,17 @@ __global__ __launch_bounds__(256) void fitness_final_kernel(const double* __rest
     __hip_atomic_store(&mb->fit_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-
+__global__ __launch_bounds__(256) void fitness_final_kernel(const double* __restrict__ part, BuildMailbox* __restrict__ mb, unsigned int token) {
+  fitness_final_body(part, mb, token);
+}
+__global__ __launch_bounds__(256) void fitness_partial_group_kernel(const FitGroup g) {
+  const FitMember& M = g.m[blockIdx.y];
+  fitness_partial_body(M.idx, M.d2, M.empty ? 0 : M.n, M.max_range, M.part, (int)blockIdx.x, 256);
+}
+__global__ __launch_bounds__(256) void fitness_final_group_kernel(const FitGroup g) {
+  const FitMember& M = g.m[blockIdx.x];
+  fitness_final_body(M.part, M.mb, M.token);
+}
 
 }  // namespace
 
@@ -431,6 +537,45 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
   return LSR_OK;
 }
 
+
+// Neighbour grids of `count` NDT targets from the voxel order their grid builder left behind (VoxelGridDev::has_sorted): one
+// launch per group of LSR_GROUP members, nothing to wait for.
+int nn_build_hash_from_grids(const VoxelGridDev* const* vgrids, HashGridDev* const* grids, int count, hipStream_t stream) {
+  int st;
+  for (int g0 = 0; g0 < count; g0 += LSR_GROUP) {
+    RefineGroup grp;
+    std::memset(&grp, 0, sizeof(grp));
+    const int ng = std::min(LSR_GROUP, count - g0);
+    int max_cells = 0;
+    for (int k = 0; k < ng; k++) {
+      const VoxelGridDev& V = *vgrids[g0 + k];
+      HashGridDev& G = *grids[g0 + k];
+      if (!V.has_sorted) { set_last_error("the voxel grid holds no cell-ordered points"); return LSR_ERR_INVALID_ARGUMENT; }
+      const size_t n = V.sorted_n, ccells = V.ncells;
+      G.cell = V.leaf / 8.0f;          // exact; 1 / cell == 8 * (1 / leaf) to the last bit
+      G.n = n;
+      for (int a = 0; a < 3; a++) { G.org[a] = 8 * V.min_b[a]; G.cdim[a] = V.div_b[a]; }
+      const size_t blocks_cap = std::min(ccells, n);
+      if ((st = G.order.reserve(n))) return st;
+      if ((st = G.packed.reserve(n))) return st;
+      if ((st = G.coarse_block.reserve(ccells))) return st;
+      if ((st = G.block_off.reserve(blocks_cap + 1))) return st;
+      if ((st = G.fine_start.reserve(blocks_cap * FINE_STRIDE))) return st;
+      G.n_blocks = 1;  // "not empty": a grid with ncells > 0 holds at least one finite point
+      RefineMember& M = grp.m[k];
+      M.sx = V.sorted.p; M.sy = M.sx + V.sorted_pitch; M.sz = M.sy + V.sorted_pitch;
+      M.sidx = V.sorted_idx.p; M.start = V.cell_start.p; M.rank = V.cell_rank.p;
+      M.ncells = (int)ccells; M.inv_cell = 1.0f / G.cell;
+      M.o0 = G.org[0]; M.o1 = G.org[1]; M.o2 = G.org[2];
+      M.coarse_block = G.coarse_block.p; M.block_off = G.block_off.p; M.fine_start = G.fine_start.p; M.packed = G.packed.p; M.order = G.order.p;
+      max_cells = std::max(max_cells, (int)ccells);
+    }
+    if (max_cells > 0) hipLaunchKernelGGL(nn_refine_group_kernel, dim3(max_cells, ng), dim3(256), 0, stream, grp);
+  }
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
 bool nn_coop_enabled() {
   static const bool on = [] { const char* e = getenv("LSR_NN_COOP"); return !(e && e[0] == '0'); }();
   return on;
@@ -524,6 +669,46 @@ int nn_fitness_begin(const DeviceCloud& source, const float* T16_host, const Has
   hipLaunchKernelGGL(fitness_final_kernel, dim3(1), dim3(256), 0, stream, d_part, sc.d_mb, token);
   LSR_HIP(hipGetLastError());
   sc.fit_token = token;
+  return LSR_OK;
+}
+
+
+// getFitnessScore of `count` candidates in three launches per group of FIT_GROUP (search, partial sums, final sum) on ONE
+// stream; every member's result arrives in its own mailbox (nn_fitness_end collects it).
+int nn_fitness_begin_group(const FitJob* jobs, int count, hipStream_t stream) {
+  int st;
+  for (int g0 = 0; g0 < count; g0 += FIT_GROUP) {
+    FitGroup grp;
+    std::memset(&grp, 0, sizeof(grp));
+    const int ng = std::min(FIT_GROUP, count - g0);
+    int max_blocks = 1;
+    for (int k = 0; k < ng; k++) {
+      const FitJob& J = jobs[g0 + k];
+      BuildScratch& sc = *J.sc;
+      int* d_idx; float* d_d2; double* d_part; int* d_work;
+      if ((st = nn_scratch(sc, J.source->n, &d_idx, &d_d2, &d_part, &d_work))) return st;
+      if ((st = sc.ensure_mailbox())) return st;
+      unsigned int token = ++sc.token;
+      if (token == 0) token = ++sc.token;
+      sc.fit_token = token;
+      FitMember& M = grp.m[k];
+      M.G = make_view(*J.grid);
+      M.qx = J.source->x(); M.qy = J.source->y(); M.qz = J.source->z();
+      M.n = (int)J.source->n;
+      M.blocks = (int)(((long)M.n * 64 + 255) / 256);
+      M.empty = (J.grid->n_blocks == 0 || M.n == 0) ? 1 : 0;   // no finite target point: no pair, the score is DBL_MAX (nn_fitness_end)
+      for (int a = 0; a < 16; a++) M.T16[a] = J.T16[a];
+      M.max_d2 = (J.max_range >= 3.0e38) ? INFINITY : (float)J.max_range * 1.0001f;
+      M.max_range = J.max_range;
+      M.idx = d_idx; M.d2 = d_d2; M.part = d_part;
+      M.mb = sc.d_mb; M.token = token;
+      if (!M.empty) max_blocks = std::max(max_blocks, M.blocks);
+    }
+    hipLaunchKernelGGL(nn1_wave_group_kernel, dim3(max_blocks, ng), dim3(256), 0, stream, grp);
+    hipLaunchKernelGGL(fitness_partial_group_kernel, dim3(256, ng), dim3(256), 0, stream, grp);
+    hipLaunchKernelGGL(fitness_final_group_kernel, dim3(ng), dim3(256), 0, stream, grp);
+  }
+  LSR_HIP(hipGetLastError());
   return LSR_OK;
 }
 

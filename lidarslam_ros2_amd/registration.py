@@ -297,10 +297,11 @@ class Registration:
         return idx, d2
 
     def setTuning(self, workgroup: Optional[int] = None, table_mode: Optional[int] = None, grid_builder: Optional[int] = None,
-                  wait_mode: Optional[int] = None, quad: Optional[int] = None):
+                  wait_mode: Optional[int] = None, quad: Optional[int] = None, sort: Optional[int] = None):
         """Tuning keys of the core (no effect on results beyond fp64 summation order): NDT workgroup size (0 auto, 128,
-        256), where the derivative pass reads the voxel table (-1 auto, 0 dense global, 1 compact global, 2 LDS), the
-        grid builder (0 auto, 1 radix sort), how the calling thread waits (0 spin, 1 yield, 2 sleep)."""
+        256), where the derivative pass reads the voxel table (-1 auto, 0 dense global, 1 compact global, 2 LDS, 3 tile), the
+        grid builder (0 auto, 1 radix sort), how the calling thread waits (0 spin, 1 yield, 2 sleep), source ordering by
+        voxel tile (-1 auto, 0 never, 1 also for global-table gathers)."""
         if workgroup is not None:
             self._seti(capi.NDT_WORKGROUP, workgroup, "setTuning(workgroup)")
         if table_mode is not None:
@@ -311,6 +312,8 @@ class Registration:
             self._seti(capi.WAIT_MODE, wait_mode, "setTuning(wait_mode)")
         if quad is not None:
             self._seti(capi.NDT_QUAD, quad, "setTuning(quad)")
+        if sort is not None:
+            self._seti(capi.NDT_SORT, sort, "setTuning(sort)")
 
     def setProfiling(self, on: bool):
         self._seti(capi.PROFILE, 1 if on else 0, "setProfiling")
@@ -431,6 +434,25 @@ def set_input_target_batch(regs: Sequence[Registration], clouds):
         r._keep["target"] = None
         if hasattr(r, "_n_target"):
             r._n_target = a[2]
+
+
+def set_input_source_batch(regs: Sequence[Registration], clouds):
+    """setInputSource of every candidate of a set in shared launches (lsr_set_input_source_batch)."""
+    lib = capi.load()
+    B = len(regs)
+    if len(clouds) != B:
+        raise ValueError("one cloud per registration object")
+    args = [_cloud_args(c, r) for r, c in zip(regs, clouds)]
+    if B and (any(a[3] != args[0][3] for a in args) or any(a[1] != args[0][1] for a in args)):
+        raise ValueError("clouds must all be host or all device, with one record stride")
+    hs = (C.c_void_p * B)(*[r._h for r in regs])
+    ptrs = (C.c_void_p * B)(*[a[0] for a in args])
+    counts = (C.c_size_t * B)(*[a[2] for a in args])
+    capi.check(lib.lsr_set_input_source_batch(hs, B, ptrs, counts, args[0][1] if B else 12, 1 if (B and args[0][3]) else 0),
+               "set_input_source_batch")
+    for r, a in zip(regs, args):
+        r._n_source = a[2]
+        r._keep["source"] = a[4] if a[3] else None
 
 
 def fitness_score_batch(regs: Sequence[Registration], max_range: float = 1.7976931348623157e308):
