@@ -31,6 +31,16 @@ namespace {
     return LSR_ERR_HIP;                          \
   }
 
+// Make everything `h` still has in flight on its own stream precede what is enqueued on `lead` next (group launches of a
+// candidate set run on the first member's stream).  An idle stream — the usual case — costs one query and no event.
+int order_lead_after(hipStream_t lead, lsr_handle h) {
+  if (h->stream == lead) return LSR_OK;
+  if (hipStreamQuery(h->stream) == hipSuccess) return LSR_OK;
+  LSR_HIP(hipEventRecord(h->ev1, h->stream));
+  LSR_HIP(hipStreamWaitEvent(lead, h->ev1, 0));
+  return LSR_OK;
+}
+
 int upload_cloud(lsr_handle h, const void* pts, size_t stride, size_t n, bool on_device, DeviceCloud& out) {
   if (stride < 12 || (stride % 4) != 0) {
     set_last_error("stride_bytes must be a multiple of 4 and >= 12");
@@ -75,7 +85,8 @@ int device_cus(int device) {
 constexpr int NDT_WGS_PER_CU = 2;
 int ndt_nblocks(size_t n, int device, int batch = 1, int threads = NDT_THREADS) {
   int nb = (int)((n + threads - 1) / threads);
-  const int resident = device_cus(device) * NDT_WGS_PER_CU;
+  static const int wgs_per_cu = [] { const char* e = std::getenv("LSR_NDT_WGS_PER_CU"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= 8) ? v : NDT_WGS_PER_CU; }();
+  const int resident = device_cus(device) * wgs_per_cu;
   const int share = std::max(1, resident / std::max(1, batch));
   nb = std::max(1, std::min(nb, std::min(share, NDT_MAX_BLOCKS)));
   return nb;
@@ -309,12 +320,9 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   }
   // The shared launches run on the lead's stream; a member on another stream may still have its setInputSource /
   // setInputTarget kernels in flight there: order the lead's stream after each of them (event + stream wait, no host wait)
-  for (int b = 1; b < B; b++) {
-    if (hs[b]->stream == lead->stream) continue;
-    LSR_HIP(hipEventRecord(hs[b]->ev1, hs[b]->stream));
-    LSR_HIP(hipStreamWaitEvent(lead->stream, hs[b]->ev1, 0));
-  }
   int st;
+  for (int b = 1; b < B; b++)
+    if ((st = order_lead_after(lead->stream, hs[b]))) return st;
   if ((st = lead->d_state.reserve(2 * (size_t)B))) return st;
   if ((st = lead->h_state.reserve(2 * (size_t)B))) return st;
   if ((st = lead->d_prob.reserve(B))) return st;
@@ -729,9 +737,7 @@ int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const
       if ((st = cloud_bbox_begin(t->cloud, h->scratch, h->stream))) return fail(st);
       continue;
     }
-    if (h->stream != lead_stream) {   // whatever this member still has in flight on its own stream comes first
-      if (hipEventRecord(h->ev1, h->stream) != hipSuccess || hipStreamWaitEvent(lead_stream, h->ev1, 0) != hipSuccess) return fail(LSR_ERR_HIP);
-    }
+    if ((st = order_lead_after(lead_stream, h))) return fail(st);   // whatever this member still has in flight on its own stream comes first
     const void* d_aos = clouds[b];
     if (!on_device && counts[b] > 0) {
       if ((st = h->staging.reserve(counts[b] * stride_bytes))) return fail(st);
@@ -753,8 +759,10 @@ int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const
       if ((st = ndt_build_grid_end(t.grid, h->scratch, lead_stream))) return fail(st);
       t.has_grid = true;
       t.grid_leaf = (float)h->ndt.resolution;
+    } else if (hipStreamSynchronize(h->stream) != hipSuccess) {
+      set_last_error("stream error in the target batch");
+      return fail(LSR_ERR_HIP);
     }
-    if (hipStreamSynchronize(h->stream) != hipSuccess) { set_last_error("stream error in the target batch"); return fail(LSR_ERR_HIP); }
   }
   if (hipStreamSynchronize(lead_stream) != hipSuccess) { set_last_error("stream error in the target batch"); return fail(LSR_ERR_HIP); }
   return LSR_OK;
@@ -802,10 +810,7 @@ int lsr_set_input_source_batch(lsr_handle* handles, int count, const void* const
   int st;
   for (int b = 0; b < count; b++) {
     lsr_handle h = handles[b];
-    if (h->stream != lead_stream) {
-      LSR_HIP(hipEventRecord(h->ev1, h->stream));
-      LSR_HIP(hipStreamWaitEvent(lead_stream, h->ev1, 0));
-    }
+    if ((st = order_lead_after(lead_stream, h))) return st;
     const void* d_aos = clouds[b];
     if (!on_device && counts[b] > 0) {
       if ((st = h->staging.reserve(counts[b] * stride_bytes))) return st;
@@ -987,9 +992,7 @@ int lsr_align_batch(lsr_handle* handles, int batch, const float* guesses, float*
   }
   lsr_handle lead = handles[0];
   LSR_CHECK_HANDLE(lead);
-  // members may have pending uploads on their own streams
-  for (int b = 1; b < batch; b++)
-    if (handles[b]->stream != lead->stream) LSR_HIP(hipStreamSynchronize(handles[b]->stream));
+  // NDT: the shared chain's stream is ordered after whatever the members still have in flight (align_ndt_batch), no host wait
   if (lead->method == LSR_METHOD_NDT) return align_ndt_batch(handles, batch, guesses, finals, results);
   // GICP: registrations are advanced one after another (each is itself a chain of wide launches)
   for (int b = 0; b < batch; b++) {
@@ -1083,10 +1086,7 @@ int lsr_get_fitness_score_batch(lsr_handle* handles, int count, double max_range
     if (hash_from_grid_possible(h) && !target_is_shared(h)) {
       grouped.push_back(b);
       if (!h->target->has_hash) { vgs.push_back(&h->target->grid); hgs.push_back(&h->target->hash); }
-      if (h->stream != lead_stream) {   // the member's source upload / anything else in flight on its own stream comes first
-        LSR_HIP(hipEventRecord(h->ev1, h->stream));
-        LSR_HIP(hipStreamWaitEvent(lead_stream, h->ev1, 0));
-      }
+      if ((st = order_lead_after(lead_stream, h))) return st;   // the member's source upload / anything else in flight on its own stream
     } else {
       single.push_back(b);
     }

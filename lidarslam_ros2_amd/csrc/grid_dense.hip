@@ -362,14 +362,21 @@ __global__ __launch_bounds__(256) void vg_ingest_group_kernel(const VgGroup g) {
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   unsigned int cnt = 0;
   const int step = M.ingest_blocks * 256;
+  // records of 16-byte aligned stride (pcl::PointXYZI: 32 bytes) are read as ONE 16-byte load per point, anything else as three
+  const bool wide = ((M.stride & 15) == 0) && ((reinterpret_cast<size_t>(M.aos) & 15) == 0);
   for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < M.n; i0 += 4 * step) {
     float p[4][3];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = i0 + u * step;
       if (i < M.n) {
-        const float* q = reinterpret_cast<const float*>(M.aos + (size_t)i * M.stride);
-        p[u][0] = q[0]; p[u][1] = q[1]; p[u][2] = q[2];
+        if (wide) {
+          const float4 q = *reinterpret_cast<const float4*>(M.aos + (size_t)i * M.stride);
+          p[u][0] = q.x; p[u][1] = q.y; p[u][2] = q.z;
+        } else {
+          const float* q = reinterpret_cast<const float*>(M.aos + (size_t)i * M.stride);
+          p[u][0] = q[0]; p[u][1] = q[1]; p[u][2] = q[2];
+        }
       } else {
         p[u][0] = p[u][1] = p[u][2] = NAN;
       }
@@ -401,15 +408,14 @@ __global__ __launch_bounds__(256) void vg_ingest_group_kernel(const VgGroup g) {
     s_cnt[w] = cnt;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    BboxPart* P = &M.mb->part[blockIdx.x];
-    for (int k = 0; k < 3; k++) {
-      P->mn[k] = fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k]));
-      P->mx[k] = fmaxf(fmaxf(s_mx[0][k], s_mx[1][k]), fmaxf(s_mx[2][k], s_mx[3][k]));
-    }
-    P->n_finite = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    __threadfence_system();
-    __hip_atomic_store(&P->token, M.bbox_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x < BBOX_GRANULES) {   // seven self-validating granules, no fence (common.hpp: BboxPart)
+    const int k = threadIdx.x;
+    unsigned int bits;
+    if (k < 3) bits = __float_as_uint(fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k])));
+    else if (k < 6) bits = __float_as_uint(fmaxf(fmaxf(s_mx[0][k - 3], s_mx[1][k - 3]), fmaxf(s_mx[2][k - 3], s_mx[3][k - 3])));
+    else bits = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __hip_atomic_store(&M.mb->part[blockIdx.x].g[k], ((unsigned long long)M.bbox_token << 32) | bits, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 __global__ __launch_bounds__(256) void vg_hist_group_kernel(const VgGroup g) {

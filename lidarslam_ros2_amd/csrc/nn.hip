@@ -244,11 +244,9 @@ __global__ __launch_bounds__(NN_THREADS) void nn1_kernel(NNGridView G, const flo
 }
 
 // The same first stage on four lanes per query (nn1_query_quad): a quarter of the dependent-load chain per lane.
-__global__ __launch_bounds__(NN_THREADS) void nn1_quad_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
-                                                              const float* __restrict__ qz, int n, const float* __restrict__ T16,
-                                                              int fine_rings, int ring_cap, float max_d2, int* __restrict__ work,
-                                                              int* __restrict__ idx, float* __restrict__ d2) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void nn1_quad_body(const NNGridView& G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                              const float* __restrict__ qz, int n, const float* __restrict__ T16, int fine_rings, int ring_cap,
+                                              float max_d2, int* __restrict__ work, int* __restrict__ idx, float* __restrict__ d2, const int t) {
   const int i = t >> 2, sub = t & 3;
   if (i >= n) return;   // n * 4 threads: a quad is never split by this test
   const float x = qx[i], y = qy[i], z = qz[i];
@@ -268,6 +266,12 @@ __global__ __launch_bounds__(NN_THREADS) void nn1_quad_kernel(NNGridView G, cons
   }
   idx[i] = c.idx;
   d2[i] = c.d2;
+}
+__global__ __launch_bounds__(NN_THREADS) void nn1_quad_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                              const float* __restrict__ qz, int n, const float* __restrict__ T16,
+                                                              int fine_rings, int ring_cap, float max_d2, int* __restrict__ work,
+                                                              int* __restrict__ idx, float* __restrict__ d2) {
+  nn1_quad_body(G, qx, qy, qz, n, T16, fine_rings, ring_cap, max_d2, work, idx, d2, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // One wave per query (coop_search over the fine grid, coarse cells when needed): the form used for scan-sized query sets.
@@ -307,7 +311,7 @@ struct FitMember {
   const float *qx, *qy, *qz; int n, blocks;
   float T16[16];
   float max_d2; double max_range;
-  int* idx; float* d2; double* part;
+  int* idx; float* d2; double* part; int* work;
   BuildMailbox* mb; unsigned int token; int empty;
 };
 constexpr int FIT_GROUP = 12;
@@ -320,10 +324,10 @@ __global__ __launch_bounds__(256) void nn1_wave_group_kernel(const FitGroup g) {
 }
 
 // tail of nn1_kernel: one wave per deferred query; same (distance, index) order, same fp32 distances => same answer
-__global__ __launch_bounds__(256) void nn1_coop_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
-                                                       const float* __restrict__ qz, const float* __restrict__ T16, float max_d2,
-                                                       const int* __restrict__ work, int* __restrict__ idx, float* __restrict__ d2) {
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+__device__ __forceinline__ void nn1_coop_body(const NNGridView& G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                              const float* __restrict__ qz, const float* __restrict__ T16, float max_d2,
+                                              const int* __restrict__ work, int* __restrict__ idx, float* __restrict__ d2, const int wave,
+                                              const int n_waves) {
   const int lane = threadIdx.x & 63;
   const int n_work = work[0];
   for (int w = wave; w < n_work; w += n_waves) {
@@ -343,6 +347,11 @@ __global__ __launch_bounds__(256) void nn1_coop_kernel(NNGridView G, const float
       d2[i] = found ? mine.d : INFINITY;
     }
   }
+}
+__global__ __launch_bounds__(256) void nn1_coop_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                       const float* __restrict__ qz, const float* __restrict__ T16, float max_d2,
+                                                       const int* __restrict__ work, int* __restrict__ idx, float* __restrict__ d2) {
+  nn1_coop_body(G, qx, qy, qz, T16, max_d2, work, idx, d2, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6);
 }
 
 __global__ __launch_bounds__(NN_THREADS) void knn_kernel(NNGridView G, const float* __restrict__ qx, const float* __restrict__ qy,
@@ -401,6 +410,20 @@ __device__ __forceinline__ void fitness_final_body(const double* __restrict__ pa
 }
 __global__ __launch_bounds__(256) void fitness_final_kernel(const double* __restrict__ part, BuildMailbox* __restrict__ mb, unsigned int token) {
   fitness_final_body(part, mb, token);
+}
+// alternative form (LSR_FIT_GROUP_FORM=1): capped walk on four lanes per query + wave-cooperative tail for the queries it defers —
+// the same answers, and on paper a sixth of the instructions per query once millions of queries fill the chip; measured
+// slower than one wave per query (the deferred tail alone costs as much as it saves)
+__global__ void fit_zero_work_group_kernel(const FitGroup g) { g.m[threadIdx.x].work[0] = 0; }   // empty deferred-query lists
+__global__ __launch_bounds__(NN_THREADS) void nn1_quad_group_kernel(const FitGroup g) {
+  const FitMember& M = g.m[blockIdx.y];
+  if (M.empty) return;
+  nn1_quad_body(M.G, M.qx, M.qy, M.qz, M.n, M.T16, 1, 2, M.max_d2, M.work, M.idx, M.d2, blockIdx.x * NN_THREADS + threadIdx.x);
+}
+__global__ __launch_bounds__(256) void nn1_coop_group_kernel(const FitGroup g) {
+  const FitMember& M = g.m[blockIdx.y];
+  if (M.empty) return;
+  nn1_coop_body(M.G, M.qx, M.qy, M.qz, M.T16, M.max_d2, M.work, M.idx, M.d2, (blockIdx.x * 256 + threadIdx.x) >> 6, (gridDim.x * 256) >> 6);
 }
 __global__ __launch_bounds__(256) void fitness_partial_group_kernel(const FitGroup g) {
   const FitMember& M = g.m[blockIdx.y];
@@ -681,12 +704,13 @@ int nn_fitness_begin_group(const FitJob* jobs, int count, hipStream_t stream) {
     FitGroup grp;
     std::memset(&grp, 0, sizeof(grp));
     const int ng = std::min(FIT_GROUP, count - g0);
-    int max_blocks = 1;
+    int max_blocks = 1, max_n = 0;
     for (int k = 0; k < ng; k++) {
       const FitJob& J = jobs[g0 + k];
       BuildScratch& sc = *J.sc;
       int* d_idx; float* d_d2; double* d_part; int* d_work;
       if ((st = nn_scratch(sc, J.source->n, &d_idx, &d_d2, &d_part, &d_work))) return st;
+
       if ((st = sc.ensure_mailbox())) return st;
       unsigned int token = ++sc.token;
       if (token == 0) token = ++sc.token;
@@ -700,11 +724,19 @@ int nn_fitness_begin_group(const FitJob* jobs, int count, hipStream_t stream) {
       for (int a = 0; a < 16; a++) M.T16[a] = J.T16[a];
       M.max_d2 = (J.max_range >= 3.0e38) ? INFINITY : (float)J.max_range * 1.0001f;
       M.max_range = J.max_range;
-      M.idx = d_idx; M.d2 = d_d2; M.part = d_part;
+      M.idx = d_idx; M.d2 = d_d2; M.part = d_part; M.work = d_work;
       M.mb = sc.d_mb; M.token = token;
-      if (!M.empty) max_blocks = std::max(max_blocks, M.blocks);
+      if (!M.empty) { max_blocks = std::max(max_blocks, M.blocks); max_n = std::max(max_n, M.n); }
     }
-    hipLaunchKernelGGL(nn1_wave_group_kernel, dim3(max_blocks, ng), dim3(256), 0, stream, grp);
+    static const int form = [] { const char* e = getenv("LSR_FIT_GROUP_FORM"); return e ? atoi(e) : -1; }();   // 0 wave, 1 quad + tail, -1 by size
+    const bool quad_form = form == 1;   // measured on 64 candidates x 30k queries: 5.85 ms against 3.54 ms for one wave per query
+    if (quad_form) {
+      hipLaunchKernelGGL(fit_zero_work_group_kernel, dim3(1), dim3(ng), 0, stream, grp);
+      hipLaunchKernelGGL(nn1_quad_group_kernel, dim3((unsigned)(((long)max_n * 4 + NN_THREADS - 1) / NN_THREADS), ng), dim3(NN_THREADS), 0, stream, grp);
+      hipLaunchKernelGGL(nn1_coop_group_kernel, dim3(64, ng), dim3(256), 0, stream, grp);
+    } else {
+      hipLaunchKernelGGL(nn1_wave_group_kernel, dim3(max_blocks, ng), dim3(256), 0, stream, grp);
+    }
     hipLaunchKernelGGL(fitness_partial_group_kernel, dim3(256, ng), dim3(256), 0, stream, grp);
     hipLaunchKernelGGL(fitness_final_group_kernel, dim3(ng), dim3(256), 0, stream, grp);
   }

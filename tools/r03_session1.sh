@@ -6,7 +6,7 @@ O=$REPO/gpurun_out/${TAG:-r03_s2}
 rm -rf $O; mkdir -p $O
 cd $REPO
 export LSR_BENCH_CACHE_DIR=/tmp/lsr_bench_cache
-(timeout 1500 python -m pytest tests -m gpu -q -x --deselect tests/test_full_size_gpu.py 2>&1 | tail -40) > $O/pytest_a.log; echo "pytest_a rc=$?"; tail -3 $O/pytest_a.log
+(timeout 1500 python -m pytest tests -m gpu -q --deselect tests/test_full_size_gpu.py 2>&1 | tail -40) > $O/pytest_a.log; echo "pytest_a rc=$?"; tail -3 $O/pytest_a.log
 (timeout 900 python tools/r03_probe.py 2>&1 | tail -60) > $O/probe.log; echo "probe rc=$?"; cat $O/probe.log | cut -c1-260
 (timeout 1500 python -m pytest tests/test_full_size_gpu.py -m gpu -q 2>&1 | tail -60) > $O/pytest_full.log; echo "pytest_full rc=$?"; tail -15 $O/pytest_full.log | cut -c1-400
 (timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err); echo "bench rc=$?"; python - <<'PY'
