@@ -219,9 +219,12 @@ int lsr_share_target(lsr_handle h, lsr_handle owner);
  * (scanmatcher_component.cpp:350-353, graph_based_slam_component.cpp:229-230) — pass NULL to skip it. */
 int lsr_align(lsr_handle h, const float* guess, float* final_transformation, lsr_result* result,
               void* output_pts, size_t out_stride_bytes);
-/* B independent registrations advanced together in shared launches (loop-closure candidate set /
- * N keyframes vs submap; BASELINE.json cfg 4).  All handles must live on the same device and use
- * the same method.  guesses: B*16 floats or NULL; finals: B*16 floats; results: B entries. */
+/* B independent registrations advanced together (loop-closure candidate set / N keyframes vs submap; BASELINE.json cfg 4).
+ * NDT: ONE launch chain whose grid covers all B registrations.  GICP (the stand-alone backend's configuration,
+ * graph_based_slam/param/graphbasedslam.yaml:3): B launch chains side by side, each on its own object's stream, fed by one
+ * host loop — objects created on one shared stream get the same results without the overlap.  All handles must live on the
+ * same device and use the same method; an object may appear only once.  guesses: B*16 floats or NULL; finals: B*16 floats;
+ * results: B entries. */
 int lsr_align_batch(lsr_handle* handles, int batch, const float* guesses, float* finals, lsr_result* results);
 
 /* registration_->getFinalTransformation()  scanmatcher_component.cpp:356; graph_based_slam_component.cpp:244,253 */

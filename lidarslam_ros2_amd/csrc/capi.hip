@@ -994,13 +994,12 @@ int lsr_align_batch(lsr_handle* handles, int batch, const float* guesses, float*
   LSR_CHECK_HANDLE(lead);
   // NDT: the shared chain's stream is ordered after whatever the members still have in flight (align_ndt_batch), no host wait
   if (lead->method == LSR_METHOD_NDT) return align_ndt_batch(handles, batch, guesses, finals, results);
-  // GICP: registrations are advanced one after another (each is itself a chain of wide launches)
-  for (int b = 0; b < batch; b++) {
-    int st = gicp_align(handles[b], guesses ? guesses + 16 * b : nullptr, finals ? finals + 16 * b : nullptr,
-                        results ? results + b : nullptr);
-    if (st) return st;
-  }
-  return LSR_OK;
+  // GICP: every registration is a chain of small dependent launches on its own object's stream; the chains of the batch are fed
+  // side by side by one host loop (an object may appear only once: a chain owns its object's workspace and mailbox)
+  for (int b = 0; b < batch; b++)
+    for (int a = 0; a < b; a++)
+      if (handles[a] == handles[b]) { set_last_error("the same object appears twice in the batch"); return LSR_ERR_INVALID_ARGUMENT; }
+  return gicp_align_batch(handles, batch, guesses, finals, results);
 }
 
 int lsr_align(lsr_handle h, const float* guess, float* final_transformation, lsr_result* result, void* output_pts,

@@ -1122,77 +1122,28 @@ int gicp_get_covariances(lsr_handle_s* h, int which, double* cov) {
   return LSR_OK;
 }
 
-int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res) {
-  if (!h->target || h->target->n == 0) { set_last_error("align before setInputTarget"); return LSR_ERR_NO_TARGET; }
-  if (!h->has_source) { set_last_error("align before setInputSource"); return LSR_ERR_NO_SOURCE; }
-  int st = ensure_covariances(h);
-  if (st) return st;
-  hipStream_t s = h->stream;
-  const int n = (int)h->source.n;
-  const TargetData& t = *h->target;
-  float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  const float* G = guess ? guess : I16;
-
-  // workspace: out cloud | pairs | partials | per-align block {inner state, T16, Rm, outer state, count} | guess
-  const int nblocks = std::max(1, std::min((n + GN_THREADS - 1) / GN_THREADS, 512));
-  GicpWorkspace& ws = h->gicp_ws;
-  if ((st = ws.out.resize(n))) return st;
-  if ((st = ws.pairs.reserve((size_t)n * sizeof(PairRec)))) return st;
-  if ((st = ws.buf.reserve((size_t)2 * nblocks * 32 + 64))) return st;   // two banks of partial rows (fused chain)
-  if ((st = ws.state.reserve(2 * sizeof(IterBlock) + 256))) return st;   // the block is double buffered by step parity
-  if ((st = ws.pin.reserve(sizeof(IterBlock) + 64))) return st;
-  double* d_partials = ws.buf.p;
-  IterBlock* d_blk = reinterpret_cast<IterBlock*>(ws.state.p);
-  PairRec* d_pairs = reinterpret_cast<PairRec*>(ws.pairs.p);
-
-  if (!ws.d_mailbox) {
-    if ((st = ws.mailbox.reserve(1, hipHostMallocMapped | hipHostMallocCoherent))) return st;
-    std::memset(ws.mailbox.p, 0, sizeof(GicpMailbox));
-    LSR_HIP(hipHostGetDevicePointer((void**)&ws.d_mailbox, ws.mailbox.p, 0));
-  }
-  const GicpMailbox* mb = ws.mailbox.p;
-  unsigned int token = ++ws.token;
-  if (token == 0) token = ++ws.token;  // 0 is the mailbox's idle value
-  const auto t_begin = std::chrono::steady_clock::now();
-
-  // ---- the whole align as ONE upload: outer state at the entry of computeTransformation + the first outer iteration
-  IterBlock* hb = reinterpret_cast<IterBlock*>(ws.pin.p);
-  std::memset(hb, 0, sizeof(IterBlock));
-  OuterState& O = hb->out;
-  std::memcpy(O.trans, I16, sizeof(I16));
-  std::memcpy(O.prev, I16, sizeof(I16));
-  std::memcpy(O.G, G, sizeof(I16));
-  O.rot_eps = h->gicp.rot_eps;
-  O.trans_eps = h->gicp.trans_eps;
-  O.max_iterations = h->gicp.max_iterations;
-  O.corr_mark = -1;
-  O.token = token;
-  hb->st.max_inner = h->gicp.max_inner;
-  gicp_begin_outer(*hb);
-  LSR_HIP(hipMemcpyAsync(d_blk, hb, sizeof(IterBlock), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(gicp_apply_guess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->source.x(), h->source.y(), h->source.z(),
-                     n, d_blk->out.G, ws.out.x(), ws.out.y(), ws.out.z());
-  const float thr2 = (float)(h->gicp.max_corr_dist * h->gicp.max_corr_dist);
-
-  // ---- launch chain.  A group = one correspondence pass + `steps` x (accumulate, update); every launch gates itself on
-  // the device-side phase, so a group enqueued too early (the previous inner loop still running) or too late (the align
-  // over) costs ~2 us per launch and nothing else.  The host keeps groups queued ahead and polls the mailbox.
-  const int spread = (n <= 65536) ? 2 : 1;
-  if ((st = ws.last_nn.reserve((size_t)n + 1))) return st;
-  int updates = 0;
-  const bool coop_corr = nn_coop_enabled();
-  if (coop_corr && (st = ws.nn_d2.reserve((size_t)n + 1))) return st;
-  const bool fused = gicp_fused_enabled();
-  // seeded 16-lane search for the outer iterations after the first (env LSR_GICP_BALL=0: the general search every time)
-  static const bool ball_on = [] { const char* e = getenv("LSR_GICP_BALL"); return !(e && e[0] == '0'); }();
-  const bool ball = fused && ball_on;
+// One GICP align in flight: the launch chain of gicp_align as a resumable object, so that several registrations (a candidate set
+// with the backend's stand-alone configuration, graph_based_slam/param/graphbasedslam.yaml:3) can be fed side by side, each on
+// its own stream with its own mailbox.
+namespace {
+struct GicpChain {
+  lsr_handle_s* h = nullptr;
+  hipStream_t s = nullptr;
+  int n = 0, nblocks = 1, updates = 0, spread = 1;
+  unsigned int token = 0;
+  float thr2 = 0.f;
+  bool coop_corr = false, fused = false, ball = false, done = false;
   int* d_work = nullptr;
-  if (ball) {
-    if ((st = ws.corr_work.reserve((size_t)n + 2))) return st;
-    d_work = ws.corr_work.p;
-    LSR_HIP(hipMemsetAsync(d_work, 0, sizeof(int), s));
-  }
-  auto enqueue_group = [&](int steps) {
+  double* d_partials = nullptr;
+  IterBlock* d_blk = nullptr;
+  PairRec* d_pairs = nullptr;
+  long hard_cap = 0;
+  unsigned long long last_progress = 0;
+  std::chrono::steady_clock::time_point t_begin, t_progress;
+
+  void enqueue_group(int steps) {
+    GicpWorkspace& ws = h->gicp_ws;
+    const TargetData& t = *h->target;
     if (fused) {   // the correspondence launches work on the block the next step will read
       IterBlock* cur = d_blk + (updates & 1);
       if (ball)
@@ -1231,55 +1182,179 @@ int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* 
       updates++;
       hipLaunchKernelGGL(gicp_update_kernel, dim3(1), dim3(256), 0, s, d_blk, d_partials, nblocks, ws.d_mailbox, token, updates);
     }
-  };
-  // the first outer iteration typically needs 3-4 Gauss-Newton steps, later ones one or two; the fused chain needs one step
-  // more per outer iteration (the step that finds the loop finished accumulates nothing)
-  enqueue_group(fused ? 5 : 4);
-  enqueue_group(3);
-  enqueue_group(3);
-  LSR_HIP(hipGetLastError());
-  const int wait_mode = h->scratch.wait_mode;
-  const long hard_cap = (long)(h->gicp.max_iterations + 2) * (h->gicp.max_inner + 2) + 16;  // update launches an align can need
-  {
-    unsigned long long last_progress = 0;
-    auto t_progress = std::chrono::steady_clock::now();
-    for (unsigned long long spins = 1;; spins++) {
-      if (__atomic_load_n(&mb->done, __ATOMIC_ACQUIRE) == token) break;
-      const unsigned long long pr = __atomic_load_n(&mb->progress, __ATOMIC_RELAXED);
-      const int ran = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : 0;
-      if (updates - ran < 5) {  // fewer than two groups left in the queue: top up
-        if (updates > hard_cap) { set_last_error("GICP launch chain did not finish within its launch cap"); return LSR_ERR_HIP; }
-        enqueue_group(3);
-        enqueue_group(3);
-        LSR_HIP(hipGetLastError());
-        continue;
+  }
+
+  // everything up to the first three groups of launches
+  int begin(lsr_handle_s* handle, const float* guess) {
+    h = handle;
+    if (!h->target || h->target->n == 0) { set_last_error("align before setInputTarget"); return LSR_ERR_NO_TARGET; }
+    if (!h->has_source) { set_last_error("align before setInputSource"); return LSR_ERR_NO_SOURCE; }
+    int st = ensure_covariances(h);
+    if (st) return st;
+    s = h->stream;
+    n = (int)h->source.n;
+    float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const float* G = guess ? guess : I16;
+
+    // workspace: out cloud | pairs | partials | per-align block {inner state, T16, Rm, outer state, count} | guess
+    nblocks = std::max(1, std::min((n + GN_THREADS - 1) / GN_THREADS, 512));
+    GicpWorkspace& ws = h->gicp_ws;
+    if ((st = ws.out.resize(n))) return st;
+    if ((st = ws.pairs.reserve((size_t)n * sizeof(PairRec)))) return st;
+    if ((st = ws.buf.reserve((size_t)2 * nblocks * 32 + 64))) return st;   // two banks of partial rows (fused chain)
+    if ((st = ws.state.reserve(2 * sizeof(IterBlock) + 256))) return st;   // the block is double buffered by step parity
+    if ((st = ws.pin.reserve(sizeof(IterBlock) + 64))) return st;
+    d_partials = ws.buf.p;
+    d_blk = reinterpret_cast<IterBlock*>(ws.state.p);
+    d_pairs = reinterpret_cast<PairRec*>(ws.pairs.p);
+
+    if (!ws.d_mailbox) {
+      if ((st = ws.mailbox.reserve(1, hipHostMallocMapped | hipHostMallocCoherent))) return st;
+      std::memset(ws.mailbox.p, 0, sizeof(GicpMailbox));
+      LSR_HIP(hipHostGetDevicePointer((void**)&ws.d_mailbox, ws.mailbox.p, 0));
+    }
+    token = ++ws.token;
+    if (token == 0) token = ++ws.token;  // 0 is the mailbox's idle value
+    t_begin = std::chrono::steady_clock::now();
+
+    // ---- the whole align as ONE upload: outer state at the entry of computeTransformation + the first outer iteration
+    IterBlock* hb = reinterpret_cast<IterBlock*>(ws.pin.p);
+    std::memset(hb, 0, sizeof(IterBlock));
+    OuterState& O = hb->out;
+    std::memcpy(O.trans, I16, sizeof(I16));
+    std::memcpy(O.prev, I16, sizeof(I16));
+    std::memcpy(O.G, G, sizeof(I16));
+    O.rot_eps = h->gicp.rot_eps;
+    O.trans_eps = h->gicp.trans_eps;
+    O.max_iterations = h->gicp.max_iterations;
+    O.corr_mark = -1;
+    O.token = token;
+    hb->st.max_inner = h->gicp.max_inner;
+    gicp_begin_outer(*hb);
+    LSR_HIP(hipMemcpyAsync(d_blk, hb, sizeof(IterBlock), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(gicp_apply_guess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->source.x(), h->source.y(), h->source.z(),
+                       n, d_blk->out.G, ws.out.x(), ws.out.y(), ws.out.z());
+    thr2 = (float)(h->gicp.max_corr_dist * h->gicp.max_corr_dist);
+
+    // ---- launch chain.  A group = one correspondence pass + `steps` x (accumulate, update); every launch gates itself on
+    // the device-side phase, so a group enqueued too early (the previous inner loop still running) or too late (the align
+    // over) costs ~2 us per launch and nothing else.  The host keeps groups queued ahead and polls the mailbox.
+    spread = (n <= 65536) ? 2 : 1;
+    if ((st = ws.last_nn.reserve((size_t)n + 1))) return st;
+    updates = 0;
+    coop_corr = nn_coop_enabled();
+    if (coop_corr && (st = ws.nn_d2.reserve((size_t)n + 1))) return st;
+    fused = gicp_fused_enabled();
+    // seeded 16-lane search for the outer iterations after the first (env LSR_GICP_BALL=0: the general search every time)
+    static const bool ball_on = [] { const char* e = getenv("LSR_GICP_BALL"); return !(e && e[0] == '0'); }();
+    ball = fused && ball_on;
+    d_work = nullptr;
+    if (ball) {
+      if ((st = ws.corr_work.reserve((size_t)n + 2))) return st;
+      d_work = ws.corr_work.p;
+      LSR_HIP(hipMemsetAsync(d_work, 0, sizeof(int), s));
+    }
+    // the first outer iteration typically needs 3-4 Gauss-Newton steps, later ones one or two; the fused chain needs one step
+    // more per outer iteration (the step that finds the loop finished accumulates nothing)
+    enqueue_group(fused ? 5 : 4);
+    enqueue_group(3);
+    enqueue_group(3);
+    LSR_HIP(hipGetLastError());
+    hard_cap = (long)(h->gicp.max_iterations + 2) * (h->gicp.max_inner + 2) + 16;  // update launches an align can need
+    last_progress = 0;
+    t_progress = std::chrono::steady_clock::now();
+    done = false;
+    return LSR_OK;
+  }
+
+  // one poll of the mailbox: tops the queue up when fewer than two groups are left; sets `done` when the flag is up
+  int poll(unsigned long long spins) {
+    const GicpMailbox* mb = h->gicp_ws.mailbox.p;
+    if (__atomic_load_n(&mb->done, __ATOMIC_ACQUIRE) == token) { done = true; return LSR_OK; }
+    const unsigned long long pr = __atomic_load_n(&mb->progress, __ATOMIC_RELAXED);
+    const int ran = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : 0;
+    if (updates - ran < 5) {  // fewer than two groups left in the queue: top up
+      if (updates > hard_cap) { set_last_error("GICP launch chain did not finish within its launch cap"); return LSR_ERR_HIP; }
+      enqueue_group(3);
+      enqueue_group(3);
+      LSR_HIP(hipGetLastError());
+      return LSR_OK;
+    }
+    if ((spins & 0x3FFF) == 0 || h->scratch.wait_mode == WAIT_SLEEP) {  // a device that stops making progress must not hang the caller forever
+      const auto now = std::chrono::steady_clock::now();
+      if (pr != last_progress) { last_progress = pr; t_progress = now; }
+      if (std::chrono::duration<double>(now - t_progress).count() > 30.0) {
+        set_last_error(std::string("GICP launch chain made no progress for 30 s (stream: ") + hipGetErrorString(hipStreamQuery(s)) + ")");
+        return LSR_ERR_HIP;
       }
-      if ((spins & 0x3FFF) == 0 || wait_mode == WAIT_SLEEP) {  // a device that stops making progress must not hang the caller forever
-        const auto now = std::chrono::steady_clock::now();
-        if (pr != last_progress) { last_progress = pr; t_progress = now; }
-        if (std::chrono::duration<double>(now - t_progress).count() > 30.0) {
-          set_last_error(std::string("GICP launch chain made no progress for 30 s (stream: ") + hipGetErrorString(hipStreamQuery(s)) + ")");
-          return LSR_ERR_HIP;
-        }
-      }
-      if (wait_mode == WAIT_YIELD) std::this_thread::yield();
-      else if (wait_mode == WAIT_SLEEP) std::this_thread::sleep_for(std::chrono::microseconds(20));
-      else __builtin_ia32_pause();
+    }
+    return LSR_OK;
+  }
+
+  void finish(float* final_T, lsr_result* res) {
+    const GicpMailbox* mb = h->gicp_ws.mailbox.p;
+    // host clock from the first enqueue to the raised flag (the launches still queued exit at their head)
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    std::memcpy(h->final_T, mb->final_T, sizeof(float) * 16);
+    h->converged = mb->converged;
+    if (final_T) std::memcpy(final_T, h->final_T, sizeof(float) * 16);
+    if (res) {
+      res->converged = h->converged;
+      res->iterations = mb->nr_iterations;
+      res->score = mb->last_cost;
+      res->n_evaluations = mb->gn_steps;
+      res->n_correspondences = mb->last_cnt;
+      res->gpu_ms = ms;
     }
   }
-  // host clock from the first enqueue to the raised flag (the launches still queued exit at their head)
-  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-  std::memcpy(h->final_T, mb->final_T, sizeof(float) * 16);
-  h->converged = mb->converged;
-  if (final_T) std::memcpy(final_T, h->final_T, sizeof(float) * 16);
-  if (res) {
-    res->converged = h->converged;
-    res->iterations = mb->nr_iterations;
-    res->score = mb->last_cost;
-    res->n_evaluations = mb->gn_steps;
-    res->n_correspondences = mb->last_cnt;
-    res->gpu_ms = ms;
+};
+
+void wait_between_polls(int wait_mode) {
+  if (wait_mode == WAIT_YIELD) std::this_thread::yield();
+  else if (wait_mode == WAIT_SLEEP) std::this_thread::sleep_for(std::chrono::microseconds(20));
+  else __builtin_ia32_pause();
+}
+}  // namespace
+
+int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res) {
+  GicpChain c;
+  int st = c.begin(h, guess);
+  if (st) return st;
+  for (unsigned long long spins = 1; !c.done; spins++) {
+    if ((st = c.poll(spins))) return st;
+    if (!c.done) wait_between_polls(h->scratch.wait_mode);
   }
+  c.finish(final_T, res);
+  return LSR_OK;
+}
+
+// B independent GICP registrations side by side: every chain on its own object's stream, one host loop feeds them all (a
+// chain is a sequence of small dependent launches, far from filling the chip: B of them overlap almost completely).  Objects
+// that share a stream still work — their chains then simply queue one after the other.
+int gicp_align_batch(lsr_handle_s* const* hs, int B, const float* guesses, float* finals, lsr_result* results) {
+  std::vector<GicpChain> chains((size_t)B);
+  int st;
+  for (int b = 0; b < B; b++)
+    if ((st = chains[b].begin(hs[b], guesses ? guesses + 16 * b : nullptr))) {
+      for (int a = 0; a < b; a++) (void)hipStreamSynchronize(hs[a]->stream);   // nothing of a failed batch stays in flight
+      return st;
+    }
+  int n_done = 0, first_error = LSR_OK;
+  for (unsigned long long spins = 1; n_done < B; spins++) {
+    for (int b = 0; b < B; b++) {
+      GicpChain& c = chains[b];
+      if (c.done) continue;
+      st = c.poll(spins);
+      if (st) { if (!first_error) first_error = st; c.done = true; n_done++; continue; }
+      if (c.done) n_done++;
+    }
+    if (n_done < B) wait_between_polls(hs[0]->scratch.wait_mode);
+  }
+  if (first_error) {
+    for (int b = 0; b < B; b++) (void)hipStreamSynchronize(hs[b]->stream);
+    return first_error;
+  }
+  for (int b = 0; b < B; b++) chains[b].finish(finals ? finals + 16 * b : nullptr, results ? results + b : nullptr);
   return LSR_OK;
 }
 

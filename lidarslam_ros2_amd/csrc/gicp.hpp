@@ -45,5 +45,7 @@ struct GicpWorkspace {
 };
 
 int gicp_align(lsr_handle_s* h, const float* guess, float* final_T, lsr_result* res);
+// B registrations side by side (each chain on its own object's stream, one host loop feeding them all)
+int gicp_align_batch(lsr_handle_s* const* hs, int B, const float* guesses, float* finals, lsr_result* results);
 int gicp_get_covariances(lsr_handle_s* h, int which, double* cov);
 }  // namespace lsr

@@ -158,6 +158,7 @@ struct RefineMember {
   int *coarse_block, *block_off, *fine_start; float4* packed; int* order;
 };
 struct RefineGroup { RefineMember m[LSR_GROUP]; };
+constexpr int NN_REFINE_THREADS = 1024;   // the busiest voxels of a submap hold tens of thousands of points: their workgroup sets the kernel's time
 __device__ __forceinline__ void nn_refine_body(const RefineMember& M, const int cell) {
   __shared__ unsigned int s_cnt[FINE_PER_BLOCK], s_off[FINE_PER_BLOCK + 1], s_part[256];
   const int tid = threadIdx.x;
@@ -167,37 +168,40 @@ __device__ __forceinline__ void nn_refine_body(const RefineMember& M, const int 
     return;
   }
   const int b = (int)M.rank[cell];
-  for (int k = tid; k < FINE_PER_BLOCK; k += 256) s_cnt[k] = 0u;
+  for (int k = tid; k < FINE_PER_BLOCK; k += NN_REFINE_THREADS) s_cnt[k] = 0u;
   __syncthreads();
-  for (unsigned int j = beg + tid; j < end; j += 256) {
+  for (unsigned int j = beg + tid; j < end; j += NN_REFINE_THREADS) {
     const int fx = (int)floorf(M.sx[j] * M.inv_cell) - M.o0, fy = (int)floorf(M.sy[j] * M.inv_cell) - M.o1, fz = (int)floorf(M.sz[j] * M.inv_cell) - M.o2;
     atomicAdd(&s_cnt[(fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6)], 1u);
   }
   __syncthreads();
-  // exclusive scan of the 512 counts: two per thread + Hillis-Steele over the 256 pair sums
-  const unsigned int c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
-  s_part[tid] = c0 + c1;
+  // exclusive scan of the 512 counts on the first 256 threads: two per thread + Hillis-Steele over the 256 pair sums
+  const int t2 = tid & 255;
+  const unsigned int c0 = s_cnt[2 * t2], c1 = s_cnt[2 * t2 + 1];
+  if (tid < 256) s_part[tid] = c0 + c1;
   __syncthreads();
   for (int off = 1; off < 256; off <<= 1) {
-    const unsigned int v = (tid >= off) ? s_part[tid - off] : 0u;
+    const unsigned int v = (tid < 256 && tid >= off) ? s_part[tid - off] : 0u;
     __syncthreads();
-    s_part[tid] += v;
+    if (tid < 256) s_part[tid] += v;
     __syncthreads();
   }
-  const unsigned int base = s_part[tid] - (c0 + c1);
-  s_off[2 * tid] = base;
-  s_off[2 * tid + 1] = base + c0;
-  if (tid == 255) s_off[FINE_PER_BLOCK] = s_part[255];
-  s_cnt[2 * tid] = 0u;       // becomes the cursor of the scatter
-  s_cnt[2 * tid + 1] = 0u;
+  if (tid < 256) {
+    const unsigned int base = s_part[tid] - (c0 + c1);
+    s_off[2 * tid] = base;
+    s_off[2 * tid + 1] = base + c0;
+    if (tid == 255) s_off[FINE_PER_BLOCK] = s_part[255];
+    s_cnt[2 * tid] = 0u;       // becomes the cursor of the scatter
+    s_cnt[2 * tid + 1] = 0u;
+  }
   __syncthreads();
-  for (int f = tid; f <= FINE_PER_BLOCK; f += 256) M.fine_start[(size_t)b * FINE_STRIDE + f] = (int)(beg + s_off[f]);
+  for (int f = tid; f <= FINE_PER_BLOCK; f += NN_REFINE_THREADS) M.fine_start[(size_t)b * FINE_STRIDE + f] = (int)(beg + s_off[f]);
   if (tid == 0) {
     M.coarse_block[cell] = b;
     M.block_off[b] = (int)beg;
     M.block_off[b + 1] = (int)end;  // the next occupied voxel (if any) rewrites the same value
   }
-  for (unsigned int j = beg + tid; j < end; j += 256) {
+  for (unsigned int j = beg + tid; j < end; j += NN_REFINE_THREADS) {
     const float px = M.sx[j], py = M.sy[j], pz = M.sz[j];
     const int fx = (int)floorf(px * M.inv_cell) - M.o0, fy = (int)floorf(py * M.inv_cell) - M.o1, fz = (int)floorf(pz * M.inv_cell) - M.o2;
     const int fine = (fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6);
@@ -207,7 +211,7 @@ __device__ __forceinline__ void nn_refine_body(const RefineMember& M, const int 
     M.order[pos] = oi;
   }
 }
-__global__ __launch_bounds__(256) void nn_refine_group_kernel(const RefineGroup g) {
+__global__ __launch_bounds__(NN_REFINE_THREADS) void nn_refine_group_kernel(const RefineGroup g) {
   const RefineMember& M = g.m[blockIdx.y];
   if ((int)blockIdx.x >= M.ncells) return;
   nn_refine_body(M, (int)blockIdx.x);
@@ -593,7 +597,7 @@ int nn_build_hash_from_grids(const VoxelGridDev* const* vgrids, HashGridDev* con
       M.coarse_block = G.coarse_block.p; M.block_off = G.block_off.p; M.fine_start = G.fine_start.p; M.packed = G.packed.p; M.order = G.order.p;
       max_cells = std::max(max_cells, (int)ccells);
     }
-    if (max_cells > 0) hipLaunchKernelGGL(nn_refine_group_kernel, dim3(max_cells, ng), dim3(256), 0, stream, grp);
+    if (max_cells > 0) hipLaunchKernelGGL(nn_refine_group_kernel, dim3(max_cells, ng), dim3(NN_REFINE_THREADS), 0, stream, grp);
   }
   LSR_HIP(hipGetLastError());
   return LSR_OK;

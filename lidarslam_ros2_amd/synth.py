@@ -102,6 +102,40 @@ def trajectory_pose(x: float) -> np.ndarray:
     return pose_matrix(x, 0.0, 0.0, 0.02 * math.sin(0.1 * x))
 
 
+_RAYCAST_C = None   # ctypes handle of synth_raycast.c (False: unavailable, numpy is used)
+
+
+def _raycast_c():
+    """The intersection loop compiled from synth_raycast.c (gcc -O2 -ffp-contract=off: the same IEEE double operations as the
+    numpy code below, bit-identical results, ~50x faster).  Built next to this file on first use; any failure falls back to
+    numpy silently — the clouds are the same either way.  LSR_SYNTH_NUMPY=1 forces the numpy path."""
+    global _RAYCAST_C
+    if _RAYCAST_C is not None:
+        return _RAYCAST_C or None
+    _RAYCAST_C = False
+    import os
+    if os.environ.get("LSR_SYNTH_NUMPY"):
+        return None
+    try:
+        import ctypes as C
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        src, so = os.path.join(here, "synth_raycast.c"), os.path.join(here, "libsynth_raycast.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            tmp = so + ".%d.tmp" % os.getpid()
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", src, "-o", tmp, "-lm"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            os.replace(tmp, so)
+        lib = C.CDLL(so)
+        dp = C.POINTER(C.c_double)
+        lib.synth_raycast.argtypes = [dp, C.c_long, dp, C.c_double, dp, C.c_int, dp, C.c_int, dp]
+        lib.synth_raycast.restype = None
+        _RAYCAST_C = lib
+    except Exception:
+        _RAYCAST_C = False
+    return _RAYCAST_C or None
+
+
 def raycast_geometry(world: World, sensor: Sensor, T: np.ndarray):
     """The deterministic (and expensive) half of one revolution from pose T (sensor->map): ray/primitive intersections.
     Returns (keep, t) — the boolean mask of rays that hit something inside the sensor's range and their ranges.  Has no
@@ -110,6 +144,17 @@ def raycast_geometry(world: World, sensor: Sensor, T: np.ndarray):
     R, o = T[:3, :3], T[:3, 3]
     d = d_s @ R.T
     n = d.shape[0]
+    lib = _raycast_c()
+    if lib is not None:
+        import ctypes as C
+        dp = C.POINTER(C.c_double)
+        dc, oc = np.ascontiguousarray(d, np.float64), np.ascontiguousarray(o, np.float64)
+        bx, cy = np.ascontiguousarray(world.boxes, np.float64), np.ascontiguousarray(world.cyls, np.float64)
+        t_best = np.empty(n, np.float64)
+        lib.synth_raycast(dc.ctypes.data_as(dp), n, oc.ctypes.data_as(dp), float(world.ground_z), bx.ctypes.data_as(dp), int(bx.shape[0]),
+                          cy.ctypes.data_as(dp), int(cy.shape[0]), t_best.ctypes.data_as(dp))
+        keep = np.isfinite(t_best) & (t_best < sensor.max_range) & (t_best > sensor.min_range)
+        return keep, t_best[keep]
     t_best = np.full(n, np.inf)
     # ground
     with np.errstate(divide="ignore", invalid="ignore"):

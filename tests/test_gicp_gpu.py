@@ -250,3 +250,44 @@ def test_rank_deficient_system_returns_a_finite_pose():
     assert np.all(np.isfinite(T)), T
     assert np.abs(T[:3, 3]).max() < 5.0        # no astronomically large step was taken
     assert g.getFinalNumIteration() >= 1
+
+
+def test_gicp_batch_runs_side_by_side_and_equals_the_single_aligns(case):
+    """lsr_align_batch with GICP objects feeds B launch chains side by side (each on its own object's stream): every member must
+    end EXACTLY where its own align() puts it — the same kernels in the same order, only interleaved on the device — for distinct
+    targets, for objects sharing one target (N keyframes vs one submap), and an object must not appear twice."""
+    import time
+
+    from lidarslam_ros2_amd import align_batch
+
+    rng = np.random.default_rng(9)
+    B = 6
+    regs, guesses, singles = [], [], []
+    for b in range(B):
+        g = make_gicp()
+        if b < 3:
+            shift = np.float32([0.4 * b, -0.3 * b, 0.0])
+            g.setInputTarget(case.target + shift)
+            g.setInputSource(case.source[: 3900 - 150 * b] + shift)
+            G = case.guess.copy(); G[:3, 3] += shift - G[:3, :3] @ shift
+        else:
+            g.shareTargetOf(regs[0])          # the same submap for three more scans
+            g._n_target = case.target.shape[0]
+            g.setInputSource(case.source[: 3800 - 211 * b])
+            G = case.guess.copy(); G[:3, 3] += rng.uniform(-0.1, 0.1, 3).astype(np.float32)
+        regs.append(g); guesses.append(G)
+    t0 = time.perf_counter()
+    for g, G in zip(regs, guesses):
+        g.align(G)
+        singles.append((g.getFinalTransformation().copy(), g.last_result))
+    t_single = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    finals, results = align_batch(regs, guesses)
+    t_batch = time.perf_counter() - t0
+    for b in range(B):
+        assert np.array_equal(finals[b], singles[b][0]), b
+        assert results[b]["iterations"] == singles[b][1]["iterations"] and results[b]["n_evaluations"] == singles[b][1]["n_evaluations"]
+        assert results[b]["converged"]
+    print(f"GICP batch of {B}: {1e3 * t_batch:.2f} ms vs one by one {1e3 * t_single:.2f} ms")
+    with pytest.raises(Exception):
+        align_batch([regs[0], regs[0]], guesses[:2])

@@ -35,8 +35,8 @@ if single is not None:
            "bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
            "correction": "2 x FETCH_SIZE (gfx950 counts the 128-byte requests of wide coalesced reads at 64 B) + WRITE_SIZE",
            "source": f"tools/pmc_ndt.sh {tag} -> profiles/{tag}_pmc_ndt_eval.md"}
-    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS",
-              "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
+    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+              "SQ_ACTIVE_INST_LDS", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
         if med(c) is not None:
             out[c] = med(c)
     lines += ["", f"HBM bytes per launch of `{out['kernel']}`: 2 x {fetch_kb:.1f} KB + {write_kb:.1f} KB = {out['bytes_per_launch'] / 1e6:.3f} MB"]
@@ -51,7 +51,7 @@ if len(quads) > 1:
     fkb, wkb = medb("FETCH_SIZE"), medb("WRITE_SIZE") or 0.0
     out["cfg5"] = {"kernel": f"{big[0]} grid {big[1]} x workgroup {big[2]} (single 120k-pt registration, dense global table)",
                    "fetch_size_kb": fkb, "write_size_kb": wkb, "bytes_per_launch": int((2.0 * fkb + wkb) * 1024)}
-    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
+    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
         if medb(c) is not None:
             out["cfg5"][c] = medb(c)
     lines += ["", f"HBM bytes per launch of `{out['cfg5']['kernel']}`: 2 x {fkb:.1f} KB + {wkb:.1f} KB = {out['cfg5']['bytes_per_launch'] / 1e6:.3f} MB"]
