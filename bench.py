@@ -516,7 +516,11 @@ def cfg5_leg(make_ndt, dense, torch, synth):
     for res_o in (1.0, 1.5):
         try:
             ro = make_ndt(eps=0.0, mi=10, resolution=res_o)
-            t0 = time.perf_counter(); ro.setInputTarget(tgt); ro.setInputTarget(tgt); t_t = (time.perf_counter() - t0) / 2
+            ro.setInputTarget(tgt)                      # first call: allocations
+            tts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); ro.setInputTarget(tgt); tts.append(time.perf_counter() - t0)
+            t_t = float(np.median(tts))
             ro.setInputSource(src)
             ro.align(dense.guess)
             ro.setProfiling(True); ro.getProfile(reset=True); ro.align(dense.guess); po = ro.getProfile(reset=True); ro.setProfiling(False)

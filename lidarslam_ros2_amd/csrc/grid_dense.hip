@@ -341,11 +341,11 @@ __global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* _
 
 // ---- the same counting sort for key spaces beyond VG_DENSE_MAX_CELLS (up to VG_DENSE_MAX_CELLS_WIDE: a 2 m grid over a 20-frame
 // submap is 22 113 cells): the per-cell counters of the scatter are 32-bit words packing TWO 16-bit wave counters, so the table
-// fits LDS with twice the cells; a workgroup is two waves walking 16 384 points (64 steps... x 128), which keeps the
-// block-histogram rows (workgroups x cells) as small as the narrow form's.
+// fits LDS with twice the cells; a workgroup is two waves walking 4 096 points.
 constexpr int VGW_THREADS = 128;
-constexpr int VGW_CHUNK = 16384;                  // points per workgroup: 2 waves x 128 steps x 64 lanes
-constexpr int VGW_STEPS = VGW_CHUNK / VGW_THREADS; // 128 steps per wave
+constexpr int VGW_CHUNK = 4096;                    // points per workgroup: 2 waves x 32 steps x 64 lanes (16 384-point chunks left a
+                                                   // 2.5M-point submap with 153 workgroups of two waves: 0.33 ms, no faster than the radix sort)
+constexpr int VGW_STEPS = VGW_CHUNK / VGW_THREADS; // 32 steps per wave
 __global__ __launch_bounds__(VGW_THREADS) void vg_hist_wide_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                    const float* __restrict__ z, int n, float inv_leaf, int mb0, int mb1, int mb2,
                                                                    int mul1, int mul2, int ncells, unsigned short* __restrict__ keys,
@@ -382,10 +382,10 @@ __global__ __launch_bounds__(VGW_THREADS) void vg_hist_wide_kernel(const float* 
   }
   __syncthreads();
   unsigned short* row = hist + (size_t)blockIdx.x * C;
-  for (int k = tid; k < C; k += VGW_THREADS) row[k] = (unsigned short)s_hist[k];  // <= VGW_CHUNK = 16384
+  for (int k = tid; k < C; k += VGW_THREADS) row[k] = (unsigned short)s_hist[k];  // <= VGW_CHUNK
 }
 
-// wave w of block b owns points [b*16384 + w*8192, +8192), walked in 128 steps of 64 consecutive points; s_c[k] packs the two
+// wave w of block b owns points [b*VGW_CHUNK + w*VGW_CHUNK/2, +VGW_CHUNK/2), walked in steps of 64 consecutive points; s_c[k] packs the two
 // waves' 16-bit counters (counts, then wave 1's start = wave 0's count, then the running offsets)
 __global__ __launch_bounds__(VGW_THREADS) void vg_scatter_wide_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                       const float* __restrict__ z, int n, const unsigned short* __restrict__ keys,
