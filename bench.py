@@ -403,8 +403,10 @@ def roofline_leg(ndt, step, n_src, grid):
         r["traffic_source"] = os.path.relpath(PMC_FILE, ROOT) + " <- " + pmc.get("source", "")
         r["frac_by_traffic"] = r["traffic"] / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS
         r["traffic_kernel"] = pmc.get("kernel")
-        if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_BUSY_CYCLES"):
-            r["valu_utilisation"] = pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"]      # reported next to frac
+        if pmc.get("SQ_INSTS_VALU"):
+            # VALU utilisation next to frac = wave-instructions x 4 issue cycles / (1024 SIMDs x launch duration at 2.4 GHz)
+            r["valu_utilisation"] = pmc["SQ_INSTS_VALU"] * 4.0 / (1024.0 * avg_us * 2400.0)
+            r["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]
         if pmc.get("SQ_WAIT_ANY") and pmc.get("SQ_WAVE_CYCLES"):
             r["wave_cycles_waiting"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
         if pmc.get("SQ_LDS_BANK_CONFLICT") and pmc.get("SQ_ACTIVE_INST_LDS"):

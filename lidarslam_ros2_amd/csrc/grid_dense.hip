@@ -339,105 +339,6 @@ __global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* _
 }
 
 
-// ---- the same counting sort for key spaces beyond VG_DENSE_MAX_CELLS (up to VG_DENSE_MAX_CELLS_WIDE: a 2 m grid over a 20-frame
-// submap is 22 113 cells): the per-cell counters of the scatter are 32-bit words packing TWO 16-bit wave counters, so the table
-// fits LDS with twice the cells; a workgroup is two waves walking 4 096 points.
-constexpr int VGW_THREADS = 128;
-constexpr int VGW_CHUNK = 4096;                    // points per workgroup: 2 waves x 32 steps x 64 lanes (16 384-point chunks left a
-                                                   // 2.5M-point submap with 153 workgroups of two waves: 0.33 ms, no faster than the radix sort)
-constexpr int VGW_STEPS = VGW_CHUNK / VGW_THREADS; // 32 steps per wave
-__global__ __launch_bounds__(VGW_THREADS) void vg_hist_wide_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                                   const float* __restrict__ z, int n, float inv_leaf, int mb0, int mb1, int mb2,
-                                                                   int mul1, int mul2, int ncells, unsigned short* __restrict__ keys,
-                                                                   unsigned short* __restrict__ hist) {
-  extern __shared__ unsigned int s_hist[];  // [ncells + 1]
-  const int C = ncells + 1, tid = threadIdx.x;
-  for (int k = tid; k < C; k += VGW_THREADS) s_hist[k] = 0u;
-  __syncthreads();
-  const int base = blockIdx.x * VGW_CHUNK;
-  for (int j0 = 0; j0 < VGW_STEPS; j0 += 8) {
-    float px[8], py[8], pz[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {  // eight loads per plane in flight
-      const int i = base + (j0 + u) * VGW_THREADS + tid;
-      const bool in = i < n;
-      px[u] = in ? x[i] : 0.f; py[u] = in ? y[i] : 0.f; pz[u] = in ? z[i] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = base + (j0 + u) * VGW_THREADS + tid;
-      if (i < n) {
-        unsigned int k = (unsigned int)ncells;
-        if (isfinite(px[u]) && isfinite(py[u]) && isfinite(pz[u])) {
-          const int i0 = (int)(floorf(px[u] * inv_leaf) - (float)mb0);
-          const int i1 = (int)(floorf(py[u] * inv_leaf) - (float)mb1);
-          const int i2 = (int)(floorf(pz[u] * inv_leaf) - (float)mb2);
-          k = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
-          if (k >= (unsigned int)ncells) k = (unsigned int)ncells;
-        }
-        keys[i] = (unsigned short)k;
-        atomicAdd(&s_hist[k], 1u);
-      }
-    }
-  }
-  __syncthreads();
-  unsigned short* row = hist + (size_t)blockIdx.x * C;
-  for (int k = tid; k < C; k += VGW_THREADS) row[k] = (unsigned short)s_hist[k];  // <= VGW_CHUNK
-}
-
-// wave w of block b owns points [b*VGW_CHUNK + w*VGW_CHUNK/2, +VGW_CHUNK/2), walked in steps of 64 consecutive points; s_c[k] packs the two
-// waves' 16-bit counters (counts, then wave 1's start = wave 0's count, then the running offsets)
-__global__ __launch_bounds__(VGW_THREADS) void vg_scatter_wide_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                                      const float* __restrict__ z, int n, const unsigned short* __restrict__ keys,
-                                                                      const unsigned int* __restrict__ blkoff, const unsigned int* __restrict__ start,
-                                                                      int C, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
-                                                                      int* __restrict__ oidx) {
-  extern __shared__ unsigned int s_c32[];  // [C]
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  for (int k = tid; k < C; k += VGW_THREADS) s_c32[k] = 0u;
-  __syncthreads();
-  const int base_i = blockIdx.x * VGW_CHUNK + w * (VGW_CHUNK / 2) + lane;
-  const int sh = 16 * w;
-  for (int j0 = 0; j0 < VGW_STEPS; j0 += 16) {   // pass 1: per-wave counts of every key
-    unsigned int key[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int i = base_i + (j0 + u) * 64;
-      key[u] = (i < n) ? (unsigned int)keys[i] : 0xFFFFu;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++)
-      if (key[u] != 0xFFFFu) atomicAdd(&s_c32[key[u]], 1u << sh);
-  }
-  __syncthreads();
-  for (int k = tid; k < C; k += VGW_THREADS) s_c32[k] = (s_c32[k] & 0xFFFFu) << 16;   // wave 0 starts at 0, wave 1 after wave 0's points
-  __syncthreads();
-  const unsigned int* boff = blkoff + (size_t)blockIdx.x * C;
-  for (int j0 = 0; j0 < VGW_STEPS; j0 += 16) {   // pass 2: ranks and the scatter, steps in point order
-    unsigned int key[16], absb[16];
-    float px[16], py[16], pz[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int i = base_i + (j0 + u) * 64;
-      const bool in = i < n;
-      key[u] = in ? (unsigned int)keys[i] : 0xFFFFu;
-      px[u] = in ? x[i] : 0.f; py[u] = in ? y[i] : 0.f; pz[u] = in ? z[i] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++) absb[u] = (key[u] != 0xFFFFu) ? (start[key[u]] + boff[key[u]]) : 0u;
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const unsigned int k = key[u];
-      if (k != 0xFFFFu) {
-        const unsigned int old = atomicAdd(&s_c32[k], 1u << sh);
-        const unsigned int pos = absb[u] + ((old >> sh) & 0xFFFFu);
-        ox[pos] = px[u]; oy[pos] = py[u]; oz[pos] = pz[u];
-        if (oidx) oidx[pos] = base_i + (j0 + u) * 64;
-      }
-    }
-  }
-}
-
 // ---- the same builders over a GROUP of targets: blockIdx.y selects the member, whose parameters travel in the kernel arguments ----
 struct VgMember {
   const unsigned char* aos; size_t stride;        // ingest: strided xyz records in device memory
@@ -591,9 +492,7 @@ __global__ __launch_bounds__(256) void src_hist_kernel(const float* __restrict__
 int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
   const int n = (int)cloud.n;
   const int ncells = (int)grid.ncells, C = ncells + 1;
-  const bool wide = ncells > VG_DENSE_MAX_CELLS;   // two-wave workgroups, 32-bit packed counters (up to VG_DENSE_MAX_CELLS_WIDE cells)
-  const int chunk = wide ? VGW_CHUNK : VG_CHUNK;
-  const int nblk = (n + chunk - 1) / chunk;
+  const int nblk = (n + VG_CHUNK - 1) / VG_CHUNK;
   const float inv_leaf = 1.0f / leaf;
   int st;
   // scratch words: total[C] | blkoff[nblk*C] | hist(u16)[nblk*C] | keys(u16)[n]; the cell-ordered points, their indices, the cell
@@ -626,25 +525,15 @@ int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
   if (dev >= 0 && dev < 64 && !attr_done[dev]) {
     LSR_HIP(hipFuncSetAttribute((const void*)vg_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VG_DENSE_MAX_CELLS * 4 + 4));
     LSR_HIP(hipFuncSetAttribute((const void*)vg_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VG_DENSE_MAX_CELLS * 8 + 8));
-    LSR_HIP(hipFuncSetAttribute((const void*)vg_hist_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VG_DENSE_MAX_CELLS_WIDE * 4 + 4));
-    LSR_HIP(hipFuncSetAttribute((const void*)vg_scatter_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VG_DENSE_MAX_CELLS_WIDE * 4 + 4));
     attr_done[dev] = true;
   }
   const int mul1 = grid.div_b[0], mul2 = grid.div_b[0] * grid.div_b[1];
-  if (wide)
-    hipLaunchKernelGGL(vg_hist_wide_kernel, dim3(nblk), dim3(VGW_THREADS), (size_t)C * 4, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
-                       grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, ncells, keys, hist);
-  else
-    hipLaunchKernelGGL(vg_hist_kernel, dim3(nblk), dim3(256), (size_t)C * 4, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
+  hipLaunchKernelGGL(vg_hist_kernel, dim3(nblk), dim3(256), (size_t)C * 4, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
                        grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, ncells, keys, hist);
   hipLaunchKernelGGL(vg_scan_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, hist, nblk, C, blkoff, total);
   hipLaunchKernelGGL(vg_cellscan_kernel, dim3(1), dim3(1024), 0, stream, total, C, start, grid.cell_rank.p);
-  if (wide)
-    hipLaunchKernelGGL(vg_scatter_wide_kernel, dim3(nblk), dim3(VGW_THREADS), (size_t)C * 4, stream, cloud.x(), cloud.y(), cloud.z(), n, keys,
-                       blkoff, start, C, sx, sy, sz, grid.sorted_idx.p);
-  else
-    hipLaunchKernelGGL(vg_scatter_kernel, dim3(nblk), dim3(256), (size_t)C * 8, stream, cloud.x(), cloud.y(), cloud.z(), n, keys, blkoff,
-                       start, C, sx, sy, sz, grid.sorted_idx.p);
+  hipLaunchKernelGGL(vg_scatter_kernel, dim3(nblk), dim3(256), (size_t)C * 8, stream, cloud.x(), cloud.y(), cloud.z(), n, keys, blkoff,
+                     start, C, sx, sy, sz, grid.sorted_idx.p);
   hipLaunchKernelGGL(vg_leaf_kernel, dim3(ncells), dim3(VG_LEAF_THREADS), 0, stream, sx, sy, sz, start, ncells, 6, 0.01, grid.rec.p,
                      grid.mean64.p, grid.icov64.p, grid.leaf_key.p, grid.leaf_n.p, grid.cell_slot.p);
   LSR_HIP(hipGetLastError());

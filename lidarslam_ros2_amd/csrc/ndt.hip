@@ -2288,7 +2288,7 @@ int ndt_grid_geometry(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, 
     grid.div_b[k] = grid.max_b[k] - grid.min_b[k] + 1;
   }
   grid.ncells = (size_t)grid.div_b[0] * grid.div_b[1] * grid.div_b[2];
-  *path = (grid.ncells <= (size_t)VG_DENSE_MAX_CELLS_WIDE && !sc.force_sort_path) ? 1 : 2;
+  *path = (grid.ncells <= (size_t)VG_DENSE_MAX_CELLS && !sc.force_sort_path) ? 1 : 2;
   return LSR_OK;
 }
 
@@ -2391,7 +2391,7 @@ int ndt_targets_build_begin(TargetBuildJob* jobs, int count, hipStream_t stream)
   for (int b = 0; b < count; b++) {
     TargetBuildJob& J = jobs[b];
     if ((st = ndt_grid_geometry(*J.cloud, J.leaf, *J.grid, *J.sc, stream, &J.path))) return st;
-    if (J.path == 1 && J.grid->ncells <= (size_t)VG_DENSE_MAX_CELLS) dense.push_back(&J);   // the group kernels are the narrow form
+    if (J.path == 1) dense.push_back(&J);
   }
   if (!dense.empty()) {
     std::vector<VoxelGridDev*> grids;
@@ -2406,17 +2406,8 @@ int ndt_targets_build_begin(TargetBuildJob* jobs, int count, hipStream_t stream)
     if ((st = ndt_pack_lds_tables(grids.data(), scs.data(), tokens.data(), (int)dense.size(), stream))) return st;
     for (size_t k = 0; k < dense.size(); k++) { dense[k]->sc->grid_pending = true; dense[k]->sc->grid_token = tokens[k]; }
   }
-  for (int b = 0; b < count; b++) {
-    TargetBuildJob& J = jobs[b];
-    if (J.path == 2 && (st = ndt_build_grid_general(*J.cloud, J.leaf, *J.grid, *J.sc, stream))) return st;
-    if (J.path == 1 && J.grid->ncells > (size_t)VG_DENSE_MAX_CELLS) {   // wide key space: the single-target builder, left pending like the others
-      const unsigned int token = next_token(*J.sc);
-      if ((st = ndt_build_grid_dense(*J.cloud, J.leaf, *J.grid, *J.sc, stream))) return st;
-      if ((st = ndt_pack_lds_table(*J.grid, *J.sc, true, token, stream))) return st;
-      J.sc->grid_pending = true;
-      J.sc->grid_token = token;
-    }
-  }
+  for (int b = 0; b < count; b++)
+    if (jobs[b].path == 2 && (st = ndt_build_grid_general(*jobs[b].cloud, jobs[b].leaf, *jobs[b].grid, *jobs[b].sc, stream))) return st;
   return LSR_OK;
 }
 

@@ -180,8 +180,9 @@ int ndt_grid_geometry(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, 
 
 // K1/K2 for dense key spaces (grid_dense.hip): counting sort + per-cell sums + finalisation, everything enqueued, no host
 // round trip.  grid.min_b / div_b / ncells must be set.
-constexpr int VG_DENSE_MAX_CELLS = 16383;        // four-wave workgroups, 64-bit packed counters (and the group kernels)
-constexpr int VG_DENSE_MAX_CELLS_WIDE = 36000;   // two-wave workgroups, 32-bit packed counters: 144 KiB of LDS
+constexpr int VG_DENSE_MAX_CELLS = 16383;   // beyond: radix sort.  (A two-wave form with 32-bit packed counters for up to 36 000 cells was
+                                            // built and measured on cfg 5's 22 113-cell grid: 0.33-0.35 ms against the radix sort's 0.30 — every
+                                            // 4096-point workgroup clears, writes and prefixes a 22k-entry table; removed.)
 int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
 // Order the source cloud by voxel tile (NDT_TAB_TILE): counting sort of the points by the Morton code of the 2^shift x 2^shift
 // column of grid cells their guess-moved image falls into (grid_dense.hip).  Consecutive points of `out` are neighbours in

@@ -158,7 +158,7 @@ struct RefineMember {
   int *coarse_block, *block_off, *fine_start; float4* packed; int* order;
 };
 struct RefineGroup { RefineMember m[LSR_GROUP]; };
-constexpr int NN_REFINE_THREADS = 1024;   // the busiest voxels of a submap hold tens of thousands of points: their workgroup sets the kernel's time
+constexpr int NN_REFINE_THREADS = 256;    // (1024 threads per voxel were measured slower on 64 x 661k-point windows: 258 vs 214 us per group of 16)
 __device__ __forceinline__ void nn_refine_body(const RefineMember& M, const int cell) {
   __shared__ unsigned int s_cnt[FINE_PER_BLOCK], s_off[FINE_PER_BLOCK + 1], s_part[256];
   const int tid = threadIdx.x;

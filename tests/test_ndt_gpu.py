@@ -281,22 +281,10 @@ def test_launch_variants_agree_with_each_other(case):
         assert out[v][0] == sq and np.array_equal(out[v][1], gq) and np.array_equal(out[v][2], Hq), v
 
 
-def _wide_resolution(target):
-    """a resolution whose grid over `target` has between 16 384 and 36 000 cells: the two-wave ("wide") form of the builder"""
-    for res in np.arange(4.0, 1.0, -0.125):
-        lo, hi = np.floor(target.min(0) / np.float32(res)), np.floor(target.max(0) / np.float32(res))
-        n = int(np.prod(hi - lo + 1))
-        if 16383 < n <= 36000:
-            return float(res)
-    raise AssertionError("no resolution puts this cloud into the wide range")
-
-
-@pytest.mark.parametrize("res", [5.0, 3.0, "wide"])
+@pytest.mark.parametrize("res", [5.0, 3.0])
 def test_counting_sort_builder_equals_radix_sort_builder(case, res):
-    """K1/K2 by the counting-sort builder (dense key spaces; "wide": the two-wave form for 16 384 .. 36 000 cells) and by the
-    radix-sort builder: identical voxel set, counts and bbox; means / inverse covariances differ only by the fp64 summation order."""
-    if res == "wide":
-        res = _wide_resolution(case.target)
+    """K1/K2 by the counting-sort builder (dense key spaces) and by the radix-sort builder: identical voxel set, counts and
+    bbox; means / inverse covariances differ only by the fp64 summation order."""
     tgt = synth.as_pointxyzi(case.target)
     tgt[7::97, 0] = np.nan     # a few non-finite points: dropped by both builders
     a, b = make_ndt(res), make_ndt(res)
