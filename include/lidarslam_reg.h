@@ -253,6 +253,13 @@ typedef struct lsr_shard_record {   /* 64 bytes */
 } lsr_shard_record;
 /* first index and count of rank's share: the first (n_items % world) ranks get one extra item */
 void lsr_shard_range(int n_items, int world, int rank, int* first, int* count);
+/* Cost-aware plan for batches whose members differ in size (the ring gate's candidates: targets from a few thousand to
+ * 661 k points): longest-processing-time-first — items by cost descending (ties: lower index), each to the least-loaded
+ * rank (ties: lower rank).  cost may be NULL (all equal: round-robin).  owner[i] = rank of item i; order = the batch
+ * regrouped rank by rank, each rank's items longest first; rank r owns order[rank_first[r] .. rank_first[r+1]).
+ * Device-free and deterministic: every rank computes the same plan from the same costs. */
+int lsr_shard_plan(int n_items, const double* cost, int world, int32_t* owner /* n_items */, int32_t* order /* n_items */,
+                   int32_t* rank_first /* world + 1 */);
 /* rank 0: 128-byte ncclUniqueId to hand to the other ranks (by whatever channel the application has) */
 int lsr_comm_unique_id(void* id128);
 /* every rank: ncclCommInitRank on device_id (id128 may be NULL when world == 1) */
@@ -263,6 +270,11 @@ int lsr_comm_destroy(lsr_comm c);
  * all_records: global_count entries, in batch order, identical on every rank. */
 int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_count, int global_count, const float* local_guesses,
                             int with_fitness, lsr_shard_record* all_records);
+
+/* The same with a plan from lsr_shard_plan: local_handles are order[rank_first[rank] ..] in that order (longest first).
+ * all_records stays in BATCH order (record of item i at all_records[i]) on every rank. */
+int lsr_align_batch_planned(lsr_comm c, lsr_handle* local_handles, int local_count, int global_count, const int32_t* order,
+                            const int32_t* rank_first, const float* local_guesses, int with_fitness, lsr_shard_record* all_records);
 
 /* ---- loop-closure gate -------------------------------------------------- */
 /* One lidarslam_msgs/msg/SubMap (SubMap.msg:1-4): accumulated travel distance, geometry_msgs/Pose, and the

@@ -1,5 +1,5 @@
-// Multi-GPU sharding of a batch of independent registrations at the C ABI: one process per GPU, static
-// block partition of the batch, no collective on the data path, ONE ncclAllGather of fixed 64-byte result records over
+// Multi-GPU sharding of a batch of independent registrations at the C ABI: one process per GPU, a static
+// block partition or a cost-aware longest-first plan of the batch, no collective on the data path, ONE ncclAllGather of fixed 64-byte result records over
 // xGMI at the end.  RCCL is loaded lazily (dlopen): single-GPU users of the library never touch it.
 #include <dlfcn.h>
 
@@ -75,6 +75,37 @@ void lsr_shard_range(int n_items, int world, int rank, int* first, int* count) {
   if (count) *count = base + (rank < extra ? 1 : 0);
 }
 
+// Longest-processing-time-first: items by cost descending (ties: lower index first), each to the rank with the least load so
+// far (ties: lower rank).  Greedy LPT is within 4/3 - 1/(3 world) of the best makespan; with equal costs it is round-robin.
+int lsr_shard_plan(int n_items, const double* cost, int world, int32_t* owner, int32_t* order, int32_t* rank_first) {
+  if (n_items < 0 || world < 1 || (n_items > 0 && (!owner || !order)) || !rank_first) { lsr::set_last_error("bad shard-plan arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  std::vector<int> by_cost((size_t)n_items);
+  for (int i = 0; i < n_items; i++) by_cost[i] = i;
+  if (cost) {
+    for (int i = 0; i < n_items; i++)
+      if (!(cost[i] >= 0.0) || std::isinf(cost[i])) { lsr::set_last_error("shard-plan costs must be finite and non-negative"); return LSR_ERR_INVALID_ARGUMENT; }
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  }
+  std::vector<double> load((size_t)world, 0.0);
+  std::vector<int> count((size_t)world, 0);
+  for (int k = 0; k < n_items; k++) {
+    int best = 0;
+    if (cost) {
+      for (int r = 1; r < world; r++) if (load[r] < load[best]) best = r;
+    } else {
+      best = k % world;
+    }
+    owner[by_cost[k]] = best;
+    load[best] += cost ? cost[by_cost[k]] : 1.0;
+    count[best]++;
+  }
+  rank_first[0] = 0;
+  for (int r = 0; r < world; r++) rank_first[r + 1] = rank_first[r] + count[r];
+  std::vector<int> fill(rank_first, rank_first + world);
+  for (int k = 0; k < n_items; k++) order[fill[owner[by_cost[k]]]++] = by_cost[k];   // each rank's list: longest first
+  return LSR_OK;
+}
+
 int lsr_comm_unique_id(void* id128) {
   if (!id128) return LSR_ERR_INVALID_ARGUMENT;
   Rccl* r = rccl();
@@ -131,11 +162,21 @@ static void invalid_record(lsr_shard_record& R) {
   R.score = NAN; R.iterations = 0.f; R.converged = -1.f; R.fitness = NAN;
 }
 
-int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_count, int global_count, const float* local_guesses,
-                            int with_fitness, lsr_shard_record* all_records) {
-  if (!c || global_count <= 0 || !all_records) { lsr::set_last_error("bad sharded-batch arguments"); return LSR_ERR_INVALID_ARGUMENT; }
-  int first = 0, mine = 0;
-  lsr_shard_range(global_count, c->world, c->rank, &first, &mine);
+int lsr_align_batch_planned(lsr_comm c, lsr_handle* local_handles, int local_count, int global_count, const int32_t* order,
+                            const int32_t* rank_first, const float* local_guesses, int with_fitness, lsr_shard_record* all_records) {
+  if (!c || global_count <= 0 || !all_records || !order || !rank_first) { lsr::set_last_error("bad sharded-batch arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  // the plan is an argument every rank passes: check it here, before anything is exchanged (a bad plan is the same on all ranks)
+  if (rank_first[0] != 0 || rank_first[c->world] != global_count) { lsr::set_last_error("shard plan does not cover the batch"); return LSR_ERR_INVALID_ARGUMENT; }
+  {
+    std::vector<char> seen((size_t)global_count, 0);
+    for (int r = 0; r < c->world; r++)
+      if (rank_first[r + 1] < rank_first[r]) { lsr::set_last_error("shard plan: rank_first must not decrease"); return LSR_ERR_INVALID_ARGUMENT; }
+    for (int k = 0; k < global_count; k++) {
+      if (order[k] < 0 || order[k] >= global_count || seen[order[k]]) { lsr::set_last_error("shard plan: order is not a permutation of the batch"); return LSR_ERR_INVALID_ARGUMENT; }
+      seen[order[k]] = 1;
+    }
+  }
+  const int first = rank_first[c->rank], mine = rank_first[c->rank + 1] - first;
   // ---- this rank's share: no collective on the data path.  Argument errors of THIS rank are local failures too.
   int local_status = LSR_OK;
   std::string local_error;
@@ -144,7 +185,7 @@ int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_cou
   if (local_count < 0 || (local_count > 0 && !local_handles)) {
     local_status = LSR_ERR_INVALID_ARGUMENT; local_error = "bad sharded-batch arguments";
   } else if (mine != local_count) {
-    local_status = LSR_ERR_INVALID_ARGUMENT; local_error = "local_count does not match this rank's share of the batch (lsr_shard_range)";
+    local_status = LSR_ERR_INVALID_ARGUMENT; local_error = "local_count does not match this rank's share of the batch (lsr_shard_range / lsr_shard_plan)";
   } else if (local_count > 0) {
     std::vector<float> finals((size_t)local_count * 16);
     std::vector<lsr_result> res((size_t)local_count);
@@ -171,7 +212,7 @@ int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_cou
     return collective_status;
   };
   if (c->world == 1 && !c->comm) {
-    std::memcpy(all_records, local.data(), sizeof(lsr_shard_record) * (size_t)global_count);
+    for (int k = 0; k < global_count; k++) all_records[order[k]] = local[k];
     return finish(LSR_OK);
   }
   // ---- ONE all-gather of fixed-size blocks (padded to the largest share): 64 B x 64 candidates = 4 KiB, latency bound
@@ -179,7 +220,8 @@ int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_cou
   if (!r || !c->comm) { lsr::set_last_error("communicator has no RCCL handle"); return LSR_ERR_NOT_IMPLEMENTED; }
   lsr::DeviceGuard guard(c->device);
   if (!guard.ok) { lsr::set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
-  const int max_count = (global_count + c->world - 1) / c->world;
+  int max_count = 1;
+  for (int rk = 0; rk < c->world; rk++) max_count = std::max(max_count, rank_first[rk + 1] - rank_first[rk]);
   int st;
   if ((st = c->d_send.reserve((size_t)max_count))) return st;
   if ((st = c->d_recv.reserve((size_t)max_count * c->world))) return st;
@@ -193,16 +235,29 @@ int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_cou
   LSR_HIP(hipStreamSynchronize(c->stream));
   bool remote_invalid = false;
   for (int rk = 0; rk < c->world; rk++) {
-    int f = 0, n = 0;
-    lsr_shard_range(global_count, c->world, rk, &f, &n);
-    if (n) std::memcpy(all_records + f, table.data() + (size_t)rk * max_count, sizeof(lsr_shard_record) * (size_t)n);
-    for (int k = 0; k < n; k++) remote_invalid = remote_invalid || (rk != c->rank && all_records[f + k].converged < 0.f);
+    const int f = rank_first[rk], n = rank_first[rk + 1] - f;
+    for (int k = 0; k < n; k++) {
+      const lsr_shard_record& R = table[(size_t)rk * max_count + k];
+      all_records[order[f + k]] = R;
+      remote_invalid = remote_invalid || (rk != c->rank && R.converged < 0.f);
+    }
   }
   if (!local_status && remote_invalid) {   // the table is complete, but some other rank's share failed: say so
     lsr::set_last_error("another rank's share of the batch failed: its records are flagged converged = -1");
     return LSR_ERR_HIP;
   }
   return finish(LSR_OK);
+}
+
+// the static block partition is the plan { order = identity, rank_first = lsr_shard_range }
+int lsr_align_batch_sharded(lsr_comm c, lsr_handle* local_handles, int local_count, int global_count, const float* local_guesses,
+                            int with_fitness, lsr_shard_record* all_records) {
+  if (!c || global_count <= 0 || !all_records) { lsr::set_last_error("bad sharded-batch arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  std::vector<int32_t> order((size_t)global_count), rank_first((size_t)c->world + 1);
+  for (int k = 0; k < global_count; k++) order[k] = k;
+  for (int r = 0; r <= c->world; r++) { int f = global_count, n = 0; if (r < c->world) lsr_shard_range(global_count, c->world, r, &f, &n); rank_first[r] = f; }
+  return lsr_align_batch_planned(c, local_handles, local_count, global_count, order.data(), rank_first.data(), local_guesses, with_fitness,
+                                 all_records);
 }
 
 }  // extern "C"

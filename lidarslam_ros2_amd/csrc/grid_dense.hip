@@ -590,7 +590,9 @@ int ndt_targets_ingest(TargetBuildJob* jobs, int count, hipStream_t stream) {
       if (token == 0) token = ++J.sc->token;
       M.aos = static_cast<const unsigned char*>(J.d_aos); M.stride = J.stride;
       M.x = J.cloud->x(); M.y = J.cloud->y(); M.z = J.cloud->z();
-      M.ingest_blocks = std::max(1, std::min((int)((J.n + 1023) / 1024), BBOX_MAX_PARTS));
+      // workgroups (= bounding-box records the host folds) per member: a full group fills the chip with far fewer each
+      const size_t per_block = (ng >= 8) ? 8192 : 1024;
+      M.ingest_blocks = std::max(1, std::min((int)((J.n + per_block - 1) / per_block), BBOX_MAX_PARTS));
       M.mb = J.sc->d_mb; M.bbox_token = token;
       J.sc->bbox_parts = M.ingest_blocks;
       J.sc->bbox_token = token;

@@ -1919,9 +1919,14 @@ int cloud_bbox_end(const DeviceCloud& cloud, float* mn, float* mx, unsigned int*
     const BboxPart& P = sc.mb.p->part[b];
     float v[6];
     for (int k = 0; k < BBOX_GRANULES; k++) {
-      const volatile unsigned int* halves = reinterpret_cast<const volatile unsigned int*>(&P.g[k]);   // [0] value bits, [1] token
-      if ((st = wait_mailbox_word(halves + 1, token, stream, sc.wait_mode, "bounding box"))) return st;
-      const unsigned long long g = __atomic_load_n(&P.g[k], __ATOMIC_ACQUIRE);   // one 8-byte store on the device side: value and token travel together
+      // one 8-byte store on the device side: value and token travel together.  Checked inline (a candidate set folds tens of
+      // thousands of granules); only a granule that has not landed yet takes the polling path.
+      unsigned long long g = __atomic_load_n(&P.g[k], __ATOMIC_ACQUIRE);
+      if ((unsigned int)(g >> 32) != token) {
+        const volatile unsigned int* halves = reinterpret_cast<const volatile unsigned int*>(&P.g[k]);   // [0] value bits, [1] token
+        if ((st = wait_mailbox_word(halves + 1, token, stream, sc.wait_mode, "bounding box"))) return st;
+        g = __atomic_load_n(&P.g[k], __ATOMIC_ACQUIRE);
+      }
       const unsigned int bits = (unsigned int)(g & 0xFFFFFFFFull);
       if (k < 6) std::memcpy(&v[k], &bits, 4); else cnt += bits;
     }

@@ -176,7 +176,16 @@ def _free_port():
     return p
 
 
-def _gloo_worker(rank, world, port, n_items, out_dir):
+def _ring_gate_costs(n_items):
+    """Sizes as the ring gate produces them: a few full submaps, many small ones (cost in point visits)."""
+    from lidarslam_ros2_amd.sharding import registration_cost
+
+    rng = np.random.default_rng(77)
+    n_target = np.where(rng.random(n_items) < 0.25, 661_000, rng.integers(4_000, 120_000, n_items))
+    return np.array([registration_cost(int(t), 33_000) for t in n_target])
+
+
+def _gloo_worker(rank, world, port, n_items, out_dir, planned=False):
     import torch.distributed as dist
 
     sys.path.insert(0, ROOT)
@@ -194,9 +203,16 @@ def _gloo_worker(rank, world, port, n_items, out_dir):
             recs.append(pack_record(T, score=float(i) / 2, iterations=i % 5, converged=(i % 2 == 0), fitness=0.1 * i))
         return recs
 
-    res = register_sharded(n_items, register_local)
+    seen = []
+
+    def register_seen(indices):
+        seen.extend(indices)
+        return register_local(indices)
+
+    res = register_sharded(n_items, register_seen, costs=_ring_gate_costs(n_items) if planned else None)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array([[r["T"][0, 3], r["T"][1, 3], r["T"][2, 3], r["score"],
                                                                    r["iterations"], r["converged"]] for r in res]))
+    np.save(os.path.join(out_dir, f"seen{rank}.npy"), np.array(seen, np.int64))
     dist.destroy_process_group()
 
 
@@ -216,6 +232,56 @@ def test_sharded_batch_all_gather_gloo_world2(tmp_path, n_items):
     owner[list(shard_range(n_items, world, 1))] = 1
     assert np.array_equal(a[:, 2], owner)             # each item was registered by the rank that owns it
     assert np.array_equal(a[:, 4], np.arange(n_items) % 5)
+
+
+def test_shard_plan_is_longest_first_and_the_c_plan_is_the_python_plan():
+    """lsr_shard_plan (C ABI, device-free) == sharding.shard_plan; every rank's list is longest first; the plan's makespan is
+    never worse than the block partition's and within the LPT bound of the trivial lower bounds."""
+    from lidarslam_ros2_amd.sharding import block_plan, c_shard_plan, shard_plan
+
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            for costs in (_ring_gate_costs(n), np.ones(n), rng.integers(1, 4, n).astype(np.float64)):
+                P, Q = shard_plan(costs, world), c_shard_plan(costs, world)
+                assert np.array_equal(P.owner, Q.owner) and np.array_equal(P.order, Q.order) and np.array_equal(P.rank_first, Q.rank_first)
+                assert sorted(P.order.tolist()) == list(range(n))
+                for r in range(world):
+                    it = P.items(r)
+                    assert all(P.owner[i] == r for i in it)
+                    assert all(costs[a] >= costs[b] for a, b in zip(it, it[1:]))
+                if n:
+                    span, lower = P.loads(costs).max(), max(costs.sum() / world, costs.max())
+                    assert span <= block_plan(n, world).loads(costs).max() + 1e-9
+                    assert span <= (4.0 / 3.0 - 1.0 / (3.0 * world)) * lower + costs.max() * (world > 1) + 1e-9
+    P = shard_plan(np.ones(64), 8)                       # equal costs: round-robin, 8 each (cfg 4 over 8 GPUs)
+    assert [len(P.items(r)) for r in range(8)] == [8] * 8 and P.items(1)[:3] == [1, 9, 17]
+    costs = _ring_gate_costs(64)                         # the case it is for: block partition vs plan on ring-gate sizes
+    assert shard_plan(costs, 8).loads(costs).max() < 0.8 * block_plan(64, 8).loads(costs).max()
+    with pytest.raises(ValueError):
+        shard_plan([1.0, float("nan")], 2)
+    from lidarslam_ros2_amd import _capi
+    with pytest.raises(_capi.RegistrationError):
+        c_shard_plan(np.array([1.0, -2.0]), 2)
+
+
+@pytest.mark.parametrize("n_items", [7, 64])
+def test_planned_batch_all_gather_gloo_world2(tmp_path, n_items):
+    """N>1 path on CPU with the cost-aware plan: each rank registers plan.items(rank) longest first, the table comes back in
+    batch order on both ranks."""
+    import torch.multiprocessing as mp
+
+    from lidarslam_ros2_amd.sharding import shard_plan
+
+    world, port = 2, _free_port()
+    mp.spawn(_gloo_worker, args=(world, port, n_items, str(tmp_path), True), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:, 0], np.arange(n_items)) and np.array_equal(a[:, 1], 10 * np.arange(n_items))
+    plan = shard_plan(_ring_gate_costs(n_items), world)
+    assert np.array_equal(a[:, 2], plan.owner)
+    for r in range(world):
+        assert np.load(tmp_path / f"seen{r}.npy").tolist() == plan.items(r)
 
 
 def _build_adapter(tmp_path):

@@ -112,6 +112,31 @@ def test_c_abi_sharded_batch_with_a_one_rank_communicator():
     comm.close()
 
 
+def test_c_abi_planned_batch_with_a_one_rank_communicator():
+    """lsr_align_batch_planned: members of different size handed over longest first (lsr_shard_plan), records back in batch
+    order and equal to the block-partition call's; a plan that is not a permutation is refused."""
+    from lidarslam_ros2_amd import synth
+    from lidarslam_ros2_amd._capi import RegistrationError
+    from lidarslam_ros2_amd.sharding import Comm, ShardPlan, align_batch_sharded, c_shard_plan, registration_cost
+
+    sizes = [1500, 4000, 2500, 3000, 2000]
+    cases = [synth.small_case(n_source=n, n_keyframes=3, seed=c) for c, n in enumerate(sizes)]
+    plan = c_shard_plan([registration_cost(len(c.target), len(c.source)) for c in cases], 1)
+    assert sorted(plan.order.tolist()) == list(range(5)) and plan.order.tolist() != list(range(5))
+    comm = Comm(0, 1, 0)
+    regs = _make_regs(cases, 0)
+    a = align_batch_sharded(comm, regs, len(cases), [c.guess for c in cases], with_fitness=True)
+    regs2 = _make_regs([cases[i] for i in plan.items(0)], 0)
+    b = align_batch_sharded(comm, regs2, len(cases), [cases[i].guess for i in plan.items(0)], with_fitness=True, plan=plan)
+    for k in range(len(cases)):
+        assert np.array_equal(a[k]["T"], b[k]["T"]) and a[k]["iterations"] == b[k]["iterations"]
+        assert a[k]["fitness"] == pytest.approx(b[k]["fitness"], rel=1e-6)
+    bad = ShardPlan(plan.owner, [0, 0, 1, 2, 3], plan.rank_first)
+    with pytest.raises(RegistrationError):
+        align_batch_sharded(comm, regs2, len(cases), None, plan=bad)
+    comm.close()
+
+
 def _worker_c_abi(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
