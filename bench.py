@@ -45,6 +45,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+PMC_GICP_FILE = os.path.join(ROOT, "profiles", "pmc_gicp_latest.json")  # written by tools/pmc_gicp.sh
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_ndt_eval_latest.json")  # written by tools/pmc_ndt.sh (rocprofv3 --pmc passes)
 
 
@@ -598,6 +599,18 @@ def gicp_leg(gc, dev_index, tstream, torch, synth):
               "outer_iterations": gicp.last_result["iterations"], "gauss_newton_steps": gicp.last_result["n_evaluations"],
               "correspondences": gicp.last_result["n_correspondences"], "error_vs_truth": {"translation_m": gdt, "rotation_rad": gang},
               "what": "cfg 3: GICP, same 30k scan, target re-filtered at 0.2, corr dist 5.0, eps 1e-8; setInputSource (20-NN covariances) + align"})
+    # K6 (correspondence search + pair records) against HBM: counter bytes and kernel time per outer iteration from the PMC
+    # passes of tools/pmc_gicp.sh (separate rocprofv3 runs; file committed under profiles/)
+    try:
+        pg = json.load(open(PMC_GICP_FILE))
+        k6 = pg.get("k6_per_outer_iteration")
+        if k6 and k6.get("us"):
+            s["k6_correspondences"] = {"hbm_bytes_per_outer_iteration": int(k6["bytes"]), "kernel_us_per_outer_iteration": float(k6["us"]),
+                                       "achieved_gb_per_s": k6["bytes"] / (k6["us"] * 1e-6) / 1e9,
+                                       "frac_of_hbm_peak": k6["bytes"] / (k6["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                       "bound": "latency (dependent cell probes of a wave-per-point search)", "source": pg.get("source")}
+    except (OSError, ValueError, KeyError):
+        pass
     return s
 
 

@@ -1,28 +1,33 @@
 #!/bin/bash
-# One GPU session that produces everything profiles/ holds for a round.  usage (on the GPU box): bash tools/round_profiles.sh r02
+# One GPU session that produces everything profiles/ holds for a round.  usage (on the GPU box): bash tools/round_profiles.sh r03
 # Output: gpurun_out/profiles_<tag>/ (copy into profiles/ afterwards).  PMC passes are separate rocprofv3 runs with
 # --kernel-trace only (tools/pmc_ndt.sh).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 P=$REPO/gpurun_out/profiles_$TAG
 rm -rf $P; mkdir -p $P
 cd $REPO
 export LSR_BENCH_CACHE_DIR=/tmp/lsr_bench_cache   # synthetic clouds ray-cast once per session (bench.py, tools/_cache.py)
-# 1. default bench run (the driver's command), JSON line kept
-timeout 900 python bench.py > $P/${TAG}_bench_final.json 2> $P/bench.err; echo "bench rc=$?"
-# 2. PMC passes on the derivative kernel -> traffic file read by bench.py
+# 1. PMC passes on the derivative kernel and on the GICP kernels -> the traffic files bench.py reads (profiles/*.json)
 bash tools/pmc_ndt.sh $TAG > $P/pmc.log 2>&1; tail -4 $P/pmc.log | head -3
 cp gpurun_out/pmc_ndt/${TAG}_pmc_ndt_eval.md gpurun_out/pmc_ndt/pmc_ndt_eval_latest.json $P/
+cp gpurun_out/pmc_ndt/pmc_ndt_eval_latest.json profiles/pmc_ndt_eval_latest.json
+bash tools/pmc_gicp.sh $TAG > $P/pmc_gicp.log 2>&1; tail -3 $P/pmc_gicp.log | cut -c1-300
+cp gpurun_out/pmc_gicp/${TAG}_pmc_gicp.md gpurun_out/pmc_gicp/pmc_gicp_latest.json $P/
+cp gpurun_out/pmc_gicp/pmc_gicp_latest.json profiles/pmc_gicp_latest.json
+# 2. default bench run (the driver's command), JSON line kept
+timeout 900 python bench.py > $P/${TAG}_bench_final.json 2> $P/bench.err; echo "bench rc=$?"
 # 3. kernel-trace summaries
 stats() {  # name, command...
   name=$1; shift
   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$name && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o $name -- "$@" > $P/$name.stdout 2> $P/$name.stderr); echo "rocprof $name rc=$?"
-  { echo "# rocprofv3 --kernel-trace --stats -- $* ($TAG, MI355X)"; echo; python tools/stats_to_md.py /tmp/prof_$name/${name}_kernel_stats.csv 30; echo; echo '```'; grep -v "^W2\|^E2\|amdgpu.ids" $P/$name.stdout | tail -8 | cut -c1-2500; echo '```'; } > $P/${TAG}_rocprofv3_${name}_stats.md
+  cp /tmp/prof_$name/${name}_kernel_stats.csv $P/${TAG}_rocprofv3_${name}_kernel_stats.csv   # the raw summary, as rocprofv3 wrote it
+  { echo "# rocprofv3 --kernel-trace --stats -- $* ($TAG, MI355X; raw CSV: ${TAG}_rocprofv3_${name}_kernel_stats.csv)"; echo; python tools/stats_to_md.py /tmp/prof_$name/${name}_kernel_stats.csv 30; echo; echo '```'; grep -v "^W2\|^E2\|amdgpu.ids" $P/$name.stdout | tail -8 | cut -c1-2500; echo '```'; } > $P/${TAG}_rocprofv3_${name}_stats.md
 }
 stats bench python $REPO/bench.py
 stats gicp python $REPO/tools/r02_gicp_probe.py
-NC=16 stats cfg4 python $REPO/tools/r02_cfg4_probe.py
+stats cfg4 python $REPO/tools/r03_cfg4_probe.py
 stats target python $REPO/tools/target_probe.py
 # 4. two ranks sharing this one device (gloo): exercises the self-spawn + sharded C-ABI path
 LSR_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 > $P/${TAG}_bench_2ranks_one_device.json 2> $P/bench2.err; echo "bench2 rc=$?"
