@@ -760,14 +760,22 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
                 outliers[str(c)] = {"translation_m": float(dt), "rotation_rad": float(ang), "newton_iterations": int(rr.iterations)}
             it_equal = it_equal and int(rr.iterations) == int(fx["iterations"][c])
             fits.append(abs(float(rr.fitness) - float(fx["fitness"][c])) / float(fx["fitness"][c]))
+        try:   # the CPU path's own spread on the candidates listed as beyond the bar
+            fxt = np.load(os.path.join(ROOT, "tests", "golden", "cfg4_candidates_oracle_tight.npz"))
+            for c in outliers:
+                outliers[c]["cpu_spread_translation_m"] = float(fxt["cpu_spread_translation_m"][int(c)])
+                outliers[c]["cpu_spread_rotation_rad"] = float(fxt["cpu_spread_rotation_rad"][int(c)])
+        except (OSError, KeyError):
+            pass
         if dts:
             res["vs_cpu_oracle_fixture"] = {"candidates_checked": len(dts), "max_translation_m": float(max(dts)),
                                             "max_rotation_rad": float(max(angs)), "newton_iterations_all_equal": bool(it_equal),
                                             "max_fitness_rel_diff": float(max(fits)),
                                             "within_1e-3m_1e-4rad": len(dts) - len(outliers), "beyond": outliers,
-                                            "note": "candidates 21 and 34 walk ~30 clamped 0.1 m steps along an ill-conditioned Newton direction at "
-                                                    "eps 0.01; two CPU builds of the oracle (with / without FMA contraction) differ by 1.3e-3 m on "
-                                                    "34 as well (tests/sensitivity_cfg4.py, DESIGN.md 2)",
+                                            "note": "eps 0.01 (the backend's schedule) stops anywhere within its 0.01 m step tolerance: a candidate "
+                                                    "beyond the bar here is one whose CPU result itself moves that far under fp32-ulp perturbations "
+                                                    "(cpu_spread_* of tests/golden/cfg4_candidates_oracle_tight.npz: 18 and 34); at eps 1e-6 all 64 agree "
+                                                    "within 1.4e-4 m (tests/test_full_size_gpu.py, DESIGN.md 2)",
                                             "fixture": "tests/golden/cfg4_candidates_oracle.npz (CPU oracle, all 64 candidates)"}
     if t_serial is not None:
         res["serial_one_by_one"] = {"value": n_total / t_serial, "unit": "registrations/s", "ms_per_candidate_set": 1e3 * t_serial}

@@ -214,6 +214,9 @@ int ensure_ndt_grid(lsr_handle h) {
 // An NDT target whose voxel grid was built by the counting-sort builder keeps its points in voxel order: the neighbour grid is
 // a refinement of that order (one launch, nn_build_hash_from_grids) instead of a second sort of the cloud.
 bool hash_from_grid_possible(lsr_handle h) {
+  // A/B switch (env LSR_NN_FROM_GRID=0: always build the neighbour grid from the cloud); read once
+  static const bool enabled = [] { const char* e = getenv("LSR_NN_FROM_GRID"); return !(e && e[0] == '0'); }();
+  if (!enabled) return false;
   const TargetData& t = *h->target;
   return h->method == LSR_METHOD_NDT && t.has_grid && t.grid.has_sorted && t.grid.ncells > 0 && t.grid.sorted_n == t.cloud.n;
 }

@@ -24,6 +24,15 @@ static bool gicp_fused_enabled() {
   return on && nn_coop_enabled();
 }
 
+// Largest ball (fine cells per axis, 3..8: an x-range of <= 8 cells touches at most two coarse cells) the seeded correspondence
+// kernel searches itself; larger ones go to the general search, which costs a wave per point and a long chain of dependent
+// probes: measured on cfg 3 (setInputSource + align) 3 cells 0.834 ms, 5 cells 0.734, 7 cells 0.739, 8 cells 0.750.
+// env LSR_GICP_BALL_CELLS, read once.
+static int gicp_ball_cells() {
+  static const int v = [] { const char* e = getenv("LSR_GICP_BALL_CELLS"); const int c = e ? atoi(e) : 5; return c < 3 ? 3 : c > 8 ? 8 : c; }();
+  return v;
+}
+
 namespace {
 
 constexpr int GN_THREADS = 256;
@@ -345,8 +354,8 @@ __global__ __launch_bounds__(NN_THREADS) void gicp_corr_kernel(NNGridView G, con
 // iteration's neighbour.  Pairs: one thread per point builds the Mahalanobis matrix of its correspondence.
 // Seeded form (outer iterations after the first), SIXTEEN lanes per point.  The previous neighbour's distance d is an upper
 // bound on the answer, so the answer lies in the ball of radius d around the moved point: the fine cells that ball touches
-// (at most 3 per axis, else the point goes to `work` for the general search) are ALL the search has to read — no shells,
-// no bound tests.  One row of <= 3 cells per (y, z) pair, one lane per (row, coarse segment), the candidates of the group
+// (at most max_cells per axis, else the point goes to `work` for the general search) are ALL the search has to read — no shells,
+// no bound tests.  One row of <= max_cells cells per (y, z) pair, one lane per (row, coarse segment), the candidates of the group
 // laid end to end and read 16 at a time; four points per wave.  Exact: every point at distance <= d is in one of those
 // cells (the cell index is a monotone map; the reach is padded against rounding), ties included.
 // work[0] = number of deferred points (zeroed by the pair kernel after use), work[1..] = their indices.
@@ -354,7 +363,8 @@ __global__ __launch_bounds__(256) void gicp_corr_ball_kernel(NNGridView G, const
                                                              const float* __restrict__ oz, int n, const float* __restrict__ T16,
                                                              float thr2, const float* __restrict__ tx, const float* __restrict__ ty,
                                                              const float* __restrict__ tz, const OuterState* __restrict__ O,
-                                                             int* __restrict__ last_nn, float* __restrict__ nn_d2, int* __restrict__ work) {
+                                                             int* __restrict__ last_nn, float* __restrict__ nn_d2, int* __restrict__ work,
+                                                             const int max_cells) {
   const int ph = O->phase;
   if (O->outer_done || (ph & 1) || ph == 0) return;  // the first outer iteration has no seeds: the general search does it
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -373,19 +383,20 @@ __global__ __launch_bounds__(256) void gicp_corr_ball_kernel(NNGridView G, const
     bi = seed;
     if (!(bd < thr2)) general = true;   // the seed itself is beyond the gate: the ball would be the gate's
   }
-  if (!general && !ball_cell_range(G, q, bd, 3, lo, hi)) general = true;   // more than 3 cells on some axis
+  if (!general && !ball_cell_range(G, q, bd, max_cells, lo, hi)) general = true;   // more than max_cells (<= 8) cells on some axis
   if (general) {
     if (gl == 0) work[1 + atomicAdd(work, 1)] = i;
     return;
   }
   const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;   // >= 1 unless the ball misses the grid (then no slot is valid)
   const int n_slots = (ny > 0 && nz > 0 && hi[0] >= lo[0]) ? ny * nz * 2 : 0;
+  const unsigned int ny_magic = 65536u / (unsigned int)max(ny, 1) + 1u;
   for (int s0 = 0; s0 < n_slots; s0 += 16) {
     const int slot = s0 + gl;
     int beg = 0, len = 0;
     if (slot < n_slots) {
       const int cseg = slot & 1, row = slot >> 1;
-      const int dz = (row >= 2 * ny) ? 2 : (row >= ny) ? 1 : 0;
+      const int dz = (int)(((unsigned int)row * ny_magic) >> 16);   // row / ny (row < 128, ny <= 8)
       const int y = lo[1] + (row - dz * ny), z = lo[2] + dz;
       const int cx = (lo[0] >> 3) + cseg;
       if (cx <= (hi[0] >> 3)) {
@@ -603,6 +614,8 @@ __global__ __launch_bounds__(GN_THREADS) void gicp_gn_kernel(const float* __rest
 // step would be inf/NaN or astronomically large, so the step is dropped (delta = 0): the inner loop then ends on its
 // iteration cap with x unchanged and align() returns a finite pose (healthy systems never come near the threshold).
 __device__ void solve6_gn(const double* H, const double* b, double* x) {
+  // Gauss-Jordan with partial pivoting, element for element the arithmetic of solve6_gn_wave below (the two chains must give
+  // bit-identical steps: tests/test_gicp_gpu.py::test_search_and_chain_variants_give_identical_results)
   double A[6][7];
   double scale = 0.0;
   for (int i = 0; i < 6; i++) {
@@ -624,29 +637,66 @@ __device__ void solve6_gn(const double* H, const double* b, double* x) {
     for (int i = k + 1; i < 6; i++) {
       const bool sw = (piv == i);
 #pragma unroll
-      for (int j = k; j < 7; j++) {
+      for (int j = 0; j < 7; j++) {
         const double a = A[k][j], c = A[i][j];
         A[k][j] = sw ? c : a;
         A[i][j] = sw ? a : c;
       }
     }
     const double inv = 1.0 / A[k][k];
+    double rowk[7];
 #pragma unroll
-    for (int i = k + 1; i < 6; i++) {
+    for (int j = 0; j < 7; j++) rowk[j] = A[k][j];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      if (i == k) continue;
       const double f = A[i][k] * inv;
 #pragma unroll
-      for (int j = k + 1; j < 7; j++) A[i][j] -= f * A[k][j];
+      for (int j = 0; j < 7; j++) A[i][j] -= f * rowk[j];
     }
   }
 #pragma unroll
-  for (int k = 5; k >= 0; k--) {
-    double s = A[k][6];
-#pragma unroll
-    for (int j = k + 1; j < 6; j++) s -= A[k][j] * x[j];
-    x[k] = s / A[k][k];
+  for (int k = 0; k < 6; k++) x[k] = singular ? 0.0 : A[k][6] / A[k][k];
+}
+
+// The same on ONE WAVE: lane 8 r + c holds element (r, c) of the augmented 6 x 7 matrix [H | -g], built straight from the sums
+// (H = 2 sums / m, upper triangle at sums[7..27]; g = 2 sums[1..6] / m); every elimination step is a handful of cross-lane
+// reads instead of ~100 dependent fp64 operations on one lane (the one-lane solve was ~2 us of every Gauss-Newton step).
+// dx (LDS, 6 doubles) receives the step.
+__device__ __forceinline__ void solve6_gn_wave(const double* sums, double m, double* dx) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane >> 3, c = lane & 7;
+  double v = 0.0;
+  if (r < 6 && c < 6) {
+    const int i = min(r, c), j = max(r, c);
+    v = 2.0 * sums[7 + 6 * i - (i * (i - 1)) / 2 + (j - i)] / m;
+  } else if (r < 6 && c == 6) {
+    v = -(2.0 * sums[1 + r] / m);
   }
-  if (singular)
-    for (int k = 0; k < 6; k++) x[k] = 0.0;
+  double scale = (r < 6 && c < 6) ? fabs(v) : 0.0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) scale = fmax(scale, __shfl_xor(scale, w, 64));
+  bool singular = !(scale > 0.0) || !(scale < 1.0e300);
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double best = fabs(__shfl(v, k * 8 + k, 64));
+    int piv = k;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double t = fabs(__shfl(v, i * 8 + k, 64));
+      if (t > best) { best = t; piv = i; }
+    }
+    if (!(best > 1.0e-13 * scale)) singular = true;
+    const double from_piv = __shfl(v, piv * 8 + c, 64), from_k = __shfl(v, k * 8 + c, 64);
+    v = (r == k) ? from_piv : ((r == piv) ? from_k : v);
+    const double akk = __shfl(v, k * 8 + k, 64), akj = __shfl(v, k * 8 + c, 64), aik = __shfl(v, r * 8 + k, 64);
+    const double inv = 1.0 / akk;
+    const double f = aik * inv;
+    if (r != k && r < 6) v -= f * akj;
+  }
+  const int jj = min(lane, 5);
+  const double num = __shfl(v, jj * 8 + 6, 64), den = __shfl(v, jj * 8 + jj, 64);
+  if (lane < 6) dx[lane] = singular ? 0.0 : num / den;
 }
 
 // column-major fp32 product (previous_transformation_ * guess)
@@ -807,7 +857,9 @@ __global__ __launch_bounds__(256) void gicp_update_kernel(IterBlock* __restrict_
 // and no single-workgroup launch on the critical path.  The block is double buffered by step parity (step s reads
 // blk[s & 1], workgroup 0 writes blk[(s + 1) & 1]); the correspondence launches between steps s-1 and s work on blk[s & 1].
 // Returns true when this launch has pairs to accumulate at the state it leaves in B.
-__device__ int gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb, unsigned int token, bool publish) {
+// need_solve (nullable): instead of solving on the calling lane, raise *need_solve and return -1; the caller solves on the wave
+// (solve6_gn_wave) and finishes the step with gicp_advance_take_step().
+__device__ int gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb, unsigned int token, bool publish, int* need_solve) {
   GnState* S = &Bk.st;
   OuterState* O = &Bk.out;
   if (!Bk.have_partials) {
@@ -834,6 +886,7 @@ __device__ int gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb,
     gn = sqrt(gn);
     S->gnorm = gn;
     if (!(gn < 1e-2 || S->inner_iter >= S->max_inner || !(gn == gn))) {  // else BFGS testGradient(1e-2) / max_inner_iterations_: loop over
+      if (need_solve) { *need_solve = 1; return -1; }
       double neg[6], dx[6];
       for (int k = 0; k < 6; k++) neg[k] = -g[k];
       solve6_gn(H, neg, dx);
@@ -939,7 +992,25 @@ __global__ __launch_bounds__(GN_THREADS) void gicp_step_kernel(IterBlock* __rest
   __syncthreads();
   __shared__ float s_f6[6];
   __shared__ double s_d6[6];
-  if (t == 0) s_do = gicp_advance(Bk, s_sum, mb, token, blockIdx.x == 0);
+  __shared__ double s_dx[8];
+  __shared__ int s_need;
+  if (t < 64) {   // wave 0: the scalar bookkeeping on lane 0, the 6x6 solve on the wave (lockstep + in-order LDS: no workgroup barrier)
+    int code = 0;
+    if (t == 0) { s_need = 0; code = gicp_advance(Bk, s_sum, mb, token, blockIdx.x == 0, &s_need); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (s_need) {
+      solve6_gn_wave(s_sum, (double)Bk.st.m, s_dx);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (t == 0) {
+        for (int k = 0; k < 6; k++) Bk.st.x[k] += s_dx[k];
+        Bk.st.inner_iter++;
+        code = 1 | 2;   // evaluate at the new x, whose trigonometry is spread over lanes below
+      }
+    }
+    if (t == 0) s_do = code;
+  }
   __syncthreads();
   if (s_do & 2) {   // sin/cos of the three angles: fp32 on lanes 0..2 of wave 0, fp64 on lanes 0..2 of wave 1, side by side
     if (t < 3) {
@@ -1149,7 +1220,7 @@ struct GicpChain {
       if (ball)
         hipLaunchKernelGGL(gicp_corr_ball_kernel, dim3((unsigned)(((long)n * 16 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
                            ws.out.x(), ws.out.y(), ws.out.z(), n, cur->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &cur->out,
-                           ws.last_nn.p, ws.nn_d2.p, d_work);
+                           ws.last_nn.p, ws.nn_d2.p, d_work, gicp_ball_cells());
       // the first group is the first outer iteration (every point, one wave each); later groups only run the general search
       // on what the seeded kernel deferred (grid-stride over the list: a small grid, not 7 500 workgroups that exit)
       const unsigned full_grid = (unsigned)(((long)n * 64 + 255) / 256);

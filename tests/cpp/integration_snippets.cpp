@@ -99,7 +99,7 @@ void pc2_sites(lsr_handle h, const mock::PointCloud2* msg, uint32_t off_x, uint3
 
 // ---- §3d: a candidate set over the GPUs of a node ---------------------------------------------------------------------
 void sharded_site(int rank, int world, int device, lsr_handle* handles, const void* const* target_ptrs, const size_t* target_counts,
-                  const std::vector<std::shared_ptr<pcl::PointCloud<pcl::PointXYZI>>>& src, const float* guesses) {
+                  const void* const* source_ptrs, const size_t* source_counts, const float* guesses) {
   // [snippet: sharded]
   // one process (or thread with its own device) per GPU; rank 0 creates the id and hands it to the others
   char id[128]; if (rank == 0) lsr_comm_unique_id(id);  /* broadcast `id` by whatever the application has */
@@ -107,12 +107,28 @@ void sharded_site(int rank, int world, int device, lsr_handle* handles, const vo
   int first, mine; lsr_shard_range(64, world, rank, &first, &mine);        // this rank's block of the 64 candidates
   // the k-th local object gets candidate first+k: all targets in one staged call (the grid builds overlap on the device)
   lsr_set_input_target_batch(handles, mine, target_ptrs, target_counts, sizeof(pcl::PointXYZI), /*on_device=*/0);
-  for (int k = 0; k < mine; k++) lsr_set_input_source(handles[k], src[k]->points.data(), sizeof(pcl::PointXYZI), src[k]->size());
+  lsr_set_input_source_batch(handles, mine, source_ptrs, source_counts, sizeof(pcl::PointXYZI), /*on_device=*/0);
   // one shared launch chain + lsr_get_fitness_score_batch inside, then ONE
   // ncclAllGather of 64-byte records: every rank gets all 64 results in candidate order
   std::vector<lsr_shard_record> all(64);
   lsr_align_batch_sharded(comm, handles, mine, 64, guesses, /*with_fitness=*/1, all.data());
   lsr_comm_destroy(comm);
+  // [end snippet]
+}
+
+void planned_site(lsr_comm comm, int rank, int world, int n_cand, lsr_handle* handles, const size_t* target_counts_all,
+                  const size_t* source_counts_all, const float* guesses) {
+  // [snippet: planned]
+  // candidates of different size (the ring gate: targets from a few thousand to 661 k points): a cost-aware plan instead of
+  // blocks — every rank computes the same plan from the same costs; rank r owns order[rank_first[r] .. rank_first[r+1]),
+  // longest first, and hands its objects over in that order
+  std::vector<double> cost(n_cand);
+  for (int i = 0; i < n_cand; i++) cost[i] = 6.0 * target_counts_all[i] + 34.0 * source_counts_all[i];   // point visits
+  std::vector<int32_t> owner(n_cand), order(n_cand), rank_first(world + 1);
+  lsr_shard_plan(n_cand, cost.data(), world, owner.data(), order.data(), rank_first.data());
+  const int mine = rank_first[rank + 1] - rank_first[rank];   // local object k registers candidate order[rank_first[rank] + k]
+  std::vector<lsr_shard_record> all(n_cand);                  // comes back in candidate order on every rank
+  lsr_align_batch_planned(comm, handles, mine, n_cand, order.data(), rank_first.data(), guesses, /*with_fitness=*/1, all.data());
   // [end snippet]
 }
 

@@ -406,7 +406,7 @@ def test_integration_md_snippets_compile_against_the_header(tmp_path):
     src = {}
     src.update(_snippets(os.path.join(ROOT, "include", "lidarslam_reg", "gfx950_registration.hpp")))
     src.update(_snippets(os.path.join(ROOT, "tests", "cpp", "integration_snippets.cpp")))
-    assert set(src) == {"binding", "construction", "fitness", "search_loop", "pc2", "sharded"}
+    assert set(src) == {"binding", "construction", "fitness", "search_loop", "pc2", "sharded", "planned"}
     assert set(doc) == set(src), (sorted(doc), sorted(src))
     for name in src:
         assert doc[name] == src[name], f"INTEGRATION.md block '{name}' differs from the compiled source"

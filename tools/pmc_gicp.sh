@@ -8,7 +8,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/pmc_gicp
 rm -rf $OUT; mkdir -p $OUT
-run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $REPO/tools/r02_gicp_probe.py > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+timeout 600 python $REPO/tools/r02_gicp_probe.py > $OUT/warmup.log 2>&1; echo "warm-up rc=$?"
+run() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $REPO/tools/r02_gicp_probe.py > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY
