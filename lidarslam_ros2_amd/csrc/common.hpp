@@ -116,7 +116,8 @@ struct DeviceCloud {
 };
 
 // ---- target-side NDT structure (K1/K2 output) ------------------------------------------------
-// One 64-byte record per occupied leaf: {mean.xyz, c00}, {c01, c02, c11, c12}, {c22, n, -, -}, pad.
+// One 64-byte record per leaf: {mean_hi.xyz, c00}, {c01, c02, c11, c12}, {c22, mean_lo.xyz}, {n, -, -, -}: the mean as head +
+// tail fp32 (x' - mean is formed as (x' - hi) - lo, ndt_point.hpp); an unusable leaf is all-NaN and drops itself.
 struct VoxelGridDev {
   float leaf = 1.f;
   int min_b[3] = {0, 0, 0}, max_b[3] = {-1, -1, -1}, div_b[3] = {0, 0, 0};

@@ -1,10 +1,17 @@
 // GICP for gfx950 (replaces pclomp::GeneralizedIterativeClosestPoint).
-//   K5  gicp_cov_kernel      fused exact 20-NN (voxel-grid search, LDS top-k lists) + covariance +
-//                            3x3 symmetric eigen-decomposition + U diag(1,1,eps) U^T
-//   K6  gicp_corr_kernel     1-NN of (transformation_ * guess * src) in the target within corr_dist,
-//                            M_i = (R C1_i R^T + C2_j)^-1 in fp64, packed pair records for K7
-//   K7  gicp_gn_kernel       per-pair residual / Jacobian, 28 fp64 sums (cost, 6-gradient, 21-Hessian)
-//       gicp_update_kernel   fixed-order sum of the per-workgroup rows, 6x6 solve, state update
+//   K5  gicp_knn_wave_kernel      exact 20-NN of every source (target) point, one wave per point (nn_device.hpp: coop_search)
+//       gicp_cov_from_nbr_kernel  covariance of the neighbours + 3x3 symmetric eigen-decomposition + U diag(1,1,eps) U^T
+//   K6  gicp_corr_ball_kernel     1-NN of (transformation_ * guess * src) in the target, seeded by the previous outer iteration's
+//                                 neighbour: the cells of the ball of that radius are all it reads (16 lanes per point)
+//       gicp_corr_search_kernel   the first outer iteration, and the points the seeded kernel defers: one wave per point
+//       gicp_corr_pairs_kernel    M_i = (R C1_i R^T + C2_j)^-1 in fp64, packed pair records for K7
+//   K7  gicp_step_kernel          one Gauss-Newton step per launch: consumes the partial rows of the previous step (fixed-order
+//                                 sum, gradient test, 6x6 solve on a wave, state update, the reference's outer bookkeeping),
+//                                 then accumulates 28 fp64 sums (cost, 6-gradient, 21-Hessian) at the new state
+// The whole outer loop runs on the device; the host (GicpChain) keeps launches queued and polls a mailbox.
+// gicp_cov_kernel / gicp_cov_coop_kernel / gicp_corr_kernel / gicp_gn_kernel / gicp_update_kernel are the per-thread and
+// unfused forms of rounds 1-2: kept as independent cross-checks behind LSR_NN_COOP=0 / LSR_GICP_FUSED=0 / LSR_GICP_BALL=0
+// (tests/test_gicp_gpu.py holds the production kernels to them bit for bit).
 // The reference minimises the same cost with BFGS; north_star asks for Gauss-Newton accumulation, so
 // the inner solver here is GN with the reference's stopping rule (|grad| < 1e-2 or max_inner
 // iterations).  Same cost and correspondences => same minimiser; the oracle carries both solvers.

@@ -3,16 +3,21 @@
 // graph_based_slam_component.cpp:227) built with a hand-written LDS-histogram counting sort instead of
 // a general radix sort:
 //
-//   bbox (publishes into the host mailbox)                                        1 launch, host polls one word
-//   vg_hist_kernel     key per point (uint16) + per-block LDS histogram           reads 12 B/pt, writes 2 B/pt
-//   vg_scan_kernel     per cell: exclusive scan over the blocks                   nblk x C words
-//   vg_cellscan_kernel one workgroup: exclusive scan over the cells -> start[]
-//   vg_scatter_kernel  STABLE scatter of x,y,z into cell order                    reads 14 B/pt, writes 12 B/pt
-//   vg_leaf_kernel     one workgroup per cell: fp64 sums in a fixed order + leaf finalisation (K2)   reads 12 B/pt
-//   lds_pack_kernel    LDS image of the usable leaves, counts into the host mailbox
+//   bbox / vg_ingest   bounding box as {value, token} granules straight into the host mailbox (vg_ingest: fused with the
+//                      de-interleave of the PointXYZI records)                    host folds the records, no fence on the device
+//   vg_hist            key per point (uint16) + per-block LDS histogram           reads 12 B/pt, writes 2 B/pt
+//   vg_scan            per cell: exclusive scan over the blocks                   nblk x C words
+//   vg_cellscan        one workgroup: exclusive scan over the cells -> start[], rank[] of the occupied cells
+//   vg_scatter         STABLE scatter of x,y,z (+ original index) into cell order reads 14 B/pt, writes 16 B/pt
+//   vg_leaf            one workgroup per cell: fp64 sums in a fixed order + leaf finalisation (K2)   reads 12 B/pt
+//   lds_pack           LDS image of the usable leaves, counts into the host mailbox (ndt.hip)
 //
-// = 7 launches, no device-to-host copy, two host polls (bbox, done) — against ~35 launches and three stream
-// synchronisations of the sort-based builder (which remains for larger key spaces, ndt.hip).
+// Every stage exists as a body + a single-target kernel + a GROUP kernel (up to LSR_GROUP = 16 targets per launch, the
+// members' pointers and sizes in the kernel arguments, blockIdx.y = member): a candidate set pays one launch per stage per
+// 16 targets.  The voxel-ordered points stay with the grid (sorted planes, sorted_idx, cell_start, cell_rank): the
+// neighbour grid of getFitnessScore is a refinement of that order (nn.hip).  No device-to-host copy, two host polls (bbox,
+// done) — against ~35 launches and three stream synchronisations of the sort-based builder (which remains for larger key
+// spaces, ndt.hip).
 // Determinism: integer histograms; the scatter ranks equal keys by point index (wave ballots, waves ordered through
 // packed 16-bit per-wave counters); the sums of a leaf are formed in an order that depends on its point count only.
 #include <chrono>

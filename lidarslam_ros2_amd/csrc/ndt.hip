@@ -563,7 +563,7 @@ __device__ __forceinline__ int ndt_controller_mt(LdsState* S, const LdsDouble* s
   return next;
 }
 
-// Newton half (computeTransformation), in two small pieces around the call of solve6 so that nothing but
+// Newton half (computeTransformation), in two small pieces around the 6x6 solve (solve6_wave) so that nothing but
 // the two LDS pointers is live across a call (a callee-saved register costs its user a scratch spill).
 // End of a Newton iteration: pose update, convergence test.  Returns CTL_NEWTON_BEGIN, or CTL_DONE after finishing.
 __device__ __forceinline__ int ndt_newton_end(LdsState* S) {
@@ -588,7 +588,7 @@ __device__ __forceinline__ int ndt_newton_end(LdsState* S) {
   return CTL_NEWTON_BEGIN;
 }
 
-// Start of a Newton iteration, after solve6 left delta = -H^{-1} g in `delta`: direction, computeStepLengthMT prologue,
+// Start of a Newton iteration, after solve6_wave left delta = -H^{-1} g in `delta`: direction, computeStepLengthMT prologue,
 // first step of the line search.  Returns CTL_DONE (request written or align finished) or CTL_NEWTON_END (zero slope).
 __device__ __forceinline__ int ndt_newton_begin(LdsState* S, const LdsDouble* delta_lds) {
   const double mu = 1.e-4;

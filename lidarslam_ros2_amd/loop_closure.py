@@ -15,7 +15,7 @@ from typing import List, Sequence
 import numpy as np
 
 from . import _capi
-from .registration import Registration, _cloud_args
+from .registration import Registration, _cloud_args, _is_torch_cuda, _order_after_torch
 
 
 @dataclass
@@ -60,7 +60,7 @@ def search_loop(registration: Registration, submaps: Sequence[SubMap], params: L
     keep = []
     on_device, stride = None, None
     for i, sm in enumerate(submaps):
-        ptr, st, cnt, dev, holder = _cloud_args(sm.cloud, registration)
+        ptr, st, cnt, dev, holder = _cloud_args(sm.cloud)
         keep.append(holder)
         if on_device is None:
             on_device, stride = dev, st
@@ -71,6 +71,11 @@ def search_loop(registration: Registration, submaps: Sequence[SubMap], params: L
         arr[i].distance = float(sm.distance)
         arr[i].cloud = ptr.value
         arr[i].n_points = cnt
+    # ONE ordering of the handle's stream after torch's current stream, after every .contiguous() copy above has been enqueued
+    # there (an event per submap was 21 x (event record + stream wait) = 0.1 ms of a 0.55 ms call)
+    dev_holders = [h for h in keep if _is_torch_cuda(h)]
+    if dev_holders:
+        _order_after_torch(registration, dev_holders[-1])
     cp = _capi.LoopParams(params.threshold_loop_closure_score, params.distance_loop_closure,
                           params.range_of_searching_loop_closure, params.search_submap_num, params.voxel_leaf_size,
                           params.top_k, 0)

@@ -143,7 +143,10 @@ class Registration:
     def setInputTargetFrames(self, frames, poses):
         """Submap assembly on the device: frame f transformed by poses[f] (4x4), concatenated, then
         setInputTarget (scanmatcher_component.cpp:449-464,307).  Frames: host arrays or CUDA tensors, same layout."""
-        args = [_cloud_args(f, self) for f in frames]
+        args = [_cloud_args(f) for f in frames]
+        dev_frames = [a[4] for a in args if _is_torch_cuda(a[4])]
+        if dev_frames:
+            _order_after_torch(self, dev_frames[-1])   # one ordering, after every .contiguous() copy has been enqueued
         dev = args[0][3]
         if any(a[3] != dev for a in args) or any(a[1] != args[0][1] for a in args):
             raise ValueError("frames must all be host or all device, with one record stride")
