@@ -83,6 +83,7 @@ int device_cus(int device) {
 // — and lets each of them walk several batches of points instead.  (Round 2 launched ceil(n / 128) workgroups: at cfg 5 that
 // was 938 of them taking turns on 256 CUs, each turn with its own head.)
 constexpr int NDT_WGS_PER_CU = 2;
+constexpr int NDT_QUAD_BATCH_MAX = 1;
 int ndt_nblocks(size_t n, int device, int batch = 1, int threads = NDT_THREADS) {
   int nb = (int)((n + threads - 1) / threads);
   static const int wgs_per_cu = [] { const char* e = std::getenv("LSR_NDT_WGS_PER_CU"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= 8) ? v : NDT_WGS_PER_CU; }();
@@ -149,7 +150,11 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   }
   const int lds_cap = device_lds_bytes(lead->device);
   const int override_mode = lead->ndt_table_mode;
-  const bool want_quad_single = (B == 1 && lead->ndt_quad != 0);
+  // four lanes per point for ONE registration; batches use the one-lane kernel — measured on cfg-4 sets of 8 / 16 / 64 candidates
+  // (align stage): one-lane 0.61 / 0.90 / 2.73 ms, four-lane 0.76 / 1.09 / 4.06 ms (env LSR_NDT_QUAD_BATCH_MAX raises the batch
+  // size up to which the four-lane kernel is used; read once)
+  static const int quad_batch_max = [] { const char* e = std::getenv("LSR_NDT_QUAD_BATCH_MAX"); const int v = e ? std::atoi(e) : NDT_QUAD_BATCH_MAX; return v < 1 ? 1 : v; }();
+  const bool want_quad_single = (B <= quad_batch_max && lead->ndt_quad != 0);
   const int static_lds = want_quad_single ? NDT_QUAD_STATIC_LDS : NDT_ROW_STATIC_LDS;
   const int table_cap = std::min(want_quad_single ? NDT_LDS_TABLE_MAX_QUAD : NDT_LDS_TABLE_MAX, lds_cap - static_lds);
   const bool lds_ok = all_lds && lds_max <= table_cap;
