@@ -218,6 +218,12 @@ int ensure_ndt_grid(lsr_handle h) {
 
 // An NDT target whose voxel grid was built by the counting-sort builder keeps its points in voxel order: the neighbour grid is
 // a refinement of that order (one launch, nn_build_hash_from_grids) instead of a second sort of the cloud.
+// A/B switch (env LSR_NN_PREFETCH=0: the neighbour grids of a candidate set are built by getFitnessScore, not under the align chain)
+bool nn_prefetch_enabled() {
+  static const bool on = [] { const char* e = getenv("LSR_NN_PREFETCH"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 bool hash_from_grid_possible(lsr_handle h) {
   // A/B switch (env LSR_NN_FROM_GRID=0: always build the neighbour grid from the cloud); read once
   static const bool enabled = [] { const char* e = getenv("LSR_NN_FROM_GRID"); return !(e && e[0] == '0'); }();
@@ -393,8 +399,40 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     if (cfg.quad) LSR_HIP(hipMemsetAsync(lead->d_bins.p, 0, sizeof(long long) * (size_t)B * NDT_NBANKS * NDT_BANK_WORDS, lead->stream));
   }
   if (lead->profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
+  // A candidate set is scored right after it is registered (graph_based_slam_component.cpp:230-231): the neighbour grids that
+  // getFitnessScore needs are refined from the voxel order NOW, on a side stream, under the launch chain — the chain is a
+  // sequence of short dependent launches that leaves most of the chip idle, the refinement is one wide launch per 16 targets.
+  bool prefetched = false;
+  if (B > 1 && nn_prefetch_enabled()) {
+    std::vector<const VoxelGridDev*> vgs;
+    std::vector<HashGridDev*> hgs;
+    std::vector<lsr_handle> owners;
+    for (int b = 0; b < B; b++) {
+      lsr_handle h = hs[b];
+      if (!hash_from_grid_possible(h) || target_is_shared(h) || h->target->has_hash) continue;
+      bool seen = false;
+      for (lsr_handle o : owners) seen = seen || (o->target == h->target);
+      if (seen) continue;
+      vgs.push_back(&h->target->grid); hgs.push_back(&h->target->hash); owners.push_back(h);
+    }
+    if (!vgs.empty()) {
+      if (!lead->side_stream) LSR_HIP(hipStreamCreateWithFlags(&lead->side_stream, hipStreamNonBlocking));
+      if (!lead->side_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_ev, hipEventDisableTiming));
+      LSR_HIP(hipEventRecord(lead->side_ev, lead->stream));             // the targets' builds are behind this point of the lead's stream
+      LSR_HIP(hipStreamWaitEvent(lead->side_stream, lead->side_ev, 0));
+      if ((st = nn_build_hash_from_grids(vgs.data(), hgs.data(), (int)vgs.size(), lead->side_stream))) return st;
+      LSR_HIP(hipEventRecord(lead->side_ev, lead->side_stream));
+      prefetched = true;
+      for (lsr_handle o : owners) o->target->has_hash = true;
+    }
+  }
   int launches = 0;
   st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, cfg, min_evals, hard_cap, token, &launches);
+  if (prefetched) {
+    // finished long before the chain as a rule; waiting here keeps every later use of the grids (any stream, any call) simple
+    if (hipEventSynchronize(lead->side_ev) != hipSuccess && !st) { set_last_error("neighbour-grid refinement failed"); st = LSR_ERR_HIP; }
+    if (st) for (int b = 0; b < B; b++) if (hs[b]->target) hs[b]->target->has_hash = false;
+  }
   if (st) return st;
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   const NdtMailbox* M = lead->mailbox.p;
@@ -519,6 +557,8 @@ int lsr_destroy(lsr_handle h) {
   if (!h) return LSR_OK;
   DeviceGuard guard(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+  if (h->side_ev) (void)hipEventDestroy(h->side_ev);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   h->target.reset();

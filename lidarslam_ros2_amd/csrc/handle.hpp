@@ -16,6 +16,10 @@ struct lsr_handle_s {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // profiling brackets (LSR_PROFILE)
+  // side stream of a batch lead: the neighbour grids of a candidate set are refined there while the shared NDT launch chain
+  // runs on `stream` (align_ndt_batch); created on first use
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_ev = nullptr;
 
   NdtParamsHost ndt;
   GicpParamsHost gicp;
