@@ -418,8 +418,9 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     if (!vgs.empty()) {
       if (!lead->side_stream) LSR_HIP(hipStreamCreateWithFlags(&lead->side_stream, hipStreamNonBlocking));
       if (!lead->side_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_ev, hipEventDisableTiming));
-      LSR_HIP(hipEventRecord(lead->side_ev, lead->stream));             // the targets' builds are behind this point of the lead's stream
-      LSR_HIP(hipStreamWaitEvent(lead->side_stream, lead->side_ev, 0));
+      if (!lead->side_fork_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_fork_ev, hipEventDisableTiming));
+      LSR_HIP(hipEventRecord(lead->side_fork_ev, lead->stream));        // the targets' builds are behind this point of the lead's stream
+      LSR_HIP(hipStreamWaitEvent(lead->side_stream, lead->side_fork_ev, 0));
       if ((st = nn_build_hash_from_grids(vgs.data(), hgs.data(), (int)vgs.size(), lead->side_stream))) return st;
       LSR_HIP(hipEventRecord(lead->side_ev, lead->side_stream));
       prefetched = true;
@@ -559,6 +560,7 @@ int lsr_destroy(lsr_handle h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->side_ev) (void)hipEventDestroy(h->side_ev);
+  if (h->side_fork_ev) (void)hipEventDestroy(h->side_fork_ev);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   h->target.reset();

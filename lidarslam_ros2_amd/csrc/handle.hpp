@@ -19,7 +19,7 @@ struct lsr_handle_s {
   // side stream of a batch lead: the neighbour grids of a candidate set are refined there while the shared NDT launch chain
   // runs on `stream` (align_ndt_batch); created on first use
   hipStream_t side_stream = nullptr;
-  hipEvent_t side_ev = nullptr;
+  hipEvent_t side_ev = nullptr, side_fork_ev = nullptr;
 
   NdtParamsHost ndt;
   GicpParamsHost gicp;

@@ -316,15 +316,16 @@ struct FitMember {
   float T16[16];
   float max_d2; double max_range;
   int* idx; float* d2; double* part; int* work;
-  BuildMailbox* mb; unsigned int token; int empty;
+  BuildMailbox* mb; unsigned int token; int empty; int fine_rings;
 };
 constexpr int FIT_GROUP = 12;
+constexpr int NN_FITNESS_FINE_RINGS = 0;   // measured on 64 candidate windows (fitness stage): 2.54 ms with 1, 2.39 ms with 0
 struct FitGroup { FitMember m[FIT_GROUP]; };
 static_assert(sizeof(FitGroup) <= 3800, "a group's parameters must fit the kernel argument segment");
 __global__ __launch_bounds__(256) void nn1_wave_group_kernel(const FitGroup g) {
   const FitMember& M = g.m[blockIdx.y];
   if ((int)blockIdx.x >= M.blocks || M.empty) return;
-  nn1_wave_body(M.G, M.qx, M.qy, M.qz, M.n, M.T16, 1, M.max_d2, M.idx, M.d2, (blockIdx.x * 256 + threadIdx.x) >> 6, (M.blocks * 256) >> 6);
+  nn1_wave_body(M.G, M.qx, M.qy, M.qz, M.n, M.T16, M.fine_rings, M.max_d2, M.idx, M.d2, (blockIdx.x * 256 + threadIdx.x) >> 6, (M.blocks * 256) >> 6);
 }
 
 // tail of nn1_kernel: one wave per deferred query; same (distance, index) order, same fp32 distances => same answer
@@ -608,6 +609,13 @@ bool nn_coop_enabled() {
   return on;
 }
 
+// Shells the fitness search reads before it tests the shell bound for the first time (env LSR_NN_FINE_RINGS, read once): 0 lets a
+// query whose own cell already proves its neighbour stop there.
+static int nn_fitness_fine_rings() {
+  static const int v = [] { const char* e = getenv("LSR_NN_FINE_RINGS"); const int r = e ? atoi(e) : NN_FITNESS_FINE_RINGS; return r < 0 ? 0 : r > 4 ? 4 : r; }();
+  return v;
+}
+
 int nn_search_device(const DeviceCloud& q, const float* d_T16, const HashGridDev& grid, int fine_rings, float max_d2,
                      int* d_idx, float* d_d2, hipStream_t stream, int* d_work) {
   const int n = (int)q.n;
@@ -687,7 +695,7 @@ int nn_fitness_begin(const DeviceCloud& source, const float* T16_host, const Has
   if (st) return st;
   LSR_HIP(hipMemcpyAsync(d_T16.p, T16_host, 16 * sizeof(float), hipMemcpyHostToDevice, stream));
   const float max_d2 = (max_range >= 3.0e38) ? INFINITY : (float)max_range * 1.0001f;
-  if ((st = nn_search_device(source, d_T16.p, grid, 1, max_d2, d_idx, d_d2, stream, d_work))) return st;
+  if ((st = nn_search_device(source, d_T16.p, grid, nn_fitness_fine_rings(), max_d2, d_idx, d_d2, stream, d_work))) return st;
   const int nb = 256;
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(nb), dim3(256), 0, stream, d_idx, d_d2, (int)source.n, max_range, d_part);
   if ((st = sc.ensure_mailbox())) return st;
@@ -730,6 +738,7 @@ int nn_fitness_begin_group(const FitJob* jobs, int count, hipStream_t stream) {
       M.max_range = J.max_range;
       M.idx = d_idx; M.d2 = d_d2; M.part = d_part; M.work = d_work;
       M.mb = sc.d_mb; M.token = token;
+      M.fine_rings = nn_fitness_fine_rings();
       if (!M.empty) { max_blocks = std::max(max_blocks, M.blocks); max_n = std::max(max_n, M.n); }
     }
     static const int form = [] { const char* e = getenv("LSR_FIT_GROUP_FORM"); return e ? atoi(e) : -1; }();   // 0 wave, 1 quad + tail, -1 by size
