@@ -2391,14 +2391,19 @@ int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
 // Members with a dense key space are built by the GROUP kernels of grid_dense.hip — one launch per stage for up to LSR_GROUP
 // members — and left pending; the others are built one by one right here.
 int ndt_targets_build_begin(TargetBuildJob* jobs, int count, hipStream_t stream) {
-  std::vector<TargetBuildJob*> dense;
   int st;
-  for (int b = 0; b < count; b++) {
-    TargetBuildJob& J = jobs[b];
-    if ((st = ndt_grid_geometry(*J.cloud, J.leaf, *J.grid, *J.sc, stream, &J.path))) return st;
-    if (J.path == 1) dense.push_back(&J);
-  }
-  if (!dense.empty()) {
+  // group by group: as soon as the bounding boxes of 16 members have arrived (the host folds their records while the ingest
+  // launches of the later groups are still running) their builds are enqueued — the device never waits for the host to have
+  // folded the whole set
+  for (int g0 = 0; g0 < count; g0 += LSR_GROUP) {
+    const int g1 = std::min(count, g0 + LSR_GROUP);
+    std::vector<TargetBuildJob*> dense;
+    for (int b = g0; b < g1; b++) {
+      TargetBuildJob& J = jobs[b];
+      if ((st = ndt_grid_geometry(*J.cloud, J.leaf, *J.grid, *J.sc, stream, &J.path))) return st;
+      if (J.path == 1) dense.push_back(&J);
+    }
+    if (dense.empty()) continue;
     std::vector<VoxelGridDev*> grids;
     std::vector<BuildScratch*> scs;
     std::vector<unsigned int> tokens;
