@@ -372,3 +372,47 @@ def test_target_batch_and_fitness_batch_equal_the_single_calls(case):
     assert regs[0].gridInfo()["n_leaves"] == len(singles[0][0]["idx"])
     with pytest.raises(Exception):
         set_input_target_batch([regs[0], regs[0]], clouds[:2])
+
+
+def test_ragged_candidate_sets(case):
+    """A candidate set whose members differ: sources from 60 to 4500 points, an EMPTY source (nothing to match: pose = guess, as the
+    single call answers), a source with non-finite points, targets of different size — every member must come out as its own
+    single registration would; a member WITHOUT target points makes the set's align fail with NO_TARGET and leaves the objects
+    usable (the next set on the same objects works)."""
+    from lidarslam_ros2_amd import _capi, align_batch
+    from lidarslam_ros2_amd.registration import fitness_score_batch, set_input_source_batch, set_input_target_batch
+
+    rng = np.random.default_rng(5)
+    sources = [case.source, case.source[:60], np.zeros((0, 3), np.float32), case.source[::3],
+               np.concatenate([case.source[:2000], np.array([[np.nan, 0, 0], [0, np.inf, 0]], np.float32)]), case.source[:1000]]
+    targets = [case.target, case.target[::2], case.target, case.target[: len(case.target) // 3], case.target, case.target[::5]]
+    guesses = [case.guess.copy() for _ in sources]
+    for g in guesses:
+        g[:3, 3] += rng.normal(0, 0.05, 3).astype(np.float32)
+    regs = [make_ndt(3.0) for _ in sources]
+    set_input_target_batch(regs, targets)
+    set_input_source_batch(regs, sources)
+    finals, res = align_batch(regs, guesses)
+    fits = fitness_score_batch([r for k, r in enumerate(regs) if len(sources[k])])
+    k_fit = 0
+    for k in range(len(sources)):
+        one = make_ndt(3.0)
+        one.setInputTarget(targets[k]); one.setInputSource(sources[k]); one.align(guesses[k])
+        if len(sources[k]) == 0:
+            assert np.array_equal(finals[k], guesses[k]) and res[k]["iterations"] == 0
+            continue
+        dt, ang = pose_delta(finals[k], one.getFinalTransformation())
+        assert dt <= POSE_T_TOL and ang <= POSE_R_TOL, (k, dt, ang)
+        assert res[k]["iterations"] == one.getFinalNumIteration(), k
+        f1 = one.getFitnessScore()
+        assert abs(fits[k_fit] - f1) <= 1e-4 * f1 + 4.0 * (dt + 30 * ang) * np.sqrt(f1), (k, fits[k_fit], f1)
+        k_fit += 1
+    # a member without target points: the set's align refuses like the single call does, nothing wedges
+    set_input_target_batch(regs, [np.zeros((0, 3), np.float32)] + targets[1:])
+    with pytest.raises(_capi.RegistrationError) as ei:
+        align_batch(regs, guesses)
+    assert ei.value.status == -4                                   # LSR_ERR_NO_TARGET
+    set_input_target_batch(regs, targets)
+    finals2, _ = align_batch(regs, guesses)
+    for k in range(len(sources)):
+        assert np.array_equal(finals2[k], finals[k]), k            # same objects, same inputs: the same answer again
