@@ -233,6 +233,12 @@ int lsr_get_final_transformation(lsr_handle h, float* out16);
 int lsr_has_converged(lsr_handle h, int* out);
 /* registration_->getFitnessScore(max_range = DBL_MAX)  graph_based_slam_component.cpp:231; scanmatcher_component.cpp:376 */
 int lsr_get_fitness_score(lsr_handle h, double max_range, double* out);
+/* align() followed by getFitnessScore(max_range) for every candidate of a set in ONE call (graph_based_slam_component.cpp:230-231
+ * inside the candidate loop): finals / results as lsr_align_batch, fitness[b] as lsr_get_fitness_score_batch — with the fitness
+ * search of every candidate that finishes early running under the launch chain of the ones still registering. */
+int lsr_align_fitness_batch(lsr_handle* handles, int count, const float* guesses, float* finals, lsr_result* results, double max_range,
+                            double* fitness);
+
 /* registration_->getFitnessScore() of every candidate of a set (graph_based_slam_component.cpp:231 inside the candidate loop):
  * out[b] = what lsr_get_fitness_score(handles[b], max_range, ..) returns; all searches are enqueued before the first wait. */
 int lsr_get_fitness_score_batch(lsr_handle* handles, int count, double max_range, double* out);

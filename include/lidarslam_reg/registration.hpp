@@ -155,6 +155,31 @@ class Registration {
     }
     return true;
   }
+  // align() + getFitnessScore() of every member in one call (graph_based_slam_component.cpp:230-231): the searches of the members
+  // that finish early run under the launch chain of the others; `scores` receives one value per member
+  static bool alignAndScoreBatch(const std::vector<Registration*>& regs, const std::vector<Matrix4f>& guesses, std::vector<double>& scores,
+                                 double max_range = DBL_MAX) {
+    if (regs.empty() || regs.size() != guesses.size()) return false;
+    std::vector<lsr_handle> hs;
+    std::vector<float> g(16 * regs.size()), f(16 * regs.size());
+    std::vector<lsr_result> res(regs.size());
+    scores.assign(regs.size(), DBL_MAX);
+    for (size_t b = 0; b < regs.size(); b++) {
+      hs.push_back(regs[b]->h_);
+      std::memcpy(g.data() + 16 * b, guesses[b].m, sizeof(float) * 16);
+    }
+    const int st = lsr_align_fitness_batch(hs.data(), (int)hs.size(), g.data(), f.data(), res.data(), max_range, scores.data());
+    if (st != LSR_OK) {
+      std::fprintf(stderr, "[lidarslam_reg::alignAndScoreBatch] %s: %s\n", lsr_status_string(st), lsr_last_error());
+      for (auto* r : regs) r->last_.converged = 0;
+      return false;
+    }
+    for (size_t b = 0; b < regs.size(); b++) {
+      std::memcpy(regs[b]->final_.m, f.data() + 16 * b, sizeof(float) * 16);
+      regs[b]->last_ = res[b];
+    }
+    return true;
+  }
   static std::vector<double> getFitnessScores(const std::vector<Registration*>& regs, double max_range = DBL_MAX) {
     std::vector<lsr_handle> hs;
     for (auto* r : regs) hs.push_back(r->h_);

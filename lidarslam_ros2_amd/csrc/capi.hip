@@ -3,6 +3,8 @@
 // entry point runs HIP kernels on a gfx950 device or returns an error status.
 #include <algorithm>
 #include <chrono>
+#include <functional>
+#include <limits>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -255,8 +257,9 @@ int ensure_target_hash(lsr_handle h) {
 // launch seq-1 (ndt.hip), so an align of E derivative passes takes E+1 launches.  The host keeps a couple of launches
 // queued ahead of the device and never synchronises the stream or copies state back inside the chain; after the last
 // `done` at most LOW_WATER + REFILL queued launches remain, which exit at their head.
+// on_poll (nullable): called between polls while the chain runs (the eager fitness dispatch of a candidate set hangs off it).
 int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_probs, const NdtLaunchCfg& cfg, int first, int hard_cap,
-                   unsigned int token, int* launches_out) {
+                   unsigned int token, int* launches_out, const std::function<int()>* on_poll = nullptr) {
   // spin: two launches queued ahead are enough; yield / sleep give the core away between polls, so more launches are
   // kept queued to ride out the scheduler's latency (surplus launches exit at their head, ~2 us each)
   const int wait_mode = h->scratch.wait_mode;
@@ -298,6 +301,7 @@ int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_
         return LSR_ERR_HIP;
       }
     }
+    if (on_poll && (spins & 0xF) == 0 && (st = (*on_poll)())) return st;
     if (wait_mode == WAIT_YIELD) std::this_thread::yield();
     else if (wait_mode == WAIT_SLEEP) std::this_thread::sleep_for(std::chrono::microseconds(20));
     else __builtin_ia32_pause();
@@ -317,8 +321,14 @@ int ndt_min_evals(const NdtParamsHost& p) {
   return 8;
 }
 
-int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, lsr_result* results) {
+// fitness_out (nullable): getFitnessScore(max_range) of every member as well (graph_based_slam_component.cpp:230-231 calls the two back
+// to back).  For members whose neighbour grid is refined from their voxel grid the search of a member is enqueued on the side
+// stream AS SOON AS ITS REGISTRATION HAS FINISHED, under the launch chain of the members still running; fitness_out[b] is NaN for
+// a member that was not served that way (the caller falls back to lsr_get_fitness_score_batch for those).
+int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, lsr_result* results, double* fitness_out = nullptr,
+                    double max_range = 1.7976931348623157e308) {
   lsr_handle lead = hs[0];
+  if (fitness_out) for (int b = 0; b < B; b++) fitness_out[b] = std::numeric_limits<double>::quiet_NaN();
   for (int b = 0; b < B; b++) {
     lsr_handle h = hs[b];
     if (!h->target || h->target->n == 0) { set_last_error("align before setInputTarget"); return LSR_ERR_NO_TARGET; }
@@ -427,12 +437,63 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
       for (lsr_handle o : owners) o->target->has_hash = true;
     }
   }
+  // eager fitness: members that can be served by the group search on the side stream (their grid is there or being refined there)
+  std::vector<char> eager_ok((size_t)B, 0), eager_sent((size_t)B, 0);
+  std::vector<int> eager_ready;
+  bool eager = false;
+  if (fitness_out && B > 1 && nn_prefetch_enabled()) {
+    for (int b = 0; b < B; b++) {
+      lsr_handle h = hs[b];
+      bool twice = false;
+      for (int a = 0; a < b; a++) twice = twice || (hs[a] == h);
+      eager_ok[b] = (!twice && hash_from_grid_possible(h) && !target_is_shared(h) && h->target->has_hash) ? 1 : 0;
+      eager = eager || eager_ok[b];
+    }
+    if (eager && !prefetched) {   // every grid was there already: the side stream still has to start behind the lead's stream
+      if (!lead->side_stream) LSR_HIP(hipStreamCreateWithFlags(&lead->side_stream, hipStreamNonBlocking));
+      if (!lead->side_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_ev, hipEventDisableTiming));
+      if (!lead->side_fork_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_fork_ev, hipEventDisableTiming));
+      LSR_HIP(hipEventRecord(lead->side_fork_ev, lead->stream));
+      LSR_HIP(hipStreamWaitEvent(lead->side_stream, lead->side_fork_ev, 0));
+    }
+  }
+  const NdtMailbox* MB = lead->mailbox.p;
+  auto eager_dispatch = [&](bool all) -> int {
+    for (int b = 0; b < B; b++)
+      if (eager_ok[b] && !eager_sent[b] && __atomic_load_n(&MB[b].done, __ATOMIC_ACQUIRE) == token) { eager_sent[b] = 1; eager_ready.push_back(b); }
+    // a launch group serves up to 12 members: wait for a full group while the chain is still running
+    while (!eager_ready.empty() && (all || eager_ready.size() >= 12)) {
+      const int n = (int)std::min<size_t>(12, eager_ready.size());
+      std::vector<FitJob> jobs;
+      for (int k = 0; k < n; k++) {
+        const int b = eager_ready[k];
+        jobs.push_back(FitJob{&hs[b]->source, MB[b].final_T, &hs[b]->target->hash, max_range, &hs[b]->scratch});
+      }
+      const int fst = nn_fitness_begin_group(jobs.data(), n, lead->side_stream);
+      if (fst) return fst;
+      eager_ready.erase(eager_ready.begin(), eager_ready.begin() + n);
+    }
+    return LSR_OK;
+  };
+  const std::function<int()> poll_hook = [&]() { return eager_dispatch(false); };
   int launches = 0;
-  st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, cfg, min_evals, hard_cap, token, &launches);
-  if (prefetched) {
-    // finished long before the chain as a rule; waiting here keeps every later use of the grids (any stream, any call) simple
-    if (hipEventSynchronize(lead->side_ev) != hipSuccess && !st) { set_last_error("neighbour-grid refinement failed"); st = LSR_ERR_HIP; }
-    if (st) for (int b = 0; b < B; b++) if (hs[b]->target) hs[b]->target->has_hash = false;
+  st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, cfg, min_evals, hard_cap, token, &launches, eager ? &poll_hook : nullptr);
+  if (eager && !st) st = eager_dispatch(true);
+  if (prefetched || eager) {
+    // the side stream's work — grid refinement, searches — ends here: every later use of the grids and of the members' scratch
+    // (any stream, any call) then needs no ordering against it
+    if (eager) (void)hipEventRecord(lead->side_ev, lead->side_stream);
+    if (hipEventSynchronize(lead->side_ev) != hipSuccess && !st) { set_last_error("side-stream work of the candidate set failed"); st = LSR_ERR_HIP; }
+    if (st && prefetched) for (int b = 0; b < B; b++) if (hs[b]->target) hs[b]->target->has_hash = false;
+  }
+  if (eager) {
+    for (int b = 0; b < B; b++) {
+      if (!eager_sent[b]) continue;
+      double v = 0;
+      const int fst = nn_fitness_end(hs[b]->scratch, lead->side_stream, &v);   // already in the mailbox
+      if (fst && !st) st = fst;
+      if (!fst) fitness_out[b] = v;
+    }
   }
   if (st) return st;
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1050,6 +1111,39 @@ int lsr_align_batch(lsr_handle* handles, int batch, const float* guesses, float*
     for (int a = 0; a < b; a++)
       if (handles[a] == handles[b]) { set_last_error("the same object appears twice in the batch"); return LSR_ERR_INVALID_ARGUMENT; }
   return gicp_align_batch(handles, batch, guesses, finals, results);
+}
+
+// registration_->align() followed by registration_->getFitnessScore() for every candidate of a set
+// (graph_based_slam_component.cpp:230-231): what lsr_align_batch + lsr_get_fitness_score_batch return, with the searches of the
+// members that finish early running under the launch chain of the others.
+int lsr_align_fitness_batch(lsr_handle* handles, int batch, const float* guesses, float* finals, lsr_result* results, double max_range,
+                            double* fitness) {
+  if (!handles || batch <= 0 || !fitness) { set_last_error("empty batch"); return LSR_ERR_INVALID_ARGUMENT; }
+  for (int b = 0; b < batch; b++) {
+    if (!handles[b]) { set_last_error("null handle in batch"); return LSR_ERR_INVALID_ARGUMENT; }
+    if (handles[b]->device != handles[0]->device || handles[b]->method != handles[0]->method) {
+      set_last_error("batched handles must share device and method");
+      return LSR_ERR_INVALID_ARGUMENT;
+    }
+  }
+  lsr_handle lead = handles[0];
+  LSR_CHECK_HANDLE(lead);
+  if (lead->method != LSR_METHOD_NDT) {
+    const int st = lsr_align_batch(handles, batch, guesses, finals, results);
+    return st ? st : lsr_get_fitness_score_batch(handles, batch, max_range, fitness);
+  }
+  int st = align_ndt_batch(handles, batch, guesses, finals, results, fitness, max_range);
+  if (st) return st;
+  std::vector<lsr_handle> rest;
+  std::vector<int> where;
+  for (int b = 0; b < batch; b++)
+    if (fitness[b] != fitness[b]) { rest.push_back(handles[b]); where.push_back(b); }   // not served under the chain
+  if (!rest.empty()) {
+    std::vector<double> v(rest.size());
+    if ((st = lsr_get_fitness_score_batch(rest.data(), (int)rest.size(), max_range, v.data()))) return st;
+    for (size_t k = 0; k < rest.size(); k++) fitness[where[k]] = v[k];
+  }
+  return LSR_OK;
 }
 
 int lsr_align(lsr_handle h, const float* guess, float* final_transformation, lsr_result* result, void* output_pts,

@@ -189,10 +189,11 @@ int lsr_align_batch_planned(lsr_comm c, lsr_handle* local_handles, int local_cou
   } else if (local_count > 0) {
     std::vector<float> finals((size_t)local_count * 16);
     std::vector<lsr_result> res((size_t)local_count);
-    int st = lsr_align_batch(local_handles, local_count, local_guesses, finals.data(), res.data());
     std::vector<double> fit((size_t)local_count, (double)NAN);
-    if (!st && with_fitness)   // every candidate's search + reduction enqueued before the first result is read
-      st = lsr_get_fitness_score_batch(local_handles, local_count, 1.7976931348623157e308, fit.data());
+    // with fitness: one call — the searches of the candidates that finish early run under the launch chain of the others
+    int st = with_fitness ? lsr_align_fitness_batch(local_handles, local_count, local_guesses, finals.data(), res.data(),
+                                                    1.7976931348623157e308, fit.data())
+                          : lsr_align_batch(local_handles, local_count, local_guesses, finals.data(), res.data());
     if (st) {
       local_status = st; local_error = lsr_last_error();
     } else {

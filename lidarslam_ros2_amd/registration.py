@@ -487,3 +487,27 @@ def align_batch(regs: Sequence[Registration], guesses=None):
         r._last = capi.Result.from_buffer_copy(res[b])
         out.append(r.last_result)
     return finals, out
+
+
+def align_fitness_batch(regs: Sequence[Registration], guesses=None, max_range: float = 1.7976931348623157e308):
+    """align() followed by getFitnessScore() for every candidate of a set in one call (graph_based_slam_component.cpp:230-231):
+    returns (finals (B,4,4) fp32, list of result dicts, fitness scores (B,) fp64) — what align_batch + fitness_score_batch return,
+    with the searches of the candidates that finish early running under the launch chain of the others."""
+    lib = capi.load()
+    B = len(regs)
+    hs = (C.c_void_p * B)(*[r._h for r in regs])
+    g = None
+    if guesses is not None:
+        g = np.ascontiguousarray(np.stack([_mat_to_col16(x) for x in guesses]), np.float32)
+    fin = np.zeros((B, 16), np.float32)
+    res = (capi.Result * B)()
+    fit = np.zeros(B, np.float64)
+    capi.check(lib.lsr_align_fitness_batch(hs, B, g.ctypes.data_as(C.POINTER(C.c_float)) if g is not None else None,
+                                           fin.ctypes.data_as(C.POINTER(C.c_float)), res, C.c_double(max_range),
+                                           fit.ctypes.data_as(C.POINTER(C.c_double))), "align_fitness_batch")
+    finals = np.stack([_col16_to_mat(fin[b]) for b in range(B)])
+    out = []
+    for b, r in enumerate(regs):
+        r._last = capi.Result.from_buffer_copy(res[b])
+        out.append(r.last_result)
+    return finals, out, fit

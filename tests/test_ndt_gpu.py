@@ -421,3 +421,35 @@ def test_ragged_candidate_sets(case):
     finals2, _ = align_batch(regs, guesses)
     for k in range(len(sources)):
         assert np.array_equal(finals2[k], finals[k]), k            # same objects, same inputs: the same answer again
+
+
+def test_align_fitness_batch_equals_the_two_calls(case):
+    """lsr_align_fitness_batch (align + getFitnessScore of a candidate set in one call, the searches of early finishers under the
+    launch chain of the others) returns exactly what lsr_align_batch followed by lsr_get_fitness_score_batch return — same poses
+    bit for bit, same scores — for sets of 1, 5 and 19 members with sources of different size and guesses of different quality
+    (members finish between 1 and ~15 Newton iterations apart)."""
+    from lidarslam_ros2_amd import align_batch
+    from lidarslam_ros2_amd.registration import (align_fitness_batch, fitness_score_batch, set_input_source_batch,
+                                                 set_input_target_batch)
+
+    rng = np.random.default_rng(17)
+    for B in (1, 5, 19):
+        sources = [case.source[:: 1 + (k % 4)] for k in range(B)]
+        targets = [case.target if k % 3 else case.target[::2] for k in range(B)]
+        guesses = []
+        for k in range(B):
+            g = case.guess.copy()
+            g[:3, 3] += rng.normal(0, 0.02 + 0.1 * (k % 5), 3).astype(np.float32)
+            guesses.append(g)
+        a, b = [make_ndt(3.0) for _ in range(B)], [make_ndt(3.0) for _ in range(B)]
+        for regs in (a, b):
+            set_input_target_batch(regs, targets)
+            set_input_source_batch(regs, sources)
+        f1, r1 = align_batch(a, guesses)
+        s1 = fitness_score_batch(a)
+        f2, r2, s2 = align_fitness_batch(b, guesses)
+        for k in range(B):
+            assert np.array_equal(f1[k], f2[k]), (B, k)
+            assert r1[k]["iterations"] == r2[k]["iterations"] and r1[k]["converged"] == r2[k]["converged"]
+            assert s2[k] == pytest.approx(s1[k], rel=1e-12), (B, k)
+            assert b[k].getFitnessScore() == pytest.approx(s1[k], rel=1e-12)      # the objects are left as after the two calls

@@ -34,5 +34,12 @@ for it in range(8):
     t4 = time.perf_counter()
     if it >= 2:
         T["target"].append(t1 - t0); T["source"].append(t2 - t1); T["align"].append(t3 - t2); T["fitness"].append(t4 - t3)
+tf = []
+for it in range(8):
+    _capi.check(lib.lsr_set_input_target_batch(hs, N, tptr, tcnt, 32, 1), "t"); _capi.check(lib.lsr_set_input_source_batch(hs, N, sptr, scnt, 32, 1), "s")
+    t0 = time.perf_counter()
+    _capi.check(lib.lsr_align_fitness_batch(hs, N, G.ctypes.data_as(fptr), finals.ctypes.data_as(fptr), res, C.c_double(1.7976931348623157e308), fit), "af")
+    tf.append(time.perf_counter() - t0)
+print("cfg4 x%d lsr_align_fitness_batch (median ms): %.3f  (align + fitness as two calls: %.3f)" % (N, 1e3 * np.median(tf[2:]), 1e3 * (np.median(T["align"]) + np.median(T["fitness"]))), flush=True)
 print("cfg4 x%d C entries (median ms): " % N + " | ".join("%s %.3f" % (k, 1e3 * np.median(v)) for k, v in T.items()) +
       " | total %.3f" % (1e3 * sum(np.median(v) for v in T.values())), flush=True)
