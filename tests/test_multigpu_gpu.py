@@ -199,9 +199,17 @@ a = align_batch_sharded(plain, make(cases), len(cases), [c.guess for c in cases]
 plain.close()
 real = Comm(0, 1, 0, Comm.unique_id())       # ncclGetUniqueId + ncclCommInitRank(nranks = 1): the records go through ncclAllGather
 b = align_batch_sharded(real, make(cases), len(cases), [c.guess for c in cases], with_fitness=True)
-real.close()
 for x, y in zip(a, b):
     assert np.array_equal(x["T"], y["T"]) and x["iterations"] == y["iterations"] and x["fitness"] == y["fitness"] and x["converged"] == y["converged"]
+# the cost-aware plan through the same collective: members handed over longest first, table back in batch order
+from lidarslam_ros2_amd.sharding import c_shard_plan
+plan = c_shard_plan([float(len(c.source)) * (1 + k % 3) for k, c in enumerate(cases)], 1)
+order = plan.items(0)
+c = align_batch_sharded(real, make([cases[i] for i in order]), len(cases), [cases[i].guess for i in order], with_fitness=True, plan=plan)
+real.close()
+for x, y in zip(a, c):
+    assert np.array_equal(x["T"], y["T"]) and x["iterations"] == y["iterations"] and x["converged"] == y["converged"]
+    assert abs(x["fitness"] - y["fitness"]) <= 1e-6 * abs(x["fitness"])
 print("RCCL1 OK")
 """
 
