@@ -487,8 +487,11 @@ struct CoopList {
   int i;
 };
 
+// bound2: an upper bound on the k-th best distance known to the caller (the k-th entry of the list the fine shells left behind),
+// INFINITY if none: coarse cells and candidates beyond it are skipped before the list has filled up again — the walk starts
+// afresh, but it no longer reads whole 8 x 8 x 8 blocks that cannot matter.
 __device__ __forceinline__ void coop_knn(const NNGridView& G, float qx, float qy, float qz, int k, float max_d2, int self_skip,
-                                         CoopList& mine) {
+                                         CoopList& mine, const float bound2 = INFINITY) {
   const int lane = threadIdx.x & 63;
   mine.d = INFINITY;
   mine.i = INT_MAX;
@@ -526,7 +529,7 @@ __device__ __forceinline__ void coop_knn(const NNGridView& G, float qx, float qy
             bd2 += dd * dd;
           }
           bd2 *= 0.9999f;
-          if ((worst_i != INT_MAX && bd2 > worst) || bd2 > max_d2) continue;   // list full <=> last slot filled
+          if ((worst_i != INT_MAX && bd2 > worst) || bd2 > max_d2 || bd2 > bound2) continue;   // list full <=> last slot filled
           const int beg = G.block_off[blk], end = G.block_off[blk + 1];
           for (int s0 = beg; s0 < end; s0 += 64) {
             const int s = s0 + lane;
@@ -535,7 +538,7 @@ __device__ __forceinline__ void coop_knn(const NNGridView& G, float qx, float qy
             const float4 pt = G.p[sl];
             const float d = dist2_rn(qx, qy, qz, pt.x, pt.y, pt.z);
             const int oi = __float_as_int(pt.w);
-            bool qual = valid && (oi != self_skip) && (d < worst || (d == worst && oi < worst_i));
+            bool qual = valid && (oi != self_skip) && (d <= bound2) && (d < worst || (d == worst && oi < worst_i));
             unsigned long long mask = __ballot(qual);
             while (mask) {
               const int src = __ffsll((long long)mask) - 1;
@@ -566,7 +569,7 @@ __device__ __forceinline__ void coop_knn(const NNGridView& G, float qx, float qy
     }
     loc = fmaxf(loc, 0.f);
     const float loc2 = loc * loc * 0.9999f;
-    if ((worst_i != INT_MAX && worst <= loc2) || loc2 > max_d2) return;
+    if ((worst_i != INT_MAX && worst <= loc2) || loc2 > max_d2 || loc2 > bound2) return;
   }
 }
 // ---- wave-cooperative exact k-NN over the FINE grid (k <= 64; k == 1 has its own list-free form) ------------------
@@ -682,7 +685,11 @@ __device__ __forceinline__ void coop_search(const NNGridView& G, float qx, float
                                             int self_skip, CoopList& mine) {
   const CoopList seed = mine;
   if (coop_fine_knn<K1>(G, qx, qy, qz, k, fine_rings, max_d2, self_skip, mine)) return;
-  coop_knn(G, qx, qy, qz, k, max_d2, self_skip, mine);   // starts afresh (it visits every cell itself)
+  // what the fine shells found bounds the answer: the k-th entry of their list (k-NN), their best (1-NN)
+  const float kth_d = __shfl(mine.d, K1 ? 0 : k - 1, 64);
+  const int kth_i = __shfl(mine.i, K1 ? 0 : k - 1, 64);
+  const float bound2 = (kth_i != INT_MAX) ? kth_d : INFINITY;
+  coop_knn(G, qx, qy, qz, k, max_d2, self_skip, mine, bound2);   // starts afresh (it visits every cell itself)
   if (K1) {
     // coop_knn keeps the list in lane 0..k-1; hand the best (and a seed that beats it) to every lane
     float d = __shfl(mine.d, 0, 64);
