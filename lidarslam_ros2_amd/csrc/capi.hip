@@ -1422,17 +1422,22 @@ int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, si
   }
   if (batched) {
     std::vector<float> finals((size_t)k_eval * 16);
-    int st = align_ndt_batch(workers.data(), k_eval, nullptr, finals.data(), results.data());
+    // align + getFitnessScore of the k candidates (graph_based_slam_component.cpp:230-231): the searches of the candidates that
+    // finish early run under the launch chain of the others
+    std::vector<double> fit((size_t)k_eval);
+    int st = align_ndt_batch(workers.data(), k_eval, nullptr, finals.data(), results.data(), fit.data(), 1.7976931348623157e308);
     if (st) return st;
     for (int e = 0; e < k_eval; e++) {
       lsr_handle w = workers[e];
       lsr_loop_edge& E = edges[e];
       std::memset(&E, 0, sizeof(E));
       std::memcpy(E.final_transformation, finals.data() + 16 * e, sizeof(float) * 16);
-      if ((st = ensure_target_hash(w))) return st;
-      double fitness = 0;
-      if ((st = nn_fitness_score(w->source, w->final_T, w->target->hash, 1.7976931348623157e308, &fitness, w->scratch, w->d_T16, w->stream)))
-        return st;
+      double fitness = fit[e];
+      if (fitness != fitness) {   // not served under the chain (its grid is not a refinement of a counting-sort voxel grid)
+        if ((st = ensure_target_hash(w))) return st;
+        if ((st = nn_fitness_score(w->source, w->final_T, w->target->hash, 1.7976931348623157e308, &fitness, w->scratch, w->d_T16, w->stream)))
+          return st;
+      }
       E.fitness_score = fitness;
     }
     // `h` reports the best candidate like a single registration would (getFinalTransformation / hasConverged)
