@@ -411,7 +411,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   if (lead->profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   // A candidate set is scored right after it is registered (graph_based_slam_component.cpp:230-231): the neighbour grids that
   // getFitnessScore needs are refined from the voxel order NOW, on a side stream, under the launch chain — the chain is a
-  // sequence of short dependent launches that leaves most of the chip idle, the refinement is one wide launch per 16 targets.
+  // sequence of short dependent launches that does not fill the chip, the refinement is one wide launch per 16 targets.
   bool prefetched = false;
   if (B > 1 && nn_prefetch_enabled()) {
     std::vector<const VoxelGridDev*> vgs;
@@ -438,7 +438,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     }
   }
   // eager fitness: members that can be served by the group search on the side stream (their grid is there or being refined there)
-  std::vector<char> eager_ok((size_t)B, 0), eager_sent((size_t)B, 0);
+  std::vector<char> eager_ok((size_t)B, 0), eager_queued((size_t)B, 0), eager_sent((size_t)B, 0);   // eligible / finished and waiting for a group / search enqueued
   std::vector<int> eager_ready;
   bool eager = false;
   if (fitness_out && B > 1 && nn_prefetch_enabled()) {
@@ -460,7 +460,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   const NdtMailbox* MB = lead->mailbox.p;
   auto eager_dispatch = [&](bool all) -> int {
     for (int b = 0; b < B; b++)
-      if (eager_ok[b] && !eager_sent[b] && __atomic_load_n(&MB[b].done, __ATOMIC_ACQUIRE) == token) { eager_sent[b] = 1; eager_ready.push_back(b); }
+      if (eager_ok[b] && !eager_queued[b] && __atomic_load_n(&MB[b].done, __ATOMIC_ACQUIRE) == token) { eager_queued[b] = 1; eager_ready.push_back(b); }
     // a launch group serves up to 12 members: wait for a full group while the chain is still running
     while (!eager_ready.empty() && (all || eager_ready.size() >= 12)) {
       const int n = (int)std::min<size_t>(12, eager_ready.size());
@@ -471,6 +471,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
       }
       const int fst = nn_fitness_begin_group(jobs.data(), n, lead->side_stream);
       if (fst) return fst;
+      for (int k = 0; k < n; k++) eager_sent[eager_ready[k]] = 1;
       eager_ready.erase(eager_ready.begin(), eager_ready.begin() + n);
     }
     return LSR_OK;
