@@ -731,6 +731,13 @@ int lsr_get_i32(lsr_handle h, int key, int* v) {
 
 static int set_target_impl(lsr_handle h, const void* pts, size_t stride, size_t n, bool on_device) {
   LSR_CHECK_HANDLE(h);
+  if (h->method == LSR_METHOD_NDT && !h->scratch.force_sort_path) {
+    // a set of one: de-interleave and bounding box in one launch, the same counting-sort kernels (661k-point submap: 104 -> 94 us)
+    lsr_handle one[1] = {h};
+    const void* cloud[1] = {pts};
+    const size_t count[1] = {n};
+    return lsr_set_input_target_batch(one, 1, cloud, count, stride, on_device ? 1 : 0);
+  }
   auto t = fresh_target(h);
   int st = upload_cloud(h, pts, stride, n, on_device, t->cloud);
   if (st) return st;
