@@ -129,14 +129,14 @@ def main():
     cache = None
     if os.environ.get("LSR_BENCH_CACHE_DIR"):
         cache = os.path.join(os.environ["LSR_BENCH_CACHE_DIR"],
-                             f"bench_r{rank}w{world}_s{n_stream}_c{args.candidates}_e{int(extras)}.pkl")
+                             f"bench2_r{rank}w{world}_s{n_stream}_c{args.candidates}_e{int(extras)}.pkl")
     if cache and os.path.exists(cache):
         import pickle
         with open(cache, "rb") as f:
             case, stream, cands, dense, gc = pickle.load(f)
     else:
         with mp.get_context("fork").Pool(nwork) as pool:
-            case = synth.cfg_ndt_30k(seed=0, pool=pool)                 # the 10-frame submap (same on every rank) + its own next scan
+            case = synth.cfg_ndt_30k(seed=0, pool=pool, keep_parts=(extras and rank == 0))   # the 10-frame submap (same on every rank) + its own next scan
             stream = synth.cfg_scan_stream(n_stream, seed=rank, pool=pool)   # this rank's scan stream
             cands = pool.map(_candidate_job, my_cands, chunksize=1) if my_cands else []
             dense = synth.cfg_dense_120k(seed=rank, pool=pool) if extras else None   # every rank: its own cfg 5 scan + submap
@@ -351,7 +351,8 @@ def main():
         if world == 1 and extras:
             legs = [("set_input_target", lambda: target_leg(ndt, tgt_dev, case)),
                     ("scan_stream", lambda: stream_leg(args, lib, make_ndt, ndt, stream, src_dev, g16, n_src_pts, torch, synth)),
-                    ("loop_gate", lambda: loop_gate_leg(dev_index, tstream, torch, synth, stash))]
+                    ("loop_gate", lambda: loop_gate_leg(dev_index, tstream, torch, synth, stash)),
+                    ("next_rows", lambda: next_rows_leg(case, dev_index, tstream, torch, synth, args))]
             for name, fn in legs:
                 try:
                     out[name] = fn()
@@ -612,6 +613,77 @@ def gicp_leg(gc, dev_index, tstream, torch, synth):
     except (OSError, ValueError, KeyError):
         pass
     return s
+
+
+def next_rows_leg(case, dev_index, tstream, torch, synth, args):
+    """SURVEY.md 8f rows N1 / N2 / N4 measured on what the frontend holds BEFORE its preprocessing: the raw source scan and the ten
+    keyframe clouds of the cfg-1/2 submap.  N1+N4: range filter + VoxelGrid(0.2) + setInputSource from the PointCloud2 payload
+    (scanmatcher_component.cpp:201-218,324-329) — payload resident in HBM, and from a host payload (PCIe-inclusive); the
+    toROSMsg direction.  N2: transformPointCloud x 10 + concatenation + setInputTarget (:449-464,307) against setInputTarget of
+    the already assembled submap.  The CPU figures are the oracle's restatements on one thread (bounded: a few calls)."""
+    from lidarslam_ros2_amd import NormalDistributionsTransform
+
+    if case.raw_source is None or case.frames is None:
+        return {"skipped": "workload generated without its parts"}
+    out = {}
+    med = lambda ts: 1e3 * float(np.median(ts))
+    ndt = NormalDistributionsTransform(device=dev_index, stream=tstream)
+    ndt.setResolution(5.0)
+    raw = synth.as_pointxyzi(case.raw_source)                       # (n, 8) fp32 = pcl::PointXYZI records, intensity 0
+    n_raw = int(raw.shape[0])
+    raw_dev = torch.from_numpy(raw).cuda()
+    payload_host = raw.view(np.uint8).reshape(n_raw, 32)
+    payload_dev = torch.from_numpy(payload_host.copy()).cuda()
+    torch.cuda.synchronize()
+    rmin, rmax, leaf = 0.1, 100.0, 0.2                              # scan_min_range / scan_max_range / vg_size_for_input (scanmatcher_component.cpp:42-45)
+
+    def timed(fn, reps=15, warm=3):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t0)
+        return med(ts), r
+
+    t_dev, n_kept = timed(lambda: ndt.setInputSourceFrontend(raw_dev, rmin, rmax, leaf))
+    t_pc2_dev, n_kept2 = timed(lambda: ndt.setInputSourcePointCloud2(payload_dev, n_raw, 32, (0, 4, 8, 16), rmin, rmax, leaf))
+    t_pc2_host, _ = timed(lambda: ndt.setInputSourcePointCloud2(payload_host, n_raw, 32, (0, 4, 8, 16), rmin, rmax, leaf))
+    t_get, back = timed(lambda: ndt.getInputSourcePointCloud2())
+    bytes_n1 = n_raw * 16 + int(n_kept) * 16
+    out["source_preprocess"] = {"raw_points": n_raw, "points_kept": int(n_kept), "pc2_points_kept": int(n_kept2),
+                                "ms_device_records": t_dev, "ms_device_pointcloud2_payload": t_pc2_dev,
+                                "ms_host_pointcloud2_payload_pcie_inclusive": t_pc2_host, "ms_get_source_pointcloud2_to_host": t_get,
+                                "algorithmic_GBps_device_payload": bytes_n1 / (t_pc2_dev * 1e-3) / 1e9,
+                                "what": "range filter [0, 100 m] + VoxelGrid(0.2) incl. intensity + setInputSource (N1 + N4)"}
+    # N2: submap assembly on the device
+    frames_dev = [torch.from_numpy(synth.as_pointxyzi(f)).cuda() for f in case.frames]
+    tgt_dev = torch.from_numpy(synth.as_pointxyzi(case.target)).cuda()
+    torch.cuda.synchronize()
+    t_frames, _ = timed(lambda: ndt.setInputTargetFrames(frames_dev, case.frame_poses), reps=12)
+    grid_frames = ndt.gridInfo()
+    t_plain, _ = timed(lambda: ndt.setInputTarget(tgt_dev), reps=12)
+    grid_plain = ndt.gridInfo()
+    n_t = int(case.target.shape[0])
+    out["submap_assembly"] = {"frames": len(case.frames), "target_points": n_t, "ms_frames_to_voxel_grid": t_frames,
+                              "ms_assembled_cloud_to_voxel_grid": t_plain, "ms_assembly_alone": t_frames - t_plain,
+                              "same_voxel_grid": bool(grid_frames["n_valid"] == grid_plain["n_valid"] and
+                                                      np.array_equal(grid_frames["min_b"], grid_plain["min_b"])),
+                              "assembly_GBps": (n_t * (32 + 12)) / (max(t_frames - t_plain, 1e-6) * 1e-3) / 1e9,
+                              "what": "10 x transformPointCloud + concatenation + setInputTarget from HBM-resident keyframes (N2)"}
+    if not args.no_cpu:
+        from oracle import oracle as O
+
+        t0 = time.perf_counter()
+        r64 = np.sqrt(case.raw_source[:, 0].astype(np.float64) ** 2 + case.raw_source[:, 1].astype(np.float64) ** 2)
+        kept = case.raw_source[(rmin < r64) & (r64 < rmax)]          # the reference's test: horizontal range, open interval
+        v = O.voxel_grid_filter_xyzi(synth.as_pointxyzi(kept), leaf, 4)
+        t_cpu = time.perf_counter() - t0
+        got = back.view(np.float32).reshape(-1, 8)[:, [0, 1, 2, 4]]
+        out["source_preprocess"]["cpu_port_ms"] = 1e3 * t_cpu
+        out["source_preprocess"]["parity_vs_cpu"] = {"same_count": bool(v.shape[0] == got.shape[0]),
+                                                     "max_abs_diff": float(np.abs(v - got).max()) if v.shape == got.shape else None}
+    ndt.close()
+    return out
 
 
 def loop_gate_leg(dev_index, tstream, torch, synth, stash):

@@ -265,13 +265,17 @@ class RegistrationCase:
     guess: np.ndarray        # (4,4) fp32
     truth: np.ndarray        # (4,4) fp64 ground-truth source->map pose
     name: str = ""
+    # the parts the case was assembled from (keep_parts=True): what the frontend holds BEFORE its own preprocessing
+    raw_source: "np.ndarray | None" = None      # the source scan as the sensor delivers it (no VoxelGrid, no sub-sampling)
+    frames: "list | None" = None                # the keyframe clouds, VoxelGrid(vg_map)-filtered, each in its OWN sensor frame
+    frame_poses: "list | None" = None           # their poses (4x4): target = concat(pose_k * frame_k)
 
 
 def make_case(*, sensor: Sensor | None = None, world: World | None = None, n_keyframes: int = 10,
               start_x: float = 0.0, keyframe_spacing: float = 1.5, scan_spacing: float = 0.5,
               vg_map: float = 0.1, vg_input: float = 0.2, n_source: int | None = 30000,
               vg_target: float | None = None, guess_perturb: tuple | None = None, seed: int = 0,
-              azimuth_oversample: int = 1, name: str = "", pool=None) -> RegistrationCase:
+              azimuth_oversample: int = 1, name: str = "", pool=None, keep_parts: bool = False) -> RegistrationCase:
     """Frontend-style case: target = n_keyframes scans (each VoxelGrid(vg_map), moved to the map
     frame, concatenated without re-filtering: scanmatcher_component.cpp:452-464); source = the
     next scan, VoxelGrid(vg_input) then cut to exactly n_source points; guess = pose of the
@@ -287,9 +291,10 @@ def make_case(*, sensor: Sensor | None = None, world: World | None = None, n_key
     T_src = trajectory_pose(x_src)
     poses = [trajectory_pose(start_x + keyframe_spacing * k) for k in range(n_keyframes)] + [T_src]
     scans = raycast_many(world, sensor, poses, rng, pool)   # `pool` only parallelises the intersections: same clouds
-    chunks = []
+    chunks, frames = [], []
     for k in range(n_keyframes):
-        chunks.append(transform_points(poses[k], voxel_downsample(scans[k], vg_map)))
+        frames.append(voxel_downsample(scans[k], vg_map))
+        chunks.append(transform_points(poses[k], frames[k]))
     target = np.concatenate(chunks, 0)
     if vg_target is not None:  # GICP frontend path re-filters the target (scanmatcher_component.cpp:309-315)
         target = voxel_downsample(target, vg_target)
@@ -301,15 +306,19 @@ def make_case(*, sensor: Sensor | None = None, world: World | None = None, n_key
     else:
         dx, dy, dyaw = guess_perturb
         guess = pose_matrix(x_src + dx, dy, 0.0, 0.02 * math.sin(0.1 * x_src) + dyaw)
+    if keep_parts:
+        return RegistrationCase(target, src, guess.astype(np.float32), T_src, name, raw_source=scans[n_keyframes], frames=frames,
+                                frame_poses=[np.asarray(P, np.float64) for P in poses[:n_keyframes]])
     return RegistrationCase(target, src, guess.astype(np.float32), T_src, name)
 
 
 # ---- BASELINE.json configs ---------------------------------------------------------------
-def cfg_ndt_30k(seed: int = 0, start_x: float = 0.0, guess_perturb=None, world: World | None = None, pool=None) -> RegistrationCase:
+def cfg_ndt_30k(seed: int = 0, start_x: float = 0.0, guess_perturb=None, world: World | None = None, pool=None,
+                keep_parts: bool = False) -> RegistrationCase:
     """cfg 1/2: 30k-pt VLP-32 scan (vg 0.2) vs 10-frame submap (vg 0.1)."""
     return make_case(sensor=vlp32(), n_keyframes=10, vg_map=0.1, vg_input=0.2, n_source=30000, seed=seed,
                      start_x=start_x, guess_perturb=guess_perturb, world=world, azimuth_oversample=3,
-                     name="ndt_30k_vs_10frame", pool=pool)
+                     name="ndt_30k_vs_10frame", pool=pool, keep_parts=keep_parts)
 
 
 def cfg_scan_stream(n_scans: int, seed: int = 0, pool=None, world: World | None = None) -> list:
