@@ -879,21 +879,22 @@ __device__ int gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb,
     }
   } else {
     const double m = (double)S->m;
-    double g[6], H[36];
+    double g[6];
     S->f = s_sum[0] / m;
     for (int k = 0; k < 6; k++) g[k] = 2.0 * s_sum[1 + k] / m;
-    int idx = 7;
-    for (int i = 0; i < 6; i++)
-      for (int j = i; j < 6; j++) {
-        H[i * 6 + j] = H[j * 6 + i] = 2.0 * s_sum[idx] / m;
-        idx++;
-      }
     double gn = 0;
     for (int k = 0; k < 6; k++) gn += g[k] * g[k];
     gn = sqrt(gn);
     S->gnorm = gn;
     if (!(gn < 1e-2 || S->inner_iter >= S->max_inner || !(gn == gn))) {  // else BFGS testGradient(1e-2) / max_inner_iterations_: loop over
-      if (need_solve) { *need_solve = 1; return -1; }
+      if (need_solve) { *need_solve = 1; return -1; }   // the wave forms H itself (solve6_gn_wave): 21 fp64 divisions less on this lane
+      double H[36];
+      int idx = 7;
+      for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) {
+          H[i * 6 + j] = H[j * 6 + i] = 2.0 * s_sum[idx] / m;
+          idx++;
+        }
       double neg[6], dx[6];
       for (int k = 0; k < 6; k++) neg[k] = -g[k];
       solve6_gn(H, neg, dx);
