@@ -81,19 +81,23 @@ int device_cus(int device) {
 
 // Workgroups per registration.  Every workgroup of a pass pays the fixed head of the launch (totals of the previous pass,
 // controller step, next request: 2.5-4 us) before it evaluates a point, so a pass never launches more workgroups than the
-// chip holds at once — two per CU for both kernels (quad kernel: 8 waves of <= 128 VGPRs; one-lane kernel: 4 waves of <= 256)
-// — and lets each of them walk several batches of points instead.  (Round 2 launched ceil(n / 128) workgroups: at cfg 5 that
-// was 938 of them taking turns on 256 CUs, each turn with its own head.)
-constexpr int NDT_WGS_PER_CU = 2;
+// chip holds at once — 2048 threads per CU: two 512-thread workgroups of the quad kernel (128 points each) or of the lane
+// kernel, one of its 1024-thread workgroups — and lets each of them walk several batches of points instead.
+// `threads`: THREADS per workgroup; `points`: source points a workgroup takes per trip (quad kernel: threads / 4).
 constexpr int NDT_QUAD_BATCH_MAX = 1;
-int ndt_nblocks(size_t n, int device, int batch = 1, int threads = NDT_THREADS) {
-  int nb = (int)((n + threads - 1) / threads);
-  static const int wgs_per_cu = [] { const char* e = std::getenv("LSR_NDT_WGS_PER_CU"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= 8) ? v : NDT_WGS_PER_CU; }();
-  const int resident = device_cus(device) * wgs_per_cu;
-  const int share = std::max(1, resident / std::max(1, batch));
+int ndt_resident_wgs(int device, int threads) {
+  static const int wgs_per_cu = [] { const char* e = std::getenv("LSR_NDT_WGS_PER_CU"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 0; }();
+  return device_cus(device) * (wgs_per_cu ? wgs_per_cu : std::max(1, 2048 / std::max(64, threads)));
+}
+int ndt_nblocks(size_t n, int device, int batch, int threads, int points) {
+  int nb = (int)((n + points - 1) / points);
+  const int share = std::max(1, ndt_resident_wgs(device, threads) / std::max(1, batch));
   nb = std::max(1, std::min(nb, std::min(share, NDT_MAX_BLOCKS)));
   return nb;
 }
+// workgroup geometry of a launch configuration
+int cfg_wg_threads(const NdtLaunchCfg& cfg) { return cfg.quad ? 4 * cfg.threads : cfg.threads; }
+int cfg_wg_points(const NdtLaunchCfg& cfg) { return cfg.threads; }
 
 // LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock; 160 KiB on gfx950): the table modes that
 // stage into LDS are only chosen when their buffers fit, anything else reads the global table.
@@ -111,14 +115,14 @@ int device_lds_bytes(int device) {
   return v;
 }
 constexpr int NDT_QUAD_STATIC_LDS = 32 * 1024;   // static LDS of the quad kernel next to its table / tile buffer (27 KiB + margin)
-constexpr int NDT_ROW_STATIC_LDS = 12 * 1024;    // ... of the one-lane kernel (256 threads)
+constexpr int NDT_LANE_STATIC_LDS = 6 * 1024;    // ... of the lane kernel (bins, state image; its staging tiles are dynamic LDS)
 
-void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_partials, const NdtLaunchCfg& cfg) {
+void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, long long* d_bins, const NdtLaunchCfg& cfg) {
   const VoxelGridDev& g = h->target->grid;
   const DeviceCloud& src = cfg.sorted ? h->source_sorted : h->source;   // the tile-ordered copy (always in tile mode)
   P.sx = src.x(); P.sy = src.y(); P.sz = src.z();
   P.n = (int)h->source.n;
-  P.nblocks = ndt_nblocks(h->source.n, h->device, cfg.batch, cfg.threads);
+  P.nblocks = ndt_nblocks(h->source.n, h->device, cfg.batch, cfg_wg_threads(cfg), cfg_wg_points(cfg));
   P.lds_image = g.lds_image.p;
   P.lds_map_bytes = g.lds_map_bytes;
   P.lds_bytes = g.lds_bytes;
@@ -130,8 +134,7 @@ void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, double* d_part
   P.leaf = g.leaf;
   P.tile_bytes = (cfg.tab == NDT_TAB_TILE) ? cfg.lds_bytes : 0;
   P.st = d_state;
-  P.partials = d_partials;
-  P.bins = h->d_bins.p;
+  P.bins = d_bins;
   P.mailbox = nullptr;
 }
 
@@ -152,12 +155,14 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   }
   const int lds_cap = device_lds_bytes(lead->device);
   const int override_mode = lead->ndt_table_mode;
-  // four lanes per point for ONE registration; batches use the one-lane kernel — measured on cfg-4 sets of 8 / 16 / 64 candidates
-  // (align stage): one-lane 0.61 / 0.90 / 2.73 ms, four-lane 0.76 / 1.09 / 4.06 ms (env LSR_NDT_QUAD_BATCH_MAX raises the batch
-  // size up to which the four-lane kernel is used; read once)
+  // four lanes per point for ONE registration (latency: a 30k-point scan on every CU); the lane kernel for candidate sets and
+  // on request (LSR_NDT_QUAD = 0) — both return the same bits, so the choice is a matter of speed only.  Measured on cfg-4 sets of
+  // 8 / 16 / 64 candidates (align stage, round 3's kernels): one lane per point 0.61 / 0.90 / 2.73 ms, four lanes 0.76 / 1.09 / 4.06 ms
+  // (env LSR_NDT_QUAD_BATCH_MAX raises the batch size up to which the four-lane kernel is used; read once)
   static const int quad_batch_max = [] { const char* e = std::getenv("LSR_NDT_QUAD_BATCH_MAX"); const int v = e ? std::atoi(e) : NDT_QUAD_BATCH_MAX; return v < 1 ? 1 : v; }();
   const bool want_quad_single = (B <= quad_batch_max && lead->ndt_quad != 0);
-  const int static_lds = want_quad_single ? NDT_QUAD_STATIC_LDS : NDT_ROW_STATIC_LDS;
+  const int lane_threads = (lead->ndt_threads == 512 || lead->ndt_threads == 1024) ? lead->ndt_threads : NDT_LANE_THREADS;
+  const int static_lds = want_quad_single ? NDT_QUAD_STATIC_LDS : NDT_LANE_STATIC_LDS + ndt_lane_tile_bytes(lane_threads);
   const int table_cap = std::min(want_quad_single ? NDT_LDS_TABLE_MAX_QUAD : NDT_LDS_TABLE_MAX, lds_cap - static_lds);
   const bool lds_ok = all_lds && lds_max <= table_cap;
   const bool tile_ok = all_dense && lead->ndt_quad != 0 && lead->ndt_sort != 0 && NDT_TILE_BYTES + NDT_QUAD_STATIC_LDS <= lds_cap;
@@ -173,7 +178,7 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   cfg.quad = (want_quad_single || tab == NDT_TAB_TILE) ? 1 : 0;
   cfg.lds_bytes = (tab == NDT_TAB_LDS) ? lds_max : (tab == NDT_TAB_TILE ? NDT_TILE_BYTES : 0);
   if (cfg.quad) cfg.threads = (lead->ndt_threads == 64 || lead->ndt_threads == 128) ? lead->ndt_threads : NDT_QUAD_POINTS;  // POINTS per workgroup
-  else cfg.threads = (lead->ndt_threads == 128 || lead->ndt_threads == 256) ? lead->ndt_threads : NDT_THREADS;
+  else cfg.threads = lane_threads;
   // source ordered by voxel tile: always for the tile mode (its boxes are small only then); for global-table gathers on request
   // (LSR_NDT_SORT = 1): neighbouring lanes then read neighbouring records
   cfg.sorted = (tab == NDT_TAB_TILE) || (lead->ndt_sort == 1 && tab != NDT_TAB_LDS);
@@ -226,6 +231,12 @@ bool nn_prefetch_enabled() {
   return on;
 }
 
+// A/B switch (env LSR_NDT_WIDEN=0: the launches of a candidate set keep their first geometry)
+bool lane_widen_enabled() {
+  static const bool on = [] { const char* e = getenv("LSR_NDT_WIDEN"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 bool hash_from_grid_possible(lsr_handle h) {
   // A/B switch (env LSR_NN_FROM_GRID=0: always build the neighbour grid from the cloud); read once
   static const bool enabled = [] { const char* e = getenv("LSR_NN_FROM_GRID"); return !(e && e[0] == '0'); }();
@@ -258,8 +269,12 @@ int ensure_target_hash(lsr_handle h) {
 // queued ahead of the device and never synchronises the stream or copies state back inside the chain; after the last
 // `done` at most LOW_WATER + REFILL queued launches remain, which exit at their head.
 // on_poll (nullable): called between polls while the chain runs (the eager fitness dispatch of a candidate set hangs off it).
-int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_probs, const NdtLaunchCfg& cfg, int first, int hard_cap,
-                   unsigned int token, int* launches_out, const std::function<int()>* on_poll = nullptr) {
+// nb_full > 0 (lane kernel, candidate sets): the launches are widened as members finish — grid.x = resident workgroups /
+// members still running, at most nb_full (= one trip per lane for the largest member); the canonical sum does not depend on it.
+int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_probs, const NdtLaunchCfg& cfg_in, int first, int hard_cap,
+                   unsigned int token, int* launches_out, const std::function<int()>* on_poll = nullptr, int nb_full = 0) {
+  NdtLaunchCfg cfg = cfg_in;
+  const int resident = ndt_resident_wgs(h->device, cfg_wg_threads(cfg));
   // spin: two launches queued ahead are enough; yield / sleep give the core away between polls, so more launches are
   // kept queued to ride out the scheduler's latency (surplus launches exit at their head, ~2 us each)
   const int wait_mode = h->scratch.wait_mode;
@@ -281,6 +296,11 @@ int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_
     const int entered = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : -1;  // -1: nothing of this align yet
     if (launched < hard_cap && launched - 1 - entered < LOW_WATER) {
       const int c = std::min(REFILL, hard_cap - launched);
+      if (nb_full > 0 && batch > 1) {
+        int running = 0;
+        for (int b = n_done; b < batch; b++) running += (__atomic_load_n(&mb[b].done, __ATOMIC_RELAXED) != token);
+        cfg.max_blocks = std::max(cfg_in.max_blocks, std::min(nb_full, resident / std::max(1, running)));
+      }
       if ((st = ndt_launch_evals(d_probs, h_single, cfg, launched, c, h->stream))) return st;
       launched += c;
       continue;
@@ -356,19 +376,9 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   cfg.batch = B;
   cfg.neighborhood = lead->ndt.neighborhood;
   choose_table_mode(lead, hs, B, cfg);
-  if (cfg.quad) {   // accumulator banks of the quad kernel, one set per member, cleared before launch 0
-    if ((st = lead->d_bins.reserve((size_t)B * NDT_NBANKS * NDT_BANK_WORDS))) return st;
-  }
-  size_t tot_blocks = 0;
-  int max_blocks = 1;
-  for (int b = 0; b < B; b++) {
-    int nb = ndt_nblocks(hs[b]->source.n, lead->device, B, cfg.threads);
-    tot_blocks += nb;
-    max_blocks = std::max(max_blocks, nb);
-  }
-  cfg.max_blocks = max_blocks;
-  if ((st = lead->d_partials.reserve(2 * tot_blocks * NDT_NRED))) return st;
-  size_t blk_off = 0;
+  // accumulator banks, one set per member, cleared before launch 0
+  if ((st = lead->d_bins.reserve((size_t)B * NDT_NBANKS * NDT_BANK_WORDS))) return st;
+  int max_blocks = 1, nb_full = 1;
   int min_evals = 1, hard_cap = 1;
   long pts = 0;
   for (int b = 0; b < B; b++) {
@@ -379,13 +389,15 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
       // order this member's source by voxel tile of its guess-moved points (4 launches on the chain's stream)
       if ((st = ndt_sort_source(h->source, lead->h_state.p[2 * b].T, h->target->grid, h->source_sorted, h->scratch, lead->stream))) return st;
     }
-    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_partials.p + 2 * blk_off * NDT_NRED, cfg);
-    lead->h_prob.p[b].bins = cfg.quad ? lead->d_bins.p + (size_t)b * NDT_NBANKS * NDT_BANK_WORDS : nullptr;
-    blk_off += lead->h_prob.p[b].nblocks;
+    fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_bins.p + (size_t)b * NDT_NBANKS * NDT_BANK_WORDS, cfg);
+    max_blocks = std::max(max_blocks, lead->h_prob.p[b].nblocks);
+    nb_full = std::max(nb_full, (int)((h->source.n + cfg_wg_points(cfg) - 1) / cfg_wg_points(cfg)));
     min_evals = std::max(min_evals, ndt_min_evals(h->ndt));
     hard_cap = std::max(hard_cap, ndt_hard_cap(h->ndt));
     pts += (long)h->source.n;
   }
+  cfg.max_blocks = max_blocks;
+  nb_full = std::min(nb_full, NDT_MAX_BLOCKS);
   // host mailboxes, one per registration (pinned, host-coherent, mapped into the device)
   if ((size_t)B > lead->mailbox.cap) {
     LSR_HIP(hipStreamSynchronize(lead->stream));  // launches still queued from the previous align report into the old block
@@ -403,10 +415,10 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   if (B > 1)  // a single registration carries its NdtProblem in the kernel arguments
     LSR_HIP(hipMemcpyAsync(lead->d_prob.p, lead->h_prob.p, sizeof(NdtProblem) * B, hipMemcpyHostToDevice, lead->stream));
   if (B == 1) {  // state in the kernel arguments of one small launch (no SDMA copy, no memset)
-    if ((st = ndt_init_single(lead->h_state.p[0], lead->d_state.p, cfg.quad ? lead->d_bins.p : nullptr, lead->stream))) return st;
+    if ((st = ndt_init_single(lead->h_state.p[0], lead->d_state.p, lead->d_bins.p, lead->stream))) return st;
   } else {
     LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
-    if (cfg.quad) LSR_HIP(hipMemsetAsync(lead->d_bins.p, 0, sizeof(long long) * (size_t)B * NDT_NBANKS * NDT_BANK_WORDS, lead->stream));
+    LSR_HIP(hipMemsetAsync(lead->d_bins.p, 0, sizeof(long long) * (size_t)B * NDT_NBANKS * NDT_BANK_WORDS, lead->stream));
   }
   if (lead->profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   // A candidate set is scored right after it is registered (graph_based_slam_component.cpp:230-231): the neighbour grids that
@@ -478,7 +490,8 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   };
   const std::function<int()> poll_hook = [&]() { return eager_dispatch(false); };
   int launches = 0;
-  st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, cfg, min_evals, hard_cap, token, &launches, eager ? &poll_hook : nullptr);
+  st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, cfg, min_evals, hard_cap, token, &launches, eager ? &poll_hook : nullptr,
+                      (!cfg.quad && lane_widen_enabled()) ? nb_full : 0);
   if (eager && !st) st = eager_dispatch(true);
   if (prefetched || eager) {
     // the side stream's work — grid refinement, searches — ends here: every later use of the grids and of the members' scratch
@@ -587,7 +600,7 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   h->ndt.resolution = 1.0; h->ndt.step_size = 0.1; h->ndt.outlier_ratio = 0.55; h->ndt.trans_eps = 0.1;
   h->ndt.max_iterations = 35; h->ndt.neighborhood = LSR_DIRECT7; h->ndt.d1_sign = 1;
   // tuning defaults may be preset from the environment (A/B runs without touching the caller)
-  if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) h->ndt_threads = v; }
+  if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 512 || v == 1024) h->ndt_threads = v; }
   if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 3) h->ndt_table_mode = v; }
   if (const char* e = std::getenv("LSR_NDT_QUAD")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_quad = v; }
   if (const char* e = std::getenv("LSR_NDT_SORT")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_sort = v; }
@@ -684,7 +697,7 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
     case LSR_HESSIAN_D1_SIGN: h->ndt.d1_sign = (v >= 0) ? 1 : -1; return LSR_OK;
     case LSR_PROFILE: h->profile = v ? 1 : 0; return LSR_OK;
     case LSR_NDT_WORKGROUP:
-      if (v != 0 && v != 64 && v != 128 && v != 256) { set_last_error("NDT workgroup key must be 0 (auto), 64, 128 or 256"); return LSR_ERR_INVALID_ARGUMENT; }
+      if (v != 0 && v != 64 && v != 128 && v != 512 && v != 1024) { set_last_error("NDT workgroup key must be 0 (auto), 64 / 128 (quad kernel: points) or 512 / 1024 (lane kernel: threads)"); return LSR_ERR_INVALID_ARGUMENT; }
       h->ndt_threads = v; return LSR_OK;
     case LSR_NDT_TABLE_MODE:
       if (v < -1 || v > 3) { set_last_error("NDT table mode must be -1 (auto), 0 dense, 1 compact, 2 LDS, 3 tile"); return LSR_ERR_INVALID_ARGUMENT; }
@@ -1551,20 +1564,16 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
     lsr_handle one[1] = {h};
     choose_table_mode(h, one, 1, cfg);
   }
-  if (cfg.quad) {
-    if ((st = h->d_bins.reserve((size_t)NDT_NBANKS * NDT_BANK_WORDS))) return st;
-    LSR_HIP(hipMemsetAsync(h->d_bins.p, 0, sizeof(long long) * NDT_NBANKS * NDT_BANK_WORDS, h->stream));
-  }
-  int nb = ndt_nblocks(h->source.n, h->device, 1, cfg.threads);
-  cfg.max_blocks = nb;
-  if ((st = h->d_partials.reserve(2 * (size_t)nb * NDT_NRED))) return st;
+  if ((st = h->d_bins.reserve((size_t)NDT_NBANKS * NDT_BANK_WORDS))) return st;
+  LSR_HIP(hipMemsetAsync(h->d_bins.p, 0, sizeof(long long) * NDT_NBANKS * NDT_BANK_WORDS, h->stream));
+  cfg.max_blocks = ndt_nblocks(h->source.n, h->device, 1, cfg_wg_threads(cfg), cfg_wg_points(cfg));
   ndt_fill_diag_state(h->h_state.p[0], p6, T16, compute_hessian, h->ndt, (int)h->source.n);
   h->h_state.p[1] = h->h_state.p[0];
   if (cfg.sorted && (st = ndt_sort_source(h->source, h->h_state.p[0].T, h->target->grid, h->source_sorted, h->scratch, h->stream))) return st;
-  fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_partials.p, cfg);
+  fill_problem(h->h_prob.p[0], h, h->d_state.p, h->d_bins.p, cfg);
   LSR_HIP(hipMemcpyAsync(h->d_prob.p, h->h_prob.p, sizeof(NdtProblem), hipMemcpyHostToDevice, h->stream));
   LSR_HIP(hipMemcpyAsync(h->d_state.p, h->h_state.p, 2 * sizeof(NdtState), hipMemcpyHostToDevice, h->stream));
-  // launch 0 evaluates, launch 1 sums the rows into the state (PH_DIAG) -> state buffer (2 & 1) = 0
+  // launch 0 evaluates, launch 1 folds the bank into the state (PH_DIAG) -> state buffer (2 & 1) = 0
   if ((st = ndt_launch_evals(h->d_prob.p, h->h_prob.p, cfg, 0, 2, h->stream))) return st;
   LSR_HIP(hipMemcpyAsync(h->h_state.p, h->d_state.p, sizeof(NdtState), hipMemcpyDeviceToHost, h->stream));
   LSR_HIP(hipStreamSynchronize(h->stream));

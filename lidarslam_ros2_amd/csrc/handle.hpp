@@ -26,9 +26,9 @@ struct lsr_handle_s {
   double euclidean_fitness_eps = -1.7976931348623157e308;
   int num_threads = 0, ransac_iterations = 0;
   int profile = 0;
-  int ndt_threads = 0;       // LSR_NDT_WORKGROUP: 0 = automatic, 128 / 256
+  int ndt_threads = 0;       // LSR_NDT_WORKGROUP: 0 = automatic; quad kernel: 64 / 128 points, lane kernel: 512 / 1024 threads
   int ndt_table_mode = -1;   // LSR_NDT_TABLE_MODE: -1 = automatic, else lsr::NdtTableMode
-  int ndt_quad = -1;         // LSR_NDT_QUAD: -1 = automatic (single registrations), 0 = one lane per point, 1 = four
+  int ndt_quad = -1;         // LSR_NDT_QUAD: -1 = automatic (single registrations: four lanes per point), 0 = lane kernel, 1 = four
   int ndt_sort = -1;         // LSR_NDT_SORT: -1 = automatic (tile mode only), 0 = never, 1 = also for global-table gathers
 
   std::shared_ptr<TargetData> target;
@@ -47,8 +47,7 @@ struct lsr_handle_s {
 
   // NDT run-time buffers (batch-capable: the leader of a batch owns arrays for all members)
   DevBuf<NdtState> d_state;
-  DevBuf<double> d_partials;
-  DevBuf<long long> d_bins;   // quad kernel: NDT_NBANKS banks of int64 accumulators
+  DevBuf<long long> d_bins;   // NDT_NBANKS banks of int64 accumulators per registration (exact chunk sums, ndt.hip: canon)
   DevBuf<NdtProblem> d_prob;
   PinBuf<NdtState> h_state;
   PinBuf<NdtProblem> h_prob;

@@ -774,299 +774,89 @@ struct Offsets<27> {
   }
 };
 
-// One derivative pass (K3) preceded by the controller step (K4) that consumes the PREVIOUS pass.
-//
-// "Pull" structure: launch number `seq` starts — in EVERY workgroup, redundantly and deterministically
-// — by summing the partial rows launch seq-1 left behind (fixed order), advancing the Newton /
-// More-Thuente controller on an LDS image of the state and building the next evaluation request;
-// only then does it evaluate its own points and leave its partial row.  No workgroup ever waits for
-// another one inside a launch: no tickets, no atomics, no write-through stores, no tail executed by a
-// single workgroup — the kernel boundary is the only synchronisation.  State and rows are double
-// buffered by launch parity (launch seq reads state[seq&1], rows[(seq-1)&1]; workgroup 0 writes
-// state[(seq+1)&1]; everybody writes rows[seq&1]), so a late-starting workgroup can never observe a
-// value produced by its own launch.
-//  BYVAL: a single-registration launch carries its NdtProblem in the kernel arguments, which removes
-//         one dependent memory round trip from the latency chain of every pass.
-//  TAB:   where the leaf records live (NdtTableMode).  NDT_TAB_LDS stages the whole valid-voxel table
-//         (uint16 cell->slot map + 48-byte records, <= NDT_LDS_TABLE_MAX) into LDS with wave-wide 16-byte
-//         global->LDS DMA issued right after the state has landed: the copy flies while one lane runs the
-//         controller, and the 7 x 3 dependent gathers of a point become ds_read_b128 (no L2 round trip).
-//  THREADS: workgroup size (256: fewer partial rows for every head to read; 128: every CU gets a workgroup
-//         for a 30k-point scan and the LDS gathers of a CU halve).
-template <int NOFF, bool BYVAL, int TAB, int THREADS>
-__global__ __launch_bounds__(THREADS) void ndt_eval_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq) {
-  const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
-  if ((int)blockIdx.x >= P.nblocks) return;
-  const int tid = threadIdx.x;
-  LSR_STAMP(0)
-  LSR_STAMP_T(9, THREADS - 64)
-  LSR_PASS_BEGIN()
-  LSR_SPAN_BEGIN(seq)
+// ===========================================================================================
+// The canonical sum of a pass: one input, one answer
+// ===========================================================================================
+// Every derivative kernel — four lanes per point or one, any workgroup size, any number of workgroups, a registration alone
+// or inside a candidate set — returns the SAME 29 doubles for the same request, bit for bit, because the sum is defined on
+// the input and not on the launch:
+//  * a point's 29 fp32 terms: its neighbours are dealt to four partial sums (partial q takes neighbours q, q + 4, q + 8, ... in
+//    that order), the partials are added as (p0 + p1) + (p2 + p3) (ndt_point.hpp forbids fp contraction outside its fmaf calls);
+//  * a CHUNK = 64 consecutive source points [64 c, 64 c + 63] (absent points count as zeros): its fp64 total is formed by a
+//    fixed tree — gradient-only passes (8 values): eight runs of 8 consecutive points, each summed left to right in fp64, then a
+//    butterfly over the runs (xor 1, 2, 4); passes with Hessian (29 values): four runs of 16, then a butterfly (xor 1, 2);
+//  * chunk totals are added EXACTLY: each is split into NDT_NBINS signed 31-bit pieces against the fixed binary quanta
+//    q_k = 2^(62 - 31 (k + 1)) (ndt.hpp) and the pieces are summed as integers — associative, so neither the order in which
+//    chunks arrive nor the workgroup that owns a chunk can change a bit.
+// What this buys: lsr_align of one registration (quad kernel) and the same registration inside lsr_align_batch (lane kernel)
+// walk the same Newton / More-Thuente trajectory to the same final_T; tests assert array_equal, not a tolerance.
+namespace canon {
+constexpr int TILE_PITCH = 68;    // floats per row of a staging tile: rows 16-byte aligned, consecutive rows four banks apart
+constexpr int TILE_ROWS = 16;     // values staged at a time (a Hessian pass goes through the tile twice)
+constexpr int TILE_FLOATS = TILE_ROWS * TILE_PITCH;
 
-  constexpr int NQ = THREADS / 4;    // quad sums per value
-  constexpr int PITCH = NQ + 8;      // doubles per row of the transpose buffer (conflict free ds_*_b64)
-  constexpr int NGRP = THREADS / 16; // row groups of the head: 16 lanes x 16 bytes cover one 256-byte partial row
-  constexpr int SEGS = THREADS / 32; // interleaved segments per value in the final row sum
-  // LDS: [value][quad sums] transpose buffer — also the row-sum scratch of the head —, the state image, the totals.
-  __shared__ double s_raw[29 * PITCH];
-  __shared__ double s_sum[NDT_NRED];
-  __shared__ double s_lu[8][2];
-  constexpr int STATE_Q = (int)(sizeof(NdtState) / 16);
-  static_assert(sizeof(NdtState) % 16 == 0 && STATE_Q <= THREADS, "NdtState copy assumes <= THREADS uint4");
-  static_assert(NGRP * NDT_NRED <= 29 * PITCH, "head scratch aliases the transpose buffer");
-  __shared__ uint4 s_state_q[STATE_Q];
-  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_state_q);
-  double(*s_part)[PITCH] = reinterpret_cast<double(*)[PITCH]>(s_raw);
-  double(*s_grp)[NDT_NRED] = reinterpret_cast<double(*)[NDT_NRED]>(s_raw);  // [NGRP][32] doubles, head only
-  extern __shared__ uint4 s_table[];  // NDT_TAB_LDS: [uint16 cell->slot map | 48-byte records]
+__device__ __forceinline__ double quantum(const int k) { return __hiloint2double((1023 + 62 - 31 * (k + 1)) << 20, 0); }
+__device__ __forceinline__ double iquantum(const int k) { return __hiloint2double((1023 - 62 + 31 * (k + 1)) << 20, 0); }
 
-  const NdtState* __restrict__ Sin = P.st + (seq & 1);
-  NdtState* __restrict__ Sout = P.st + ((seq + 1) & 1);
-
-  // ---- head: issue everything this workgroup needs from HBM/L2 at once
-  const int stride = P.nblocks * THREADS;
-  int i = blockIdx.x * THREADS + tid;
-  float x = 0.f, y = 0.f, z = 0.f;
-  unsigned int ang_entry = 0u;
-  {
-    const uint4* gq = reinterpret_cast<const uint4*>(Sin);
-    const uint4 stq = (tid < STATE_Q) ? gq[tid] : make_uint4(0u, 0u, 0u, 0u);
-    // rows of the previous launch, 16 bytes per lane: lane pair-index v2 = values {2 v2, 2 v2 + 1}; group g owns rows
-    // g, g + NGRP, ...; 8 loads in flight per lane
-    const int v2 = tid & 15, grp = tid >> 4;
-    double2 sum = make_double2(0.0, 0.0);
-    if (seq > 0) {
-      const double2* base = reinterpret_cast<const double2*>(P.partials + (size_t)((seq + 1) & 1) * P.nblocks * NDT_NRED) + v2;
-      for (int b0 = grp; b0 < P.nblocks; b0 += 8 * NGRP) {
-        double2 r[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int b = b0 + NGRP * k;
-          r[k] = (b < P.nblocks) ? base[(size_t)b * (NDT_NRED / 2)] : make_double2(0.0, 0.0);
-        }
-        sum.x += ((r[0].x + r[1].x) + (r[2].x + r[3].x)) + ((r[4].x + r[5].x) + (r[6].x + r[7].x));
-        sum.y += ((r[0].y + r[1].y) + (r[2].y + r[3].y)) + ((r[4].y + r[5].y) + (r[6].y + r[7].y));
-      }
-    }
-    s_grp[grp][2 * v2] = sum.x;
-    s_grp[grp][2 * v2 + 1] = sum.y;
-    if (tid < STATE_Q) s_state_q[tid] = stq;
-    // Issued AFTER the shared (hot) lines have landed, on purpose: vmcnt retires in order, so loads issued earlier would
-    // make the head wait for this workgroup's own points (first touch of their lines).  They are needed after the
-    // controller and fly across the barriers of the head (which wait for LDS traffic only).
-    if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }
-    if (tid < 72) ang_entry = k_angle_entries[tid];  // consumed by build_request
-  }
-  LSR_STAMP_T(8, 0)
-  LSR_STAMP_T(10, THREADS - 64)
-  barrier_lds_only();  // not __syncthreads(): the point loads stay in flight
-  LdsState* L = (LdsState*)s_state;
-  LSR_STAMP(1)
-  LSR_PASS_MARK(_p_t1)
-  if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0)  // progress report for the host's launch feeder (relaxed)
-    __hip_atomic_store(&P.mailbox->progress, ((unsigned long long)(unsigned int)L->token << 32) | (unsigned int)seq,
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (uniform_i(L->done)) {  // finished earlier: keep both state buffers identical so later launches see it too
-    if (blockIdx.x == 0 && seq > 0) {
-      uint4* gq = reinterpret_cast<uint4*>(Sout);
-      if (tid < STATE_Q) gq[tid] = s_state_q[tid];
-    }
-    return;
-  }
-  if (TAB == NDT_TAB_LDS) {
-    // voxel table -> LDS by DMA (no VGPR staging): one wave-wide instruction moves 64 x 16 B = 1 KiB to a wave-uniform
-    // LDS base; pose independent, so it is issued BEFORE the controller runs and lands in its shadow
-    // Wave 0 issues none: it calls the controller, and a device function starts with s_waitcnt vmcnt(0) by ABI.
-    const int nchunks = P.lds_bytes >> 10;
-    const unsigned char* img = reinterpret_cast<const unsigned char*>(P.lds_image) + (size_t)(tid & 63) * 16;
-    unsigned char* dst = reinterpret_cast<unsigned char*>(s_table);
-    if (tid >= 64)
-      for (int c = (tid >> 6) - 1; c < nchunks; c += THREADS / 64 - 1)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + (size_t)c * 1024),
-                                         (__attribute__((address_space(3))) void*)(dst + (size_t)c * 1024), 16, 0, 0);
-  }
-  if (seq > 0) {
-    // rows hold what the request in the state asked for: 29 sums with Hessian, 8 without
-    const int nprev = (uniform_i(L->want_hessian) != 0) ? 29 : NDT_NRED_GRAD;
-    if (tid < NDT_NRED) {
-      double t = 0.0;
-      if (tid < nprev) {
-        double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-        for (int g2 = 0; g2 < NGRP; g2 += 2) { t0 += s_grp[g2][tid]; t1 += s_grp[g2 + 1][tid]; }
-        t = t0 + t1;
-      }
-      s_sum[tid] = t;
-    }
-    barrier_lds_only();
-    LSR_STAMP(6)
-    LSR_CTL_BEGIN(L)
-    if (tid < 64) ndt_controller_wave0(L, (const LdsDouble*)s_sum);
-    barrier_lds_only();
-    LSR_CTL_END(0)
-    LSR_STAMP(5)
-    build_request<THREADS>(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[4][0]), ang_entry);
-    LSR_CTL_END(2)
-    LSR_STAMP(4)
-  }
-  if (blockIdx.x == 0) {
-    uint4* gq = reinterpret_cast<uint4*>(Sout);
-    if (tid < STATE_Q) gq[tid] = s_state_q[tid];
-  }
-  if (uniform_i(L->done)) {
-    // the controller has just finished this align(): publish the result into the host mailbox, flag last
-    if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0) {
-      NdtMailbox* mb = P.mailbox;
-#pragma unroll
-      for (int k = 0; k < 16; k++) mb->final_T[k] = L->final_T[k];
-      mb->converged = L->converged;
-      mb->nr_iterations = L->nr_iterations;
-      mb->n_evals = L->n_evals;
-      mb->trans_probability = L->trans_probability;
-      mb->last_pairs = L->last_pairs;
-      __threadfence_system();
-      __hip_atomic_store(&mb->done, (unsigned int)L->token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return;
-  }
-  LSR_STAMP(7)
-  LSR_PASS_MARK(_p_t7)
-
-  // ---- this launch's request, straight from the LDS image
-  const bool hess = uniform_i(L->want_hessian) != 0;
-  const double d1d = uniform_d(L->d1);
-  const float d2 = uniform_f((float)L->d2);
-  float T[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = uniform_f(L->T[k]);
-  const float leaf = P.leaf;
-  __syncthreads();  // s_grp (aliases the transpose buffer) is dead from here on; the table DMA has landed (vmcnt(0))
-
-  const unsigned short* s_map = reinterpret_cast<const unsigned short*>(s_table);
-  const float4* s_rec = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(s_table) + P.lds_map_bytes);
-
-  double acc[29];
-#pragma unroll
-  for (int k = 0; k < 29; k++) acc[k] = 0.0;
-
-  while (i < P.n) {
-    const float tx = xform_ref(T[0], T[1], T[2], T[3], x, y, z);
-    const float ty = xform_ref(T[4], T[5], T[6], T[7], x, y, z);
-    const float tz = xform_ref(T[8], T[9], T[10], T[11], x, y, z);
-    // DIRECT-N neighbourhood of the TRANSFORMED point: floor(x'/leaf) in fp32.
-    const float fx = floorf(tx / leaf), fy = floorf(ty / leaf), fz = floorf(tz / leaf);
-    // NaN / far-out-of-range points land outside the grid and contribute nothing.
-    const bool finite_ok = (fabsf(fx) < 1.0e9f) && (fabsf(fy) < 1.0e9f) && (fabsf(fz) < 1.0e9f);
-    const int ci = finite_ok ? (int)fx : INT_MIN / 2, cj = finite_ok ? (int)fy : INT_MIN / 2, ck = finite_ok ? (int)fz : INT_MIN / 2;
-
-    // Branch-free neighbourhood: every record load is issued up front (out-of-range neighbours read
-    // cell 0 / slot 0 and are masked), so a point costs ONE gather round trip instead of one per neighbour.
-    bool valid[NOFF];
-    int cellv[NOFF];
-#pragma unroll
-    for (int o = 0; o < NOFF; o++) {
-      int dx, dy, dz;
-      Offsets<NOFF>::get(o, dx, dy, dz);
-      const int a = ci + dx, b = cj + dy, c = ck + dz;
-      const bool in = (a >= P.min_b[0]) & (a <= P.max_b[0]) & (b >= P.min_b[1]) & (b <= P.max_b[1]) &
-                      (c >= P.min_b[2]) & (c <= P.max_b[2]);
-      valid[o] = in;
-      cellv[o] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
-    }
-    float score = 0.f, npairs = 0.f;
-    float A0 = 0.f, A1 = 0.f, A2 = 0.f;                                      // sum w * C q
-    float E00 = 0.f, E01 = 0.f, E02 = 0.f, E11 = 0.f, E12 = 0.f, E22 = 0.f;  // sum w * (C - d2 Cq Cq^T)
-    // every record load of the point is issued up front: ONE gather round trip.  (Groups of four neighbours — 166 VGPRs, three
-    // waves per SIMD instead of 242 / two — were measured on a 64-candidate batch: 2.77 vs 2.70 ms, no gain.)
-    constexpr int GROUP = NOFF;
-#pragma unroll
-    for (int o0 = 0; o0 < NOFF; o0 += GROUP) {
-      float4 r0[GROUP], r1[GROUP], r2[GROUP];
-      bool ok[GROUP];
-#pragma unroll
-      for (int u = 0; u < GROUP; u++) {
-        const int o = o0 + u;
-        ok[u] = (o < NOFF) && valid[o < NOFF ? o : 0];
-        const int cell = cellv[o < NOFF ? o : 0];
-        if (TAB == NDT_TAB_LDS) {
-          const int sl = (int)s_map[cell];
-          ok[u] = ok[u] & (sl != 0xFFFF);  // the LDS table only holds usable leaves (n >= 6, valid covariance)
-          const int slot = ok[u] ? sl : 0;
-          r0[u] = s_rec[slot * 3 + 0];
-          r1[u] = s_rec[slot * 3 + 1];
-          r2[u] = s_rec[slot * 3 + 2];
-        } else {
-          size_t ridx = (size_t)cell;
-          if (TAB != NDT_TAB_DENSE) {
-            const int sl = P.cell_slot[cell];
-            ok[u] = ok[u] & (sl >= 0);
-            ridx = (size_t)(sl >= 0 ? sl : 0);
-          }
-          // empty / under-populated / invalidated cells hold NaN records: the pair drops itself
-          r0[u] = P.rec[ridx * 4 + 0];
-          r1[u] = P.rec[ridx * 4 + 1];
-          r2[u] = P.rec[ridx * 4 + 2];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < GROUP; u++)
-        if (o0 + u < NOFF)
-          pair_terms(ok[u], hess, tx, ty, tz, r0[u], r1[u], r2[u], d2, d1d, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22);
-    }
-    const float px = x, py = y, pz = z;
-    i += stride;
-    if (i < P.n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }   // next point's loads fly under the maths below
-    if (npairs == 0.f) continue;
-    float ot[29];
-    point_terms(hess, px, py, pz, score, npairs, A0, A1, A2, E00, E01, E02, E11, E12, E22, L->jang, L->hang, ot);
-    if (hess) {
-#pragma unroll
-      for (int k = 0; k < 29; k++) acc[k] += (double)ot[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < NDT_NRED_GRAD; k++) acc[k] += (double)ot[k];
-    }
-  }
-
-  LSR_STAMP(2)
-  LSR_PASS_MARK(_p_t2)
-  // ---- workgroup reduction: quad sum in registers (DPP) -> LDS transpose [value][quad sums] ->
-  //      SEGS interleaved segment sums per value -> one partial row
-  const int nred = hess ? 29 : NDT_NRED_GRAD;
-  if (hess) {
-#pragma unroll
-    for (int k = 0; k < 29; k++) {
-      double v = acc[k];
-      v += dpp_quad_xor<0xB1>(v);  // lanes {0<->1, 2<->3}
-      v += dpp_quad_xor<0x4E>(v);  // lanes {0<->2, 1<->3}
-      if ((tid & 3) == 0) s_part[k][tid >> 2] = v;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < NDT_NRED_GRAD; k++) {
-      double v = acc[k];
-      v += dpp_quad_xor<0xB1>(v);
-      v += dpp_quad_xor<0x4E>(v);
-      if ((tid & 3) == 0) s_part[k][tid >> 2] = v;
-    }
-  }
-  __syncthreads();
-  double* prow = P.partials + ((size_t)(seq & 1) * P.nblocks + blockIdx.x) * NDT_NRED;
-  {
-    const int v = tid / SEGS, seg = tid % SEGS;  // 32 values x SEGS interleaved segments of the NQ quad sums
-    double t = 0.0;
-    if (v < nred) {
-#pragma unroll
-      for (int k = 0; k < NQ / SEGS; k++) t += s_part[v][seg + SEGS * k];
-    }
-#pragma unroll
-    for (int m = 1; m < SEGS; m <<= 1) t += __shfl_xor(t, m, 64);
-    if (seg == 0 && v < nred) prow[v] = t;  // consumed by EVERY workgroup at the head of the next launch
-  }
-  LSR_STAMP(3)
-  LSR_PASS_END(hess)
-  LSR_SPAN_END(seq)
+// piece k of the exact split of t: the pieces of one value can be formed independently of each other (five lanes, one piece
+// each) because t minus its multiple-of-q_(k-1) part is exact in fp64.  |t| >= 2^62 or NaN: no piece, *poison raised.
+__device__ __forceinline__ int piece(const double t, const int k, bool* poison) {
+  *poison = !(fabs(t) < 4611686018427387904.0);
+  if (*poison) return 0;
+  double r = t;
+  if (k > 0) r = t - trunc(t * iquantum(k - 1)) * quantum(k - 1);   // |r| < q_(k-1) = 2^31 q_k, exact
+  return (int)(r * iquantum(k));                                     // truncation toward zero
 }
+
+// 8 consecutive fp32 terms at p (16-byte aligned, LDS), lanes l & 7 = run: the chunk total of a gradient-only pass, in every lane
+__device__ __forceinline__ double reduce_grad(const float* p) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4);
+  double t = (double)a.x;
+  t += (double)a.y; t += (double)a.z; t += (double)a.w;
+  t += (double)b.x; t += (double)b.y; t += (double)b.z; t += (double)b.w;
+  t += dpp_quad_xor<0xB1>(t);    // runs {0<->1, 2<->3, ...}
+  t += dpp_quad_xor<0x4E>(t);    // pairs of runs
+  t += dpp_quad_xor<0x141>(t);   // row_half_mirror: lane 7 - l of the 8-lane group = the other quad (whose lanes all hold its sum)
+  return t;
+}
+// 16 consecutive fp32 terms at p, lanes l & 3 = run: the chunk total of a pass with Hessian, in every lane of the quad
+__device__ __forceinline__ double reduce_hess(const float* p) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4), c = *reinterpret_cast<const f4*>(p + 8),
+           d = *reinterpret_cast<const f4*>(p + 12);
+  double t = (double)a.x;
+  t += (double)a.y; t += (double)a.z; t += (double)a.w;
+  t += (double)b.x; t += (double)b.y; t += (double)b.z; t += (double)b.w;
+  t += (double)c.x; t += (double)c.y; t += (double)c.z; t += (double)c.w;
+  t += (double)d.x; t += (double)d.y; t += (double)d.z; t += (double)d.w;
+  t += dpp_quad_xor<0xB1>(t);
+  t += dpp_quad_xor<0x4E>(t);
+  return t;
+}
+// piece k of chunk total t of value v -> a workgroup's LDS bins [NDT_NBINS][32] (poison: slot 31 of bin 0, raised by the k = 0 caller)
+__device__ __forceinline__ void add_piece_lds(unsigned long long* ibin, const int v, const int k, const double t) {
+  bool poison;
+  const int m = piece(t, k, &poison);
+  if (m != 0) atomicAdd(&ibin[k * 32 + v], (unsigned long long)(long long)m);
+  if (poison && k == 0) atomicAdd(&ibin[31], 1ull);
+}
+}  // namespace canon
+
+// The derivative pass (K3) is preceded, in the same launch, by the controller step (K4) that consumes the PREVIOUS pass.
+//
+// "Pull" structure: launch number `seq` starts — in EVERY workgroup, redundantly and deterministically — by folding the
+// accumulator bank launch seq-1 left behind, advancing the Newton / More-Thuente controller on an LDS image of the state and
+// building the next evaluation request; only then does it evaluate its own points and add their chunk sums to its own bank.
+// No workgroup ever waits for another one inside a launch: the kernel boundary is the only synchronisation.  State is double
+// buffered by launch parity (launch seq reads state[seq & 1]; workgroup 0 writes state[(seq + 1) & 1]), the banks rotate
+// (launch seq adds to bank seq % 3, reads bank (seq - 1) % 3 and clears bank (seq + 1) % 3), so a late-starting workgroup
+// can never observe a value produced by its own launch.
+//  BYVAL: a single-registration launch carries its NdtProblem in the kernel arguments, which removes one dependent memory
+//         round trip from the latency chain of every pass.
+//  TAB:   where the leaf records live (NdtTableMode).  NDT_TAB_LDS stages the whole valid-voxel table (uint16 cell->slot map +
+//         48-byte records) into LDS with wave-wide 16-byte global->LDS DMA issued right after the state has landed: the copy
+//         flies while wave 0 runs the controller, and the dependent gathers of a point become ds_read_b128.
 
 // ===========================================================================================
 // K3 + K4, "quad" variant for single registrations: FOUR lanes per source point
@@ -1120,9 +910,9 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   // floats per row of the per-point buffers, chosen against the 32-lane groups of ds_*_b32: phase A writes rows
   // ql + 4m at columns pq (4 rows x 8 columns per group): pitch = 8 (mod 32) spreads them over all 32 banks; phase C reads
   // rows cv at columns cseg + SEGS k (2 rows x 16 columns per group): pitch = 16 (mod 32)
-  constexpr int PITCH_PT = PTS + 8, PITCH_O = PTS + 16;
-  constexpr int SEGS = THREADS / 32;       // interleaved segments per value in the workgroup sum
+  constexpr int PITCH_PT = PTS + 8, PITCH_O = PTS + 4;   // s_o rows 16-byte aligned, four banks apart (phase C reads runs with ds_read_b128)
   constexpr int NT = (NOFF + 3) / 4;       // neighbours per lane
+  static_assert(PTS % 64 == 0, "a workgroup batch is a whole number of canonical chunks");
   const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
   if ((int)blockIdx.x >= P.nblocks) return;
   const int tid = threadIdx.x, ql = tid & 3, pq = tid >> 2;
@@ -1132,7 +922,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   LSR_SPAN_BEGIN(seq)
 
   __shared__ float s_pt[14][PITCH_PT];   // phase A -> B: per point {score, #pairs, A (3), E (6), x, y, z}
-  __shared__ float s_o[29][PITCH_O];     // phase B -> C: the 29 per-point terms
+  __shared__ __attribute__((aligned(16))) float s_o[29][PITCH_O];   // phase B -> C: the 29 per-point terms (phase C reads runs as 16-byte vectors)
   __shared__ double s_bin[NDT_NBINS][32];
   __shared__ double s_sum[NDT_NRED];
   __shared__ double s_lu[8][2];
@@ -1273,10 +1063,8 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   //  B the 29 Jacobian / Hessian terms of the point.  With Hessian: the 14 per-point sums go through LDS to ONE lane per point
   //    (two full waves instead of eight quarter-full ones: ~150 instructions per wave); gradient-only passes (three in four)
   //    form their 8 terms right where the sums are, in every lane of the quad — ~30 instructions, no barrier, no LDS round trip;
-  //  C (all lanes): fp64 sum over the points, SEGS segments per value.
-  const int nred = hess ? 29 : NDT_NRED_GRAD;
-  const int cv = tid / SEGS, cseg = tid % SEGS;
-  double csum = 0.0;
+  //  C: the canonical chunk sums (canon:: above) of the batch's PTS / 64 chunks, straight into the accumulator bank.
+  long long* const bank = P.bins + (size_t)(seq % NDT_NBANKS) * NDT_BANK_WORDS + (size_t)(blockIdx.x & (NDT_NSHARDS - 1)) * (NDT_NBINS * 32);
   for (int base = blockIdx.x * PTS; base < P.n; base += stride) {  // uniform across the workgroup
     // ---- phase A
     {
@@ -1454,10 +1242,44 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
       barrier_lds_only();
     }
     LSR_STAMP(14)
-    // ---- phase C: the float terms of the reference's per-point sums, accumulated in double
-    if (cv < nred) {
-#pragma unroll
-      for (int k = 0; k < PTS / SEGS; k++) csum += (double)s_o[cv][cseg + SEGS * k];
+    // ---- phase C: the float terms of the reference's per-point sums, summed in double chunk by chunk (canon::) and added
+    // to the bank piece by piece: the integer pieces of the batch's chunks meet in one lane first (shuffle), so a value
+    // costs at most NDT_NBINS atomics per batch
+    if (!hess) {
+      constexpr int RUNS = PTS / 8;                       // runs of 8 points per value: 8 per chunk
+      if (tid < NDT_NRED_GRAD * RUNS) {                   // whole waves
+        const int v = tid / RUNS, k = tid & 7;
+        const double t = canon::reduce_grad(&s_o[v][8 * (tid % RUNS)]);
+        bool poison;
+        long long m = canon::piece(t, k < NDT_NBINS ? k : 0, &poison);   // 64-bit from here: two 31-bit pieces may not fit 32 bits
+        int pz = poison ? 1 : 0;
+        if (PTS == 128) { m += (long long)__shfl_xor((int)m, 8, 64); pz |= __shfl_xor(pz, 8, 64); }   // the batch's second chunk
+        if ((tid & (RUNS - 1)) < NDT_NBINS) {
+          if (m != 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + k * 32 + v), (unsigned long long)m);
+          if (pz && k == 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + 31), 1ull);
+        }
+      }
+    } else {
+      constexpr int RUNS = PTS / 16;                      // runs of 16 points per value: 4 per chunk
+      if (tid < ((29 * RUNS + 63) & ~63)) {               // whole waves, the lanes beyond value 28 idle along
+        const int v = tid / RUNS, sg = tid & 3;
+        double t = 0.0;
+        if (v < 29) t = canon::reduce_hess(&s_o[v][16 * (tid % RUNS)]);
+        bool poison, poison0;
+        long long m = canon::piece(t, sg + 1, &poison);   // lanes 0..3 of a chunk take pieces 1..4,
+        long long m0 = canon::piece(t, 0, &poison0);      // lane 0 also piece 0 (zero unless the total exceeds 2^31)
+        int pz = poison0 ? 1 : 0;
+        if (PTS == 128) {   // the batch's second chunk (64-bit sums: two 31-bit pieces may not fit 32 bits)
+          m += (long long)__shfl_xor((int)m, 4, 64); m0 += (long long)__shfl_xor((int)m0, 4, 64); pz |= __shfl_xor(pz, 4, 64);
+        }
+        if (v < 29 && (tid & (RUNS - 1)) < 4) {
+          if (m != 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + (sg + 1) * 32 + v), (unsigned long long)m);
+          if (sg == 0) {
+            if (m0 != 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + v), (unsigned long long)m0);
+            if (pz) atomicAdd(reinterpret_cast<unsigned long long*>(bank + 31), 1ull);
+          }
+        }
+      }
     }
     // the next batch writes s_pt / s_o again: with Hessian (and in tile mode) its writes are behind a barrier of the next round;
     // a gradient-only round without the tile barriers writes s_o straight away
@@ -1466,32 +1288,306 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
 
   LSR_STAMP(2)
   LSR_PASS_MARK(_p_t2)
-  {
-    const int v = cv;
-    double t = csum;
-#pragma unroll
-    for (int m = 1; m < SEGS; m <<= 1) t += __shfl_xor(t, m, 64);
-    if (cseg == 0 && v < nred) {
-      // exact split of the partial into 31-bit chunks, one integer atomic per non-zero chunk
-      long long* bank = P.bins + (size_t)(seq % NDT_NBANKS) * NDT_BANK_WORDS + (size_t)(blockIdx.x & (NDT_NSHARDS - 1)) * (NDT_NBINS * 32);
-      double r = t;
-      if (!(fabs(r) < 4611686018427387904.0)) {  // 2^62: overflow or NaN
-        atomicAdd(reinterpret_cast<unsigned long long*>(bank + 31), 1ull);
-        r = 0.0;
-      }
-#pragma unroll
-      for (int k = 0; k < NDT_NBINS; k++) {
-        const double q = __hiloint2double((1023 + 62 - 31 * (k + 1)) << 20, 0);
-        const double iq = __hiloint2double((1023 - 62 + 31 * (k + 1)) << 20, 0);
-        const int m = (int)(r * iq);  // truncation: |r| < 2^31 q
-        r = fma(-(double)m, q, r);    // exact remainder
-        if (m != 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + k * 32 + v), (unsigned long long)(long long)m);
-      }
-    }
-  }
   LSR_STAMP(3)
   LSR_PASS_END(hess)
   LSR_SPAN_END(seq)
+}
+
+// ===========================================================================================
+// K3 + K4, "lane" variant: ONE lane per source point, wave-private canonical reduction
+// ===========================================================================================
+// The kernel of candidate SETS (many registrations per launch, blockIdx.y = registration) and of single registrations with
+// enough points to fill the chip on their own.  Same arithmetic as the quad kernel to the last bit (canon:: above): a lane
+// forms its point's four partial neighbour sums one after the other and adds them in the quad's tree order, the 64 points of a
+// wave ARE one canonical chunk, and the chunk is reduced by the wave alone — terms staged through a wave-private LDS tile,
+// canon::reduce_grad / reduce_hess, chunk totals split into the exact integer bins — so there is no workgroup barrier
+// anywhere after the head, no per-lane fp64 accumulator (round 3's one-lane kernel carried 29 of them = 58 VGPRs and summed a
+// lane's points across its batches, which made the answer depend on the launch geometry) and no partial rows.
+//  THREADS: 512 or 1024 lanes sharing one LDS image of the voxel table (1024: one workgroup per CU, the table is copied once
+//           per CU and pass).
+//  nb: workgroups per registration in THIS launch (grid.x) — the answer does not depend on it, so the host widens it from
+//      launch to launch as the registrations of a set finish (run_ndt_feeder).
+//  tab_bytes: size of the table region at the start of the dynamic LDS (largest image of the set, multiple of 1 KiB); the
+//      staging tiles follow it.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v4f LdsV4;
+typedef __attribute__((address_space(1))) const v4f GlbV4;
+typedef __attribute__((address_space(1))) const float GlbFloat;
+typedef __attribute__((address_space(1))) const int GlbInt;
+
+template <int NOFF, int TAB, int THREADS, bool BYVAL>
+__global__ __launch_bounds__(THREADS) void ndt_eval_lane_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq,
+                                                                const int nb, const int tab_bytes) {
+  constexpr int NWAVES = THREADS / 64;
+  constexpr int NT = (NOFF + 3) / 4;                // neighbours per partial sum
+  constexpr int GROUP = 4;                          // records fetched per gather round trip
+  const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // a workgroup without points only stays if it is the one that carries the controller state forward
+  if (blockIdx.x > 0 && (long long)blockIdx.x * THREADS >= (long long)P.n) return;
+
+  __shared__ double s_bin[NDT_NBINS][32];
+  __shared__ unsigned long long s_ibin[NDT_NBINS * 32];   // this workgroup's chunk totals, exact (ds_add_u64)
+  __shared__ double s_sum[NDT_NRED];
+  __shared__ double s_lu[8][2];
+  constexpr int STATE_Q = (int)(sizeof(NdtState) / 16);
+  static_assert(STATE_Q <= THREADS, "NdtState copy assumes <= THREADS uint4");
+  __shared__ uint4 s_state_q[STATE_Q];
+  unsigned int* s_state = reinterpret_cast<unsigned int*>(s_state_q);
+  extern __shared__ uint4 s_table[];   // [voxel table image: tab_bytes | NWAVES staging tiles of canon::TILE_FLOATS floats]
+
+  const NdtState* __restrict__ Sin = P.st + (seq & 1);
+  NdtState* __restrict__ Sout = P.st + ((seq + 1) & 1);
+
+  // ---- head: the same steps as the quad kernel's (bins of the previous launch, controller on wave 0, table DMA by the others)
+  const int n = P.n;
+  const int stride = nb * THREADS;
+  int i = blockIdx.x * THREADS + tid;
+  float x = 0.f, y = 0.f, z = 0.f;
+  unsigned int ang_entry = 0u, ang_entry_b = 0u;
+  {
+    const uint4* gq = reinterpret_cast<const uint4*>(Sin);
+    const uint4 stq = (tid < STATE_Q) ? gq[tid] : make_uint4(0u, 0u, 0u, 0u);
+    long long msum = 0;
+    if (seq > 0 && tid < NDT_NBINS * 32) {
+      const long long* b = P.bins + (size_t)((seq + 2) % NDT_NBANKS) * NDT_BANK_WORDS + tid;
+      long long m[NDT_NSHARDS];
+#pragma unroll
+      for (int sh = 0; sh < NDT_NSHARDS; sh++) m[sh] = b[sh * (NDT_NBINS * 32)];
+      msum = ((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7]));
+    }
+    if (tid < NDT_NBINS * 32) {
+      s_bin[tid >> 5][tid & 31] = (double)msum * canon::quantum(tid >> 5);
+      s_ibin[tid] = 0ull;
+    }
+    if (tid < STATE_Q) s_state_q[tid] = stq;
+    if (i < n) { x = P.sx[i]; y = P.sy[i]; z = P.sz[i]; }   // after the shared lines, on purpose (vmcnt retires in order)
+    if (tid < 64) ang_entry = k_angle_entries[tid];
+    if (tid < 8) ang_entry_b = k_angle_entries[64 + tid];
+  }
+  barrier_lds_only();
+  LdsState* L = (LdsState*)s_state;
+  if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0)
+    __hip_atomic_store(&P.mailbox->progress, ((unsigned long long)(unsigned int)L->token << 32) | (unsigned int)seq,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (uniform_i(L->done)) {
+    if (blockIdx.x == 0 && seq > 0) {
+      uint4* gq = reinterpret_cast<uint4*>(Sout);
+      if (tid < STATE_Q) gq[tid] = s_state_q[tid];
+    }
+    return;
+  }
+  if (TAB == NDT_TAB_LDS) {
+    const int nchunks = P.lds_bytes >> 10;
+    const unsigned char* img = reinterpret_cast<const unsigned char*>(P.lds_image) + (size_t)lane * 16;
+    unsigned char* dst = reinterpret_cast<unsigned char*>(s_table);
+    if (tid >= 64)
+      for (int c = wave - 1; c < nchunks; c += NWAVES - 1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + (size_t)c * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + (size_t)c * 1024), 16, 0, 0);
+  }
+  if (tid < 64) {
+    if (seq > 0) {
+      if (tid < NDT_NRED) {
+        double t = (((s_bin[4][tid] + s_bin[3][tid]) + s_bin[2][tid]) + s_bin[1][tid]) + s_bin[0][tid];
+        if (s_bin[0][31] != 0.0 || s_bin[1][31] != 0.0) t = __longlong_as_double(0x7FF8000000000000ll);
+        s_sum[tid] = t;
+      }
+      wave_lds_fence();
+      ndt_controller_wave0(L, (const LdsDouble*)s_sum);
+      wave_lds_fence();
+      build_request_wave0(reinterpret_cast<NdtState*>(s_state), &s_lu[0][0], reinterpret_cast<float*>(&s_lu[4][0]), ang_entry, ang_entry_b);
+    }
+    if (blockIdx.x == 0) {
+      uint4* gq = reinterpret_cast<uint4*>(Sout);
+      gq[tid] = s_state_q[tid];
+      if (tid + 64 < STATE_Q) gq[tid + 64] = s_state_q[tid + 64];
+    }
+  }
+  __syncthreads();  // the request is complete and the table DMA has landed (vmcnt(0) + barrier)
+  if (uniform_i(L->done)) {
+    if (P.mailbox != nullptr && blockIdx.x == 0 && tid == 0) {
+      NdtMailbox* mb = P.mailbox;
+#pragma unroll
+      for (int k = 0; k < 16; k++) mb->final_T[k] = L->final_T[k];
+      mb->converged = L->converged;
+      mb->nr_iterations = L->nr_iterations;
+      mb->n_evals = L->n_evals;
+      mb->trans_probability = L->trans_probability;
+      mb->last_pairs = L->last_pairs;
+      __threadfence_system();
+      __hip_atomic_store(&mb->done, (unsigned int)L->token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  if (blockIdx.x == 0) {  // clear the bank launch seq + 1 will add to (read last by launch seq - 1, which is complete)
+    uint4* zb = reinterpret_cast<uint4*>(P.bins + (size_t)((seq + 1) % NDT_NBANKS) * NDT_BANK_WORDS);
+    for (int k = tid; k < NDT_BANK_WORDS / 2; k += THREADS) zb[k] = make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  // ---- this launch's request: wave-uniform values in scalar registers
+  const bool hess = uniform_i(L->want_hessian) != 0;
+  const double d1d = uniform_d(L->d1);
+  const float d2 = uniform_f((float)L->d2);
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = uniform_f(L->T[k]);
+  const float leaf = P.leaf;
+  const int mb0 = P.min_b[0], mb1 = P.min_b[1], mb2 = P.min_b[2];
+  const int xb0 = P.max_b[0], xb1 = P.max_b[1], xb2 = P.max_b[2];
+  const int mul1 = P.mul1, mul2 = P.mul2;
+  const __attribute__((address_space(3))) unsigned short* s_map = (const __attribute__((address_space(3))) unsigned short*)s_table;
+  const int map_bytes = P.lds_map_bytes;
+  float* s_tile = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(s_table) + tab_bytes) + wave * canon::TILE_FLOATS;
+  // pointers read from a problem record in memory are generic to the compiler (flat loads, which also count against the LDS
+  // counter): say where they point
+  const GlbV4* g_rec = (const GlbV4*)P.rec;
+  const GlbInt* g_cell_slot = (const GlbInt*)P.cell_slot;
+  const GlbFloat* g_sx = (const GlbFloat*)P.sx;
+  const GlbFloat* g_sy = (const GlbFloat*)P.sy;
+  const GlbFloat* g_sz = (const GlbFloat*)P.sz;
+  (void)g_rec; (void)g_cell_slot; (void)s_map; (void)map_bytes;
+
+  for (int base = blockIdx.x * THREADS + wave * 64; base < n; base += stride) {   // wave-uniform: one canonical chunk per trip
+    const bool have = i < n;
+    const float px = x, py = y, pz = z;
+    const float tx = xform_ref(T[0], T[1], T[2], T[3], px, py, pz);
+    const float ty = xform_ref(T[4], T[5], T[6], T[7], px, py, pz);
+    const float tz = xform_ref(T[8], T[9], T[10], T[11], px, py, pz);
+    i += stride;
+    if (i < n) { x = g_sx[i]; y = g_sy[i]; z = g_sz[i]; }   // the next chunk's loads fly under this one's maths
+    const float fx = floorf(tx / leaf), fy = floorf(ty / leaf), fz = floorf(tz / leaf);
+    const bool finite_ok = have && (fabsf(fx) < 1.0e9f) && (fabsf(fy) < 1.0e9f) && (fabsf(fz) < 1.0e9f);
+    const int ci = finite_ok ? (int)fx : INT_MIN / 2, cj = finite_ok ? (int)fy : INT_MIN / 2, ck = finite_ok ? (int)fz : INT_MIN / 2;
+    // per-axis bounds tests of the centre cell and its two neighbours, linear index of the centre: a neighbour's cell is
+    // centre + dx + dy mul1 + dz mul2 — no multiplication, no branch per neighbour
+    bool inx[3], iny[3], inz[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      inx[d] = (ci + d - 1 >= mb0) & (ci + d - 1 <= xb0);
+      iny[d] = (cj + d - 1 >= mb1) & (cj + d - 1 <= xb1);
+      inz[d] = (ck + d - 1 >= mb2) & (ck + d - 1 <= xb2);
+    }
+    const int centre = (ci - mb0) + (cj - mb1) * mul1 + (ck - mb2) * mul2;
+
+    // every neighbour's record address first: NOFF cell -> slot lookups in flight at once (one LDS round trip), so that the
+    // record gathers below depend on nothing but their own address
+    bool nb_ok[NOFF];
+    int nb_rec[NOFF];     // LDS table: byte offset of the record inside the table image; global tables: record index
+#pragma unroll
+    for (int o = 0; o < NOFF; o++) {
+      int dx, dy, dz;
+      Offsets<NOFF>::get(o, dx, dy, dz);
+      const bool in = inx[dx + 1] & iny[dy + 1] & inz[dz + 1];
+      const int cell = in ? centre + dx + dy * mul1 + dz * mul2 : 0;
+      nb_ok[o] = in;
+      nb_rec[o] = cell;
+    }
+    if (TAB == NDT_TAB_LDS) {
+      int sl[NOFF];
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) sl[o] = (int)s_map[nb_rec[o]];
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) {
+        nb_ok[o] = nb_ok[o] & (sl[o] != 0xFFFF);    // the LDS table only holds usable leaves
+        nb_rec[o] = map_bytes + (nb_ok[o] ? sl[o] : 0) * NDT_LDS_REC_BYTES;
+      }
+    } else if (TAB == NDT_TAB_COMPACT) {
+      int sl[NOFF];
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) sl[o] = g_cell_slot[nb_rec[o]];
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) {
+        nb_ok[o] = nb_ok[o] & (sl[o] >= 0);
+        nb_rec[o] = sl[o] >= 0 ? sl[o] : 0;
+      }
+    }
+
+    // the four partial sums of the point in the quad kernel's order: partial q takes neighbours q, q + 4, q + 8, ...;
+    // halves (0, 1) and (2, 3) are summed first, then the two halves
+    float S[11];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      float Pq[2][11];
+#pragma unroll
+      for (int k = 0; k < 11; k++) { Pq[0][k] = 0.f; Pq[1][k] = 0.f; }
+#pragma unroll
+      for (int e0 = 0; e0 < 2 * NT; e0 += GROUP) {
+        v4f r0[GROUP], r1[GROUP], r2[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; u++) {
+          const int e = e0 + u, ql = e / NT, t = e % NT, o = 2 * half + ql + 4 * t;
+          if (e < 2 * NT && o < NOFF) {
+            if (TAB == NDT_TAB_LDS) {
+              const LdsV4* rp = (const LdsV4*)((const __attribute__((address_space(3))) unsigned char*)s_table + nb_rec[o]);
+              r0[u] = rp[0]; r1[u] = rp[1]; r2[u] = rp[2];
+            } else {
+              const GlbV4* rp = g_rec + (size_t)nb_rec[o] * 4;   // empty / unusable cells hold NaN records
+              r0[u] = rp[0]; r1[u] = rp[1]; r2[u] = rp[2];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GROUP; u++) {
+          const int e = e0 + u, ql = e / NT, t = e % NT, o = 2 * half + ql + 4 * t;
+          if (e < 2 * NT && o < NOFF) {
+            float* A = Pq[ql];
+            pair_terms(nb_ok[o], hess, tx, ty, tz, make_float4(r0[u].x, r0[u].y, r0[u].z, r0[u].w), make_float4(r1[u].x, r1[u].y, r1[u].z, r1[u].w),
+                       make_float4(r2[u].x, r2[u].y, r2[u].z, r2[u].w), d2, d1d, A[0], A[1], A[2], A[3], A[4], A[5], A[6], A[7], A[8], A[9], A[10]);
+          }
+        }
+      }
+      // (lane 2 half) + (lane 2 half + 1) of the quad
+      if (half == 0) {
+#pragma unroll
+        for (int k = 0; k < 11; k++) S[k] = Pq[0][k] + Pq[1][k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 11; k++) S[k] = S[k] + (Pq[0][k] + Pq[1][k]);
+      }
+    }
+    // S = {score, #pairs, A0..2, E00, E01, E02, E11, E12, E22}
+    float o[29];
+    if (S[1] != 0.f) {
+      point_terms(hess, px, py, pz, S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8], S[9], S[10], L->jang, L->hang, o);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 29; k++) o[k] = 0.f;
+    }
+    // ---- the chunk's canonical sums -> this workgroup's exact bins
+    if (!hess) {
+#pragma unroll
+      for (int k = 0; k < NDT_NRED_GRAD; k++) s_tile[k * canon::TILE_PITCH + lane] = o[k];
+      wave_lds_fence();
+      const int v = lane >> 3, g = lane & 7;
+      const double t = canon::reduce_grad(s_tile + v * canon::TILE_PITCH + 8 * g);
+      if (g < NDT_NBINS) canon::add_piece_lds(s_ibin, v, g, t);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          if (16 * r + k < 29) s_tile[k * canon::TILE_PITCH + lane] = o[16 * r + k];
+        wave_lds_fence();
+        const int v = 16 * r + (lane >> 2), sg = lane & 3;
+        const double t = canon::reduce_hess(s_tile + (lane >> 2) * canon::TILE_PITCH + 16 * sg);
+        if (v < 29) {
+          canon::add_piece_lds(s_ibin, v, sg + 1, t);          // lanes 0..3 of the value take bins 1..4,
+          if (sg == 0) canon::add_piece_lds(s_ibin, v, 0, t);   // lane 0 also bin 0 (zero unless the total exceeds 2^31)
+        }
+      }
+    }
+  }
+
+  // ---- workgroup totals -> the registration's accumulator bank (integer atomics: exact, order independent)
+  __syncthreads();
+  if (tid < NDT_NBINS * 32) {
+    const unsigned long long m = s_ibin[tid];
+    if (m != 0ull) {
+      long long* bank = P.bins + (size_t)(seq % NDT_NBANKS) * NDT_BANK_WORDS + (size_t)(blockIdx.x & (NDT_NSHARDS - 1)) * (NDT_NBINS * 32);
+      atomicAdd(reinterpret_cast<unsigned long long*>(bank + tid), m);
+    }
+  }
 }
 
 #ifdef LSR_TIMING
@@ -1531,43 +1627,6 @@ extern "C" int lsr_debug_angle_tables(const double* p6, int d1_sign, float* jang
   return LSR_OK;
 }
 namespace lsr {
-
-template <int NOFF, int TAB, int THREADS>
-static int launch_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs,
-                          int seq) {
-  // dynamic LDS beyond the 64 KiB default needs the attribute once per kernel instantiation
-  static bool allowed[2][64] = {};  // [byval][device]
-  if (dyn_lds > 48 * 1024) {
-    int dev = 0;
-    LSR_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !allowed[byval ? 1 : 0][dev]) {
-      const void* fn = byval ? (const void*)ndt_eval_kernel<NOFF, true, TAB, THREADS> : (const void*)ndt_eval_kernel<NOFF, false, TAB, THREADS>;
-      LSR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NDT_LDS_TABLE_MAX));
-      allowed[byval ? 1 : 0][dev] = true;
-    }
-  }
-  if (byval) hipLaunchKernelGGL((ndt_eval_kernel<NOFF, true, TAB, THREADS>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq);
-  else hipLaunchKernelGGL((ndt_eval_kernel<NOFF, false, TAB, THREADS>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq);
-  return LSR_OK;
-}
-
-template <int NOFF>
-static int launch_one(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_t stream, const NdtProblem& pv,
-                      const NdtProblem* d_probs, int seq) {
-  const size_t dyn = (cfg.tab == NDT_TAB_LDS) ? (size_t)cfg.lds_bytes : 0;
-  if (cfg.threads == 128) {
-    switch (cfg.tab) {
-      case NDT_TAB_LDS: return launch_variant<NOFF, NDT_TAB_LDS, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
-      case NDT_TAB_COMPACT: return launch_variant<NOFF, NDT_TAB_COMPACT, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
-      default: return launch_variant<NOFF, NDT_TAB_DENSE, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
-    }
-  }
-  switch (cfg.tab) {
-    case NDT_TAB_LDS: return launch_variant<NOFF, NDT_TAB_LDS, 256>(byval, grid, dyn, stream, pv, d_probs, seq);
-    case NDT_TAB_COMPACT: return launch_variant<NOFF, NDT_TAB_COMPACT, 256>(byval, grid, dyn, stream, pv, d_probs, seq);
-    default: return launch_variant<NOFF, NDT_TAB_DENSE, 256>(byval, grid, dyn, stream, pv, d_probs, seq);
-  }
-}
 
 // Start of a single align(): the initial controller state travels in the KERNEL ARGUMENTS (1 KiB) and one small launch
 // writes both state buffers and clears the accumulator banks — instead of a host-to-device copy (SDMA latency) plus a
@@ -1627,38 +1686,75 @@ static int launch_quad(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream
   }
 }
 
-// Launches seq0 .. seq0+count-1 of the chain (launch seq consumes the rows of launch seq-1).
+template <int NOFF, int TAB, int THREADS>
+static int launch_lane_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq,
+                               int tab_bytes) {
+  static bool allowed[2][64] = {};
+  if (dyn_lds > 32 * 1024) {
+    int dev = 0;
+    LSR_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !allowed[byval ? 1 : 0][dev]) {
+      const void* fn = byval ? (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, true> : (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, false>;
+      // table image + staging tiles, bounded by what a workgroup can have on gfx950 (160 KiB minus the kernel's static LDS)
+      const int want = std::min((int)NDT_LDS_TABLE_MAX + ndt_lane_tile_bytes(THREADS), 160 * 1024 - 6 * 1024);
+      LSR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want));
+      allowed[byval ? 1 : 0][dev] = true;
+    }
+  }
+  const int nb = (int)grid.x;
+  if (byval) hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, true>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
+  else hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, false>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
+  return LSR_OK;
+}
+
+template <int NOFF>
+static int launch_lane(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq) {
+  const int tab_bytes = (cfg.tab == NDT_TAB_LDS) ? cfg.lds_bytes : 0;
+  const size_t dyn = (size_t)tab_bytes + (size_t)ndt_lane_tile_bytes(cfg.threads);
+  if (cfg.threads == 1024) {
+    switch (cfg.tab) {
+      case NDT_TAB_LDS: return launch_lane_variant<NOFF, NDT_TAB_LDS, 1024>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+      case NDT_TAB_COMPACT: return launch_lane_variant<NOFF, NDT_TAB_COMPACT, 1024>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+      default: return launch_lane_variant<NOFF, NDT_TAB_DENSE, 1024>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+    }
+  }
+  switch (cfg.tab) {
+    case NDT_TAB_LDS: return launch_lane_variant<NOFF, NDT_TAB_LDS, 512>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+    case NDT_TAB_COMPACT: return launch_lane_variant<NOFF, NDT_TAB_COMPACT, 512>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+    default: return launch_lane_variant<NOFF, NDT_TAB_DENSE, 512>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+  }
+}
+
+// Launches seq0 .. seq0+count-1 of the chain (launch seq consumes the bank of launch seq-1).  cfg.max_blocks = grid.x of these
+// launches: fixed over a chain of the quad kernel (its workgroups stride by P.nblocks), free from launch to launch for the lane
+// kernel (the canonical sum does not depend on it).
 int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, const NdtLaunchCfg& cfg, int seq0, int count,
                      hipStream_t stream) {
-  if (cfg.quad) {
-    const bool qbyval = (cfg.batch == 1 && h_single != nullptr);
-    if (qbyval ? !h_single->bins : !d_probs) { set_last_error("the quad kernel needs its accumulator banks / problem array"); return LSR_ERR_INVALID_ARGUMENT; }
-    dim3 qgrid(cfg.max_blocks, cfg.batch);
-    NdtProblem qpv;
-    if (qbyval) qpv = *h_single; else std::memset(&qpv, 0, sizeof(qpv));
-    for (int i = 0; i < count; i++) {
-      int st;
-      switch (cfg.neighborhood) {
-        case LSR_DIRECT1: st = launch_quad<1>(cfg, qbyval, qgrid, stream, qpv, d_probs, seq0 + i); break;
-        case LSR_DIRECT26: st = launch_quad<27>(cfg, qbyval, qgrid, stream, qpv, d_probs, seq0 + i); break;
-        default: st = launch_quad<7>(cfg, qbyval, qgrid, stream, qpv, d_probs, seq0 + i); break;
-      }
-      if (st) return st;
-    }
-    LSR_HIP(hipGetLastError());
-    return LSR_OK;
-  }
-  if (cfg.threads != 128 && cfg.threads != 256) { set_last_error("NDT workgroup size must be 128 or 256"); return LSR_ERR_INVALID_ARGUMENT; }
-  dim3 grid(cfg.max_blocks, cfg.batch);
   const bool byval = (cfg.batch == 1 && h_single != nullptr);
+  if (byval ? !h_single->bins : !d_probs) { set_last_error("the derivative kernels need their accumulator banks / problem array"); return LSR_ERR_INVALID_ARGUMENT; }
+  dim3 grid(cfg.max_blocks, cfg.batch);
   NdtProblem pv;
   if (byval) pv = *h_single; else std::memset(&pv, 0, sizeof(pv));
+  if (cfg.quad) {
+    if (cfg.threads != 64 && cfg.threads != 128) { set_last_error("quad kernel: 64 or 128 points per workgroup"); return LSR_ERR_INVALID_ARGUMENT; }
+  } else if (cfg.threads != 512 && cfg.threads != 1024) {
+    set_last_error("lane kernel: 512 or 1024 threads per workgroup");
+    return LSR_ERR_INVALID_ARGUMENT;
+  }
   for (int i = 0; i < count; i++) {
     int st;
-    switch (cfg.neighborhood) {
-      case LSR_DIRECT1: st = launch_one<1>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
-      case LSR_DIRECT26: st = launch_one<27>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
-      default: st = launch_one<7>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+    if (cfg.quad) {
+      switch (cfg.neighborhood) {
+        case LSR_DIRECT1: st = launch_quad<1>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+        case LSR_DIRECT26: st = launch_quad<27>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+        default: st = launch_quad<7>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+      }
+    } else {
+      switch (cfg.neighborhood) {
+        case LSR_DIRECT1: st = launch_lane<1>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+        case LSR_DIRECT26: st = launch_lane<27>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+        default: st = launch_lane<7>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+      }
     }
     if (st) return st;
   }

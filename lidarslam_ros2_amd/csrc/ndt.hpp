@@ -22,8 +22,10 @@ enum NdtPhase : int {
 
 constexpr int NDT_NRED = 32;       // doubles per partial row: [0]=score [1..6]=grad [7]=#pairs [8..28]=Hessian upper triangle
 constexpr int NDT_NRED_GRAD = 8;   // entries reduced on gradient-only passes
-constexpr int NDT_THREADS = 256;       // default workgroup size of the derivative pass (128 is the other instantiation)
+constexpr int NDT_LANE_THREADS = 1024;   // default workgroup size of the lane kernel (512 is the other instantiation)
 constexpr int NDT_MAX_BLOCKS = 1024;
+// dynamic LDS the lane kernel needs next to its table: one staging tile of 16 x 68 floats per wave (canon:: in ndt.hip)
+constexpr int ndt_lane_tile_bytes(int threads) { return (threads / 64) * 16 * 68 * 4; }
 constexpr int NDT_LDS_REC_BYTES = 48;  // LDS-resident leaf record: {mean.xyz, c00 | c01 c02 c11 c12 | c22, -, -, -}
 constexpr int NDT_LDS_TABLE_MAX = 128 * 1024;  // largest voxel-table image staged into LDS (160 KiB per CU on gfx950)
 constexpr int NDT_LDS_TABLE_MAX_QUAD = 120 * 1024;  // the quad kernel keeps a 31 KiB reduction buffer next to it
@@ -94,7 +96,7 @@ struct NdtProblem {
   const float* sy;
   const float* sz;
   int n;
-  int nblocks;              // workgroups assigned to this problem (partials rows)
+  int nblocks;              // quad kernel: workgroups of this problem (fixed over the chain: they stride by it)
   const int* cell_slot;
   const float4* rec;
   int min_b[3];
@@ -105,9 +107,8 @@ struct NdtProblem {
   const uint4* lds_image;   // NDT_TAB_LDS: [map | records], padded to a multiple of 1 KiB (one wave-wide 16-byte DMA)
   int lds_bytes;
   int tile_bytes;           // NDT_TAB_TILE: capacity of the per-workgroup LDS tile buffer (dynamic LDS of the launch)
-  long long* bins;          // quad kernel: [NDT_NBANKS][NDT_NSHARDS][NDT_NBINS][32] int64 accumulators (zeroed by the host before launch 0)
+  long long* bins;          // [NDT_NBANKS][NDT_NSHARDS][NDT_NBINS][32] int64 accumulators (zeroed before launch 0)
   NdtState* st;             // [2] double buffered by launch parity
-  double* partials;         // [2][nblocks][NDT_NRED]
   NdtMailbox* mailbox;      // device view of the host mailbox (single registrations fed by polling) or nullptr
 };
 
@@ -137,12 +138,12 @@ struct NdtLaunchCfg {
   int max_blocks = 1;      // grid.x (largest nblocks of the batch)
   int neighborhood = LSR_DIRECT7;
   int tab = NDT_TAB_DENSE; // NdtTableMode
-  int threads = NDT_THREADS;
+  int threads = NDT_LANE_THREADS;  // lane kernel: threads per workgroup (512 / 1024); quad kernel: POINTS per workgroup (64 / 128)
   int lds_bytes = 0;       // dynamic LDS (largest lds_bytes of the batch) when tab == NDT_TAB_LDS
   int sorted = 0;          // 1: the problems read the tile-ordered copy of the source (ndt_sort_source)
-  int quad = 0;            // 1: four lanes per source point, 512-thread workgroups, binned integer accumulation (single
-                           // registrations: spreads a 30k-point scan over every CU; batches whose tables need NDT_TAB_TILE);
-                           // 0: one lane per point, partial rows
+  int quad = 0;            // 1: four lanes per source point, 512-thread workgroups (single registrations: spreads a 30k-point scan
+                           // over every CU; batches whose tables need NDT_TAB_TILE); 0: the lane kernel, one lane per point
+                           // (candidate sets, large single scans).  Both return the same bits (canon:: in ndt.hip).
 };
 constexpr int NDT_QUAD_THREADS = 512;
 constexpr int NDT_QUAD_POINTS = NDT_QUAD_THREADS / 4;  // source points per workgroup pass

@@ -16,6 +16,7 @@ namespace lsr {
 // with explicit fmaf so that the device compiler's contraction choices and the host emulation agree bit for bit.
 __host__ __device__ inline void compose_R12(const float cx, const float cy, const float cz, const float sx, const float sy, const float sz,
                                             float* T) {
+#pragma clang fp contract(off)
   const float a00 = cy, a02 = sy;
   const float a10 = sx * sy, a11 = cx, a12 = -sx * cy;
   const float a20 = -cx * sy, a21 = sx, a22 = cx * cy;
@@ -38,6 +39,11 @@ __host__ __device__ inline void T12_to_colmajor16(const float* T, float* M) {
   M[12] = T[3]; M[13] = T[7]; M[14] = T[11]; M[15] = 1.f;
 }
 
+// Every function of this header opens with `#pragma clang fp contract(off)`: hipcc's default (-ffp-contract=fast-honor-pragmas)
+// fuses a product with the addition that consumes it wherever its scheduler likes — differently in two kernels that inline the
+// same function (round 3's ISA: xform_ref came out as one fma in one row and two in another) — so the only fused operations
+// here are the explicit fmaf() calls, and a point's 29 terms are the same bits in every kernel variant and in the host emulation.
+//
 // Point transform in the REFERENCE's rounding order — pcl::transformPointCloud: ((m00 x + m01 y) + m02 z) + m03, every product
 // and sum rounded to fp32, no fused multiply-add.  The order matters more than it looks: a coordinate of ~50 m carries an
 // fp32 rounding error of ~2e-6 m, q = x' - mean is ~1 m, and the gradient of a pass moves by 3e-7 (relative) between this
@@ -45,6 +51,7 @@ __host__ __device__ inline void T12_to_colmajor16(const float* T, float* M) {
 // Newton direction (BASELINE cfg 4, candidate 21) 2.4 mm away from the reference's result (tests/test_ndt_host_emu_cpu.py).
 __device__ __forceinline__ float xform_ref(const float a, const float b, const float c, const float d, const float x, const float y,
                                            const float z) {
+#pragma clang fp contract(off)
   return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a, x), __fmul_rn(b, y)), __fmul_rn(c, z)), d);
 }
 
@@ -61,6 +68,7 @@ __device__ __forceinline__ void pair_terms(const bool leaf_ok, const bool hess, 
                                            const float4 r0, const float4 r1, const float4 r2, const float d2, const double d1d,
                                            float& score, float& npairs, float& A0, float& A1, float& A2, float& E00, float& E01,
                                            float& E02, float& E11, float& E12, float& E22) {
+#pragma clang fp contract(off)
   const float q0 = (tx - r0.x) - r2.y, q1 = (ty - r0.y) - r2.z, q2 = (tz - r0.z) - r2.w;
   const float c00 = r0.w, c01 = r1.x, c02 = r1.y, c11 = r1.z, c12 = r1.w, c22 = r2.x;
   const float Cq0 = fmaf(c00, q0, fmaf(c01, q1, c02 * q2));
@@ -96,6 +104,7 @@ __device__ __forceinline__ void point_terms(const bool hess, const float px, con
                                             const float npairs, const float A0, const float A1, const float A2, const float E00,
                                             const float E01, const float E02, const float E11, const float E12, const float E22,
                                             JP ja, HP ha, float* __restrict__ o) {
+#pragma clang fp contract(off)
   const float j_a = fmaf(ja[0], px, fmaf(ja[1], py, ja[2] * pz));
   const float j_b = fmaf(ja[3], px, fmaf(ja[4], py, ja[5] * pz));
   const float j_c = fmaf(ja[6], px, fmaf(ja[7], py, ja[8] * pz));

@@ -301,8 +301,9 @@ class Registration:
 
     def setTuning(self, workgroup: Optional[int] = None, table_mode: Optional[int] = None, grid_builder: Optional[int] = None,
                   wait_mode: Optional[int] = None, quad: Optional[int] = None, sort: Optional[int] = None):
-        """Tuning keys of the core (no effect on results beyond fp64 summation order): NDT workgroup size (0 auto, 128,
-        256), where the derivative pass reads the voxel table (-1 auto, 0 dense global, 1 compact global, 2 LDS, 3 tile), the
+        """Tuning keys of the core (no effect on results: every derivative kernel returns the same bits): NDT workgroup (0 auto;
+        quad kernel: 64 / 128 points, lane kernel: 512 / 1024 threads), kernel (quad: -1 auto, 0 lane kernel, 1 quad kernel),
+        where the derivative pass reads the voxel table (-1 auto, 0 dense global, 1 compact global, 2 LDS, 3 tile), the
         grid builder (0 auto, 1 radix sort), how the calling thread waits (0 spin, 1 yield, 2 sleep), source ordering by
         voxel tile (-1 auto, 0 never, 1 also for global-table gathers)."""
         if workgroup is not None:
