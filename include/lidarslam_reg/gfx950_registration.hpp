@@ -17,13 +17,19 @@ template <typename PointSource, typename PointTarget>
 class Gfx950Registration : public pcl::Registration<PointSource, PointTarget> {
   using Base = pcl::Registration<PointSource, PointTarget>;
  public:
-  explicit Gfx950Registration(lsr_method method, int device = 0) {
+  // wait_mode: how the calling thread waits for the device (LSR_WAIT_MODE: 0 spin, 1 yield, 2 sleep).  Default yield: frontend
+  // and backend run side by side under a MultiThreadedExecutor (lidarslam/src/lidarslam.cpp:12-17) and a spinning wait pins one
+  // core per running align (measured cost of yielding between polls: none); a node that owns its cores passes 0.
+  explicit Gfx950Registration(lsr_method method, int device = 0, int wait_mode = 1) {
     if (lsr_create(method, device, nullptr, &h_) != LSR_OK) {          // same failure mode as an invalid
       PCL_ERROR("[gfx950] %s\n", lsr_last_error()); std::exit(1);      // registration_method: exit(1)
     }                                                                   // (scanmatcher_component.cpp:121-124)
-    // frontend and backend run side by side under a MultiThreadedExecutor (lidarslam/src/lidarslam.cpp:12-17): do not
-    // pin a core per running align (measured cost of yielding between polls: none)
-    lsr_set_i32(h_, LSR_WAIT_MODE, 1);
+    lsr_set_i32(h_, LSR_WAIT_MODE, wait_mode);
+    // pcl::Registration::align() -> initCompute() rebuilds a FLANN kd-tree over target_ after every setInputTarget
+    // (scanmatcher_component.cpp:307,353; graph_based_slam_component.cpp:227,230) — >= 100 ms of host time for the
+    // 661k-point submap, next to a 0.1 ms voxel-grid build on the device, for a tree nothing here searches.
+    // force_no_recompute = true: "this tree will NEVER be recomputed, regardless of calls to setInputTarget".
+    this->setSearchMethodTarget(this->tree_, /*force_no_recompute=*/true);
     this->reg_name_ = method == LSR_METHOD_NDT ? "Gfx950NDT" : "Gfx950GICP";
   }
   ~Gfx950Registration() override { lsr_destroy(h_); }

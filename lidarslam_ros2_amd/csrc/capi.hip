@@ -85,6 +85,7 @@ int device_cus(int device) {
 // kernel, one of its 1024-thread workgroups — and lets each of them walk several batches of points instead.
 // `threads`: THREADS per workgroup; `points`: source points a workgroup takes per trip (quad kernel: threads / 4).
 constexpr int NDT_QUAD_BATCH_MAX = 1;
+constexpr int NDT_LANE_SINGLE_MIN = 65536;   // source points from which a single registration uses the lane kernel
 int ndt_resident_wgs(int device, int threads) {
   static const int wgs_per_cu = [] { const char* e = std::getenv("LSR_NDT_WGS_PER_CU"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 0; }();
   return device_cus(device) * (wgs_per_cu ? wgs_per_cu : std::max(1, 2048 / std::max(64, threads)));
@@ -160,8 +161,12 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   // 8 / 16 / 64 candidates (align stage, round 3's kernels): one lane per point 0.61 / 0.90 / 2.73 ms, four lanes 0.76 / 1.09 / 4.06 ms
   // (env LSR_NDT_QUAD_BATCH_MAX raises the batch size up to which the four-lane kernel is used; read once)
   static const int quad_batch_max = [] { const char* e = std::getenv("LSR_NDT_QUAD_BATCH_MAX"); const int v = e ? std::atoi(e) : NDT_QUAD_BATCH_MAX; return v < 1 ? 1 : v; }();
-  const bool want_quad_single = (B <= quad_batch_max && lead->ndt_quad != 0);
-  const int lane_threads = (lead->ndt_threads == 512 || lead->ndt_threads == 1024) ? lead->ndt_threads : NDT_LANE_THREADS;
+  // ... and a single scan large enough to fill the chip with one lane per point takes the lane kernel too: cfg 5 (120k points,
+  // dense global table) 9.4 us per pass with 512-thread workgroups against 16.1 us through the quad kernel (round 4)
+  size_t n_max = 0;
+  for (int b = 0; b < B; b++) n_max = std::max(n_max, hs[b]->source.n);
+  const bool want_quad_single = (B <= quad_batch_max && (lead->ndt_quad == 1 || (lead->ndt_quad < 0 && n_max < (size_t)NDT_LANE_SINGLE_MIN)));
+  const int lane_threads = (lead->ndt_threads == 512 || lead->ndt_threads == 1024) ? lead->ndt_threads : (B == 1 ? 512 : NDT_LANE_THREADS);
   const int static_lds = want_quad_single ? NDT_QUAD_STATIC_LDS : NDT_LANE_STATIC_LDS + ndt_lane_tile_bytes(lane_threads);
   const int table_cap = std::min(want_quad_single ? NDT_LDS_TABLE_MAX_QUAD : NDT_LDS_TABLE_MAX, lds_cap - static_lds);
   const bool lds_ok = all_lds && lds_max <= table_cap;

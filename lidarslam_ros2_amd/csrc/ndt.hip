@@ -924,6 +924,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   __shared__ float s_pt[14][PITCH_PT];   // phase A -> B: per point {score, #pairs, A (3), E (6), x, y, z}
   __shared__ __attribute__((aligned(16))) float s_o[29][PITCH_O];   // phase B -> C: the 29 per-point terms (phase C reads runs as 16-byte vectors)
   __shared__ double s_bin[NDT_NBINS][32];
+  __shared__ unsigned long long s_ibin[NDT_NBINS * 32];   // workgroups that walk several batches collect their pieces here first
   __shared__ double s_sum[NDT_NRED];
   __shared__ double s_lu[8][2];
   __shared__ int s_box[8];               // NDT_TAB_TILE: min (0..2) / max (3..5) centre cell of this workgroup's points
@@ -957,6 +958,7 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
       // quantum of bin k: 2^(62 - 31 (k + 1)); an int64 below 2^53 converts exactly
       const double q = __hiloint2double((1023 + 62 - 31 * (k + 1)) << 20, 0);
       s_bin[k][tid & 31] = (double)msum * q;
+      s_ibin[tid] = 0ull;
     }
     if (tid < STATE_Q) s_state_q[tid] = stq;
     if (TAB == NDT_TAB_TILE && tid >= THREADS - 6) s_box[THREADS - 1 - tid] = (THREADS - 1 - tid < 3) ? INT_MAX : INT_MIN;
@@ -1065,6 +1067,9 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
   //    form their 8 terms right where the sums are, in every lane of the quad — ~30 instructions, no barrier, no LDS round trip;
   //  C: the canonical chunk sums (canon:: above) of the batch's PTS / 64 chunks, straight into the accumulator bank.
   long long* const bank = P.bins + (size_t)(seq % NDT_NBANKS) * NDT_BANK_WORDS + (size_t)(blockIdx.x & (NDT_NSHARDS - 1)) * (NDT_NBINS * 32);
+  // a workgroup with ONE batch (a 30k-point scan: all of them) sends its pieces straight to the bank; one that walks several
+  // collects them in LDS and sends the sums once (atomics on one address serialise in the L2: cfg 5 would queue twice as many)
+  const bool one_batch = (long long)blockIdx.x * PTS + stride >= (long long)P.n;
   for (int base = blockIdx.x * PTS; base < P.n; base += stride) {  // uniform across the workgroup
     // ---- phase A
     {
@@ -1255,8 +1260,9 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
         int pz = poison ? 1 : 0;
         if (PTS == 128) { m += (long long)__shfl_xor((int)m, 8, 64); pz |= __shfl_xor(pz, 8, 64); }   // the batch's second chunk
         if ((tid & (RUNS - 1)) < NDT_NBINS) {
-          if (m != 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + k * 32 + v), (unsigned long long)m);
-          if (pz && k == 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + 31), 1ull);
+          unsigned long long* dst = one_batch ? reinterpret_cast<unsigned long long*>(bank) : s_ibin;
+          if (m != 0) atomicAdd(dst + k * 32 + v, (unsigned long long)m);
+          if (pz && k == 0) atomicAdd(dst + 31, 1ull);
         }
       }
     } else {
@@ -1273,10 +1279,11 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
           m += (long long)__shfl_xor((int)m, 4, 64); m0 += (long long)__shfl_xor((int)m0, 4, 64); pz |= __shfl_xor(pz, 4, 64);
         }
         if (v < 29 && (tid & (RUNS - 1)) < 4) {
-          if (m != 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + (sg + 1) * 32 + v), (unsigned long long)m);
+          unsigned long long* dst = one_batch ? reinterpret_cast<unsigned long long*>(bank) : s_ibin;
+          if (m != 0) atomicAdd(dst + (sg + 1) * 32 + v, (unsigned long long)m);
           if (sg == 0) {
-            if (m0 != 0) atomicAdd(reinterpret_cast<unsigned long long*>(bank + v), (unsigned long long)m0);
-            if (pz) atomicAdd(reinterpret_cast<unsigned long long*>(bank + 31), 1ull);
+            if (m0 != 0) atomicAdd(dst + v, (unsigned long long)m0);
+            if (pz) atomicAdd(dst + 31, 1ull);
           }
         }
       }
@@ -1288,6 +1295,13 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
 
   LSR_STAMP(2)
   LSR_PASS_MARK(_p_t2)
+  if (!one_batch) {
+    __syncthreads();
+    if (tid < NDT_NBINS * 32) {
+      const unsigned long long m = s_ibin[tid];
+      if (m != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(bank + tid), m);
+    }
+  }
   LSR_STAMP(3)
   LSR_PASS_END(hess)
   LSR_SPAN_END(seq)

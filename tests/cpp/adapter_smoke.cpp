@@ -94,8 +94,8 @@ int main() {
     for (int c = 0; c < 3 && ok; c++) {
       auto Tb = regs[c]->getFinalTransformation();
       for (int k = 0; k < 3; k++)
-        if (!(std::fabs(Tb(k, 3) - single_t[c][k]) < 1e-4f)) ok = false;   // batch launches group the partial sums differently
-      if (!regs[c]->hasConverged() || !(std::fabs(fits[c] - single_fit[c]) <= 1e-4 * single_fit[c])) ok = false;
+        if (Tb(k, 3) != single_t[c][k]) ok = false;   // one input, one answer: the batch returns the single registration's bits
+      if (!regs[c]->hasConverged() || !(std::fabs(fits[c] - single_fit[c]) <= 1e-9 * single_fit[c])) ok = false;
     }
     // the same set through the one-call form: same poses, same scores
     std::vector<double> fits2;
@@ -103,7 +103,7 @@ int main() {
     for (int c = 0; c < 3 && ok; c++) {
       auto Tb = regs[c]->getFinalTransformation();
       for (int k = 0; k < 3; k++)
-        if (!(std::fabs(Tb(k, 3) - single_t[c][k]) < 1e-4f)) ok = false;
+        if (Tb(k, 3) != single_t[c][k]) ok = false;
       if (!(std::fabs(fits2[c] - fits[c]) <= 1e-9 * fits[c])) ok = false;
     }
     std::printf("BATCH ok=%d\n", ok ? 1 : 0);

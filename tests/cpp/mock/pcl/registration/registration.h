@@ -2,7 +2,10 @@
 // pcl::Registration / pcl::PointCloud / pcl::PointXYZI / Eigen::Matrix4f that include/lidarslam_reg/gfx950_registration.hpp
 // and the INTEGRATION.md snippets touch, so that they are COMPILED in this repository (PCL itself is not in the image).
 // Names, signatures and virtual-ness follow PCL: setInputSource / setInputTarget virtual, align non-virtual calling the
-// pure virtual computeTransformation, getFitnessScore NON-virtual.
+// pure virtual computeTransformation, getFitnessScore NON-virtual — and align() keeps PCL's initCompute() contract
+// (registration.hpp: fails without target_; rebuilds the target kd-tree whenever a new target was set unless
+// force_no_recompute_), with a build counter on the stand-in kd-tree so that a test can SEE whether a binding makes the host
+// build a FLANN tree over the 661k-point submap it never searches.
 #pragma once
 #include <cstddef>
 #include <cstdio>
@@ -38,17 +41,39 @@ struct PointCloud {
   std::size_t size() const { return points.size(); }
 };
 
+namespace search {
+template <typename PointT>
+struct KdTree {   // pcl::search::KdTree<PointT>: setInputCloud is the O(M log M) FLANN build
+  using Ptr = std::shared_ptr<KdTree<PointT>>;
+  static int& builds() { static int n = 0; return n; }
+  static std::size_t& points_indexed() { static std::size_t n = 0; return n; }
+  void setInputCloud(const typename PointCloud<PointT>::ConstPtr& cloud) { builds()++; points_indexed() += cloud ? cloud->size() : 0; }
+};
+}  // namespace search
+
 template <typename PointSource, typename PointTarget>
 class Registration {
  public:
+  using KdTree = pcl::search::KdTree<PointTarget>;
+  using KdTreePtr = typename KdTree::Ptr;
   using PointCloudSource = pcl::PointCloud<PointSource>;
   using PointCloudSourceConstPtr = typename PointCloudSource::ConstPtr;
   using PointCloudTarget = pcl::PointCloud<PointTarget>;
   using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
-  Registration() : final_transformation_(Eigen::Matrix4f::Identity()), transformation_(Eigen::Matrix4f::Identity()) {}
+  Registration() : tree_(new KdTree), final_transformation_(Eigen::Matrix4f::Identity()), transformation_(Eigen::Matrix4f::Identity()) {}
   virtual ~Registration() = default;
   virtual void setInputSource(const PointCloudSourceConstPtr& cloud) { input_ = cloud; }
-  virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) { target_ = cloud; }
+  virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) {
+    if (!cloud || cloud->points.empty()) { PCL_ERROR("[pcl::%s::setInputTarget] Invalid or empty point cloud dataset given!\n", reg_name_.c_str()); return; }
+    target_ = cloud;
+    target_cloud_updated_ = true;
+  }
+  // registration.h: "force_no_recompute: if set to true, this tree will NEVER be recomputed, regardless of calls to setInputTarget"
+  void setSearchMethodTarget(const KdTreePtr& tree, bool force_no_recompute = false) {
+    tree_ = tree;
+    if (force_no_recompute) force_no_recompute_ = true;
+    target_cloud_updated_ = true;
+  }
   void setTransformationEpsilon(double e) { transformation_epsilon_ = e; }
   void setMaximumIterations(int n) { max_iterations_ = n; }
   void setMaxCorrespondenceDistance(double d) { corr_dist_threshold_ = d; }
@@ -59,12 +84,24 @@ class Registration {
   double getFitnessScore(double = std::numeric_limits<double>::max()) { return -1.0; }   // NON-virtual in PCL (host FLANN search)
   void align(PointCloudSource& output) { align(output, Eigen::Matrix4f::Identity()); }
   void align(PointCloudSource& output, const Eigen::Matrix4f& guess) {
+    if (!initCompute()) return;
     if (input_) output.points = input_->points;      // PCL copies the source into `output` first
     converged_ = false;
+    final_transformation_ = transformation_ = Eigen::Matrix4f::Identity();
     computeTransformation(output, guess);
   }
 
  protected:
+  bool initCompute() {   // pcl::Registration::initCompute (registration.hpp)
+    if (!target_) { PCL_ERROR("[pcl::registration::%s::compute] No input target dataset was given!\n", reg_name_.c_str()); return false; }
+    if (target_cloud_updated_ && !force_no_recompute_) {   // "Only update target kd-tree if a new target cloud was set"
+      tree_->setInputCloud(target_);
+      target_cloud_updated_ = false;
+    }
+    return input_ != nullptr;
+  }
+  KdTreePtr tree_;
+  bool target_cloud_updated_ = true, force_no_recompute_ = false;
   virtual void computeTransformation(PointCloudSource& output, const Eigen::Matrix4f& guess) = 0;
   std::string reg_name_;
   PointCloudSourceConstPtr input_;

@@ -208,10 +208,12 @@ def test_cfg4_hard_candidates_match_the_cpu_fixture(pool):
 
 # ---- cfg 4: ALL 64 candidates against the committed CPU-oracle fixtures -------------------------------------------------
 # tests/golden/cfg4_candidates_oracle.npz (eps 0.01, the backend's schedule; make_cfg4_fixture.py) and
-# tests/golden/cfg4_candidates_oracle_tight.npz (eps 1e-6 + the CPU-vs-CPU spread of the eps-0.01 schedule under fp32-ulp
-# perturbations: an FMA-contracted build and ulp-jittered sources; make_cfg4_tight_fixture.py).
+# tests/golden/cfg4_candidates_oracle_tight.npz (eps 1e-6; make_cfg4_tight_fixture.py).
+# Round 3 had to bound candidates 18 / 34 by a multiple of the CPU path's own spread: the batch path ended 1.4 mm from the
+# fixture.  The cause was not conditioning but the compiler fusing the point transform differently in the two kernels; with the
+# fp32 operation order pinned (ndt_point.hpp) and the canonical sums (ndt.hip: canon) every candidate is within 5e-5 m of the CPU
+# result on BOTH paths — which are now one path: the staged batch and the one-by-one loop return the same bits.
 BAR_T, BAR_R = 1e-3, 1e-4          # north_star: <= 1e-3 m translation, <= 1e-4 rad rotation
-SPREAD_FACTOR = 3.0                # a candidate beyond the bar must stay within this many times its measured CPU spread
 
 
 def _fit_tol(dt, ang, fit):
@@ -274,15 +276,35 @@ def _register_all(cases, eps, batched):
     return finals, its, fits
 
 
+@pytest.fixture(scope="module")
+def cfg4_runs(cfg4_all):
+    """(eps, batched) -> (finals, iterations, fitness) of all 64 candidates, computed once"""
+    fx, fxt, cases = cfg4_all
+    return {(eps, batched): _register_all(cases, eps, batched) for eps in (0.01, 1e-6) for batched in (True, False)}
+
+
+@pytest.mark.parametrize("eps", [0.01, 1e-6], ids=["backend-schedule", "tight"])
+def test_cfg4_staged_batch_and_one_by_one_return_the_same_bits(cfg4_runs, eps):
+    """One input, one answer at BASELINE size: the 64 candidates registered through the staged batch entries (lane kernel, shared
+    launch chain, launches widened as members finish) and one after the other (quad kernel) end at the SAME final_T after the
+    same number of Newton iterations; the fitness scores then differ only by the fp64 order of the mean."""
+    fb, ib, sb = cfg4_runs[(eps, True)]
+    fs, is_, ss = cfg4_runs[(eps, False)]
+    for c in range(64):
+        assert np.array_equal(fb[c], fs[c]), (c, pose_delta(fb[c], fs[c]))
+        assert ib[c] == is_[c], c
+        assert abs(sb[c] - ss[c]) <= 1e-12 * ss[c], c
+
+
 @pytest.mark.parametrize("batched", [True, False], ids=["staged-batch", "one-by-one"])
-def test_cfg4_all_64_candidates_match_the_cpu_fixture_tight(cfg4_all, batched):
+def test_cfg4_all_64_candidates_match_the_cpu_fixture_tight(cfg4_all, cfg4_runs, batched):
     """Tight mode (transformation_epsilon 1e-6, max_iterations 100): both sides reach the optimum of their candidate, so EVERY
     one of the 64 must agree inside the north_star bar — the ill-conditioned ones (18, 21, 34) included — with the fitness score
     at that pose equal to 1e-4.  Iteration counts are NOT compared here: at a 1e-6 step threshold the loop stops on the
     noise floor of the line search (the CPU emulation of the GPU's arithmetic, tests/ndt_host_emu.py, and the oracle differ
     by up to a dozen iterations there while ending 1e-4 m apart at most); they are compared at eps 0.01, where they are equal."""
     fx, fxt, cases = cfg4_all
-    finals, its, fits = _register_all(cases, 1e-6, batched)
+    finals, its, fits = cfg4_runs[(1e-6, batched)]
     bad, rows = {}, []
     for c in range(64):
         dt, ang = pose_delta(finals[c], fxt["final_tight"][c])
@@ -295,30 +317,20 @@ def test_cfg4_all_64_candidates_match_the_cpu_fixture_tight(cfg4_all, batched):
 
 
 @pytest.mark.parametrize("batched", [True, False], ids=["staged-batch", "one-by-one"])
-def test_cfg4_all_64_candidates_match_the_cpu_fixture(cfg4_all, batched):
+def test_cfg4_all_64_candidates_match_the_cpu_fixture(cfg4_all, cfg4_runs, batched):
     """The backend's own schedule (eps 0.01, max_iterations 100; graph_based_slam_component.cpp:64-72): the same number of
-    Newton iterations on all 64; pose inside the bar and fitness to 1e-4 on every candidate whose CPU result is itself stable
-    under fp32-ulp perturbations; the others (the fixture's cpu_spread_* beyond half the bar: the clamped 0.1 m walks along an
-    ill-conditioned Newton direction) must stay within SPREAD_FACTOR times the spread the CPU path shows against itself."""
+    Newton iterations on all 64, EVERY pose inside the north_star bar (measured: worst 4.9e-5 m / 4.9e-6 rad — a twentieth of
+    it), fitness to 1e-4 at that pose.  No named exceptions, no spread factor."""
     fx, fxt, cases = cfg4_all
-    finals, its, fits = _register_all(cases, 0.01, batched)
-    sp_t, sp_r = fxt["cpu_spread_translation_m"], fxt["cpu_spread_rotation_rad"]
-    bad, sensitive, rows = {}, [], []
+    finals, its, fits = cfg4_runs[(0.01, batched)]
+    bad, rows = {}, []
     for c in range(64):
         dt, ang = pose_delta(finals[c], fx["final"][c])
-        rows.append([c, dt, ang, float(abs(fits[c] - fx["fitness"][c]) / fx["fitness"][c]), int(its[c]), int(fx["iterations"][c])])
+        fit_rel = abs(fits[c] - fx["fitness"][c]) / fx["fitness"][c]
+        rows.append([c, dt, ang, float(fit_rel), int(its[c]), int(fx["iterations"][c])])
         if its[c] != int(fx["iterations"][c]):
             bad[c] = ("iterations", its[c], int(fx["iterations"][c]))
-            continue
-        if sp_t[c] > 0.5 * BAR_T or sp_r[c] > 0.5 * BAR_R:
-            sensitive.append(c)
-            lim_t, lim_r = max(BAR_T, SPREAD_FACTOR * sp_t[c]), max(BAR_R, SPREAD_FACTOR * sp_r[c])
-        else:
-            lim_t, lim_r = BAR_T, BAR_R
-        fit_tol = _fit_tol(dt, ang, fx["fitness"][c])
-        fit_rel = abs(fits[c] - fx["fitness"][c]) / fx["fitness"][c]
-        if dt > lim_t or ang > lim_r or fit_rel > fit_tol:
-            bad[c] = (dt, ang, fit_rel, "limits", lim_t, lim_r, fit_tol)
+        elif dt > BAR_T or ang > BAR_R or fit_rel > _fit_tol(dt, ang, fx["fitness"][c]):
+            bad[c] = (dt, ang, fit_rel)
     _dump("cfg4_parity_eps001_%s.json" % ("batch" if batched else "single"), rows)
-    assert len(sensitive) <= 6, sensitive      # the named list stays a short list
-    assert not bad, (bad, sensitive)
+    assert not bad, bad

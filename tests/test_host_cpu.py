@@ -322,6 +322,42 @@ def test_cpp_adapter_runs_the_frontend_call_sequence(tmp_path):
     assert "LOOP st=0 n=1 from=0 to=3 accepted=1" in out, out
 
 
+def _build_binding(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "binding_smoke")
+    libdir = os.path.join(ROOT, "lidarslam_ros2_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "cpp", "mock"),
+                           os.path.join(ROOT, "tests", "cpp", "binding_smoke.cpp"), "-o", exe, "-L" + libdir,
+                           "-llidarslam_reg", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_pcl_binding_compiles_and_fails_loudly_without_a_device(tmp_path):
+    """include/lidarslam_reg/gfx950_registration.hpp against the PCL stand-in whose align() keeps pcl::Registration's
+    initCompute() contract; without a device the program reports it (no CPU path)."""
+    import subprocess
+
+    import torch
+
+    out = subprocess.run([_build_binding(tmp_path)], capture_output=True, text=True, timeout=120).stdout
+    assert out.startswith("NO_TARGET" if torch.cuda.is_available() else "NO_DEVICE"), out
+
+
+@pytest.mark.gpu
+def test_pcl_binding_never_builds_a_host_kdtree_over_the_target(tmp_path):
+    """pcl::Registration::align() -> initCompute() rebuilds a FLANN kd-tree over target_ after every
+    setInputTarget (scanmatcher_component.cpp:307,353) — the binding opts out with setSearchMethodTarget(tree,
+    force_no_recompute = true).  Three frontend cycles through the base-class pointer: converged, zero kd-tree builds;
+    align() before setInputTarget() is refused by initCompute() the PCL way."""
+    import subprocess
+
+    out = subprocess.run([_build_binding(tmp_path)], capture_output=True, text=True, timeout=120).stdout
+    assert "NO_TARGET converged=0" in out, out
+    assert "OK converged=1" in out, out
+    assert "KDTREE builds=0 points_indexed=0" in out, out
+
+
 def test_c_abi_argument_validation_needs_no_device():
     """Error conventions of the boundary: status codes, never an exception or a crash — checked on
     the paths that do not need a device (null handles, invalid method, status strings)."""
