@@ -320,9 +320,10 @@ typedef struct lsr_loop_edge {
  * set as target (:207-227), then align() without guess (:230), getFitnessScore() (:231), the threshold (:233) and the
  * relative pose of the edge (:236-245) — clouds stay in HBM from the first transform to the fitness sum.
  * edges: up to edge_capacity entries, nearest candidate first; *n_evaluated = candidates registered (0 = no candidate).
- * Afterwards `h` answers getFinalTransformation / hasConverged for the nearest candidate.  Its input target: with
- * top_k = 1 the candidate's window (the reference's state after the loop); with top_k > 1 (NDT) NONE — the k windows lived
- * on worker objects, so align / getFitnessScore on `h` return LSR_ERR_NO_TARGET until the next setInputTarget.
+ * Afterwards `h` answers getFinalTransformation / hasConverged for the nearest candidate and holds that candidate's window
+ * as its input target — the reference's state after the loop (:227) — whatever top_k was (with top_k > 1 the k windows are
+ * built on worker objects and the nearest one's is handed to `h`), so a later getFitnessScore() on `h` scores exactly the
+ * pose it reports.
  * The pose-graph optimisation that follows (doPoseAdjustment, g2o) is the caller's. */
 int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, size_t stride_bytes, int on_device,
                     const lsr_loop_params* params, lsr_loop_edge* edges, int edge_capacity, int* n_evaluated);

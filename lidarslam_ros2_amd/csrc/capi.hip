@@ -945,25 +945,38 @@ int lsr_set_input_source_batch(lsr_handle* handles, int count, const void* const
   hipStream_t lead_stream = handles[0]->stream;
   std::vector<DeinterleaveJob> jobs((size_t)count);
   int st;
+  // No member may be left claiming a source it never received: the old clouds are being overwritten, so every member loses its
+  // source up front and gets it back only when the whole set has been staged and de-interleaved.  On a failure the staging
+  // copies already enqueued are drained before returning (the callers may reuse their host buffers).
+  for (int b = 0; b < count; b++) { handles[b]->has_source = false; handles[b]->source_cov_valid = false; }
+  auto fail = [&](int status) {
+    (void)hipStreamSynchronize(lead_stream);
+    return status;
+  };
   for (int b = 0; b < count; b++) {
     lsr_handle h = handles[b];
-    if ((st = order_lead_after(lead_stream, h))) return st;
+    if ((st = order_lead_after(lead_stream, h))) return fail(st);
     const void* d_aos = clouds[b];
     if (!on_device && counts[b] > 0) {
-      if ((st = h->staging.reserve(counts[b] * stride_bytes))) return st;
-      LSR_HIP(hipMemcpyAsync(h->staging.p, clouds[b], counts[b] * stride_bytes, hipMemcpyHostToDevice, lead_stream));
+      if ((st = h->staging.reserve(counts[b] * stride_bytes))) return fail(st);
+      if (hipMemcpyAsync(h->staging.p, clouds[b], counts[b] * stride_bytes, hipMemcpyHostToDevice, lead_stream) != hipSuccess) {
+        set_last_error("staging copy of a source failed");
+        return fail(LSR_ERR_HIP);
+      }
       d_aos = h->staging.p;
     }
     jobs[b] = DeinterleaveJob{d_aos, stride_bytes, counts[b], &h->source};
-    h->has_source = true;
-    h->source_cov_valid = false;
   }
-  if ((st = deinterleave_group(jobs.data(), count, lead_stream))) return st;
+  if ((st = deinterleave_group(jobs.data(), count, lead_stream))) return fail(st);
   // every member's own stream continues after the shared launch (its next align / fitness call runs there)
-  LSR_HIP(hipEventRecord(handles[0]->ev0, lead_stream));
+  if (hipEventRecord(handles[0]->ev0, lead_stream) != hipSuccess) { set_last_error("hipEventRecord failed"); return fail(LSR_ERR_HIP); }
   for (int b = 1; b < count; b++)
-    if (handles[b]->stream != lead_stream) LSR_HIP(hipStreamWaitEvent(handles[b]->stream, handles[0]->ev0, 0));
-  if (!on_device) LSR_HIP(hipStreamSynchronize(lead_stream));  // the callers may reuse their host buffers
+    if (handles[b]->stream != lead_stream && hipStreamWaitEvent(handles[b]->stream, handles[0]->ev0, 0) != hipSuccess) {
+      set_last_error("hipStreamWaitEvent failed");
+      return fail(LSR_ERR_HIP);
+    }
+  if (!on_device && hipStreamSynchronize(lead_stream) != hipSuccess) { set_last_error("stream error in the source batch"); return LSR_ERR_HIP; }
+  for (int b = 0; b < count; b++) handles[b]->has_source = true;
   return LSR_OK;
 }
 
@@ -1152,6 +1165,10 @@ int lsr_align_fitness_batch(lsr_handle* handles, int batch, const float* guesses
       return LSR_ERR_INVALID_ARGUMENT;
     }
   }
+  // an object can hold ONE result: a handle listed twice would be scored at whichever of its poses was written last
+  for (int b = 0; b < batch; b++)
+    for (int a = 0; a < b; a++)
+      if (handles[a] == handles[b]) { set_last_error("the same object appears twice in the batch"); return LSR_ERR_INVALID_ARGUMENT; }
   lsr_handle lead = handles[0];
   LSR_CHECK_HANDLE(lead);
   if (lead->method != LSR_METHOD_NDT) {
@@ -1469,10 +1486,18 @@ int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, si
     // `h` reports the best candidate like a single registration would (getFinalTransformation / hasConverged)
     std::memcpy(h->final_T, edges[0].final_transformation, sizeof(float) * 16);
     h->converged = results[0].converged;
-    // ... but it holds NO input target afterwards: the k windows lived on the worker objects, and whatever `h` held before
-    // the call has nothing to do with the pose just stored — a later getFitnessScore() / align() on `h` must fail loudly
-    // (LSR_ERR_NO_TARGET) instead of pairing the two.  (The buffers stay with the object for the next setInputTarget.)
-    h->target.reset();
+    // ... and it holds that candidate's window as its input target, exactly as after top_k = 1 (where the one candidate is
+    // registered on `h` itself, graph_based_slam_component.cpp:227): a later getFitnessScore() / align() on `h` pairs the pose
+    // just stored with the window it was registered against.  The worker takes `h`'s previous target object in exchange, so
+    // both keep recycling one set of device buffers each.
+    {
+      lsr_handle w0 = workers[0];
+      std::shared_ptr<TargetData> best = w0->target, old = h->target ? h->target : h->spare_target;
+      h->target = best;
+      h->spare_target = best;
+      w0->target.reset();
+      w0->spare_target = old;
+    }
   }
   for (int e = 0; e < k_eval; e++) {
     const int id_min = cand[e].second;

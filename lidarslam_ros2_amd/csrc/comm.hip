@@ -62,8 +62,34 @@ struct lsr_comm_s {
   void* comm = nullptr;
   int rank = 0, world = 1, device = 0;
   hipStream_t stream = nullptr;
+  // Exchange buffers, allocated when the communicator is created (COMM_PREALLOC records per rank: 64 KiB + world x 64 KiB) so
+  // that the sharded calls normally allocate nothing.  d_send is kept ARMED: between calls it holds records flagged invalid
+  // (converged = -1, NaN), so a call whose upload of its own records fails still contributes well-formed "this share failed"
+  // records to the all-gather instead of leaving the collective.
   lsr::DevBuf<lsr_shard_record> d_send, d_recv;
+  size_t armed = 0;   // records of d_send currently holding the invalid pattern
 };
+constexpr size_t COMM_PREALLOC = 1024;
+
+// Where a rank's own share fails (an empty or ill-posed candidate, a HIP error in the registration OR in the exchange's own
+// memset / upload), the rank STILL takes part in the all-gather: its records travel flagged invalid (converged = -1, NaN pose /
+// score / fitness) and the error is returned after the collective — the other ranks never wait for a rank that has already
+// left (the C ABI has no timeout or abort).  The one failure that cannot join is the growth of the exchange buffers beyond
+// their preallocated size (hipMalloc): it is attempted BEFORE the rank's own work, so a rank that cannot take part says so
+// at once instead of after its peers have entered the collective.
+static void invalid_record(lsr_shard_record& R) {
+  for (int k = 0; k < 12; k++) R.T[k] = NAN;
+  R.score = NAN; R.iterations = 0.f; R.converged = -1.f; R.fitness = NAN;
+}
+// (re)fill the first `count` records of d_send with the invalid pattern (synchronous on the communicator's stream)
+static int arm_send(lsr_comm c, size_t count) {
+  std::vector<lsr_shard_record> inv(count);
+  for (auto& R : inv) invalid_record(R);
+  LSR_HIP(hipMemcpyAsync(c->d_send.p, inv.data(), sizeof(lsr_shard_record) * count, hipMemcpyHostToDevice, c->stream));
+  LSR_HIP(hipStreamSynchronize(c->stream));
+  c->armed = count;
+  return LSR_OK;
+}
 
 extern "C" {
 
@@ -139,6 +165,10 @@ int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_c
     std::memcpy(&id, id128, sizeof(id));
     const int rc = r->comm_init_rank(&c->comm, world, id, rank);
     if (rc) { (void)hipStreamDestroy(c->stream); delete c; return rccl_fail("ncclCommInitRank", rc); }
+    if (c->d_send.reserve(COMM_PREALLOC) || c->d_recv.reserve(COMM_PREALLOC * (size_t)world) || arm_send(c, COMM_PREALLOC)) {
+      (void)r->comm_destroy(c->comm); (void)hipStreamDestroy(c->stream); delete c;
+      return LSR_ERR_HIP;
+    }
   }
   *out = c;
   return LSR_OK;
@@ -152,14 +182,6 @@ int lsr_comm_destroy(lsr_comm c) {
   (void)hipStreamDestroy(c->stream);
   delete c;
   return LSR_OK;
-}
-
-// Where a rank's own share fails (an empty or ill-posed candidate, a HIP error), the rank STILL takes part in the all-gather:
-// its records travel flagged invalid (converged = -1, NaN pose / score / fitness) and the error is returned after the
-// collective — the other ranks never wait for a rank that has already left (the C ABI has no timeout or abort).
-static void invalid_record(lsr_shard_record& R) {
-  for (int k = 0; k < 12; k++) R.T[k] = NAN;
-  R.score = NAN; R.iterations = 0.f; R.converged = -1.f; R.fitness = NAN;
 }
 
 int lsr_align_batch_planned(lsr_comm c, lsr_handle* local_handles, int local_count, int global_count, const int32_t* order,
@@ -177,6 +199,22 @@ int lsr_align_batch_planned(lsr_comm c, lsr_handle* local_handles, int local_cou
     }
   }
   const int first = rank_first[c->rank], mine = rank_first[c->rank + 1] - first;
+  int max_count = 1;
+  for (int rk = 0; rk < c->world; rk++) max_count = std::max(max_count, rank_first[rk + 1] - rank_first[rk]);
+  const bool collective = !(c->world == 1 && !c->comm);
+  lsr::DeviceGuard guard(c->device);
+  if (collective) {
+    // everything that can keep this rank OUT of the collective happens before its own work (see invalid_record above)
+    if (!rccl() || !c->comm) { lsr::set_last_error("communicator has no RCCL handle"); return LSR_ERR_NOT_IMPLEMENTED; }
+    if (!guard.ok) { lsr::set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
+    int st;
+    if ((size_t)max_count > c->d_send.cap || (size_t)max_count * c->world > c->d_recv.cap) {
+      if ((st = c->d_send.reserve((size_t)max_count))) return st;
+      if ((st = c->d_recv.reserve((size_t)max_count * c->world))) return st;
+      c->armed = 0;
+    }
+    if (c->armed < (size_t)max_count && (st = arm_send(c, (size_t)max_count))) return st;
+  }
   // ---- this rank's share: no collective on the data path.  Argument errors of THIS rank are local failures too.
   int local_status = LSR_OK;
   std::string local_error;
@@ -212,23 +250,19 @@ int lsr_align_batch_planned(lsr_comm c, lsr_handle* local_handles, int local_cou
     if (local_status) { lsr::set_last_error(local_error); return local_status; }
     return collective_status;
   };
-  if (c->world == 1 && !c->comm) {
+  if (!collective) {
     for (int k = 0; k < global_count; k++) all_records[order[k]] = local[k];
     return finish(LSR_OK);
   }
-  // ---- ONE all-gather of fixed-size blocks (padded to the largest share): 64 B x 64 candidates = 4 KiB, latency bound
+  // ---- ONE all-gather of fixed-size blocks (padded to the largest share): 64 B x 64 candidates = 4 KiB, latency bound.
+  // d_send holds the invalid pattern; this rank's records replace it only if its share succeeded AND the upload works — a
+  // failing upload becomes this rank's local failure, and the collective is entered all the same.
   Rccl* r = rccl();
-  if (!r || !c->comm) { lsr::set_last_error("communicator has no RCCL handle"); return LSR_ERR_NOT_IMPLEMENTED; }
-  lsr::DeviceGuard guard(c->device);
-  if (!guard.ok) { lsr::set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
-  int max_count = 1;
-  for (int rk = 0; rk < c->world; rk++) max_count = std::max(max_count, rank_first[rk + 1] - rank_first[rk]);
-  int st;
-  if ((st = c->d_send.reserve((size_t)max_count))) return st;
-  if ((st = c->d_recv.reserve((size_t)max_count * c->world))) return st;
-  LSR_HIP(hipMemsetAsync(c->d_send.p, 0, sizeof(lsr_shard_record) * (size_t)max_count, c->stream));
-  if (mine > 0)
-    LSR_HIP(hipMemcpyAsync(c->d_send.p, local.data(), sizeof(lsr_shard_record) * (size_t)mine, hipMemcpyHostToDevice, c->stream));
+  if (!local_status && mine > 0) {
+    const hipError_t e = hipMemcpyAsync(c->d_send.p, local.data(), sizeof(lsr_shard_record) * (size_t)mine, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { local_status = LSR_ERR_HIP; local_error = std::string("upload of the shard records failed: ") + hipGetErrorString(e); }
+    else c->armed = 0;
+  }
   const int rc = r->all_gather(c->d_send.p, c->d_recv.p, sizeof(lsr_shard_record) * (size_t)max_count, /*ncclUint8*/ 1, c->comm, c->stream);
   if (rc) return rccl_fail("ncclAllGather", rc);
   std::vector<lsr_shard_record> table((size_t)max_count * c->world);
@@ -243,6 +277,7 @@ int lsr_align_batch_planned(lsr_comm c, lsr_handle* local_handles, int local_cou
       remote_invalid = remote_invalid || (rk != c->rank && R.converged < 0.f);
     }
   }
+  (void)arm_send(c, (size_t)max_count);   // leave d_send armed for the next call (best effort: the next call re-checks)
   if (!local_status && remote_invalid) {   // the table is complete, but some other rank's share failed: say so
     lsr::set_last_error("another rank's share of the batch failed: its records are flagged converged = -1");
     return LSR_ERR_HIP;

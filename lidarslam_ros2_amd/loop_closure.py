@@ -84,6 +84,8 @@ def search_loop(registration: Registration, submaps: Sequence[SubMap], params: L
     n_eval = C.c_int32(0)
     _capi.check(lib.lsr_search_loop(registration._h, arr, n, stride, int(bool(on_device)), C.byref(cp), edges, cap,
                                     C.byref(n_eval)), "searchLoop")
+    if n_eval.value and hasattr(registration, "_n_target"):
+        registration._n_target = int(edges[0].n_target_points)   # the object now holds the nearest candidate's window as its target
     out = []
     for e in edges[:n_eval.value]:
         out.append(LoopEdge(pair_id=(e.id_from, e.id_to),

@@ -76,7 +76,16 @@ def test_search_loop_matches_the_oracle_ndt(route):
 
 def test_search_loop_top_k_and_device_resident_clouds(route):
     p = dict(PARAMS, top_k=3)
-    host = search_loop(_backend_ndt(), _submaps(route), LoopClosureParams(**p))
+    backend = _backend_ndt()
+    host = search_loop(backend, _submaps(route), LoopClosureParams(**p))
+    # the object is left as top_k = 1 leaves it: pose AND target of the nearest candidate — getFitnessScore() on it
+    # scores exactly the edge it reported first
+    assert np.array_equal(backend.getFinalTransformation(), host[0].final_transformation)
+    assert backend.getFitnessScore() == pytest.approx(host[0].fitness_score, rel=1e-12)
+    one = _backend_ndt()
+    first = search_loop(one, _submaps(route), LoopClosureParams(**PARAMS))[0]
+    assert np.array_equal(first.final_transformation, host[0].final_transformation)      # one input, one answer
+    assert one.getFitnessScore() == pytest.approx(backend.getFitnessScore(), rel=1e-12)
     dev = search_loop(_backend_ndt(), _submaps(route, device=True), LoopClosureParams(**p))
     ref = oracle.search_loop(route, **p, ndt_resolution=5.0, trans_eps=0.01, max_iterations=100,
                              num_threads=min(32, oracle.max_threads()))
