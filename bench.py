@@ -263,7 +263,7 @@ def main():
     out = {
         "metric": "scan registrations/sec (30k-pt scan vs 10-frame submap)",
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "median_ms_per_step": 1e3 * float(np.median(lat)), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "accumulation_dtype": "f64", "data": "synthetic",
         "config": {"workload": "cfg2: single NDT align(), 30000-pt VLP-32 scan (vg 0.2) vs 10-frame submap (vg 0.1), "
                                "ndt_resolution 5.0, DIRECT7, max_iterations 30, transformation_epsilon 0; "
@@ -363,6 +363,16 @@ def main():
                 cpu_leg(args, out, stash, case, stream, j_last, gpu_final, res, max_iter)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
+        # the fed-chip figures next to the single-scan one: the derivative kernel on the workloads that fill the chip
+        if isinstance(out.get("roofline"), dict):
+            cr = (cfg4 or {}).get("chain_roofline") if isinstance(cfg4, dict) else None
+            if isinstance(cr, dict) and "frac" in cr:
+                out["roofline"]["batch"] = cr
+            c5 = out.get("cfg5_dense")
+            if isinstance(c5, dict) and "avg_pass_us" in c5:
+                out["roofline"]["cfg5"] = {"kernel": "ndt_eval_lane_kernel<7, dense global table, 512> (single 120k-pt scan)", "avg_launch_us": c5["avg_pass_us"],
+                                           "algorithmic_bytes_per_launch": c5.get("algorithmic_bytes_per_pass"), "frac": c5.get("algorithmic_frac_of_hbm_peak"),
+                                           "traffic": c5.get("traffic"), "frac_by_traffic": c5.get("frac_by_traffic")}
         print(json.dumps(out), flush=True)
 
     if cfg4_hung:
@@ -794,7 +804,30 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
         dist.barrier()
     t_batched = sync_max(min(one_round(True) for _ in range(3)))
     t_serial = sync_max(min(one_round(False) for _ in range(2))) if world == 1 else None
+    if world == 1 and nloc:   # one input, one answer: the one-by-one loop (quad kernel) against the staged batch (lane kernel)
+        serial_T = []
+        for r in regs:
+            fin = np.zeros(16, np.float32)
+            _capi.check(lib.lsr_get_final_transformation(r._h, fin.ctypes.data_as(fptr)), "getFinalTransformation")
+            serial_T.append(fin.copy())
     one_round(True)
+    extra = {}
+    if world == 1 and nloc:
+        same = 0
+        for b, r in enumerate(regs):
+            fin = np.zeros(16, np.float32)
+            _capi.check(lib.lsr_get_final_transformation(r._h, fin.ctypes.data_as(fptr)), "getFinalTransformation")
+            same += int(np.array_equal(fin, serial_T[b]))
+        extra["same_bits_as_one_by_one"] = {"candidates": nloc, "identical_final_transformations": same}
+        try:
+            extra["chain_roofline"] = cfg4_chain_roofline(lib, regs, hs, nloc, G, srcs, fptr)
+        except Exception as e:   # never lose the line to a diagnostic leg
+            extra["chain_roofline"] = {"error": repr(e)}
+        try:
+            extra["projected_8gpu"] = cfg4_projected_8gpu(lib, dev_index, regs, tgts, srcs, G, t_batched, fptr)
+        except Exception as e:
+            extra["projected_8gpu"] = {"error": repr(e)}
+        one_round(True)   # leave the records of the full set in `recs` for the parity block below
     # parity sanity on this rank's share: registered pose vs ground truth
     errs = []
     for b, (c, target, source, guess, truth) in enumerate(cands):
@@ -844,14 +877,98 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
                                             "max_rotation_rad": float(max(angs)), "newton_iterations_all_equal": bool(it_equal),
                                             "max_fitness_rel_diff": float(max(fits)),
                                             "within_1e-3m_1e-4rad": len(dts) - len(outliers), "beyond": outliers,
-                                            "note": "eps 0.01 (the backend's schedule) stops anywhere within its 0.01 m step tolerance: a candidate "
-                                                    "beyond the bar here is one whose CPU result itself moves that far under fp32-ulp perturbations "
-                                                    "(cpu_spread_* of tests/golden/cfg4_candidates_oracle_tight.npz: 18 and 34); at eps 1e-6 all 64 agree "
-                                                    "within 1.4e-4 m (tests/test_full_size_gpu.py, DESIGN.md 2)",
+                                            "note": "eps 0.01 (the backend's schedule), staged batch path; the one-by-one path returns the same bits "
+                                                    "(same_bits_as_one_by_one).  Round 3's 1.4 mm outlier (candidate 34) was the compiler fusing the point "
+                                                    "transform differently in two kernels, not conditioning (DESIGN.md 2)",
                                             "fixture": "tests/golden/cfg4_candidates_oracle.npz (CPU oracle, all 64 candidates)"}
     if t_serial is not None:
         res["serial_one_by_one"] = {"value": n_total / t_serial, "unit": "registrations/s", "ms_per_candidate_set": 1e3 * t_serial}
+    res.update(extra)
     return res
+
+
+def cfg4_chain_roofline(lib, regs, hs, nloc, G, srcs, fptr):
+    """The fed-chip roofline: the shared launch chain of the candidate set on its own — targets and sources
+    resident, lsr_align_batch with the lead object's profiling on: hipEvents on the chain's stream from the state upload to the
+    launch that raises the last `done`.  Algorithmic bytes = sum over members of passes x (N x 12 + pairs x 40)
+    + launches x workgroups x 256; priced against 8 TB/s.  The whole chain is priced, its thin tail (few members still running)
+    included — the launches in which all 64 members are active run at the `full_load` figure of profiles/r04_*cfg4*."""
+    from lidarslam_ros2_amd import _capi
+    lead = regs[0]
+    finals = np.zeros((nloc, 16), np.float32)
+    res = (_capi.Result * nloc)()
+    best = None
+    for rep in range(4):
+        lead.setProfiling(True); lead.getProfile(reset=True)
+        _capi.check(lib.lsr_align_batch(hs, nloc, G.ctypes.data_as(fptr), finals.ctypes.data_as(fptr), res), "lsr_align_batch")
+        prof = lead.getProfile(reset=True); lead.setProfiling(False)
+        if rep and (best is None or prof["deriv_ms_total"] < best[0]["deriv_ms_total"]):
+            best = (prof, [(int(r.n_evaluations), int(r.n_correspondences)) for r in res])
+    prof, per = best
+    n_pts = [int(t.shape[0]) for t in srcs]
+    member_passes = sum(e for e, _ in per)
+    alg = sum(e * (n * 12 + p * 40) for (e, p), n in zip(per, n_pts)) + prof["deriv_launches"] * 512 * 256
+    ms = prof["deriv_ms_total"]
+    achieved = alg / (ms * 1e-3) / 1e9
+    return {"kernel": "ndt_eval_lane_kernel<7, LDS table, 1024> (one lane per point, shared launch chain of the set)",
+            "members": nloc, "launches": prof["deriv_launches"], "member_passes": member_passes, "chain_ms": ms,
+            "us_per_member_pass": 1e3 * ms / member_passes, "algorithmic_bytes": alg, "bound": "valu (lds-gather)", "priced_against": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "mean_valid_pairs_per_point": sum(p for _, p in per) / max(1, sum(n_pts)),
+            "note": "hipEvents on the chain's stream around the whole chain (state upload -> last done), best of 3; bytes per SURVEY.md 8d"}
+
+
+def cfg4_projected_8gpu(lib, dev_index, regs, tgts, srcs, G, t_set, fptr):
+    """What ONE GPU can say about the 8-GPU figure: the eight shares of the 64-candidate set an 8-GPU node
+    would run side by side — the static block partition and the cost-aware longest-first plan (costs = point visits) — are run one
+    after the other here, each through the whole per-candidate path (lsr_set_input_target_batch, lsr_set_input_source_batch,
+    lsr_align_batch_sharded with a one-rank communicator and fitness).  64-set time / slowest share = the scaling an 8-GPU node
+    could reach before its (4 KiB, latency-bound) all-gather; a projection from single-GPU measurements, not a scaling run."""
+    from lidarslam_ros2_amd import _capi
+    n, world = len(regs), 8
+    if n < world:
+        return {"skipped": "fewer candidates than shares"}
+    comm = C.c_void_p()
+    _capi.check(lib.lsr_comm_create(None, 0, 1, dev_index, C.byref(comm)), "lsr_comm_create")
+    cost = (C.c_double * n)(*[6.0 * int(t.shape[0]) + 34.0 * int(s.shape[0]) for t, s in zip(tgts, srcs)])
+    owner, order, first = (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int32 * (world + 1))()
+    _capi.check(lib.lsr_shard_plan(n, cost, world, owner, order, first), "lsr_shard_plan")
+    plans = {"block": [list(range(*(lambda f, c: (f, f + c))(*_shard_range(lib, n, world, r)))) for r in range(world)],
+             "planned_longest_first": [[int(order[k]) for k in range(first[r], first[r + 1])] for r in range(world)]}
+    out = {}
+    for name, shares in plans.items():
+        times = []
+        for share in shares:
+            m = len(share)
+            if m == 0:
+                times.append(0.0); continue
+            hs = (C.c_void_p * m)(*[regs[i]._h for i in share])
+            tp = (C.c_void_p * m)(*[C.c_void_p(tgts[i].data_ptr()) for i in share]); tc = (C.c_size_t * m)(*[int(tgts[i].shape[0]) for i in share])
+            sp = (C.c_void_p * m)(*[C.c_void_p(srcs[i].data_ptr()) for i in share]); sc = (C.c_size_t * m)(*[int(srcs[i].shape[0]) for i in share])
+            g = np.ascontiguousarray(G[share])
+            recs = (_capi.ShardRecord * m)()
+            best = None
+            for rep in range(3):
+                t0 = time.perf_counter()
+                _capi.check(lib.lsr_set_input_target_batch(hs, m, tp, tc, 32, 1), "t")
+                _capi.check(lib.lsr_set_input_source_batch(hs, m, sp, sc, 32, 1), "s")
+                _capi.check(lib.lsr_align_batch_sharded(comm, hs, m, m, g.ctypes.data_as(fptr), 1, recs), "a")
+                dt = time.perf_counter() - t0
+                if rep and (best is None or dt < best):
+                    best = dt
+            times.append(best)
+        out[name] = {"share_ms": [round(1e3 * t, 4) for t in times], "max_share_ms": 1e3 * max(times), "mean_share_ms": 1e3 * sum(times) / len(times),
+                     "set_ms_on_one_gpu": 1e3 * t_set, "projected_speedup_8_gpus": t_set / max(times)}
+    lib.lsr_comm_destroy(comm)
+    out["note"] = ("shares run one after the other on ONE GPU; projected_speedup = 64-set time on one GPU / slowest share, before the 4 KiB "
+                   "all-gather (~0.03 ms).  north_star asks >= 6x at 8 GPUs")
+    return out
+
+
+def _shard_range(lib, n, world, r):
+    f, c = C.c_int(), C.c_int()
+    lib.lsr_shard_range(n, world, r, C.byref(f), C.byref(c))
+    return f.value, c.value
 
 
 def cpu_leg(args, out, stash, case, stream, j_last, gpu_final, res, max_iter):

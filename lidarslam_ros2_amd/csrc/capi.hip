@@ -544,7 +544,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
       results[b].iterations = M[b].nr_iterations;
       results[b].score = M[b].trans_probability;
       results[b].n_evaluations = M[b].n_evals;
-      results[b].n_correspondences = 0;
+      results[b].n_correspondences = (int)M[b].last_pairs;   // valid (point, voxel) pairs of the last derivative pass
       results[b].gpu_ms = ms;  // host clock from the state upload to the last raised flag (launches still queued are no-ops)
     }
   }

@@ -226,3 +226,24 @@ def test_c_abi_sharded_batch_through_a_real_rccl_communicator_of_one_rank():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run([sys.executable, "-c", _RCCL1_CODE], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0 and "RCCL1 OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_c_level_two_process_launcher_runs_the_rccl_path(tmp_path):
+    """csrc/comm.hip with world = 2 through the C ABI alone: tests/cpp/two_rank_comm.cpp forks, rank 0 hands
+    the RCCL id to rank 1 over a pipe, each rank registers its block of a 6-candidate set on its own GPU and both must end
+    with the table one GPU computes for all six.  Skips (in the program) on a box with fewer than two devices."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "lidarslam_ros2_amd")
+    exe = str(tmp_path / "two_rank_comm")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "two_rank_comm.cpp"),
+                           "-o", exe, "-L" + libdir, "-llidarslam_reg", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    out = r.stdout
+    if out.startswith("SKIP"):
+        pytest.skip("two-process RCCL launcher needs two devices: " + out.strip())
+    assert r.returncode == 0 and "TWO_RANK ok=1 converged=6/6" in out, (out, r.stderr[-2000:])
