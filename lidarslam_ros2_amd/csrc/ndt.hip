@@ -17,6 +17,7 @@
 #include "ndt.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 #include "grid_device.hpp"
 #include "ndt_point.hpp"

@@ -420,6 +420,148 @@ __global__ __launch_bounds__(256) void fitness_final_kernel(const double* __rest
 // the same answers, and on paper a sixth of the instructions per query once millions of queries fill the chip; measured
 // slower than one wave per query (the deferred tail alone costs as much as it saves)
 __global__ void fit_zero_work_group_kernel(const FitGroup g) { g.m[threadIdx.x].work[0] = 0; }   // empty deferred-query lists
+
+// getFitnessScore's search on SIXTEEN lanes per query, seeded by the query's own fine cell (round 4).
+// A registered scan lies on the submap: the nearest target point of a query is almost always a few centimetres away, and the
+// fine cell the query falls into (leaf / 8 = 0.625 m at the reference's resolution) almost always holds a point.  So:
+//   1. the group scans the query's OWN cell (one dependent lookup: coarse map -> fine table -> the cell's points) — if it is empty,
+//      the 3 x 3 x 3 cells around it — and keeps the best (distance, index): a real point, hence an upper bound d on the answer;
+//   2. every point at distance <= d lies in a fine cell that touches the ball of radius d around the query (the cell index is a
+//      monotone map; the reach is padded against rounding: ball_cell_range): those cells — one to eight for a registered scan, not the
+//      27 of a shell — are ALL that is left to read, one lane per (row, coarse segment), candidates laid end to end, 16 per round
+//      (the structure of gicp_corr_ball_kernel, whose seed is the previous outer iteration's neighbour);
+//   3. a query with no point within a cell of it, or whose ball spans more than FIT_BALL_CELLS cells on an axis, goes on the
+//      member's work list for the general one-wave-per-query search (nn1_list_group_kernel): exact all the same.
+// Same candidates compared in the same total order (distance, index), same fp32 distances => the answer of every other search
+// form, bit for bit (tests/test_nn_gpu.py, test_loop_closure_gpu.py hold them to each other and to the oracle).
+constexpr int FIT_BALL_CELLS = 5;
+__device__ __forceinline__ void nn1_ball_body(const NNGridView& G, const float* __restrict__ qx, const float* __restrict__ qy,
+                                              const float* __restrict__ qz, int n, const float* __restrict__ T16, int* __restrict__ work,
+                                              int* __restrict__ idx, float* __restrict__ d2, const int t) {
+  const int i = t >> 4, gl = t & 15;
+  if (i >= n) return;   // n * 16 threads: a group is never split by this test
+  const float x = qx[i], y = qy[i], z = qz[i];
+  const float q[3] = {xform_rn(T16[0], T16[4], T16[8], T16[12], x, y, z), xform_rn(T16[1], T16[5], T16[9], T16[13], x, y, z),
+                      xform_rn(T16[2], T16[6], T16[10], T16[14], x, y, z)};
+  if (!(isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]))) {   // no neighbour, as every other form answers
+    if (gl == 0) { idx[i] = -1; d2[i] = INFINITY; }
+    return;
+  }
+  float bd = INFINITY;
+  int bi = INT_MAX;
+  bool general = false;
+  // every candidate of the fine cells [lo, hi] (clamped to the grid by the caller), one lane per (row, coarse segment), the
+  // group's candidates laid end to end and read 16 at a time; then the group's best in every lane
+  auto scan_cells = [&](const int* lo, const int* hi) {
+    const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+    const int n_slots = (ny > 0 && nz > 0 && hi[0] >= lo[0]) ? ny * nz * 2 : 0;
+    const unsigned int ny_magic = 65536u / (unsigned int)max(ny, 1) + 1u;
+    for (int s0 = 0; s0 < n_slots; s0 += 16) {
+      const int slot = s0 + gl;
+      int beg = 0, len = 0;
+      if (slot < n_slots) {
+        const int cseg = slot & 1, row = slot >> 1;
+        const int dz = (int)(((unsigned int)row * ny_magic) >> 16);   // row / ny (row < 128, ny <= 8)
+        const int yy = lo[1] + (row - dz * ny), zz = lo[2] + dz;
+        const int cx = (lo[0] >> 3) + cseg;
+        if (cx <= (hi[0] >> 3)) {
+          const int blk = G.coarse_block[G.cdim[0] * ((yy >> 3) + G.cdim[1] * (zz >> 3)) + cx];
+          if (blk >= 0) {
+            const int xa = max(lo[0], cx * 8) & 7, xb = min(hi[0], cx * 8 + 7) & 7;
+            const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((yy & 7) << 3) | ((zz & 7) << 6));
+            beg = fs[xa];
+            len = fs[xb + 1] - beg;
+          }
+        }
+      }
+      int incl = len;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const int v = __shfl_up(incl, d, 16);
+        if (gl >= d) incl += v;
+      }
+      const int excl = incl - len;
+      const int total = __shfl(incl, 15, 16);
+      for (int t0 = 0; t0 < total; t0 += 16) {
+        const int f = t0 + gl;
+        int sl = 0;
+#pragma unroll
+        for (int step = 8; step >= 1; step >>= 1) {
+          const int cand = sl + step;
+          const int o = __shfl(excl, cand, 16);
+          if (o <= f) sl = cand;
+        }
+        const int sb = __shfl(beg, sl, 16), so = __shfl(excl, sl, 16);
+        if (f < total) {
+          const float4 pt = G.p[sb + (f - so)];
+          const float d = dist2_rn(q[0], q[1], q[2], pt.x, pt.y, pt.z);
+          const int oi = __float_as_int(pt.w);
+          if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+      const float od = __shfl_xor(bd, m, 16);
+      const int oi = __shfl_xor(bi, m, 16);
+      if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+  };
+  // ---- 1. a seed: the best point of the query's own fine cell; if that cell is empty, of the 3 x 3 x 3 cells around it
+  const float ff[3] = {floorf(q[0] * G.inv_cell), floorf(q[1] * G.inv_cell), floorf(q[2] * G.inv_cell)};
+  int fq[3] = {0, 0, 0};
+  if (!(fabsf(ff[0]) < 1.0e9f && fabsf(ff[1]) < 1.0e9f && fabsf(ff[2]) < 1.0e9f)) general = true;
+  if (!general) {
+    for (int a = 0; a < 3; a++) {
+      fq[a] = (int)ff[a] - G.org[a];
+      if (fq[a] < -1 || fq[a] > G.cdim[a] * 8) general = true;   // more than a cell outside the grid: the general search
+    }
+  }
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  if (!general) {
+    for (int a = 0; a < 3; a++) { lo[a] = max(fq[a], 0); hi[a] = min(fq[a], G.cdim[a] * 8 - 1); }
+    scan_cells(lo, hi);
+    if (bi == INT_MAX) {
+      for (int a = 0; a < 3; a++) { lo[a] = max(fq[a] - 1, 0); hi[a] = min(fq[a] + 1, G.cdim[a] * 8 - 1); }
+      scan_cells(lo, hi);
+    }
+    if (bi == INT_MAX) general = true;   // nothing within a cell of the query: rare for a registered scan
+  }
+  // ---- 2. the cells of the ball of radius sqrt(bd) around the query hold every point that could beat the seed
+  if (!general && !ball_cell_range(G, q, bd, FIT_BALL_CELLS, lo, hi)) general = true;
+  if (general) {
+    if (gl == 0) work[1 + atomicAdd(work, 1)] = i;
+    return;
+  }
+  scan_cells(lo, hi);
+  if (gl == 0) { idx[i] = bi; d2[i] = bd; }
+}
+__global__ __launch_bounds__(256) void nn1_list_group_kernel(const FitGroup g) {
+  const FitMember& M = g.m[blockIdx.y];
+  if (M.empty) return;
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+  const int n_work = M.work[0];
+  for (int w = wave; w < n_work; w += n_waves) {
+    const int i = M.work[1 + w];
+    const float x = M.qx[i], y = M.qy[i], z = M.qz[i];
+    const float tx = xform_rn(M.T16[0], M.T16[4], M.T16[8], M.T16[12], x, y, z), ty = xform_rn(M.T16[1], M.T16[5], M.T16[9], M.T16[13], x, y, z),
+                tz = xform_rn(M.T16[2], M.T16[6], M.T16[10], M.T16[14], x, y, z);
+    CoopList mine;
+    mine.d = INFINITY;
+    mine.i = INT_MAX;
+    coop_search<true>(M.G, tx, ty, tz, 1, M.fine_rings, M.max_d2, -1, mine);
+    if (lane == 0) {
+      const bool found = mine.i != INT_MAX;
+      M.idx[i] = found ? mine.i : -1;
+      M.d2[i] = found ? mine.d : INFINITY;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void nn1_ball_group_kernel(const FitGroup g) {
+  const FitMember& M = g.m[blockIdx.y];
+  if (M.empty) return;
+  nn1_ball_body(M.G, M.qx, M.qy, M.qz, M.n, M.T16, M.work, M.idx, M.d2, blockIdx.x * 256 + threadIdx.x);
+}
 __global__ __launch_bounds__(NN_THREADS) void nn1_quad_group_kernel(const FitGroup g) {
   const FitMember& M = g.m[blockIdx.y];
   if (M.empty) return;
@@ -743,7 +885,12 @@ int nn_fitness_begin_group(const FitJob* jobs, int count, hipStream_t stream) {
     }
     static const int form = [] { const char* e = getenv("LSR_FIT_GROUP_FORM"); return e ? atoi(e) : -1; }();   // 0 wave, 1 quad + tail, -1 by size
     const bool quad_form = form == 1;   // measured on 64 candidates x 30k queries: 5.85 ms against 3.54 ms for one wave per query
-    if (quad_form) {
+    const bool ball_form = form == 2 || form < 0;   // sixteen lanes per query seeded by its own fine cell + a tail for the rest (default)
+    if (ball_form) {
+      hipLaunchKernelGGL(fit_zero_work_group_kernel, dim3(1), dim3(ng), 0, stream, grp);
+      hipLaunchKernelGGL(nn1_ball_group_kernel, dim3((unsigned)(((long)max_n * 16 + 255) / 256), ng), dim3(256), 0, stream, grp);
+      hipLaunchKernelGGL(nn1_list_group_kernel, dim3(256, ng), dim3(256), 0, stream, grp);
+    } else if (quad_form) {
       hipLaunchKernelGGL(fit_zero_work_group_kernel, dim3(1), dim3(ng), 0, stream, grp);
       hipLaunchKernelGGL(nn1_quad_group_kernel, dim3((unsigned)(((long)max_n * 4 + NN_THREADS - 1) / NN_THREADS), ng), dim3(NN_THREADS), 0, stream, grp);
       hipLaunchKernelGGL(nn1_coop_group_kernel, dim3(64, ng), dim3(256), 0, stream, grp);

@@ -20,7 +20,7 @@ def scan():
     return synth.raycast(synth.make_world(), synth.vlp32(), synth.trajectory_pose(3.0), rng)   # raw ~45k-point scan
 
 
-@pytest.mark.parametrize("leaf", [0.1, 0.2, 0.5, 2.0])
+@pytest.mark.parametrize("leaf", [0.1, 0.2, 0.5, 2.0, 8.0])
 def test_voxel_grid_filter_matches_oracle(O, scan, leaf):
     from lidarslam_ros2_amd import NormalDistributionsTransform
 

@@ -1,0 +1,379 @@
+// SHELVED EXPERIMENT (round 4; not built, not linked): bit-identical to the product path on every test input, but SLOWER than it.
+// Measured on MI355X, 147 443-point scan, leaf 0.2 (tools/r03_preprocess_probe.py: range filter + VoxelGrid + setInputSource):
+//   rocPRIM path (product): 151 us        this file: 255 us (14 high bits) / 242 us (16) / 440 us (12)
+// Where it loses: a lidar scan is dense next to the sensor — a few dozen slabs hold thousands of points each — so (i) the slab
+// counters are hot: even with one atomic per (wave, slab) vf_count / vf_scatter take 29 / 33 us (90 / 109 us with one atomic per
+// point), and (ii) the per-workgroup bitonic sort of those slabs takes 100 us (hi 14).  What would fix it (per-workgroup LDS
+// histograms for the first digit, an LDS counting sort + per-leaf rank for dense slabs) was estimated at ~115 us end to end —
+// not enough over 151 us to justify the code in the product.  Kept here for the record of VERDICT r03 #4(ii).
+//
+// N1: pcl::VoxelGrid::filter for sparse key spaces, hand-written (scanmatcher/src/scanmatcher_component.cpp:324-328
+// every scan, :266-269 / :443-447 map side; graph_based_slam/src/graph_based_slam_component.cpp:224-226).
+//
+// A scan of ~150k points at a 0.2 m leaf lives in a key space of ~10^8 leaf indices: too sparse for the LDS counting sort of the
+// voxel-covariance builder (grid_dense.hip), and round 3 sent it through rocPRIM (merge sort + run-length encode + scan: ~20
+// launches, 0.158 ms — more than the registration it feeds).  Here the sort is a two-digit MSD split written for this problem:
+//   digit 1  the top <= 16 bits of the leaf index = a SLAB of 2^LOW consecutive leaf indices: counted with global atomics
+//            (vf_count), prefixed by one workgroup (vf_scan), scattered in ANY order through per-slab cursors (vf_scatter);
+//   digit 2  inside a slab — a handful of points for a lidar scan — the (low digit, point index) pairs are ranked: one wave per slab
+//            of <= 64 points (rank sort through cross-lane reads), one workgroup per larger slab (bitonic sort in LDS).  Ranking
+//            on (low digit, index) makes the order inside a leaf ascending point index whatever order the scatter used, so the
+//            leaf's FLOAT centroid sums are the very additions pcl::CentroidPoint performs: bit-identical to the CPU restatement.
+// The leaves of a slab are summed where they are sorted and parked at the slab's first positions; a second prefix over the
+// slabs' leaf counts (vf_leaf_scan, which also publishes the total into the host mailbox) and one gather (vf_gather) put them
+// in leaf-index order.  8 small launches, one host poll at the end (plus the bounding-box poll every builder needs).
+#include <cstdlib>
+
+#include "ndt.hpp"
+
+namespace lsr {
+namespace {
+
+constexpr int VF_HI_BITS_DEFAULT = 14;  // slabs <= 16385: the two prefix passes are four 4096-entry chunks of one workgroup
+constexpr int VF_WAVE_MAX = 64;         // slabs up to this many points: one wave
+constexpr int VF_BIG_MAX = 8192;        // slabs up to this many points: one workgroup (64 KiB of LDS); beyond: the caller falls back
+constexpr unsigned long long VF_HEAD = 1ull << 63;
+
+struct VfGeom {
+  float inv_leaf;
+  int mb0, mb1, mb2, mul1, mul2;
+  int low_bits, n_slabs;
+};
+
+__device__ __forceinline__ bool vf_key(const VfGeom& g, const float px, const float py, const float pz, unsigned int* key) {
+  if (!(isfinite(px) && isfinite(py) && isfinite(pz))) return false;
+  // ijk = (int)(floor(p * inv_leaf) - (float)min_b), as pcl::VoxelGrid computes it (ndt.hip: leaf_key_kernel)
+  const int i0 = (int)(floorf(px * g.inv_leaf) - (float)g.mb0);
+  const int i1 = (int)(floorf(py * g.inv_leaf) - (float)g.mb1);
+  const int i2 = (int)(floorf(pz * g.inv_leaf) - (float)g.mb2);
+  *key = (unsigned int)(i0 + i1 * g.mul1 + i2 * g.mul2);
+  return true;
+}
+
+// Lanes of a wave that hit the same slab share ONE atomic: a lidar scan arrives ring by ring, so the 64 points of a wave fall
+// into a handful of slabs, and the dense slabs next to the sensor receive thousands of points — one atomic per point serialised
+// on those counters (round 4, first version: 90 us for the count, 109 us for the scatter).  Returns the lane's rank among the
+// lanes of its slab and the number of such lanes; `leader` is true on the lowest of them.
+__device__ __forceinline__ void vf_peers(const bool valid, const unsigned int s, unsigned int* rank, unsigned int* cnt, bool* leader) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(valid);
+  *rank = 0; *cnt = 0; *leader = false;
+  while (todo) {   // wave-uniform: one trip per distinct slab among the lanes
+    const int first = __ffsll((long long)todo) - 1;
+    const unsigned int s0 = __shfl(s, first, 64);
+    const unsigned long long same = __ballot(valid && s == s0);
+    if (valid && s == s0) {
+      *rank = (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
+      *cnt = (unsigned int)__popcll(same);
+      *leader = lane == first;
+    }
+    todo &= ~same;
+  }
+}
+
+__global__ __launch_bounds__(256) void vf_count_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                       int n, const VfGeom g, unsigned int* __restrict__ slab_count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  unsigned int key = 0;
+  const bool valid = i < n && vf_key(g, x[i], y[i], z[i], &key);
+  const unsigned int s = key >> g.low_bits;
+  unsigned int rank, cnt;
+  bool leader;
+  vf_peers(valid, s, &rank, &cnt, &leader);
+  if (leader) atomicAdd(&slab_count[s], cnt);
+}
+
+// Exclusive prefix of `in` (n entries, padded to a multiple of 4 with zeros by the caller's layout) by ONE workgroup of 1024
+// threads: chunks of 4096 entries, one 16-byte load per lane (coalesced), wave prefix by cross-lane reads, wave totals through
+// LDS.  out[n] = total.  visit(k, value, prefix) is called for every entry (worklists, mailbox).
+template <typename Visit>
+__device__ __forceinline__ unsigned int vf_block_scan(const unsigned int* __restrict__ in, int n, unsigned int* __restrict__ out, Visit visit) {
+  __shared__ unsigned int s_wave[16];
+  __shared__ unsigned int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_carry = 0u;
+  __syncthreads();
+  for (int base = 0; base < n; base += 4096) {
+    const int k0 = base + 4 * tid;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (k0 + 3 < n) v = *reinterpret_cast<const uint4*>(in + k0);
+    else {
+      if (k0 < n) v.x = in[k0];
+      if (k0 + 1 < n) v.y = in[k0 + 1];
+      if (k0 + 2 < n) v.z = in[k0 + 2];
+    }
+    const unsigned int mine = v.x + v.y + v.z + v.w;
+    unsigned int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    unsigned int wave_off = 0;
+    for (int w = 0; w < wv; w++) wave_off += s_wave[w];
+    unsigned int chunk_total = 0;
+    for (int w = 0; w < 16; w++) chunk_total += s_wave[w];
+    const unsigned int p0 = s_carry + wave_off + incl - mine;
+    const unsigned int p1 = p0 + v.x, p2 = p1 + v.y, p3 = p2 + v.z;
+    if (k0 < n) out[k0] = p0;
+    if (k0 + 1 < n) out[k0 + 1] = p1;
+    if (k0 + 2 < n) out[k0 + 2] = p2;
+    if (k0 + 3 < n) out[k0 + 3] = p3;
+    // entries beyond n were loaded as zeros: visit() sees value 0 for them and is called by every lane (it may use wave ballots)
+    visit(k0, v.x, p0); visit(k0 + 1, v.y, p1); visit(k0 + 2, v.z, p2); visit(k0 + 3, v.w, p3);
+    __syncthreads();
+    if (tid == 0) s_carry += chunk_total;
+    __syncthreads();
+  }
+  const unsigned int total = s_carry;
+  if (tid == 0) out[n] = total;
+  return total;
+}
+
+// slab_start = exclusive prefix of slab_count; occupied slabs go on the worklist of the kernel that sorts them
+__global__ __launch_bounds__(1024) void vf_scan_kernel(const unsigned int* __restrict__ slab_count, int n_slabs, unsigned int* __restrict__ slab_start,
+                                                       unsigned int* __restrict__ small_list, unsigned int* __restrict__ big_list,
+                                                       unsigned int* __restrict__ counters /* [0] small, [1] big, [2] overflow */) {
+  // (called by every lane of every wave for each of its four entries: the worklist appends are aggregated per wave)
+  vf_block_scan(slab_count, n_slabs, slab_start, [&](int k, unsigned int c, unsigned int) {
+    const int lane = threadIdx.x & 63;
+    const bool is_small = c > 0u && c <= (unsigned int)VF_WAVE_MAX, is_big = c > (unsigned int)VF_WAVE_MAX && c <= (unsigned int)VF_BIG_MAX;
+    const unsigned long long ms = __ballot(is_small), mb = __ballot(is_big);
+    if (__ballot(c > (unsigned int)VF_BIG_MAX) && lane == 0) atomicAdd(&counters[2], 1u);
+    unsigned int bs = 0, bb = 0;
+    if (lane == 0 && ms) bs = atomicAdd(&counters[0], (unsigned int)__popcll(ms));
+    if (lane == 0 && mb) bb = atomicAdd(&counters[1], (unsigned int)__popcll(mb));
+    bs = __shfl(bs, 0, 64); bb = __shfl(bb, 0, 64);
+    if (is_small) small_list[bs + (unsigned int)__popcll(ms & ((1ull << lane) - 1ull))] = (unsigned int)k;
+    if (is_big) big_list[bb + (unsigned int)__popcll(mb & ((1ull << lane) - 1ull))] = (unsigned int)k;
+  });
+}
+
+__global__ __launch_bounds__(256) void vf_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                         int n, const VfGeom g, const unsigned int* __restrict__ slab_start,
+                                                         unsigned int* __restrict__ slab_cursor, unsigned long long* __restrict__ pairs,
+                                                         unsigned int* __restrict__ pos_slab) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  unsigned int key = 0;
+  const bool valid = i < n && vf_key(g, x[i], y[i], z[i], &key);
+  const unsigned int s = key >> g.low_bits, lo = key & ((1u << g.low_bits) - 1u);
+  unsigned int rank, cnt;
+  bool leader;
+  vf_peers(valid, s, &rank, &cnt, &leader);
+  unsigned int base = 0;
+  if (leader) base = slab_start[s] + atomicAdd(&slab_cursor[s], cnt);
+  // the leader's base travels to its peers: every lane reads it from the lowest lane of its own slab group
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(valid);
+  unsigned int my_base = 0;
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const unsigned int s0 = __shfl(s, first, 64), b0 = __shfl(base, first, 64);
+    const unsigned long long same = __ballot(valid && s == s0);
+    if (valid && s == s0) my_base = b0;
+    todo &= ~same;
+  }
+  (void)lane;
+  if (!valid) return;
+  const unsigned int pos = my_base + rank;
+  pairs[pos] = ((unsigned long long)lo << 32) | (unsigned int)i;   // ordered by (low digit, point index)
+  pos_slab[pos] = s;
+}
+
+// Sorted pair at position r of its slab -> what the centroid pass reads: the point index in the low half; in the high half the
+// head flag of a leaf's first point and the rank of that leaf among the slab's leaves.
+__device__ __forceinline__ unsigned long long vf_mark(unsigned long long sorted, bool head, unsigned int leaf_rank) {
+  const unsigned long long idx = sorted & 0xFFFFFFFFull;
+  return head ? (VF_HEAD | ((unsigned long long)leaf_rank << 32) | idx) : idx;
+}
+
+// one WAVE per slab of <= 64 points (worklist): rank sort through cross-lane reads
+__global__ __launch_bounds__(256) void vf_sort_small_kernel(const unsigned int* __restrict__ slab_start, const unsigned int* __restrict__ small_list,
+                                                            const unsigned int* __restrict__ counters, unsigned long long* __restrict__ pairs,
+                                                            unsigned int* __restrict__ slab_leaves) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+  const int n_work = (int)counters[0];
+  for (int w = wave; w < n_work; w += n_waves) {   // wave-uniform
+    const unsigned int s = small_list[w], start = slab_start[s];
+    const int n = (int)(slab_start[s + 1] - start);
+    const unsigned long long mine = lane < n ? pairs[start + lane] : ~0ull;
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+      const unsigned int olo = __shfl((unsigned int)mine, j, 64), ohi = __shfl((unsigned int)(mine >> 32), j, 64);
+      rank += ((((unsigned long long)ohi << 32) | olo) < mine) ? 1 : 0;   // pairs are distinct: a permutation of 0 .. n-1
+    }
+    // lane r <- the pair of rank r (inverse permutation through a cross-lane write: ds_permute)
+    const unsigned int slo = __builtin_amdgcn_ds_permute(rank << 2, (unsigned int)mine), shi = __builtin_amdgcn_ds_permute(rank << 2, (unsigned int)(mine >> 32));
+    const unsigned long long v = lane < n ? (((unsigned long long)shi << 32) | slo) : ~0ull;
+    const unsigned int lo = (unsigned int)(v >> 32);
+    const unsigned int prev = __shfl_up(lo, 1, 64);
+    const bool head = lane < n && (lane == 0 || lo != prev);
+    const unsigned long long heads = __ballot(head);
+    if (lane < n) pairs[start + lane] = vf_mark(v, head, (unsigned int)__popcll(heads & ((1ull << lane) - 1ull)));
+    if (lane == 0) slab_leaves[s] = (unsigned int)__popcll(heads);
+  }
+}
+
+// one WORKGROUP per slab of 65 .. VF_BIG_MAX points (worklist): bitonic sort in LDS
+__global__ __launch_bounds__(256) void vf_sort_big_kernel(const unsigned int* __restrict__ slab_start, const unsigned int* __restrict__ big_list,
+                                                          const unsigned int* __restrict__ counters, unsigned long long* __restrict__ pairs,
+                                                          unsigned int* __restrict__ slab_leaves) {
+  extern __shared__ unsigned long long s_keys[];   // [VF_BIG_MAX]
+  __shared__ unsigned int s_scan[256];
+  const int tid = threadIdx.x;
+  const unsigned int nb = counters[1];
+  for (unsigned int w = blockIdx.x; w < nb; w += gridDim.x) {
+    const unsigned int s = big_list[w], start = slab_start[s];
+    const int n = (int)(slab_start[s + 1] - start);
+    int m = 128;
+    while (m < n) m <<= 1;
+    for (int k = tid; k < m; k += 256) s_keys[k] = k < n ? pairs[start + k] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= m; size <<= 1)          // bitonic sort, ascending
+      for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+        for (int t = tid; t < m / 2; t += 256) {
+          const int i = ((t / stride) * 2 * stride) + (t % stride), j = i + stride;
+          const bool up = (i & size) == 0;
+          const unsigned long long a = s_keys[i], b = s_keys[j];
+          if ((a > b) == up) { s_keys[i] = b; s_keys[j] = a; }
+        }
+        __syncthreads();
+      }
+    // leaf heads and their ranks: thread t owns positions [t * per, (t + 1) * per)
+    const int per = (n + 255) / 256, a0 = min(n, tid * per), a1 = min(n, a0 + per);
+    unsigned int cnt = 0;
+    for (int k = a0; k < a1; k++) cnt += (k == 0 || (unsigned int)(s_keys[k] >> 32) != (unsigned int)(s_keys[k - 1] >> 32)) ? 1u : 0u;
+    s_scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const unsigned int v = (tid >= off) ? s_scan[tid - off] : 0u;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    unsigned int leaf_rank = s_scan[tid] - cnt;
+    for (int k = a0; k < a1; k++) {
+      const bool head = (k == 0 || (unsigned int)(s_keys[k] >> 32) != (unsigned int)(s_keys[k - 1] >> 32));
+      pairs[start + k] = vf_mark(s_keys[k], head, leaf_rank);
+      leaf_rank += head ? 1u : 0u;
+    }
+    if (tid == 255) slab_leaves[s] = s_scan[255];
+    __syncthreads();
+  }
+}
+
+// leaf_off = exclusive prefix of slab_leaves; the total (or -1 when a slab was too dense) goes to the host mailbox
+__global__ __launch_bounds__(1024) void vf_leaf_scan_kernel(const unsigned int* __restrict__ slab_leaves, int n_slabs, unsigned int* __restrict__ leaf_off,
+                                                            const unsigned int* __restrict__ counters, BuildMailbox* __restrict__ mb, unsigned int token) {
+  const unsigned int total = vf_block_scan(slab_leaves, n_slabs, leaf_off, [](int, unsigned int, unsigned int) {});
+  if (threadIdx.x == 0) {
+    mb->value = counters[2] ? -1 : (int)total;
+    __threadfence_system();
+    __hip_atomic_store(&mb->value_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// one thread per sorted position: the first point of a leaf sums the leaf — FLOAT accumulators over ascending point index, the
+// very additions pcl::CentroidPoint performs — and writes the centroid at leaf_off[slab] + rank of the leaf in its slab
+__global__ __launch_bounds__(256) void vf_centroid_kernel(const unsigned long long* __restrict__ pairs, const unsigned int* __restrict__ pos_slab,
+                                                          const unsigned int* __restrict__ slab_start, const unsigned int* __restrict__ leaf_off, int n_slabs,
+                                                          const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                          const float* __restrict__ w /*nullable*/, float* __restrict__ ox, float* __restrict__ oy,
+                                                          float* __restrict__ oz, float* __restrict__ ow) {
+  const unsigned int pos = blockIdx.x * 256 + threadIdx.x;
+  const unsigned int n_sorted = slab_start[n_slabs];     // the finite points
+  if (pos >= n_sorted) return;
+  const unsigned long long v = pairs[pos];
+  if (!(v & VF_HEAD)) return;
+  const unsigned int s = pos_slab[pos], end = slab_start[s + 1];
+  const unsigned int out = leaf_off[s] + (unsigned int)((v >> 32) & 0x7FFFFFFFu);
+  float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+  unsigned int cnt = 0;
+  unsigned long long cur = v;
+  for (unsigned int p = pos;;) {
+    const int pi = (int)(unsigned int)cur;
+    sx += x[pi]; sy += y[pi]; sz += z[pi];
+    if (w) sw += w[pi];
+    cnt++;
+    if (++p >= end) break;
+    cur = pairs[p];
+    if (cur & VF_HEAD) break;
+  }
+  const float m = (float)cnt;
+  ox[out] = sx / m; oy[out] = sy / m; oz[out] = sz / m;
+  if (ow) ow[out] = w ? sw / m : 0.f;
+}
+
+int vf_bits_for(unsigned int max_key) {
+  int b = 1;
+  while (b < 32 && (max_key >> b) != 0) b++;
+  return b;
+}
+
+}  // namespace
+
+// Returns LSR_OK with *handled = false when a slab exceeds what one workgroup sorts (the caller then takes the general path).
+int voxel_grid_filter_msd(const DeviceCloud& cloud, float inv_leaf, const int* min_b, const int* div_b, DeviceCloud& out, BuildScratch& sc,
+                          hipStream_t stream, bool* handled) {
+  *handled = false;
+  const int n = (int)cloud.n;
+  const unsigned int sentinel = (unsigned int)((int64_t)div_b[0] * div_b[1] * div_b[2]);   // one past the last leaf index
+  static const int hi_bits = [] { const char* e = std::getenv("LSR_VF_HI_BITS"); const int v = e ? std::atoi(e) : 0; return (v >= 8 && v <= 18) ? v : VF_HI_BITS_DEFAULT; }();
+  VfGeom g;
+  g.inv_leaf = inv_leaf; g.mb0 = min_b[0]; g.mb1 = min_b[1]; g.mb2 = min_b[2]; g.mul1 = div_b[0]; g.mul2 = div_b[0] * div_b[1];
+  const int bits = vf_bits_for(sentinel);
+  g.low_bits = bits > hi_bits ? bits - hi_bits : 0;
+  g.n_slabs = (int)(sentinel >> g.low_bits) + 1;
+  int st = sc.ensure_mailbox();
+  if (st) return st;
+  // scratch (32-bit words; every array starts on a 16-byte boundary):
+  //   zeroed: counts | cursors | leaves | counters[4]        then: starts (+1) | leaf offsets (+1) | small list | big list | slab of every position | pairs
+  const size_t S4 = ((size_t)g.n_slabs + 4) & ~(size_t)3;   // n_slabs + 1 entries, padded to a multiple of 4
+  const size_t N4 = ((size_t)n + 3) & ~(size_t)3;
+  const size_t zero_words = 3 * S4 + 4;
+  const size_t words = zero_words + 4 * S4 + N4 + 2 * N4 + 16;
+  if ((st = sc.words.reserve(32 + words))) return st;
+  unsigned int* base = sc.words.p + 32;
+  unsigned int* slab_count = base;
+  unsigned int* slab_cursor = slab_count + S4;
+  unsigned int* slab_leaves = slab_cursor + S4;
+  unsigned int* counters = slab_leaves + S4;
+  unsigned int* slab_start = base + zero_words;
+  unsigned int* leaf_off = slab_start + S4;
+  unsigned int* small_list = leaf_off + S4;
+  unsigned int* big_list = small_list + S4;
+  unsigned int* pos_slab = big_list + S4;
+  unsigned long long* pairs = reinterpret_cast<unsigned long long*>(pos_slab + N4);
+  if ((st = out.resize((size_t)n, cloud.has_i))) return st;   // capacity for the worst case; out.n is set once the leaf count is known
+  unsigned int token = ++sc.token;
+  if (token == 0) token = ++sc.token;
+  const unsigned int nblk = (unsigned int)((n + 255) / 256);
+  static bool lds_allowed[64] = {};
+  int dev = 0;
+  LSR_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !lds_allowed[dev]) {
+    LSR_HIP(hipFuncSetAttribute((const void*)vf_sort_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VF_BIG_MAX * 8));
+    lds_allowed[dev] = true;
+  }
+  LSR_HIP(hipMemsetAsync(base, 0, zero_words * sizeof(unsigned int), stream));
+  hipLaunchKernelGGL(vf_count_kernel, dim3(nblk), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, g, slab_count);
+  hipLaunchKernelGGL(vf_scan_kernel, dim3(1), dim3(1024), 0, stream, slab_count, g.n_slabs, slab_start, small_list, big_list, counters);
+  hipLaunchKernelGGL(vf_scatter_kernel, dim3(nblk), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, g, slab_start, slab_cursor, pairs, pos_slab);
+  hipLaunchKernelGGL(vf_sort_small_kernel, dim3(1024), dim3(256), 0, stream, slab_start, small_list, counters, pairs, slab_leaves);
+  hipLaunchKernelGGL(vf_sort_big_kernel, dim3(256), dim3(256), VF_BIG_MAX * 8, stream, slab_start, big_list, counters, pairs, slab_leaves);
+  hipLaunchKernelGGL(vf_leaf_scan_kernel, dim3(1), dim3(1024), 0, stream, slab_leaves, g.n_slabs, leaf_off, counters, sc.d_mb, token);
+  hipLaunchKernelGGL(vf_centroid_kernel, dim3(nblk), dim3(256), 0, stream, pairs, pos_slab, slab_start, leaf_off, g.n_slabs, cloud.x(), cloud.y(), cloud.z(),
+                     cloud.i(), out.x(), out.y(), out.z(), out.i());
+  LSR_HIP(hipGetLastError());
+  if ((st = wait_mailbox_word(&sc.mb.p->value_token, token, stream, sc.wait_mode, "voxel filter leaf count"))) return st;
+  const int n_out = sc.mb.p->value;
+  if (n_out < 0) return LSR_OK;   // a slab beyond VF_BIG_MAX points: not handled here
+  out.n = (size_t)n_out;          // planes keep the pitch of the capacity allocation
+  *handled = true;
+  return LSR_OK;
+}
+
+}  // namespace lsr

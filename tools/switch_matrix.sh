@@ -19,3 +19,5 @@ run nn_fine_rings1 LSR_NN_FINE_RINGS=1
 run fit_group_quad LSR_FIT_GROUP_FORM=1
 run table_dense LSR_NDT_TABLE_MODE=0
 run table_tile LSR_NDT_TABLE_MODE=3
+run ndt_lane512 LSR_NDT_QUAD=0 LSR_NDT_WORKGROUP=512
+run ndt_widen0 LSR_NDT_WIDEN=0
