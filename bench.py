@@ -367,6 +367,14 @@ def main():
         if isinstance(out.get("roofline"), dict):
             cr = (cfg4 or {}).get("chain_roofline") if isinstance(cfg4, dict) else None
             if isinstance(cr, dict) and "frac" in cr:
+                try:   # counter traffic of the lane kernel on a 16-member launch (tools/pmc_ndt.sh on tools/trace_probe.py)
+                    pb = json.load(open(PMC_FILE)).get("batch")
+                    if pb and pb.get("bytes_per_launch"):
+                        cr["traffic"] = int(pb["bytes_per_launch"])
+                        cr["traffic_is"] = "HBM bytes of the MEDIAN launch of a 16-member chain (2 x FETCH_SIZE + WRITE_SIZE): " + str(pb.get("kernel"))
+                        cr["traffic_per_member_pass_vs_algorithmic"] = (pb["bytes_per_launch"] / 16.0) / (cr["algorithmic_bytes"] / max(1, cr["member_passes"]))
+                except Exception:
+                    pass
                 out["roofline"]["batch"] = cr
             c5 = out.get("cfg5_dense")
             if isinstance(c5, dict) and "avg_pass_us" in c5:
@@ -1022,16 +1030,25 @@ def cpu_leg(args, out, stash, case, stream, j_last, gpu_final, res, max_iter):
                            "seconds": float(sum(t_all) + t_one), "ms_per_registration": 1e3 * med,
                            "ms_per_registration_p10_p90": [1e3 * pct(t_all, 10), 1e3 * pct(t_all, 90)],
                            "newton_iterations": ref["iterations"], "host_threads_available": avail,
+                           "cores_choice": f"the fastest of {cands} threads for one derivative pass on this box (timed above): more threads than "
+                                           f"that are slower here (the pass is 30k points; beyond {cores} threads OpenMP's fork/join and the guided "
+                                           "schedule cost more than they divide)",
                            "one_thread": {"value": 1.0 / t_one, "ms_per_registration": 1e3 * t_one, "registrations": 1},
                            "reconciliation": {"ms_parallel_pass_with_hessian": 1e3 * t_pass_h, "ms_parallel_pass_gradient_only": 1e3 * t_pass_g,
                                               "ms_sequential_computeHessian": 1e3 * t_hess_seq, "passes_with_hessian": ref["n_evals"],
                                               "passes_gradient_only": ref["n_evals_grad"], "computeHessian_calls": n_hess,
                                               "ms_predicted_from_the_pieces": 1e3 * predicted, "ms_measured": 1e3 * med,
+                                              "ms_unexplained": 1e3 * (med - predicted),
+                                              "unexplained_is": "the pieces are timed back to back at ONE pose (the guess) with warm caches; the registration "
+                                                                "alternates parallel passes with the sequential fp64 computeHessian (which evicts the voxel map "
+                                                                "from the cores' caches between them) and visits poses with more pairs per point than the guess",
                                               "note": "ndt_omp's computeHessian (after every line search that took a trial) is a plain fp64 loop over "
                                                       "all points, not OpenMP-parallel; with many threads it is most of a registration"},
                            "ms_per_derivative_pass": 1e3 * best,
                            "note": "C++/OpenMP restatement of ndt_omp (oracle/, built -O2 without -march=native like the reference's own -O2 -g), "
-                                   "not ndt_omp itself; a reported baseline, not the target"}
+                                   "not ndt_omp itself; a reported baseline, not the target.  Most of a CPU registration at this thread count is "
+                                   "ndt_omp's SEQUENTIAL computeHessian (reconciliation): the GPU evaluates the same Hessian inside the parallel pass, "
+                                   "so the GPU / CPU ratio of this line says more about that loop than about the kernels"}
     out["parity_vs_cpu"] = {"translation_m": dt, "rotation_rad": ang, "gpu_iterations": out["config"]["newton_iterations"],
                             "cpu_iterations": ref["iterations"]}
     route, lp, edges = stash.get("route"), stash.get("lp"), stash.get("edges")

@@ -1518,6 +1518,13 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_lane_kernel(const NdtProblem
       }
     }
 
+    // a neighbour NO lane of the wave can use (the layer above the scan, the one below the ground: a wave's 64 points are
+    // neighbours in space) is skipped by the whole wave — a uniform branch; a pair that is not ok leaves every sum as it was,
+    // so skipping it changes no bit
+    bool nb_any[NOFF];
+#pragma unroll
+    for (int o = 0; o < NOFF; o++) nb_any[o] = __ballot(nb_ok[o]) != 0ull;
+
     // the four partial sums of the point in the quad kernel's order: partial q takes neighbours q, q + 4, q + 8, ...;
     // halves (0, 1) and (2, 3) are summed first, then the two halves
     float S[11];
@@ -1532,7 +1539,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_lane_kernel(const NdtProblem
 #pragma unroll
         for (int u = 0; u < GROUP; u++) {
           const int e = e0 + u, ql = e / NT, t = e % NT, o = 2 * half + ql + 4 * t;
-          if (e < 2 * NT && o < NOFF) {
+          if (e < 2 * NT && o < NOFF) {   // (loaded unconditionally: a branch around the gathers costs more registers than it saves time)
             if (TAB == NDT_TAB_LDS) {
               const LdsV4* rp = (const LdsV4*)((const __attribute__((address_space(3))) unsigned char*)s_table + nb_rec[o]);
               r0[u] = rp[0]; r1[u] = rp[1]; r2[u] = rp[2];
@@ -1545,7 +1552,7 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_lane_kernel(const NdtProblem
 #pragma unroll
         for (int u = 0; u < GROUP; u++) {
           const int e = e0 + u, ql = e / NT, t = e % NT, o = 2 * half + ql + 4 * t;
-          if (e < 2 * NT && o < NOFF) {
+          if (e < 2 * NT && o < NOFF && nb_any[o]) {
             float* A = Pq[ql];
             pair_terms(nb_ok[o], hess, tx, ty, tz, make_float4(r0[u].x, r0[u].y, r0[u].z, r0[u].w), make_float4(r1[u].x, r1[u].y, r1[u].z, r1[u].w),
                        make_float4(r2[u].x, r2[u].y, r2[u].z, r2[u].w), d2, d1d, A[0], A[1], A[2], A[3], A[4], A[5], A[6], A[7], A[8], A[9], A[10]);

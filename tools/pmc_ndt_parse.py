@@ -11,7 +11,7 @@ for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True))
         k = r["Kernel_Name"]
         if "ndt_eval" not in k:
             continue
-        short = "ndt_eval_quad_kernel" if "quad" in k else "ndt_eval_kernel"
+        short = "ndt_eval_quad_kernel" if "quad" in k else "ndt_eval_lane_kernel"
         agg[(short, r["Grid_Size"], r.get("Workgroup_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 lines = ["# rocprofv3 PMC passes on the NDT derivative kernels — " + tag, "",
          "Separate runs, `--kernel-trace --pmc <counters>` only (tools/pmc_ndt.sh on tools/trace_probe.py). Per-launch medians.", "",
@@ -43,18 +43,29 @@ if single is not None:
     if out.get("SQ_WAVE_CYCLES"):
         lines.append(f"SQ_WAIT_ANY / SQ_WAVE_CYCLES = {100 * out['SQ_WAIT_ANY'] / out['SQ_WAVE_CYCLES']:.0f} % ; "
                      f"LDS bank-conflict cycles / LDS active cycles = {100 * out.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, out.get('SQ_ACTIVE_INST_LDS', 1.0)):.1f} %")
-# the cfg-5 pass: the quad kernel with the largest grid (120 000 points x 4 lanes)
-quads = [k for k in agg if k[0] == "ndt_eval_quad_kernel" and "FETCH_SIZE" in agg[k]]
-if len(quads) > 1:
-    big = max(quads, key=lambda k: int(k[1]))
-    medb = lambda c: sorted(agg[big][c])[len(agg[big][c]) // 2] if c in agg[big] else None
-    fkb, wkb = medb("FETCH_SIZE"), medb("WRITE_SIZE") or 0.0
-    out["cfg5"] = {"kernel": f"{big[0]} grid {big[1]} x workgroup {big[2]} (single 120k-pt registration, dense global table)",
-                   "fetch_size_kb": fkb, "write_size_kb": wkb, "bytes_per_launch": int((2.0 * fkb + wkb) * 1024)}
-    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
-        if medb(c) is not None:
-            out["cfg5"][c] = medb(c)
-    lines += ["", f"HBM bytes per launch of `{out['cfg5']['kernel']}`: 2 x {fkb:.1f} KB + {wkb:.1f} KB = {out['cfg5']['bytes_per_launch'] / 1e6:.3f} MB"]
+# the cfg-5 pass (round 4: the lane kernel with 512-thread workgroups on the 120 000-point scan) and the batch pass (lane kernel,
+# 1024-thread workgroups, 16 registrations per launch)
+def _entry(key, what):
+    medk = lambda c: sorted(agg[key][c])[len(agg[key][c]) // 2] if c in agg[key] else None
+    fkb, wkb = medk("FETCH_SIZE"), medk("WRITE_SIZE") or 0.0
+    e = {"kernel": f"{key[0]} grid {key[1]} x workgroup {key[2]} ({what})", "fetch_size_kb": fkb, "write_size_kb": wkb,
+         "bytes_per_launch": int((2.0 * fkb + wkb) * 1024)}
+    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+              "SQ_ACTIVE_INST_LDS", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
+        if medk(c) is not None:
+            e[c] = medk(c)
+    return e
+lanes = [k for k in agg if k[0] == "ndt_eval_lane_kernel" and "FETCH_SIZE" in agg[k]]
+c5 = [k for k in lanes if k[2] == "512"]
+if c5:
+    big = max(c5, key=lambda k: int(k[1]))
+    out["cfg5"] = _entry(big, "single 120k-pt registration, dense global table")
+    lines += ["", f"HBM bytes per launch of `{out['cfg5']['kernel']}`: 2 x {out['cfg5']['fetch_size_kb']:.1f} KB + {out['cfg5']['write_size_kb']:.1f} KB = {out['cfg5']['bytes_per_launch'] / 1e6:.3f} MB"]
+bt = [k for k in lanes if k[2] == "1024"]
+if bt:
+    big = max(bt, key=lambda k: len(agg[k]["FETCH_SIZE"]))
+    out["batch"] = _entry(big, "candidate set: 16 registrations of 30k points per launch, LDS table")
+    lines += ["", f"HBM bytes per launch of `{out['batch']['kernel']}`: 2 x {out['batch']['fetch_size_kb']:.1f} KB + {out['batch']['write_size_kb']:.1f} KB = {out['batch']['bytes_per_launch'] / 1e6:.3f} MB (median launch of the chain)"]
 open(os.path.join(root, f"{tag}_pmc_ndt_eval.md"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(root, "pmc_ndt_eval_latest.json"), "w"), indent=1)
 print("\n".join(lines[-6:]))

@@ -3,7 +3,7 @@
 # Output: gpurun_out/profiles_<tag>/ (copy into profiles/ afterwards).  PMC passes are separate rocprofv3 runs with
 # --kernel-trace only (tools/pmc_ndt.sh).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 P=$REPO/gpurun_out/profiles_$TAG
 rm -rf $P; mkdir -p $P
