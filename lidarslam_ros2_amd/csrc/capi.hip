@@ -166,7 +166,9 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   size_t n_max = 0;
   for (int b = 0; b < B; b++) n_max = std::max(n_max, hs[b]->source.n);
   const bool want_quad_single = (B <= quad_batch_max && (lead->ndt_quad == 1 || (lead->ndt_quad < 0 && n_max < (size_t)NDT_LANE_SINGLE_MIN)));
-  const int lane_threads = (lead->ndt_threads == 512 || lead->ndt_threads == 1024) ? lead->ndt_threads : (B == 1 ? 512 : NDT_LANE_THREADS);
+  // (DIRECT26: 27 neighbours per point need more than the 128 registers a 1024-thread workgroup leaves a lane — 512 threads)
+  const int lane_threads = (lead->ndt_threads == 512 || lead->ndt_threads == 1024) ? lead->ndt_threads
+                           : ((B == 1 || lead->ndt.neighborhood == LSR_DIRECT26) ? 512 : NDT_LANE_THREADS);
   const int static_lds = want_quad_single ? NDT_QUAD_STATIC_LDS : NDT_LANE_STATIC_LDS + ndt_lane_tile_bytes(lane_threads);
   const int table_cap = std::min(want_quad_single ? NDT_LDS_TABLE_MAX_QUAD : NDT_LDS_TABLE_MAX, lds_cap - static_lds);
   const bool lds_ok = all_lds && lds_max <= table_cap;
