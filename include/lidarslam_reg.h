@@ -69,8 +69,9 @@ typedef enum lsr_key {
   LSR_RANSAC_ITERATIONS = 37,         /* setRANSACIterations (accepted, ignored) graph_based_slam_component.cpp:81 */
   LSR_HESSIAN_D1_SIGN = 38,           /* +1 = upstream "+sy" quirk in h_ang d1 (default), -1 = analytic */
   LSR_PROFILE = 39,                   /* 1 = bracket the derivative launch chains with hipEvents (lsr_get_profile) */
-  /* tuning (no effect on results beyond fp64 summation order): */
-  LSR_NDT_WORKGROUP = 40,             /* one-lane kernel: threads per workgroup (128, 256); quad kernel: source points per
+  /* tuning (NO effect on results: every NDT derivative kernel returns the same bits — the sum of a pass is defined on the
+     input, csrc/ndt.hip: canon): */
+  LSR_NDT_WORKGROUP = 40,             /* lane kernel: threads per workgroup (512, 1024); quad kernel: source points per
                                          workgroup (64, 128; four lanes each); 0 = automatic */
   LSR_NDT_TABLE_MODE = 41,            /* where the pass reads leaf records: -1 = automatic, 0 = dense global table,
                                          1 = compact global table, 2 = whole table staged in LDS (when it fits), 3 = per
@@ -83,24 +84,27 @@ typedef enum lsr_key {
                                          polls, 2 = sleep 20 us between polls (a ROS2 MultiThreadedExecutor runs two
                                          registration objects side by side, lidarslam/src/lidarslam.cpp:12-17).
                                          Environment preset: LSR_WAIT_MODE=spin|yield|sleep (or 0|1|2) */
-  LSR_NDT_QUAD = 44,                  /* single NDT registrations: 1 = four lanes per source point on every CU with exact
-                                         integer-binned accumulation, 0 = one lane per point with partial rows, -1 = automatic */
+  LSR_NDT_QUAD = 44,                  /* single NDT registrations: 1 = quad kernel (four lanes per source point on every CU:
+                                         lowest latency for a 30k-point scan), 0 = lane kernel (one lane per point: what candidate
+                                         sets use), -1 = automatic (quad below 65 536 source points, lane from there on) */
   LSR_NDT_SORT = 45                   /* order the source by voxel tile of its guess-moved points at the start of align():
                                          -1 = automatic (tile table mode only), 0 = never (the tile mode then falls back to the
                                          global table), 1 = also when the records are gathered from the global table */
 } lsr_key;
 /* Environment presets read when an object is created: LSR_NDT_WORKGROUP, LSR_NDT_TABLE_MODE, LSR_NDT_QUAD, LSR_GRID_BUILDER,
- * LSR_WAIT_MODE (the keys above).  Diagnostic A/B switches read once per process, all with bit-identical results
+ * LSR_WAIT_MODE (the keys above); LSR_NDT_WIDEN=0 keeps the launches of a candidate set at their first geometry (default: widened
+ * as members finish).  Diagnostic A/B switches read once per process, all with bit-identical results
  * (tests/test_gicp_gpu.py::test_search_and_chain_variants_give_identical_results): LSR_NN_COOP=0 (per-thread neighbour
  * walks instead of one wave per query), LSR_GICP_FUSED=0 (accumulate + update launch pairs instead of the fused
- * Gauss-Newton step), LSR_GICP_BALL=0 (general correspondence search on every outer iteration). */
+ * Gauss-Newton step), LSR_GICP_BALL=0 (general correspondence search on every outer iteration), LSR_FIT_GROUP_FORM=0|1|2 (fitness
+ * search of a candidate set: one wave per query / four lanes + tail / sixteen lanes seeded by the own cell + tail, the default). */
 
 typedef struct lsr_result {
   int32_t converged;            /* hasConverged()                             scanmatcher_component.cpp:375 */
   int32_t iterations;           /* nr_iterations_ */
   double score;                 /* NDT: trans_probability_ (= score / N); GICP: final mean Mahalanobis cost */
   int32_t n_evaluations;        /* NDT: derivative passes launched; GICP: Gauss-Newton inner steps */
-  int32_t n_correspondences;    /* GICP: pairs in the last outer iteration; NDT: 0 */
+  int32_t n_correspondences;    /* GICP: pairs in the last outer iteration; NDT: valid (point, voxel) pairs of the last derivative pass */
   double gpu_ms;                /* HOST wall-clock time of the align call that produced this result, from the first
                                    enqueue to the result in host memory; for lsr_align_batch every member carries the
                                    time of the whole batch.  (Device-side time per derivative pass: lsr_get_profile.) */

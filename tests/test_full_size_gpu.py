@@ -180,6 +180,26 @@ def test_cfg5_dense_scan_matches_oracle(O, pool):
     assert ndt.getFinalNumIteration() == ref["iterations"]
 
 
+def test_cfg5_quad_and_lane_kernels_return_the_same_bits(pool):
+    """cfg 5 through every kernel: the lane kernel (automatic for >= 65 536 points; 512 and 1024 threads) and the quad kernel
+    forced (its workgroups walk several 128-point batches here and collect their integer pieces in LDS first) — the same
+    final_T after the same number of passes, bit for bit, at res 2.0 (dense global table) and res 1.0."""
+    c = synth.cfg_dense_120k(pool=pool)
+    for res in (2.0, 1.0):
+        ref = None
+        for quad, wg in ((-1, 0), (1, 0), (0, 1024), (0, 512)):
+            ndt = make_ndt(res, 0.01)
+            ndt.setTuning(quad=quad, workgroup=wg)
+            ndt.setInputTarget(c.target)
+            ndt.setInputSource(c.source)
+            ndt.align(c.guess)
+            got = (ndt.getFinalTransformation(), ndt.getFinalNumIteration(), ndt.last_result["n_evaluations"])
+            if ref is None:
+                ref = got
+            assert np.array_equal(got[0], ref[0]) and got[1:] == ref[1:], (res, quad, wg)
+            ndt.close()
+
+
 def test_cfg4_hard_candidates_match_the_cpu_fixture(pool):
     """The four cfg-4 candidates on which NDT with the backend's settings stops in a local optimum (0.2 - 1.0 m from the truth):
     the GPU path must stop in the SAME place after the SAME number of Newton iterations as the CPU oracle
