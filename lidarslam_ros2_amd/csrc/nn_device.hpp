@@ -590,6 +590,41 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
   return v;
 }
 
+// ---- 64 (distance, index) keys, one per lane, through compare-exchange networks (round 4) --------------------------------------
+// key = (distance bits << 32) | index: distances are >= 0, so the integer order IS the (distance, index) order every search
+// form ranks candidates by; COOP_EMPTY = (inf, INT_MAX) sorts last.
+typedef unsigned long long CoopKey;
+constexpr CoopKey COOP_EMPTY = 0x7F8000007FFFFFFFull;
+__device__ __forceinline__ CoopKey coop_key(float d, int i) { return ((CoopKey)(unsigned int)__float_as_int(d) << 32) | (unsigned int)i; }
+__device__ __forceinline__ CoopKey coop_key_xor(CoopKey v, int m) {
+  const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)v, m, 64), hi = (unsigned int)__shfl_xor((int)(unsigned int)(v >> 32), m, 64);
+  return ((CoopKey)hi << 32) | lo;
+}
+// one compare-exchange with the lane `stride` away: the lower lane of the pair keeps the smaller key if `ascending`
+__device__ __forceinline__ CoopKey coop_cmpx(CoopKey v, int lane, int stride, bool ascending) {
+  const CoopKey o = coop_key_xor(v, stride);
+  const bool lower = (lane & stride) == 0;
+  const bool take_min = lower == ascending;
+  return take_min ? (o < v ? o : v) : (o > v ? o : v);
+}
+// the wave's 64 keys sorted DESCENDING over the lanes (bitonic sort: 21 compare-exchanges)
+__device__ __forceinline__ CoopKey coop_sort_desc(CoopKey v, int lane) {
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+    const bool asc = (size == 64) ? false : ((lane & size) != 0);   // blocks alternate so that every pair of blocks is bitonic; the last pass is the final order
+#pragma unroll
+    for (int stride = size >> 1; stride >= 1; stride >>= 1) v = coop_cmpx(v, lane, stride, asc);
+  }
+  return v;
+}
+// a BITONIC sequence of 64 keys sorted ascending (6 compare-exchanges)
+__device__ __forceinline__ CoopKey coop_merge_asc(CoopKey v, int lane) {
+#pragma unroll
+  for (int stride = 32; stride >= 1; stride >>= 1) v = coop_cmpx(v, lane, stride, true);
+  return v;
+}
+constexpr int COOP_MERGE_MIN = 12;   // qualifying candidates of a 64-chunk from which the networks beat one insertion per candidate
+
 // k-th best list one entry per lane (sorted ascending in lanes 0..k-1), as in coop_knn.  K1: `mine` is the wave's best,
 // identical on every lane on return (seed it identically on every lane, or with (INFINITY, INT_MAX)).
 template <bool K1>
@@ -637,6 +672,21 @@ __device__ __forceinline__ bool coop_fine_knn(const NNGridView& G, float qx, flo
         } else {
           const bool qual = valid && (oi != self_skip) && (d < worst || (d == worst && oi < worst_i));
           unsigned long long mask = __ballot(qual);
+          if (__popcll(mask) >= COOP_MERGE_MIN) {
+            // many candidates at once (the first chunk of shell 1 meets an almost empty list: ~60 of 64 qualify, and one
+            // insertion costs a ballot, a popcount and four cross-lane moves): sort the chunk descending, take the lane-wise
+            // minimum with the ascending list — the 64 smallest of the 128, as a bitonic sequence — and merge it ascending.
+            // Same total order, so the same k entries in the same lanes as 60 insertions would leave.
+            const CoopKey c = coop_sort_desc(qual ? coop_key(d, oi) : COOP_EMPTY, lane);
+            const CoopKey l = (lane < k) ? coop_key(mine.d, mine.i) : COOP_EMPTY;
+            CoopKey m = coop_merge_asc(c < l ? c : l, lane);
+            if (lane >= k) m = COOP_EMPTY;
+            mine.d = __int_as_float((int)(unsigned int)(m >> 32));
+            mine.i = (int)(unsigned int)m;
+            worst = __shfl(mine.d, k - 1, 64);
+            worst_i = __shfl(mine.i, k - 1, 64);
+            mask = 0ull;
+          }
           while (mask) {
             const int src = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
