@@ -10,7 +10,7 @@ N = int(os.environ.get("NC", "64"))
 def _make():
     with mp.get_context("fork").Pool(min(64, len(os.sched_getaffinity(0)))) as p:
         return [synth.cfg_loop_candidate(c, pool=p) for c in range(N)]
-cands = cached("probe_cfg4_%d" % N, _make)
+cands = cached("probe_cfg4_cases_%d" % N, _make)
 import torch
 from lidarslam_ros2_amd import NormalDistributionsTransform, _capi
 lib = _capi.load()

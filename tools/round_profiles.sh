@@ -35,7 +35,7 @@ stats target python $REPO/tools/target_probe.py
 (timeout 300 python tools/r03_cfg4_stage_c.py 2>&1 | tail -2; NC=8 timeout 300 python tools/r03_cfg4_stage_c.py 2>&1 | tail -2) > $P/${TAG}_cfg4_stages.txt
 # 3c. micro-benchmarks behind profiles/<tag>_pass_timeline.md
 (timeout 300 tools/micro/boundary_probe) > $P/${TAG}_boundary_probe.txt 2>&1
-(make -s -C lidarslam_ros2_amd/csrc timing > /dev/null 2>&1; LSR_LIB_NAME=liblidarslam_reg_timing.so timeout 400 python tools/timing_probe.py 2>&1 | grep -v amdgpu.ids) > $P/${TAG}_timing_probe.txt
+(LSR_LIB_NAME=liblidarslam_reg_timing.so timeout 400 python tools/timing_probe.py 2>&1 | grep -v amdgpu.ids) > $P/${TAG}_timing_probe.txt
 # 4. two ranks sharing this one device (gloo): exercises the self-spawn + sharded C-ABI path
 LSR_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 > $P/${TAG}_bench_2ranks_one_device.json 2> $P/bench2.err; echo "bench2 rc=$?"
 rm -f $P/*.stderr
