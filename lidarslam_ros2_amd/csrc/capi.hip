@@ -278,50 +278,148 @@ int ensure_target_hash(lsr_handle h) {
 // on_poll (nullable): called between polls while the chain runs (the eager fitness dispatch of a candidate set hangs off it).
 // nb_full > 0 (lane kernel, candidate sets): the launches are widened as members finish — grid.x = resident workgroups /
 // members still running, at most nb_full (= one trip per lane for the largest member); the canonical sum does not depend on it.
+// --- launch-chain streams -------------------------------------------------------------------------------------------------
+// Two HIP streams run concurrently only when the runtime has mapped them to different hardware queues; mapped to the same
+// queue their launches serialise AND every switch between them costs a signal round trip (measured: 60 us per switch, a
+// three-chain set took twice as long as one chain when two chains shared a queue).  The mapping cannot be queried, so it is
+// MEASURED once per stream: a kernel on stream a spins (bounded) on a flag that a kernel enqueued AFTERWARDS on stream b sets.
+__global__ void chain_probe_wait(unsigned int* flag, unsigned int* seen, unsigned long long budget) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+  unsigned int v = 0;
+  while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 &&
+         __builtin_amdgcn_s_memrealtime() - t0 < budget) __builtin_amdgcn_s_sleep(8);
+  *seen = v ? 1u : 2u;
+}
+__global__ void chain_probe_set(unsigned int* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 1: b's kernel ran while a's was running; 0: it did not within 200 us (same hardware queue); < 0: error (negated status)
+int streams_run_concurrently(hipStream_t a, hipStream_t b, unsigned int* d_words /* 2 */) {
+  // the flag is cleared and BOTH streams are idle before the two kernels go out (b's kernel may overtake anything a still holds)
+  if (hipMemsetAsync(d_words, 0, 8, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -LSR_ERR_HIP;
+  hipLaunchKernelGGL(chain_probe_wait, dim3(1), dim3(1), 0, a, d_words, d_words + 1, 20000ull);
+  hipLaunchKernelGGL(chain_probe_set, dim3(1), dim3(1), 0, b, d_words);
+  unsigned int seen = 0;
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
+      hipMemcpy(&seen, d_words + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return -LSR_ERR_HIP;
+  return seen == 1u ? 1 : 0;
+}
+
+// The auxiliary streams of a batch lead, looked for once per handle: the side stream (grid refinement and fitness searches of a
+// candidate set, under the launch chain) and up to two more launch-chain streams, each VERIFIED to run concurrently with the
+// lead's stream and with the ones found before it.  A stream that fails the check is kept alive until the search ends, so
+// that the runtime maps the next one to another hardware queue.  When no concurrent side stream turns up an unverified one
+// is used (correct, just not overlapped); chain streams are only ever verified ones.
+int ensure_aux_streams(lsr_handle lead) {
+  if (lead->chain_probed) return LSR_OK;
+  lsr::DevBuf<unsigned int> words;
+  int st;
+  if ((st = words.reserve(2))) return st;
+  std::vector<hipStream_t> rejected, found;
+  for (int tries = 0; tries < 10 && (int)found.size() < 3; tries++) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+    bool ok = streams_run_concurrently(lead->stream, s, words.p) == 1;
+    for (size_t c = 0; ok && c < found.size(); c++) ok = streams_run_concurrently(found[c], s, words.p) == 1;
+    if (ok) found.push_back(s); else rejected.push_back(s);
+  }
+  for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+  (void)hipStreamSynchronize(lead->stream);
+  size_t k = 0;
+  if (!found.empty()) lead->side_stream = found[k++];
+  else LSR_HIP(hipStreamCreateWithFlags(&lead->side_stream, hipStreamNonBlocking));
+  lead->n_chain_streams = 0;
+  for (; k < found.size(); k++) {
+    hipEvent_t ev = nullptr;
+    if (lead->n_chain_streams < 3 && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+      lead->chain_stream[lead->n_chain_streams] = found[k]; lead->chain_ev[lead->n_chain_streams] = ev; lead->n_chain_streams++;
+    } else (void)hipStreamDestroy(found[k]);
+  }
+  if (!lead->side_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_ev, hipEventDisableTiming));
+  if (!lead->side_fork_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_fork_ev, hipEventDisableTiming));
+  if (!lead->chain_fork_ev) LSR_HIP(hipEventCreateWithFlags(&lead->chain_fork_ev, hipEventDisableTiming));
+  lead->chain_probed = true;
+  if (std::getenv("LSR_DEBUG_STREAMS"))
+    fprintf(stderr, "[lidarslam_reg] aux streams of handle %p: %zu verified concurrent, %zu rejected, %d chain stream(s)\n", (void*)lead,
+            found.size(), rejected.size(), lead->n_chain_streams);
+  return LSR_OK;
+}
+
+// how many independent launch chains a set of B registrations runs as (env LSR_NDT_CHAINS = 1..4 forces it for B >= 2*chains)
+int ndt_chain_count(int B) {
+  static const int forced = [] { const char* e = std::getenv("LSR_NDT_CHAINS"); return e ? std::atoi(e) : 0; }();
+  // measured (cfg-4 sets, align stage, 1 -> 2 chains): 4 / 8 members +4 % / +3 % (a launch of so few members is one trip per lane
+  // at four waves per SIMD either way), 12 / 16 / 24 / 32 / 48 / 64 members -14 / -9 / -17 / -10 / -10 / -9 %
+  int n = forced > 0 ? std::min(forced, 4) : (B >= 10 ? 2 : 1);
+  while (n > 1 && B < 2 * n) n--;
+  return n;
+}
+
+// n_chains > 1 (small candidate sets): the members are dealt to n_chains independent launch chains, chain c covering members
+// [chain_first[c], chain_first[c+1]) on streams[c].  A launch of a small set is mostly fixed latency (the launch boundary and
+// the head: bank fold + controller), which the other chain's launch hides; the answer of a member does not depend on which
+// launches carry it (canonical sums), so the split changes no bit.
 int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_probs, const NdtLaunchCfg& cfg_in, int first, int hard_cap,
-                   unsigned int token, int* launches_out, const std::function<int()>* on_poll = nullptr, int nb_full = 0) {
-  NdtLaunchCfg cfg = cfg_in;
-  const int resident = ndt_resident_wgs(h->device, cfg_wg_threads(cfg));
+                   unsigned int token, int* launches_out, const std::function<int()>* on_poll = nullptr, int nb_full = 0,
+                   int n_chains = 1, const int* chain_first = nullptr, const hipStream_t* streams = nullptr) {
+  constexpr int MAX_CHAINS = 4;
+  struct Chain { int b0, b1, n_done, launched; bool over; hipStream_t stream; NdtLaunchCfg cfg; };
+  Chain ch[MAX_CHAINS];
+  const int one_first[2] = {0, cfg_in.batch};
+  if (n_chains <= 1 || !chain_first || !streams) { n_chains = 1; chain_first = one_first; streams = &h->stream; }
+  if (n_chains > MAX_CHAINS) { set_last_error("too many launch chains"); return LSR_ERR_INVALID_ARGUMENT; }
+  const int resident = ndt_resident_wgs(h->device, cfg_wg_threads(cfg_in));
   // spin: two launches queued ahead are enough; yield / sleep give the core away between polls, so more launches are
   // kept queued to ride out the scheduler's latency (surplus launches exit at their head, ~2 us each)
   const int wait_mode = h->scratch.wait_mode;
   const int LOW_WATER = (wait_mode == WAIT_SPIN) ? 2 : (wait_mode == WAIT_YIELD ? 4 : 16), REFILL = (wait_mode == WAIT_SLEEP) ? 8 : 2;
-  const int batch = cfg.batch;
+  const int batch = cfg_in.batch;
   const NdtMailbox* mb = h->mailbox.p;
   const NdtProblem* h_single = (batch == 1) ? h_probs : nullptr;  // a single registration travels in the kernel arguments
-  int launched = std::max(1, std::min(first, hard_cap));
-  int st = ndt_launch_evals(d_probs, h_single, cfg, 0, launched, h->stream);
-  if (st) return st;
+  int st;
+  for (int c = 0; c < n_chains; c++) {
+    Chain& C = ch[c];
+    C.b0 = chain_first[c]; C.b1 = chain_first[c + 1]; C.n_done = C.b0; C.over = false; C.stream = streams[c];
+    C.cfg = cfg_in; C.cfg.batch = C.b1 - C.b0;
+    C.launched = std::max(1, std::min(first, hard_cap));
+    if ((st = ndt_launch_evals(d_probs + C.b0, h_single, C.cfg, 0, C.launched, C.stream))) return st;
+  }
   unsigned long long last_progress = 0;
   auto t_progress = std::chrono::steady_clock::now();
-  int n_done = 0;  // mailboxes [0, n_done) have raised their flag
-  for (unsigned long long spins = 1;; spins++) {
-    while (n_done < batch && __atomic_load_n(&mb[n_done].done, __ATOMIC_ACQUIRE) == token) n_done++;
-    if (n_done == batch) break;
-    // every registration of a launch advances together: the first unfinished one tells how far the device is
-    const unsigned long long pr = __atomic_load_n(&mb[n_done].progress, __ATOMIC_RELAXED);
-    const int entered = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : -1;  // -1: nothing of this align yet
-    if (launched < hard_cap && launched - 1 - entered < LOW_WATER) {
-      const int c = std::min(REFILL, hard_cap - launched);
-      if (nb_full > 0 && batch > 1) {
-        int running = 0;
-        for (int b = n_done; b < batch; b++) running += (__atomic_load_n(&mb[b].done, __ATOMIC_RELAXED) != token);
-        cfg.max_blocks = std::max(cfg_in.max_blocks, std::min(nb_full, resident / std::max(1, running)));
+  int chains_left = n_chains;
+  for (unsigned long long spins = 1; chains_left > 0; spins++) {
+    unsigned long long pr_sum = 0;
+    for (int c = 0; c < n_chains; c++) {
+      Chain& C = ch[c];
+      if (C.over) continue;
+      while (C.n_done < C.b1 && __atomic_load_n(&mb[C.n_done].done, __ATOMIC_ACQUIRE) == token) C.n_done++;  // [b0, n_done) have raised their flag
+      if (C.n_done == C.b1) { C.over = true; chains_left--; continue; }
+      // every registration of a launch advances together: the first unfinished one tells how far the device is
+      const unsigned long long pr = __atomic_load_n(&mb[C.n_done].progress, __ATOMIC_RELAXED);
+      pr_sum += pr;
+      const int entered = ((unsigned int)(pr >> 32) == token) ? (int)(unsigned int)pr : -1;  // -1: nothing of this align yet
+      if (C.launched < hard_cap && C.launched - 1 - entered < LOW_WATER) {
+        const int k = std::min(REFILL, hard_cap - C.launched);
+        if (nb_full > 0 && batch > 1) {
+          int running = 0;   // over all chains: they share the chip
+          for (int b = 0; b < batch; b++) running += (__atomic_load_n(&mb[b].done, __ATOMIC_RELAXED) != token);
+          C.cfg.max_blocks = std::max(cfg_in.max_blocks, std::min(nb_full, resident / std::max(1, running)));
+        }
+        if ((st = ndt_launch_evals(d_probs + C.b0, h_single, C.cfg, C.launched, k, C.stream))) return st;
+        C.launched += k;
+        continue;
       }
-      if ((st = ndt_launch_evals(d_probs, h_single, cfg, launched, c, h->stream))) return st;
-      launched += c;
-      continue;
+      if (C.launched >= hard_cap && entered >= hard_cap - 1) {  // the last permitted launch has started: let it finish
+        LSR_HIP(hipStreamSynchronize(C.stream));
+        while (C.n_done < C.b1 && __atomic_load_n(&mb[C.n_done].done, __ATOMIC_ACQUIRE) == token) C.n_done++;
+        if (C.n_done == C.b1) { C.over = true; chains_left--; continue; }
+        set_last_error("NDT controller did not finish within the launch cap");
+        return LSR_ERR_HIP;
+      }
     }
-    if (launched >= hard_cap && entered >= hard_cap - 1) {  // the last permitted launch has started: let it finish
-      LSR_HIP(hipStreamSynchronize(h->stream));
-      while (n_done < batch && __atomic_load_n(&mb[n_done].done, __ATOMIC_ACQUIRE) == token) n_done++;
-      if (n_done == batch) break;
-      set_last_error("NDT controller did not finish within the launch cap");
-      return LSR_ERR_HIP;
-    }
+    if (chains_left == 0) break;
     if ((spins & 0x3FFF) == 0 || wait_mode == WAIT_SLEEP) {  // a device that stops making progress must not hang the caller forever
       const auto now = std::chrono::steady_clock::now();
-      if (pr != last_progress) { last_progress = pr; t_progress = now; }
+      if (pr_sum != last_progress) { last_progress = pr_sum; t_progress = now; }
       if (std::chrono::duration<double>(now - t_progress).count() > 30.0) {
         const hipError_t e = hipStreamQuery(h->stream);
         set_last_error(std::string("NDT launch chain made no progress for 30 s (stream: ") + hipGetErrorString(e) + ")");
@@ -333,6 +431,8 @@ int run_ndt_feeder(lsr_handle h, const NdtProblem* d_probs, const NdtProblem* h_
     else if (wait_mode == WAIT_SLEEP) std::this_thread::sleep_for(std::chrono::microseconds(20));
     else __builtin_ia32_pause();
   }
+  int launched = 0;
+  for (int c = 0; c < n_chains; c++) launched = std::max(launched, ch[c].launched);
   *launches_out = launched;
   return LSR_OK;
 }
@@ -378,6 +478,21 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   if ((st = lead->h_state.reserve(2 * (size_t)B))) return st;
   if ((st = lead->d_prob.reserve(B))) return st;
   if ((st = lead->h_prob.reserve(B))) return st;
+  // larger sets run as several independent launch chains (run_ndt_feeder), each on a stream of its own that starts behind
+  // everything the lead's stream holds at this point (the members' builds and uploads) and does its own state uploads
+  int n_chains = lead->profile ? 1 : ndt_chain_count(B);
+  if (B > 1 && (st = ensure_aux_streams(lead))) return st;   // once per lead handle
+  n_chains = std::min(n_chains, 1 + lead->n_chain_streams);
+  int chain_first[5] = {0, B, B, B, B};
+  hipStream_t chain_streams[4] = {lead->stream, nullptr, nullptr, nullptr};
+  if (n_chains > 1) {
+    LSR_HIP(hipEventRecord(lead->chain_fork_ev, lead->stream));
+    for (int c = 0; c <= n_chains; c++) chain_first[c] = (int)((long)B * c / n_chains);
+    for (int c = 1; c < n_chains; c++) {
+      chain_streams[c] = lead->chain_stream[c - 1];
+      LSR_HIP(hipStreamWaitEvent(chain_streams[c], lead->chain_fork_ev, 0));
+    }
+  }
   // launch geometry: where the leaf records are read from, which kernel, workgroup size (lead handle's tuning keys, 0 / -1 = automatic)
   NdtLaunchCfg cfg;
   cfg.batch = B;
@@ -393,8 +508,10 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     ndt_fill_initial_state(lead->h_state.p[2 * b], guesses ? guesses + 16 * b : nullptr, h->ndt, (int)h->source.n);
     lead->h_state.p[2 * b + 1] = lead->h_state.p[2 * b];
     if (cfg.sorted) {
-      // order this member's source by voxel tile of its guess-moved points (4 launches on the chain's stream)
-      if ((st = ndt_sort_source(h->source, lead->h_state.p[2 * b].T, h->target->grid, h->source_sorted, h->scratch, lead->stream))) return st;
+      // order this member's source by voxel tile of its guess-moved points (4 launches on its chain's stream)
+      int c = 0;
+      while (c + 1 < n_chains && b >= chain_first[c + 1]) c++;
+      if ((st = ndt_sort_source(h->source, lead->h_state.p[2 * b].T, h->target->grid, h->source_sorted, h->scratch, chain_streams[c]))) return st;
     }
     fill_problem(lead->h_prob.p[b], h, lead->d_state.p + 2 * b, lead->d_bins.p + (size_t)b * NDT_NBANKS * NDT_BANK_WORDS, cfg);
     max_blocks = std::max(max_blocks, lead->h_prob.p[b].nblocks);
@@ -419,13 +536,15 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     lead->h_state.p[2 * b].token = lead->h_state.p[2 * b + 1].token = (int)token;
   }
   const auto t0 = std::chrono::steady_clock::now();
-  if (B > 1)  // a single registration carries its NdtProblem in the kernel arguments
-    LSR_HIP(hipMemcpyAsync(lead->d_prob.p, lead->h_prob.p, sizeof(NdtProblem) * B, hipMemcpyHostToDevice, lead->stream));
-  if (B == 1) {  // state in the kernel arguments of one small launch (no SDMA copy, no memset)
+  if (B == 1) {  // problem and state in the kernel arguments (no SDMA copy, no memset)
     if ((st = ndt_init_single(lead->h_state.p[0], lead->d_state.p, lead->d_bins.p, lead->stream))) return st;
   } else {
-    LSR_HIP(hipMemcpyAsync(lead->d_state.p, lead->h_state.p, sizeof(NdtState) * 2 * B, hipMemcpyHostToDevice, lead->stream));
-    LSR_HIP(hipMemsetAsync(lead->d_bins.p, 0, sizeof(long long) * (size_t)B * NDT_NBANKS * NDT_BANK_WORDS, lead->stream));
+    for (int c = 0; c < n_chains; c++) {
+      const size_t b0 = (size_t)chain_first[c], nb = (size_t)(chain_first[c + 1] - chain_first[c]);
+      LSR_HIP(hipMemcpyAsync(lead->d_prob.p + b0, lead->h_prob.p + b0, sizeof(NdtProblem) * nb, hipMemcpyHostToDevice, chain_streams[c]));
+      LSR_HIP(hipMemcpyAsync(lead->d_state.p + 2 * b0, lead->h_state.p + 2 * b0, sizeof(NdtState) * 2 * nb, hipMemcpyHostToDevice, chain_streams[c]));
+      LSR_HIP(hipMemsetAsync(lead->d_bins.p + b0 * NDT_NBANKS * NDT_BANK_WORDS, 0, sizeof(long long) * nb * NDT_NBANKS * NDT_BANK_WORDS, chain_streams[c]));
+    }
   }
   if (lead->profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   // A candidate set is scored right after it is registered (graph_based_slam_component.cpp:230-231): the neighbour grids that
@@ -445,9 +564,6 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
       vgs.push_back(&h->target->grid); hgs.push_back(&h->target->hash); owners.push_back(h);
     }
     if (!vgs.empty()) {
-      if (!lead->side_stream) LSR_HIP(hipStreamCreateWithFlags(&lead->side_stream, hipStreamNonBlocking));
-      if (!lead->side_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_ev, hipEventDisableTiming));
-      if (!lead->side_fork_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_fork_ev, hipEventDisableTiming));
       LSR_HIP(hipEventRecord(lead->side_fork_ev, lead->stream));        // the targets' builds are behind this point of the lead's stream
       LSR_HIP(hipStreamWaitEvent(lead->side_stream, lead->side_fork_ev, 0));
       if ((st = nn_build_hash_from_grids(vgs.data(), hgs.data(), (int)vgs.size(), lead->side_stream))) return st;
@@ -469,9 +585,6 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
       eager = eager || eager_ok[b];
     }
     if (eager && !prefetched) {   // every grid was there already: the side stream still has to start behind the lead's stream
-      if (!lead->side_stream) LSR_HIP(hipStreamCreateWithFlags(&lead->side_stream, hipStreamNonBlocking));
-      if (!lead->side_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_ev, hipEventDisableTiming));
-      if (!lead->side_fork_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_fork_ev, hipEventDisableTiming));
       LSR_HIP(hipEventRecord(lead->side_fork_ev, lead->stream));
       LSR_HIP(hipStreamWaitEvent(lead->side_stream, lead->side_fork_ev, 0));
     }
@@ -498,7 +611,15 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   const std::function<int()> poll_hook = [&]() { return eager_dispatch(false); };
   int launches = 0;
   st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, cfg, min_evals, hard_cap, token, &launches, eager ? &poll_hook : nullptr,
-                      (!cfg.quad && lane_widen_enabled()) ? nb_full : 0);
+                      (!cfg.quad && lane_widen_enabled()) ? nb_full : 0, n_chains, chain_first, chain_streams);
+  // whatever follows on the lead's stream (the next align's uploads, a release of the banks) stays behind the chains' queued launches
+  for (int c = 1; c < n_chains; c++) {
+    if (hipEventRecord(lead->chain_ev[c - 1], lead->chain_stream[c - 1]) != hipSuccess ||
+        hipStreamWaitEvent(lead->stream, lead->chain_ev[c - 1], 0) != hipSuccess) {
+      (void)hipStreamSynchronize(lead->chain_stream[c - 1]);
+      if (!st) { set_last_error("joining a launch chain failed"); st = LSR_ERR_HIP; }
+    }
+  }
   if (eager && !st) st = eager_dispatch(true);
   if (prefetched || eager) {
     // the side stream's work — grid refinement, searches — ends here: every later use of the grids and of the members' scratch
@@ -642,6 +763,11 @@ int lsr_destroy(lsr_handle h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->side_ev) (void)hipEventDestroy(h->side_ev);
+  if (h->chain_fork_ev) (void)hipEventDestroy(h->chain_fork_ev);
+  for (int c = 0; c < 3; c++) {
+    if (h->chain_stream[c]) { (void)hipStreamSynchronize(h->chain_stream[c]); (void)hipStreamDestroy(h->chain_stream[c]); }
+    if (h->chain_ev[c]) (void)hipEventDestroy(h->chain_ev[c]);
+  }
   if (h->side_fork_ev) (void)hipEventDestroy(h->side_fork_ev);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -20,6 +20,12 @@ struct lsr_handle_s {
   // runs on `stream` (align_ndt_batch); created on first use
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev = nullptr, side_fork_ev = nullptr;
+  // extra launch-chain streams of a batch lead: a small candidate set runs as several independent chains (run_ndt_feeder)
+  hipStream_t chain_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t chain_ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t chain_fork_ev = nullptr;
+  bool chain_probed = false;   // the streams above were looked for (each is verified to run concurrently with `stream`)
+  int n_chain_streams = 0;
 
   NdtParamsHost ndt;
   GicpParamsHost gicp;
