@@ -43,6 +43,9 @@ static int gicp_ball_cells() {
 namespace {
 
 constexpr int GN_THREADS = 256;
+// The pair count of a correspondence pass is summed over 64 counters a cache line apart (never reset within an align: the step
+// that adopts a count remembers the total): 7 500 waves adding to ONE address took 100 us, 13 ns per atomic.
+constexpr int GICP_COUNT_SHARDS = 64, GICP_SHARD_STRIDE = 16;
 constexpr int GN_NRED = 28;  // [0] cost, [1..6] J^T M r, [7..27] upper triangle of J^T M J
 
 struct PairRec {      // one candidate correspondence, written by K6, streamed by K7
@@ -89,7 +92,8 @@ struct IterBlock {    // uploaded once per align
   OuterState out;
   int count;          // pairs found by the correspondence pass
   int have_partials;  // fused chain: the previous step left partial rows at the current x (to be consumed by the next step)
-  int pad[2];
+  int count_base;     // sharded pair counters (GICP_COUNT_SHARDS): their total when the previous outer iteration adopted it
+  int pad;
 };
 
 // f6 = {cos a, sin a, cos b, sin b, cos c, sin c} of the FLOAT angles, d6 = the same of the double angles (x[3..5])
@@ -357,44 +361,49 @@ __global__ __launch_bounds__(NN_THREADS) void gicp_corr_kernel(NNGridView G, con
   if (found && (threadIdx.x & 63) == (__ffsll((long long)__ballot(1)) - 1)) atomicAdd(count, __popcll(found));
 }
 
+// M = (R C1_i R^T + C2_j)^-1 in fp64 for the correspondence (i, j) at squared distance d2; an empty record when there is none
+__device__ __forceinline__ PairRec empty_pair() {
+  PairRec r;
+  r.valid = 0;
+  r.q[0] = r.q[1] = r.q[2] = 0.f;
+  for (int k = 0; k < 6; k++) r.M[k] = 0.0;
+  return r;
+}
+
+__device__ __forceinline__ PairRec make_pair(int i, int j, float d2, float thr2, const double* __restrict__ Rm, const double* __restrict__ C1,
+                                             const double* __restrict__ C2, const float* __restrict__ tx, const float* __restrict__ ty,
+                                             const float* __restrict__ tz) {
+  PairRec r = empty_pair();
+  if (j >= 0 && d2 < thr2) {
+    const double* c1 = C1 + (size_t)i * 9;
+    const double* c2 = C2 + (size_t)j * 9;
+    double RC[9], S[9];
+    for (int u = 0; u < 3; u++)
+      for (int v = 0; v < 3; v++) RC[u * 3 + v] = Rm[u * 3] * c1[v] + Rm[u * 3 + 1] * c1[3 + v] + Rm[u * 3 + 2] * c1[6 + v];
+    for (int u = 0; u < 3; u++)
+      for (int v = 0; v < 3; v++)
+        S[u * 3 + v] = RC[u * 3] * Rm[v * 3] + RC[u * 3 + 1] * Rm[v * 3 + 1] + RC[u * 3 + 2] * Rm[v * 3 + 2] + c2[u * 3 + v];
+    // general 3x3 inverse by cofactors (what temp.inverse() does)
+    const double k00 = S[4] * S[8] - S[5] * S[7], k01 = S[5] * S[6] - S[3] * S[8], k02 = S[3] * S[7] - S[4] * S[6];
+    const double det = S[0] * k00 + S[1] * k01 + S[2] * k02;
+    const double id = 1.0 / det;
+    r.M[0] = k00 * id;
+    r.M[1] = (S[2] * S[7] - S[1] * S[8]) * id;
+    r.M[2] = (S[1] * S[5] - S[2] * S[4]) * id;
+    r.M[3] = (S[0] * S[8] - S[2] * S[6]) * id;
+    r.M[4] = (S[2] * S[3] - S[0] * S[5]) * id;
+    r.M[5] = (S[0] * S[4] - S[1] * S[3]) * id;
+    r.q[0] = tx[j]; r.q[1] = ty[j]; r.q[2] = tz[j];
+    r.valid = 1;
+  }
+  return r;
+}
+
 // K6, wave-cooperative form.  Search: one wave per source point (coop_search<1-NN>), seeded with the previous outer
 // iteration's neighbour.  Pairs: one thread per point builds the Mahalanobis matrix of its correspondence.
-// Seeded form (outer iterations after the first), SIXTEEN lanes per point.  The previous neighbour's distance d is an upper
-// bound on the answer, so the answer lies in the ball of radius d around the moved point: the fine cells that ball touches
-// (at most max_cells per axis, else the point goes to `work` for the general search) are ALL the search has to read — no shells,
-// no bound tests.  One row of <= max_cells cells per (y, z) pair, one lane per (row, coarse segment), the candidates of the group
-// laid end to end and read 16 at a time; four points per wave.  Exact: every point at distance <= d is in one of those
-// cells (the cell index is a monotone map; the reach is padded against rounding), ties included.
-// work[0] = number of deferred points (zeroed by the pair kernel after use), work[1..] = their indices.
-__global__ __launch_bounds__(256) void gicp_corr_ball_kernel(NNGridView G, const float* __restrict__ ox, const float* __restrict__ oy,
-                                                             const float* __restrict__ oz, int n, const float* __restrict__ T16,
-                                                             float thr2, const float* __restrict__ tx, const float* __restrict__ ty,
-                                                             const float* __restrict__ tz, const OuterState* __restrict__ O,
-                                                             int* __restrict__ last_nn, float* __restrict__ nn_d2, int* __restrict__ work,
-                                                             const int max_cells) {
-  const int ph = O->phase;
-  if (O->outer_done || (ph & 1) || ph == 0) return;  // the first outer iteration has no seeds: the general search does it
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = t >> 4, gl = t & 15;
-  if (i >= n) return;   // n * 16 threads: a group is never split by this test
-  const float a = ox[i], b = oy[i], c = oz[i];
-  const float q[3] = {xform_rn(T16[0], T16[4], T16[8], T16[12], a, b, c), xform_rn(T16[1], T16[5], T16[9], T16[13], a, b, c),
-                      xform_rn(T16[2], T16[6], T16[10], T16[14], a, b, c)};
-  const int seed = last_nn[i];
-  bool general = seed < 0 || !(isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]));
-  float bd = INFINITY;
-  int bi = INT_MAX;
-  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  if (!general) {
-    bd = dist2_rn(q[0], q[1], q[2], tx[seed], ty[seed], tz[seed]);
-    bi = seed;
-    if (!(bd < thr2)) general = true;   // the seed itself is beyond the gate: the ball would be the gate's
-  }
-  if (!general && !ball_cell_range(G, q, bd, max_cells, lo, hi)) general = true;   // more than max_cells (<= 8) cells on some axis
-  if (general) {
-    if (gl == 0) work[1 + atomicAdd(work, 1)] = i;
-    return;
-  }
+// The scan of the seeded search: every point of the fine cells [lo, hi] (<= 8 per axis) offered to the group's best (bd, bi), then
+// the group's sixteen lanes agree on the winner.  Called by all sixteen lanes of a group together.
+__device__ __forceinline__ void ball_scan_group(const NNGridView& G, const float* q, const int* lo, const int* hi, const int gl, float& bd, int& bi) {
   const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;   // >= 1 unless the ball misses the grid (then no slot is valid)
   const int n_slots = (ny > 0 && nz > 0 && hi[0] >= lo[0]) ? ny * nz * 2 : 0;
   const unsigned int ny_magic = 65536u / (unsigned int)max(ny, 1) + 1u;
@@ -449,6 +458,45 @@ __global__ __launch_bounds__(256) void gicp_corr_ball_kernel(NNGridView G, const
     const int oi = __shfl_xor(bi, m, 16);
     if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
   }
+}
+
+// Seeded form (outer iterations after the first), SIXTEEN lanes per point.  The previous neighbour's distance d is an upper
+// bound on the answer, so the answer lies in the ball of radius d around the moved point: the fine cells that ball touches
+// (at most max_cells per axis, else the point goes to `work` for the general search) are ALL the search has to read — no shells,
+// no bound tests.  One row of <= max_cells cells per (y, z) pair, one lane per (row, coarse segment), the candidates of the group
+// laid end to end and read 16 at a time; four points per wave.  Exact: every point at distance <= d is in one of those
+// cells (the cell index is a monotone map; the reach is padded against rounding), ties included.
+// work[0] = number of deferred points (zeroed by the pair kernel after use), work[1..] = their indices.
+__global__ __launch_bounds__(256) void gicp_corr_ball_kernel(NNGridView G, const float* __restrict__ ox, const float* __restrict__ oy,
+                                                             const float* __restrict__ oz, int n, const float* __restrict__ T16,
+                                                             float thr2, const float* __restrict__ tx, const float* __restrict__ ty,
+                                                             const float* __restrict__ tz, const OuterState* __restrict__ O,
+                                                             int* __restrict__ last_nn, float* __restrict__ nn_d2, int* __restrict__ work,
+                                                             const int max_cells) {
+  const int ph = O->phase;
+  if (O->outer_done || (ph & 1) || ph == 0) return;  // the first outer iteration has no seeds: the general search does it
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 4, gl = t & 15;
+  if (i >= n) return;   // n * 16 threads: a group is never split by this test
+  const float a = ox[i], b = oy[i], c = oz[i];
+  const float q[3] = {xform_rn(T16[0], T16[4], T16[8], T16[12], a, b, c), xform_rn(T16[1], T16[5], T16[9], T16[13], a, b, c),
+                      xform_rn(T16[2], T16[6], T16[10], T16[14], a, b, c)};
+  const int seed = last_nn[i];
+  bool general = seed < 0 || !(isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]));
+  float bd = INFINITY;
+  int bi = INT_MAX;
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  if (!general) {
+    bd = dist2_rn(q[0], q[1], q[2], tx[seed], ty[seed], tz[seed]);
+    bi = seed;
+    if (!(bd < thr2)) general = true;   // the seed itself is beyond the gate: the ball would be the gate's
+  }
+  if (!general && !ball_cell_range(G, q, bd, max_cells, lo, hi)) general = true;   // more than max_cells (<= 8) cells on some axis
+  if (general) {
+    if (gl == 0) work[1 + atomicAdd(work, 1)] = i;
+    return;
+  }
+  ball_scan_group(G, q, lo, hi, gl, bd, bi);
   if (gl == 0) {
     last_nn[i] = bi;
     nn_d2[i] = bd;
@@ -497,45 +545,115 @@ __global__ __launch_bounds__(256) void gicp_corr_pairs_kernel(int n, const doubl
                                                               const float* __restrict__ ty, const float* __restrict__ tz,
                                                               const int* __restrict__ last_nn, const float* __restrict__ nn_d2,
                                                               PairRec* __restrict__ pairs, int* __restrict__ count, OuterState* __restrict__ O,
-                                                              int* __restrict__ work /* nullable */) {
+                                                              int* __restrict__ work /* nullable */, int* __restrict__ count_shards = nullptr) {
   const int ph = O->phase;
   if (O->outer_done || (ph & 1)) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (threadIdx.x == 0) O->corr_mark = ph;  // same value from every workgroup: tells the launches behind that the pairs are fresh
   if (work && i == 0) work[0] = 0;          // the deferred-point list of this pass has been consumed
-  PairRec r;
-  r.valid = 0;
-  r.q[0] = r.q[1] = r.q[2] = 0.f;
-  for (int k = 0; k < 6; k++) r.M[k] = 0.0;
+  PairRec r = empty_pair();
   if (i < n) {
-    const int j = last_nn[i];
-    if (j >= 0 && nn_d2[i] < thr2) {
-      const double* c1 = C1 + (size_t)i * 9;
-      const double* c2 = C2 + (size_t)j * 9;
-      double RC[9], S[9];
-      for (int u = 0; u < 3; u++)
-        for (int v = 0; v < 3; v++) RC[u * 3 + v] = Rm[u * 3] * c1[v] + Rm[u * 3 + 1] * c1[3 + v] + Rm[u * 3 + 2] * c1[6 + v];
-      for (int u = 0; u < 3; u++)
-        for (int v = 0; v < 3; v++)
-          S[u * 3 + v] = RC[u * 3] * Rm[v * 3] + RC[u * 3 + 1] * Rm[v * 3 + 1] + RC[u * 3 + 2] * Rm[v * 3 + 2] + c2[u * 3 + v];
-      // general 3x3 inverse by cofactors (what temp.inverse() does)
-      const double k00 = S[4] * S[8] - S[5] * S[7], k01 = S[5] * S[6] - S[3] * S[8], k02 = S[3] * S[7] - S[4] * S[6];
-      const double det = S[0] * k00 + S[1] * k01 + S[2] * k02;
-      const double id = 1.0 / det;
-      r.M[0] = k00 * id;
-      r.M[1] = (S[2] * S[7] - S[1] * S[8]) * id;
-      r.M[2] = (S[1] * S[5] - S[2] * S[4]) * id;
-      r.M[3] = (S[0] * S[8] - S[2] * S[6]) * id;
-      r.M[4] = (S[2] * S[3] - S[0] * S[5]) * id;
-      r.M[5] = (S[0] * S[4] - S[1] * S[3]) * id;
-      r.q[0] = tx[j]; r.q[1] = ty[j]; r.q[2] = tz[j];
-      r.valid = 1;
-    }
+    r = make_pair(i, last_nn[i], nn_d2[i], thr2, Rm, C1, C2, tx, ty, tz);
     pairs[i] = r;
   }
   // one atomic per wave (ballot + popcount) instead of one per matched point
   const unsigned long long found = __ballot(r.valid != 0);
-  if (found && (threadIdx.x & 63) == (__ffsll((long long)__ballot(1)) - 1)) atomicAdd(count, __popcll(found));
+  if (found && (threadIdx.x & 63) == (__ffsll((long long)__ballot(1)) - 1))
+    atomicAdd(count_shards ? count_shards + (blockIdx.x & (GICP_COUNT_SHARDS - 1)) * GICP_SHARD_STRIDE : count, __popcll(found));
+}
+
+// K6 in ONE launch per outer iteration: the seeded sixteen-lane search (gicp_corr_ball_kernel) — a point without a previous
+// neighbour seeds itself from its own fine cell, as the fitness search does —, the points it
+// would defer searched at once by the whole wave (the body of gicp_corr_search_kernel, one deferred point after the other), and
+// the pair record of every point (gicp_corr_pairs_kernel's) written by the first lane of its group — three launches and two
+// launch boundaries per outer iteration less, no work list.  Same candidates in the same order, same fp64 expressions: the
+// records are those of the three-launch form bit for bit (tests/test_gicp_gpu.py; LSR_GICP_CORR_FUSED=0 selects that form).
+__global__ __launch_bounds__(256) void gicp_corr_seeded_kernel(NNGridView G, const float* __restrict__ ox, const float* __restrict__ oy,
+                                                               const float* __restrict__ oz, int n, const float* __restrict__ T16,
+                                                               const double* __restrict__ Rm, float thr2, const float* __restrict__ tx,
+                                                               const float* __restrict__ ty, const float* __restrict__ tz,
+                                                               const double* __restrict__ C1, const double* __restrict__ C2,
+                                                               OuterState* __restrict__ O, int* __restrict__ last_nn,
+                                                               float* __restrict__ nn_d2, PairRec* __restrict__ pairs,
+                                                               int* __restrict__ count_shards, const int max_cells) {
+  const int ph = O->phase;
+  if (O->outer_done || (ph & 1)) return;   // the inner loop of this outer iteration is still running (or all is over)
+  if (threadIdx.x == 0) O->corr_mark = ph;  // same value from every workgroup: tells the launches behind that the pairs are fresh
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 4, gl = t & 15, lane = threadIdx.x & 63;
+  const bool live = i < n;   // n * 16 threads: a group is never split by this test; dead groups stay for the wave-wide part
+  float q[3] = {0.f, 0.f, 0.f};
+  int seed = -1;
+  bool general = false;
+  float bd = INFINITY;
+  int bi = INT_MAX;
+  if (live) {
+    const float a = ox[i], b = oy[i], c = oz[i];
+    q[0] = xform_rn(T16[0], T16[4], T16[8], T16[12], a, b, c);
+    q[1] = xform_rn(T16[1], T16[5], T16[9], T16[13], a, b, c);
+    q[2] = xform_rn(T16[2], T16[6], T16[10], T16[14], a, b, c);
+    seed = (ph > 0) ? last_nn[i] : -1;   // (the first outer iteration has no previous neighbours)
+    general = !(isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]));
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    if (!general && seed >= 0) {
+      bd = dist2_rn(q[0], q[1], q[2], tx[seed], ty[seed], tz[seed]);
+      bi = seed;
+    } else if (!general) {
+      // no seed (first outer iteration; a point that had no neighbour within the gate): the best point of the query's own
+      // fine cell — of the 3 x 3 x 3 cells around it if that one is empty — is a real point, hence a bound (nn.hip: nn1_ball_body)
+      const float ff[3] = {floorf(q[0] * G.inv_cell), floorf(q[1] * G.inv_cell), floorf(q[2] * G.inv_cell)};
+      int fq[3] = {0, 0, 0};
+      if (!(fabsf(ff[0]) < 1.0e9f && fabsf(ff[1]) < 1.0e9f && fabsf(ff[2]) < 1.0e9f)) general = true;
+      if (!general) {
+        for (int a = 0; a < 3; a++) {
+          fq[a] = (int)ff[a] - G.org[a];
+          if (fq[a] < -1 || fq[a] > G.cdim[a] * 8) general = true;   // more than a cell outside the grid
+        }
+      }
+      if (!general) {
+        for (int a = 0; a < 3; a++) { lo[a] = max(fq[a], 0); hi[a] = min(fq[a], G.cdim[a] * 8 - 1); }
+        ball_scan_group(G, q, lo, hi, gl, bd, bi);
+        if (bi == INT_MAX) {
+          for (int a = 0; a < 3; a++) { lo[a] = max(fq[a] - 1, 0); hi[a] = min(fq[a] + 1, G.cdim[a] * 8 - 1); }
+          ball_scan_group(G, q, lo, hi, gl, bd, bi);
+        }
+        if (bi == INT_MAX) general = true;   // nothing within a cell of the point
+      }
+    }
+    if (!general && !(bd < thr2)) general = true;   // the bound itself is beyond the gate: the ball would be the gate's
+    if (!general && !ball_cell_range(G, q, bd, max_cells, lo, hi)) general = true;   // more than max_cells cells on some axis
+    if (!general) ball_scan_group(G, q, lo, hi, gl, bd, bi);
+  }
+  // the points the seeded search cannot serve, one after the other, all 64 lanes on each (exactly gicp_corr_search_kernel's body)
+  unsigned long long todo = __ballot(live && general && gl == 0);
+  while (todo) {
+    const int sl = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const float qx = __shfl(q[0], sl, 64), qy = __shfl(q[1], sl, 64), qz = __shfl(q[2], sl, 64);
+    const int sd = __shfl(seed, sl, 64);
+    CoopList mine;
+    mine.d = INFINITY;
+    mine.i = INT_MAX;
+    int fine_rings = 1;
+    if (sd >= 0) {
+      mine.d = dist2_rn(qx, qy, qz, tx[sd], ty[sd], tz[sd]);
+      mine.i = sd;
+      fine_rings = 0;
+    }
+    coop_search<true>(G, qx, qy, qz, 1, fine_rings, thr2, -1, mine);
+    const float rd = __shfl(mine.d, 0, 64);
+    const int ri = __shfl(mine.i, 0, 64);
+    if ((lane >> 4) == (sl >> 4)) { bd = rd; bi = (ri == INT_MAX) ? -1 : ri; }
+  }
+  PairRec r = empty_pair();
+  if (live && gl == 0) {
+    last_nn[i] = bi;
+    nn_d2[i] = bd;
+    r = make_pair(i, bi, bd, thr2, Rm, C1, C2, tx, ty, tz);
+    pairs[i] = r;
+  }
+  const unsigned long long found = __ballot(r.valid != 0);
+  if (found && lane == 0) atomicAdd(count_shards + (blockIdx.x & (GICP_COUNT_SHARDS - 1)) * GICP_SHARD_STRIDE, __popcll(found));
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -958,7 +1076,8 @@ __device__ int gicp_advance(IterBlock& Bk, const double* s_sum, GicpMailbox* mb,
 __global__ __launch_bounds__(GN_THREADS) void gicp_step_kernel(IterBlock* __restrict__ blk2, int step, const float* __restrict__ ox,
                                                                const float* __restrict__ oy, const float* __restrict__ oz, int n,
                                                                const PairRec* __restrict__ pairs, double* __restrict__ partials2,
-                                                               int nblocks, GicpMailbox* mb, unsigned int token, int launch_index) {
+                                                               int nblocks, GicpMailbox* mb, unsigned int token, int launch_index,
+                                                               const int* __restrict__ count_shards /* nullable */) {
   static_assert(sizeof(IterBlock) % 8 == 0, "IterBlock is copied as 8-byte words");
   __shared__ __attribute__((aligned(16))) unsigned long long s_raw[sizeof(IterBlock) / 8];
   __shared__ double s_grp[8][32];
@@ -1004,6 +1123,12 @@ __global__ __launch_bounds__(GN_THREADS) void gicp_step_kernel(IterBlock* __rest
   __shared__ int s_need;
   if (t < 64) {   // wave 0: the scalar bookkeeping on lane 0, the 6x6 solve on the wave (lockstep + in-order LDS: no workgroup barrier)
     int code = 0;
+    if (count_shards && !Bk.have_partials) {   // the correspondence pass has just run: its pair count = the counters' total - the last one
+      int total = count_shards[t * GICP_SHARD_STRIDE];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m, 64);
+      if (t == 0) { Bk.count = total - Bk.count_base; Bk.count_base = total; }
+    }
     if (t == 0) { s_need = 0; code = gicp_advance(Bk, s_sum, mb, token, blockIdx.x == 0, &s_need); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -1211,8 +1336,9 @@ struct GicpChain {
   int n = 0, nblocks = 1, updates = 0, spread = 1;
   unsigned int token = 0;
   float thr2 = 0.f;
-  bool coop_corr = false, fused = false, ball = false, done = false;
+  bool coop_corr = false, fused = false, ball = false, corr_fused = false, done = false;
   int* d_work = nullptr;
+  int* d_shards = nullptr;
   double* d_partials = nullptr;
   IterBlock* d_blk = nullptr;
   PairRec* d_pairs = nullptr;
@@ -1225,6 +1351,14 @@ struct GicpChain {
     const TargetData& t = *h->target;
     if (fused) {   // the correspondence launches work on the block the next step will read
       IterBlock* cur = d_blk + (updates & 1);
+      if (corr_fused) {
+        // one launch per outer iteration: seeded (or self-seeded) search + what it cannot serve + pair records
+        {
+          hipLaunchKernelGGL(gicp_corr_seeded_kernel, dim3((unsigned)(((long)n * 16 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
+                             ws.out.x(), ws.out.y(), ws.out.z(), n, cur->T16, cur->Rm, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(),
+                             h->source_cov.p, t.cov.p, &cur->out, ws.last_nn.p, ws.nn_d2.p, d_pairs, d_shards, gicp_ball_cells());
+        }
+      } else {
       if (ball)
         hipLaunchKernelGGL(gicp_corr_ball_kernel, dim3((unsigned)(((long)n * 16 + 255) / 256)), dim3(256), 0, s, make_view(t.hash),
                            ws.out.x(), ws.out.y(), ws.out.z(), n, cur->T16, thr2, t.cloud.x(), t.cloud.y(), t.cloud.z(), &cur->out,
@@ -1238,9 +1372,10 @@ struct GicpChain {
                          ws.last_nn.p, ws.nn_d2.p, d_work);
       hipLaunchKernelGGL(gicp_corr_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cur->Rm, thr2, h->source_cov.p, t.cov.p,
                          t.cloud.x(), t.cloud.y(), t.cloud.z(), ws.last_nn.p, ws.nn_d2.p, d_pairs, &cur->count, &cur->out, d_work);
+      }
       for (int it = 0; it < steps; it++) {
         hipLaunchKernelGGL(gicp_step_kernel, dim3(nblocks), dim3(GN_THREADS), 0, s, d_blk, updates, ws.out.x(), ws.out.y(), ws.out.z(), n,
-                           d_pairs, d_partials, nblocks, ws.d_mailbox, token, updates + 1);
+                           d_pairs, d_partials, nblocks, ws.d_mailbox, token, updates + 1, corr_fused ? (const int*)d_shards : (const int*)nullptr);
         updates++;
       }
       return;
@@ -1327,8 +1462,16 @@ struct GicpChain {
     // seeded 16-lane search for the outer iterations after the first (env LSR_GICP_BALL=0: the general search every time)
     static const bool ball_on = [] { const char* e = getenv("LSR_GICP_BALL"); return !(e && e[0] == '0'); }();
     ball = fused && ball_on;
+    // ... in ONE launch per outer iteration (env LSR_GICP_CORR_FUSED=0: seeded search, general search and pair records as three)
+    static const bool corr_fused_on = [] { const char* e = getenv("LSR_GICP_CORR_FUSED"); return !(e && e[0] == '0'); }();
+    corr_fused = ball && corr_fused_on;
     d_work = nullptr;
-    if (ball) {
+    d_shards = nullptr;
+    if (corr_fused) {   // no work list; the pair counters start an align at zero
+      if ((st = ws.count_shards.reserve((size_t)GICP_COUNT_SHARDS * GICP_SHARD_STRIDE))) return st;
+      d_shards = ws.count_shards.p;
+      LSR_HIP(hipMemsetAsync(d_shards, 0, sizeof(int) * GICP_COUNT_SHARDS * GICP_SHARD_STRIDE, s));
+    } else if (ball) {
       if ((st = ws.corr_work.reserve((size_t)n + 2))) return st;
       d_work = ws.corr_work.p;
       LSR_HIP(hipMemsetAsync(d_work, 0, sizeof(int), s));

@@ -39,6 +39,7 @@ struct GicpWorkspace {
   DevBuf<int> last_nn;           // K6: each source point's neighbour in the previous outer iteration (search seed)
   DevBuf<float> nn_d2;           // K6: its squared distance (search kernel -> pair kernel)
   DevBuf<int> corr_work;         // K6: [0] = count, [1..] = points the seeded search hands to the general one
+  DevBuf<int> count_shards;      // K6: pair counters of the one-launch correspondence pass, a cache line apart
   PinBuf<GicpMailbox> mailbox;
   GicpMailbox* d_mailbox = nullptr;
   unsigned int token = 0;        // one per align

@@ -223,11 +223,12 @@ def _run_variant(env_extra):
 
 def test_search_and_chain_variants_give_identical_results():
     """The wave-cooperative searches (default) against the per-thread walks (LSR_NN_COOP=0), and the fused Gauss-Newton
-    chain (default) against the accumulate + update launch pairs (LSR_GICP_FUSED=0): exact searches with one (distance, index)
+    chain (default) against the accumulate + update launch pairs (LSR_GICP_FUSED=0), the one-launch correspondence pass (default)
+    against seeded search / general search / pair records as three launches (LSR_GICP_CORR_FUSED=0): exact searches with one (distance, index)
     order and the same summation orders, so covariances, correspondences, poses, iteration counts and fitness scores must
     be bit-identical, outliers beyond the fine shells included."""
     base = _run_variant({})
-    for env in ({"LSR_NN_COOP": "0"}, {"LSR_GICP_FUSED": "0"}, {"LSR_GICP_BALL": "0"}):
+    for env in ({"LSR_NN_COOP": "0"}, {"LSR_GICP_FUSED": "0"}, {"LSR_GICP_BALL": "0"}, {"LSR_GICP_CORR_FUSED": "0"}):
         other = _run_variant(env)
         assert other == base, (env, {k: (base[k] == other[k]) for k in base})
 
