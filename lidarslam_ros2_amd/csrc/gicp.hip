@@ -401,65 +401,6 @@ __device__ __forceinline__ PairRec make_pair(int i, int j, float d2, float thr2,
 
 // K6, wave-cooperative form.  Search: one wave per source point (coop_search<1-NN>), seeded with the previous outer
 // iteration's neighbour.  Pairs: one thread per point builds the Mahalanobis matrix of its correspondence.
-// The scan of the seeded search: every point of the fine cells [lo, hi] (<= 8 per axis) offered to the group's best (bd, bi), then
-// the group's sixteen lanes agree on the winner.  Called by all sixteen lanes of a group together.
-__device__ __forceinline__ void ball_scan_group(const NNGridView& G, const float* q, const int* lo, const int* hi, const int gl, float& bd, int& bi) {
-  const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;   // >= 1 unless the ball misses the grid (then no slot is valid)
-  const int n_slots = (ny > 0 && nz > 0 && hi[0] >= lo[0]) ? ny * nz * 2 : 0;
-  const unsigned int ny_magic = 65536u / (unsigned int)max(ny, 1) + 1u;
-  for (int s0 = 0; s0 < n_slots; s0 += 16) {
-    const int slot = s0 + gl;
-    int beg = 0, len = 0;
-    if (slot < n_slots) {
-      const int cseg = slot & 1, row = slot >> 1;
-      const int dz = (int)(((unsigned int)row * ny_magic) >> 16);   // row / ny (row < 128, ny <= 8)
-      const int y = lo[1] + (row - dz * ny), z = lo[2] + dz;
-      const int cx = (lo[0] >> 3) + cseg;
-      if (cx <= (hi[0] >> 3)) {
-        const int blk = G.coarse_block[G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3)) + cx];
-        if (blk >= 0) {
-          const int xa = max(lo[0], cx * 8) & 7, xb = min(hi[0], cx * 8 + 7) & 7;
-          const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((y & 7) << 3) | ((z & 7) << 6));
-          beg = fs[xa];
-          len = fs[xb + 1] - beg;
-        }
-      }
-    }
-    // the group's candidates end to end: inclusive scan over the 16 lanes, then 16 candidates per round
-    int incl = len;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-      const int v = __shfl_up(incl, d, 16);
-      if (gl >= d) incl += v;
-    }
-    const int excl = incl - len;
-    const int total = __shfl(incl, 15, 16);
-    for (int t0 = 0; t0 < total; t0 += 16) {
-      const int f = t0 + gl;
-      int sl = 0;
-#pragma unroll
-      for (int step = 8; step >= 1; step >>= 1) {
-        const int cand = sl + step;
-        const int o = __shfl(excl, cand, 16);
-        if (o <= f) sl = cand;
-      }
-      const int sb = __shfl(beg, sl, 16), so = __shfl(excl, sl, 16);
-      if (f < total) {
-        const float4 pt = G.p[sb + (f - so)];
-        const float d = dist2_rn(q[0], q[1], q[2], pt.x, pt.y, pt.z);
-        const int oi = __float_as_int(pt.w);
-        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) {
-    const float od = __shfl_xor(bd, m, 16);
-    const int oi = __shfl_xor(bi, m, 16);
-    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
-  }
-}
-
 // Seeded form (outer iterations after the first), SIXTEEN lanes per point.  The previous neighbour's distance d is an upper
 // bound on the answer, so the answer lies in the ball of radius d around the moved point: the fine cells that ball touches
 // (at most max_cells per axis, else the point goes to `work` for the general search) are ALL the search has to read — no shells,
@@ -496,7 +437,7 @@ __global__ __launch_bounds__(256) void gicp_corr_ball_kernel(NNGridView G, const
     if (gl == 0) work[1 + atomicAdd(work, 1)] = i;
     return;
   }
-  ball_scan_group(G, q, lo, hi, gl, bd, bi);
+  scan_cells_group16(G, q, lo, hi, gl, bd, bi);
   if (gl == 0) {
     last_nn[i] = bi;
     nn_d2[i] = bd;
@@ -595,6 +536,7 @@ __global__ __launch_bounds__(256) void gicp_corr_seeded_kernel(NNGridView G, con
     seed = (ph > 0) ? last_nn[i] : -1;   // (the first outer iteration has no previous neighbours)
     general = !(isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]));
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    int seeded_reach = -1, seed_lo[3] = {0, 0, 0}, seed_hi[3] = {0, 0, 0};   // self-seeded: the cells the seed was the best of
     if (!general && seed >= 0) {
       bd = dist2_rn(q[0], q[1], q[2], tx[seed], ty[seed], tz[seed]);
       bi = seed;
@@ -611,18 +553,25 @@ __global__ __launch_bounds__(256) void gicp_corr_seeded_kernel(NNGridView G, con
         }
       }
       if (!general) {
-        for (int a = 0; a < 3; a++) { lo[a] = max(fq[a], 0); hi[a] = min(fq[a], G.cdim[a] * 8 - 1); }
-        ball_scan_group(G, q, lo, hi, gl, bd, bi);
+        if (fq[0] >= 0 && fq[0] < G.cdim[0] * 8 && fq[1] >= 0 && fq[1] < G.cdim[1] * 8 && fq[2] >= 0 && fq[2] < G.cdim[2] * 8)
+          scan_cell_group16(G, q, fq, gl, bd, bi);
+        seeded_reach = (bi != INT_MAX) ? 0 : 1;
         if (bi == INT_MAX) {
           for (int a = 0; a < 3; a++) { lo[a] = max(fq[a] - 1, 0); hi[a] = min(fq[a] + 1, G.cdim[a] * 8 - 1); }
-          ball_scan_group(G, q, lo, hi, gl, bd, bi);
+          scan_cells_group16(G, q, lo, hi, gl, bd, bi);
         }
         if (bi == INT_MAX) general = true;   // nothing within a cell of the point
+        for (int a = 0; a < 3; a++) { seed_lo[a] = fq[a] - seeded_reach; seed_hi[a] = fq[a] + seeded_reach; }
       }
     }
     if (!general && !(bd < thr2)) general = true;   // the bound itself is beyond the gate: the ball would be the gate's
     if (!general && !ball_cell_range(G, q, bd, max_cells, lo, hi)) general = true;   // more than max_cells cells on some axis
-    if (!general) ball_scan_group(G, q, lo, hi, gl, bd, bi);
+    if (!general) {
+      // a self-seeded point whose ball stays inside the cells its seed came from has read them already
+      bool covered = seeded_reach >= 0;
+      for (int a = 0; a < 3; a++) covered = covered && lo[a] >= seed_lo[a] && hi[a] <= seed_hi[a];
+      if (!covered) scan_cells_group16(G, q, lo, hi, gl, bd, bi);
+    }
   }
   // the points the seeded search cannot serve, one after the other, all 64 lanes on each (exactly gicp_corr_search_kernel's body)
   unsigned long long todo = __ballot(live && general && gl == 0);

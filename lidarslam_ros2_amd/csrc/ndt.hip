@@ -1849,8 +1849,15 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ x, 
 __global__ __launch_bounds__(256) void leaf_key_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ z, int n, float inv_leaf, int mb0, int mb1,
                                                        int mb2, int mul1, int mul2, unsigned int sentinel,
-                                                       unsigned int* __restrict__ key, int* __restrict__ val) {
+                                                       unsigned int* __restrict__ key, int* __restrict__ val,
+                                                       uint4* __restrict__ fill_a, size_t n_a, int* __restrict__ fill_b, size_t n_b,
+                                                       int* __restrict__ zero_word) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // the all-ones fills of the sort-based builder (NaN leaf records of empty cells, cell_slot = -1) and its counter ride along:
+  // three memset launches less
+  for (size_t k = (size_t)i; k < n_a; k += (size_t)gridDim.x * blockDim.x) fill_a[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  for (size_t k = (size_t)i; k < n_b; k += (size_t)gridDim.x * blockDim.x) fill_b[k] = -1;
+  if (i == 0 && zero_word) *zero_word = 0;
   if (i >= n) return;
   float px = x[i], py = y[i], pz = z[i];
   unsigned int k = sentinel;  // non-finite points: one past the last cell, sorts last
@@ -1900,24 +1907,27 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __rest
                                                             int* __restrict__ cell_slot, int* __restrict__ n_valid, int dense,
                                                             unsigned int sentinel) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_runs) return;
-  const unsigned int key = run_key[r];
-  if (key == sentinel) {  // the run of non-finite points: not a leaf
-    leaf_key[r] = -1;
-    leaf_n[r] = 0;
-    return;
+  bool valid = false;
+  if (r < n_runs) {
+    const unsigned int key = run_key[r];
+    if (key == sentinel) {  // the run of non-finite points: not a leaf
+      leaf_key[r] = -1;
+      leaf_n[r] = 0;
+    } else {
+      double mean[3], icov[9];
+      const int n = leaf_finalize_dev(sums + (size_t)r * 9, run_cnt[r], min_points, eig_mult, mean, icov, &valid);
+      leaf_key[r] = (int)key;
+      leaf_n[r] = n;
+      for (int k = 0; k < 3; k++) mean64[(size_t)r * 3 + k] = mean[k];
+      for (int k = 0; k < 9; k++) icov64[(size_t)r * 9 + k] = icov[k];
+      const size_t ri = dense ? (size_t)key : (size_t)r;  // dense: record lives at its cell index
+      leaf_record_dev(mean, icov, n, valid, rec + ri * 4);
+      cell_slot[key] = valid ? (int)ri : -1;
+    }
   }
-  double mean[3], icov[9];
-  bool valid;
-  const int n = leaf_finalize_dev(sums + (size_t)r * 9, run_cnt[r], min_points, eig_mult, mean, icov, &valid);
-  leaf_key[r] = (int)key;
-  leaf_n[r] = n;
-  for (int k = 0; k < 3; k++) mean64[(size_t)r * 3 + k] = mean[k];
-  for (int k = 0; k < 9; k++) icov64[(size_t)r * 9 + k] = icov[k];
-  const size_t ri = dense ? (size_t)key : (size_t)r;  // dense: record lives at its cell index
-  leaf_record_dev(mean, icov, n, valid, rec + ri * 4);
-  cell_slot[key] = valid ? (int)ri : -1;
-  if (valid) atomicAdd(n_valid, 1);
+  // one atomic per wave: device-scope atomics on one address are served one after the other, ~13 ns each (15 000 leaves: 0.2 ms)
+  const unsigned long long m = __ballot(valid);
+  if (m && (threadIdx.x & 63) == 0) atomicAdd(n_valid, __popcll(m));
 }
 
 __global__ __launch_bounds__(256) void deinterleave_kernel(const unsigned char* __restrict__ aos, size_t stride, int n,
@@ -2158,7 +2168,8 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
   int* d_nruns = run_off + n;
   const unsigned int sentinel = (unsigned int)((int64_t)div_b[0] * div_b[1] * div_b[2]);  // one past the last leaf index
   hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
-                     min_b[0], min_b[1], min_b[2], div_b[0], div_b[0] * div_b[1], sentinel, key_in, val_in);
+                     min_b[0], min_b[1], min_b[2], div_b[0], div_b[0] * div_b[1], sentinel, key_in, val_in, (uint4*)nullptr, (size_t)0,
+                     (int*)nullptr, (size_t)0, (int*)nullptr);
   if ((st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), sc.temp, stream))) return st;
   if ((st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
   int n_runs = 0;
@@ -2432,7 +2443,9 @@ static int ndt_build_grid_general(const DeviceCloud& cloud, float leaf, VoxelGri
   const unsigned int token = next_token(sc);
   int st = grid.cell_slot.reserve(grid.ncells);
   if (st) return st;
-  LSR_HIP(hipMemsetAsync(grid.cell_slot.p, 0xFF, grid.ncells * sizeof(int), stream));
+  // Dense leaf records (64 B per grid cell) while the table stays <= 256 MiB; compact otherwise.
+  grid.dense = grid.ncells <= ((size_t)4 << 20);
+  if (grid.dense && (st = grid.rec.reserve(grid.ncells * 4))) return st;
   const unsigned int sentinel = (unsigned int)grid.ncells;  // non-finite points: one past the last leaf index
   // scratch carved from one allocation: pad[16] | key_in[n] | key_out[n] | val_in[n] | val_out[n] | run_key[n] | run_cnt[n] | run_off[n] | nruns | nvalid
   size_t words = 16 + 7 * (size_t)n + 16;
@@ -2448,33 +2461,26 @@ static int ndt_build_grid_general(const DeviceCloud& cloud, float leaf, VoxelGri
   int* d_nvalid = d_nruns + 1;
 
   hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n,
-                     inv_leaf, grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, sentinel, key_in, val_in);
+                     inv_leaf, grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, sentinel, key_in, val_in,
+                     reinterpret_cast<uint4*>(grid.dense ? grid.rec.p : nullptr), grid.dense ? grid.ncells * 4 : (size_t)0,   // all-ones words are NaN: empty cells answer no lookup
+                     grid.cell_slot.p, grid.ncells, d_nvalid);
   // keys live in [0, ncells]: only that many radix bits are sorted
   st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), temp, stream);
   if (st) return st;
   st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, temp, stream);
   if (st) return st;
-  int n_runs = 0;
-  LSR_HIP(hipMemcpyAsync(&n_runs, d_nruns, sizeof(int), hipMemcpyDeviceToHost, stream));
-  LSR_HIP(hipStreamSynchronize(stream));
+  int n_runs = 0;   // through the host mailbox (one small launch + a poll: no copy engine, no stream synchronisation)
+  if ((st = publish_device_int(d_nruns, sc, stream, &n_runs))) return st;
   st = exclusive_scan_i32(run_cnt, run_off, n_runs, temp, stream);
   if (st) return st;
 
   st = sums.reserve((size_t)n_runs * 9);
   if (st) return st;
-  // Dense leaf records (64 B per grid cell) while the table stays <= 256 MiB; compact otherwise.
-  grid.dense = grid.ncells <= ((size_t)4 << 20);
-  if (grid.dense) {
-    if ((st = grid.rec.reserve(grid.ncells * 4))) return st;
-    LSR_HIP(hipMemsetAsync(grid.rec.p, 0xFF, grid.ncells * 4 * sizeof(float4), stream));   // all-ones words are NaN: empty cells answer no lookup
-  } else {
-    if ((st = grid.rec.reserve((size_t)n_runs * 4))) return st;
-  }
+  if (!grid.dense && (st = grid.rec.reserve((size_t)n_runs * 4))) return st;
   if ((st = grid.mean64.reserve((size_t)n_runs * 3))) return st;
   if ((st = grid.icov64.reserve((size_t)n_runs * 9))) return st;
   if ((st = grid.leaf_key.reserve(n_runs))) return st;
   if ((st = grid.leaf_n.reserve(n_runs))) return st;
-  LSR_HIP(hipMemsetAsync(d_nvalid, 0, sizeof(int), stream));
   hipLaunchKernelGGL(leaf_sum_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), val_out,
                      run_off, run_cnt, n_runs, sums.p);
   hipLaunchKernelGGL(leaf_finalize_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, stream, sums.p, run_key, run_cnt, n_runs,

@@ -450,80 +450,26 @@ __device__ __forceinline__ void nn1_ball_body(const NNGridView& G, const float* 
   float bd = INFINITY;
   int bi = INT_MAX;
   bool general = false;
-  // every candidate of the fine cells [lo, hi] (clamped to the grid by the caller), one lane per (row, coarse segment), the
-  // group's candidates laid end to end and read 16 at a time; then the group's best in every lane
-  auto scan_cells = [&](const int* lo, const int* hi) {
-    const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
-    const int n_slots = (ny > 0 && nz > 0 && hi[0] >= lo[0]) ? ny * nz * 2 : 0;
-    const unsigned int ny_magic = 65536u / (unsigned int)max(ny, 1) + 1u;
-    for (int s0 = 0; s0 < n_slots; s0 += 16) {
-      const int slot = s0 + gl;
-      int beg = 0, len = 0;
-      if (slot < n_slots) {
-        const int cseg = slot & 1, row = slot >> 1;
-        const int dz = (int)(((unsigned int)row * ny_magic) >> 16);   // row / ny (row < 128, ny <= 8)
-        const int yy = lo[1] + (row - dz * ny), zz = lo[2] + dz;
-        const int cx = (lo[0] >> 3) + cseg;
-        if (cx <= (hi[0] >> 3)) {
-          const int blk = G.coarse_block[G.cdim[0] * ((yy >> 3) + G.cdim[1] * (zz >> 3)) + cx];
-          if (blk >= 0) {
-            const int xa = max(lo[0], cx * 8) & 7, xb = min(hi[0], cx * 8 + 7) & 7;
-            const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((yy & 7) << 3) | ((zz & 7) << 6));
-            beg = fs[xa];
-            len = fs[xb + 1] - beg;
-          }
-        }
-      }
-      int incl = len;
-#pragma unroll
-      for (int d = 1; d < 16; d <<= 1) {
-        const int v = __shfl_up(incl, d, 16);
-        if (gl >= d) incl += v;
-      }
-      const int excl = incl - len;
-      const int total = __shfl(incl, 15, 16);
-      for (int t0 = 0; t0 < total; t0 += 16) {
-        const int f = t0 + gl;
-        int sl = 0;
-#pragma unroll
-        for (int step = 8; step >= 1; step >>= 1) {
-          const int cand = sl + step;
-          const int o = __shfl(excl, cand, 16);
-          if (o <= f) sl = cand;
-        }
-        const int sb = __shfl(beg, sl, 16), so = __shfl(excl, sl, 16);
-        if (f < total) {
-          const float4 pt = G.p[sb + (f - so)];
-          const float d = dist2_rn(q[0], q[1], q[2], pt.x, pt.y, pt.z);
-          const int oi = __float_as_int(pt.w);
-          if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
-        }
-      }
-    }
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) {
-      const float od = __shfl_xor(bd, m, 16);
-      const int oi = __shfl_xor(bi, m, 16);
-      if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
-    }
-  };
   // ---- 1. a seed: the best point of the query's own fine cell; if that cell is empty, of the 3 x 3 x 3 cells around it
   const float ff[3] = {floorf(q[0] * G.inv_cell), floorf(q[1] * G.inv_cell), floorf(q[2] * G.inv_cell)};
   int fq[3] = {0, 0, 0};
   if (!(fabsf(ff[0]) < 1.0e9f && fabsf(ff[1]) < 1.0e9f && fabsf(ff[2]) < 1.0e9f)) general = true;
+  bool inside = !general;   // the query's own cell is a cell of the grid
   if (!general) {
     for (int a = 0; a < 3; a++) {
       fq[a] = (int)ff[a] - G.org[a];
       if (fq[a] < -1 || fq[a] > G.cdim[a] * 8) general = true;   // more than a cell outside the grid: the general search
+      if (fq[a] < 0 || fq[a] >= G.cdim[a] * 8) inside = false;
     }
   }
   int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  bool own_cell_done = false;
   if (!general) {
-    for (int a = 0; a < 3; a++) { lo[a] = max(fq[a], 0); hi[a] = min(fq[a], G.cdim[a] * 8 - 1); }
-    scan_cells(lo, hi);
+    if (inside) scan_cell_group16(G, q, fq, gl, bd, bi);
+    own_cell_done = (bi != INT_MAX);
     if (bi == INT_MAX) {
       for (int a = 0; a < 3; a++) { lo[a] = max(fq[a] - 1, 0); hi[a] = min(fq[a] + 1, G.cdim[a] * 8 - 1); }
-      scan_cells(lo, hi);
+      scan_cells_group16(G, q, lo, hi, gl, bd, bi);
     }
     if (bi == INT_MAX) general = true;   // nothing within a cell of the query: rare for a registered scan
   }
@@ -533,7 +479,12 @@ __device__ __forceinline__ void nn1_ball_body(const NNGridView& G, const float* 
     if (gl == 0) work[1 + atomicAdd(work, 1)] = i;
     return;
   }
-  scan_cells(lo, hi);
+  // a ball that stays inside what step 1 has read — the query's own cell, or the 3 x 3 x 3 cells when that one was empty — needs
+  // no second reading: the seed is the answer
+  const int reach = own_cell_done ? 0 : 1;
+  bool covered = true;
+  for (int a = 0; a < 3; a++) covered = covered && lo[a] >= fq[a] - reach && hi[a] <= fq[a] + reach;
+  if (!covered) scan_cells_group16(G, q, lo, hi, gl, bd, bi);
   if (gl == 0) { idx[i] = bi; d2[i] = bd; }
 }
 __global__ __launch_bounds__(256) void nn1_list_group_kernel(const FitGroup g) {

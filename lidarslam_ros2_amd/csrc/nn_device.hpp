@@ -345,6 +345,99 @@ __device__ __forceinline__ bool ball_cell_range(const NNGridView& G, const float
   return true;
 }
 
+#ifndef LSR_HOST_EMU
+// ---- sixteen lanes per query (fitness search, GICP correspondences): a query group is one DPP row, so its scans, broadcasts and
+// reductions are row DPP moves — no LDS crossbar (ds_bpermute), no lane-address arithmetic.
+template <int CTRL, bool ZERO_FILL>
+__device__ __forceinline__ int row16_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, ZERO_FILL); }
+template <int CTRL>
+__device__ __forceinline__ float row16_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)); }
+constexpr int DPP_ROW_SHR = 0x110, DPP_ROW_ROR = 0x120, DPP_ROW_NEWBCAST = 0x150;
+
+// the group's best (distance, index) in every one of its sixteen lanes: rotations by 8, 4, 2, 1 (the minimum of a total order
+// does not depend on the order in which it meets its operands)
+__device__ __forceinline__ void row16_best(float& bd, int& bi) {
+#define LSR_ROW_BEST_STEP(N)                                              \
+  {                                                                       \
+    const float od = row16_f<DPP_ROW_ROR + N>(bd);                        \
+    const int oi = row16_i<DPP_ROW_ROR + N, false>(bi);                   \
+    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }           \
+  }
+  LSR_ROW_BEST_STEP(8) LSR_ROW_BEST_STEP(4) LSR_ROW_BEST_STEP(2) LSR_ROW_BEST_STEP(1)
+#undef LSR_ROW_BEST_STEP
+}
+
+// Every point of ONE fine cell fq (inside the grid) offered to the group's best, sixteen at a time; then row16_best.
+__device__ __forceinline__ void scan_cell_group16(const NNGridView& G, const float* q, const int* fq, const int gl, float& bd, int& bi) {
+  const int blk = G.coarse_block[G.cdim[0] * ((fq[1] >> 3) + G.cdim[1] * (fq[2] >> 3)) + (fq[0] >> 3)];
+  if (blk >= 0) {
+    const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((fq[1] & 7) << 3) | ((fq[2] & 7) << 6)) + (fq[0] & 7);
+    const int end = fs[1];
+    for (int f = fs[0] + gl; f < end; f += 16) {
+      const float4 pt = G.p[f];
+      const float d = dist2_rn(q[0], q[1], q[2], pt.x, pt.y, pt.z);
+      const int oi = __float_as_int(pt.w);
+      if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+    }
+  }
+  row16_best(bd, bi);
+}
+
+// Every point of the fine cells [lo, hi] (<= 8 per axis, clamped to the grid by the caller) offered to the group's best: one lane
+// per (row, coarse segment) — an x-range of <= 8 cells touches at most two coarse cells, and inside one it is contiguous in
+// memory —, the group's candidates laid end to end and read sixteen at a time; then row16_best.  Called by all sixteen lanes.
+__device__ __forceinline__ void scan_cells_group16(const NNGridView& G, const float* q, const int* lo, const int* hi, const int gl, float& bd, int& bi) {
+  const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;   // >= 1 unless the box misses the grid (then no slot is valid)
+  const int n_slots = (ny > 0 && nz > 0 && hi[0] >= lo[0]) ? ny * nz * 2 : 0;
+  const unsigned int ny_magic = 65536u / (unsigned int)max(ny, 1) + 1u;
+  for (int s0 = 0; s0 < n_slots; s0 += 16) {
+    const int slot = s0 + gl;
+    int beg = 0, len = 0;
+    if (slot < n_slots) {
+      const int cseg = slot & 1, row = slot >> 1;
+      const int dz = (int)(((unsigned int)row * ny_magic) >> 16);   // row / ny (row < 128, ny <= 8)
+      const int y = lo[1] + (row - dz * ny), z = lo[2] + dz;
+      const int cx = (lo[0] >> 3) + cseg;
+      if (cx <= (hi[0] >> 3)) {
+        const int blk = G.coarse_block[G.cdim[0] * ((y >> 3) + G.cdim[1] * (z >> 3)) + cx];
+        if (blk >= 0) {
+          const int xa = max(lo[0], cx * 8) & 7, xb = min(hi[0], cx * 8 + 7) & 7;
+          const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((y & 7) << 3) | ((z & 7) << 6));
+          beg = fs[xa];
+          len = fs[xb + 1] - beg;
+        }
+      }
+    }
+    // inclusive scan over the row (zero fill below lane d), its total from lane 15
+    int incl = len;
+    incl += row16_i<DPP_ROW_SHR + 1, true>(incl);
+    incl += row16_i<DPP_ROW_SHR + 2, true>(incl);
+    incl += row16_i<DPP_ROW_SHR + 4, true>(incl);
+    incl += row16_i<DPP_ROW_SHR + 8, true>(incl);
+    const int excl = incl - len;
+    const int total = row16_i<DPP_ROW_NEWBCAST + 15, false>(incl);
+    for (int t0 = 0; t0 < total; t0 += 16) {
+      const int f = t0 + gl;
+      int sl = 0;   // the slot that holds flat position f: the largest lane whose exclusive offset is <= f
+#pragma unroll
+      for (int step = 8; step >= 1; step >>= 1) {
+        const int cand = sl + step;
+        const int o = __shfl(excl, cand, 16);
+        if (o <= f) sl = cand;
+      }
+      const int sb = __shfl(beg, sl, 16), so = __shfl(excl, sl, 16);
+      if (f < total) {
+        const float4 pt = G.p[sb + (f - so)];
+        const float d = dist2_rn(q[0], q[1], q[2], pt.x, pt.y, pt.z);
+        const int oi = __float_as_int(pt.w);
+        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+      }
+    }
+  }
+  row16_best(bd, bi);
+}
+#endif  // LSR_HOST_EMU
+
 // ---- one (row, coarse segment) of a fine shell, for the wave-cooperative searches below (pure: also compiled by the host
 // emulation, tests/test_nn_host_emu_cpu.py checks that the slots of a shell cover its cells exactly once and that pruning
 // and clipping never drop a point that could matter)
