@@ -918,7 +918,7 @@ def cfg4_chain_roofline(lib, regs, hs, nloc, G, srcs, fptr):
     alg = sum(e * (n * 12 + p * 40) for (e, p), n in zip(per, n_pts)) + prof["deriv_launches"] * 512 * 256
     ms = prof["deriv_ms_total"]
     achieved = alg / (ms * 1e-3) / 1e9
-    return {"kernel": "ndt_eval_lane_kernel<7, LDS table, 1024> (one lane per point, shared launch chain of the set)",
+    return {"kernel": "ndt_eval_lane_kernel<7, LDS table, 512> (one lane per point, shared launch chain of the set)",
             "members": nloc, "launches": prof["deriv_launches"], "member_passes": member_passes, "chain_ms": ms,
             "us_per_member_pass": 1e3 * ms / member_passes, "algorithmic_bytes": alg, "bound": "valu (lds-gather)", "priced_against": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

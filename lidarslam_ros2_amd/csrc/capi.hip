@@ -166,9 +166,11 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   size_t n_max = 0;
   for (int b = 0; b < B; b++) n_max = std::max(n_max, hs[b]->source.n);
   const bool want_quad_single = (B <= quad_batch_max && (lead->ndt_quad == 1 || (lead->ndt_quad < 0 && n_max < (size_t)NDT_LANE_SINGLE_MIN)));
-  // (DIRECT26: 27 neighbours per point need more than the 128 registers a 1024-thread workgroup leaves a lane — 512 threads)
-  const int lane_threads = (lead->ndt_threads == 512 || lead->ndt_threads == 1024) ? lead->ndt_threads
-                           : ((B == 1 || lead->ndt.neighborhood == LSR_DIRECT26) ? 512 : NDT_LANE_THREADS);
+  // 512 threads per workgroup (1024 on request).  A workgroup's waves share ONE compute unit: 1024 threads are four waves per SIMD
+  // whatever the size of the set, 512 are two and twice the workgroups — cfg-4 sets of 4 / 8 / 16 / 64 members, align stage:
+  // 0.48 / 0.50 / 0.71 / 1.98 ms with 1024 threads, 0.40 / 0.48 / 0.65 / 1.74 ms with 512 (two chains from 6 members on).
+  // (DIRECT26's 27 neighbours per point do not fit the 128 registers a 1024-thread workgroup leaves a lane anyway.)
+  const int lane_threads = (lead->ndt_threads == 512 || lead->ndt_threads == 1024) ? lead->ndt_threads : NDT_LANE_THREADS;
   const int static_lds = want_quad_single ? NDT_QUAD_STATIC_LDS : NDT_LANE_STATIC_LDS + ndt_lane_tile_bytes(lane_threads);
   const int table_cap = std::min(want_quad_single ? NDT_LDS_TABLE_MAX_QUAD : NDT_LDS_TABLE_MAX, lds_cap - static_lds);
   const bool lds_ok = all_lds && lds_max <= table_cap;
@@ -347,9 +349,9 @@ int ensure_aux_streams(lsr_handle lead) {
 // how many independent launch chains a set of B registrations runs as (env LSR_NDT_CHAINS = 1..4 forces it for B >= 2*chains)
 int ndt_chain_count(int B) {
   static const int forced = [] { const char* e = std::getenv("LSR_NDT_CHAINS"); return e ? std::atoi(e) : 0; }();
-  // measured (cfg-4 sets, align stage, 1 -> 2 chains): 4 / 8 members +4 % / +3 % (a launch of so few members is one trip per lane
-  // at four waves per SIMD either way), 12 / 16 / 24 / 32 / 48 / 64 members -14 / -9 / -17 / -10 / -10 / -9 %
-  int n = forced > 0 ? std::min(forced, 4) : (B >= 10 ? 2 : 1);
+  // measured (cfg-4 sets, align stage, 1 -> 2 chains, 512-thread workgroups): 4 members +13 %, 6 members 0 %, 8 / 12 / 16 members
+  // -3 / -9 / -13 %; with 1024-thread workgroups 24 / 32 / 48 / 64 members -17 / -10 / -10 / -9 %
+  int n = forced > 0 ? std::min(forced, 4) : (B >= 6 ? 2 : 1);
   while (n > 1 && B < 2 * n) n--;
   return n;
 }

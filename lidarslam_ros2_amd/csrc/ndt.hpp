@@ -22,7 +22,7 @@ enum NdtPhase : int {
 
 constexpr int NDT_NRED = 32;       // doubles per partial row: [0]=score [1..6]=grad [7]=#pairs [8..28]=Hessian upper triangle
 constexpr int NDT_NRED_GRAD = 8;   // entries reduced on gradient-only passes
-constexpr int NDT_LANE_THREADS = 1024;   // default workgroup size of the lane kernel (512 is the other instantiation)
+constexpr int NDT_LANE_THREADS = 512;    // default workgroup size of the lane kernel (1024 is the other instantiation)
 constexpr int NDT_MAX_BLOCKS = 1024;
 // dynamic LDS the lane kernel needs next to its table: one staging tile of 16 x 68 floats per wave (canon:: in ndt.hip)
 constexpr int ndt_lane_tile_bytes(int threads) { return (threads / 64) * 16 * 68 * 4; }

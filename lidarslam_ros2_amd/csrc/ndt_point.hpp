@@ -55,6 +55,25 @@ __device__ __forceinline__ float xform_ref(const float a, const float b, const f
   return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a, x), __fmul_rn(b, y)), __fmul_rn(c, z)), d);
 }
 
+// expf of the device library (OCML) without its two range guards: x * log2(e) split into a rounded product and its error,
+// the integer part by rndne, 2^fraction by v_exp_f32, the integer part back by ldexp — operation for operation what expf()
+// compiles to, so every result that is not a flushed extreme is the same bit; the guards (x < -103.3 -> 0, x > 88.7 -> inf,
+// four instructions per pair, seven pairs per point) only pre-empt what ldexp does anyway: an exponent below -149 gives 0, one
+// above 127 inf, NaN stays NaN.  The argument here is -d2 q^T C q / 2 <= 0.
+__device__ __forceinline__ float exp_pair(const float x) {
+#ifdef LSR_HOST_EMU
+  return expf(x);
+#else
+#pragma clang fp contract(off)
+  const float t = x * 0x1.715476p+0f;
+  const float r = rintf(t);
+  float lo = fmaf(x, 0x1.715476p+0f, -t);
+  lo = fmaf(x, 0x1.4ae0bep-26f, lo);
+  const float f = (t - r) + lo;
+  return ldexpf(__builtin_amdgcn_exp2f(f), (int)r);
+#endif
+}
+
 // One (point, voxel) pair of eq. 6.9-6.13 in the factorised form: the point Jacobian and second derivatives
 // do not depend on the voxel, so a pair only adds to A = sum w C q and E = sum w (C - d2 Cq Cq^T); fp32 per pair with
 // ndt_omp's precision recipe: the weight is scaled by the DOUBLE gauss_d1 and rounded back to float.
@@ -75,7 +94,7 @@ __device__ __forceinline__ void pair_terms(const bool leaf_ok, const bool hess, 
   const float Cq1 = fmaf(c01, q0, fmaf(c11, q1, c12 * q2));
   const float Cq2 = fmaf(c02, q0, fmaf(c12, q1, c22 * q2));
   const float qCq = fmaf(q0, Cq0, fmaf(q1, Cq1, q2 * Cq2));
-  const float e = expf(-d2 * qCq * 0.5f);
+  const float e = exp_pair(-d2 * qCq * 0.5f);
   const float w0 = d2 * e;
   // ndt_omp drops the whole pair (score included) when d2*e is outside [0,1] or NaN
   const bool ok = leaf_ok & (w0 <= 1.f) & (w0 >= 0.f);
