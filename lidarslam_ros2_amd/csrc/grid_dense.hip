@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict
   vg_scatter_kernel_body(x, y, z, n, keys, blkoff, start, C, ox, oy, oz, oidx, (int)blockIdx.x);
 }
 
-// K1 + K2, one workgroup (4 waves) per grid cell: wave v sums the cell's points v*64 + lane + 256*t (cell order = point
-// order), waves are combined in wave order, thread 0 finalises the leaf (leaf_finalize_dev).  Dense record layout
+// K1 + K2, one WAVE per grid cell: lane l sums the cell's points l + 64*t (cell order = point order), the lanes are combined by a
+// fixed butterfly, lane 0 finalises the leaf (leaf_finalize_dev).  Dense record layout
 // (record of cell c at rec[4c]); empty cells are written as zero records.
 constexpr int VG_LEAF_THREADS = 256;
 __device__ __forceinline__ void vg_leaf_kernel_body(const float* __restrict__ sx, const float* __restrict__ sy,
@@ -275,25 +275,27 @@ __device__ __forceinline__ void vg_leaf_kernel_body(const float* __restrict__ sx
                                                                   double* __restrict__ mean64, double* __restrict__ icov64,
                                                                   int* __restrict__ leaf_key, int* __restrict__ leaf_n,
                                                                   int* __restrict__ cell_slot, const int blk_x) {
-  const int cell = blk_x, tid = threadIdx.x;
+  // one WAVE per cell, four cells per workgroup: a cell is ~1000 points (16 per lane), its finalisation one lane's serial fp64
+  // work — four times as many cells in flight per compute unit as with a workgroup per cell, no LDS, no barrier
+  const int cell = blk_x * (VG_LEAF_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (cell >= ncells) return;
   const unsigned int off = start[cell];
   const int cnt = (int)(start[cell + 1] - off);
   if (cnt == 0) {
-    if (tid == 0) {
+    if (lane == 0) {
       const double zero[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       leaf_record_dev(zero, zero, 0, false, rec + (size_t)cell * 4);   // NaN pieces: an empty cell answers no lookup
       leaf_key[cell] = -1; leaf_n[cell] = 0; cell_slot[cell] = -1;
     }
     return;
   }
-  __shared__ double s_w[VG_LEAF_THREADS / 64][9];
   double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const float* bx = sx + off; const float* by = sy + off; const float* bz = sz + off;
-  int j = tid;
-  for (; j + 7 * VG_LEAF_THREADS < cnt; j += 8 * VG_LEAF_THREADS) {  // eight independent loads per plane in flight
+  int j = lane;
+  for (; j + 7 * 64 < cnt; j += 8 * 64) {  // eight independent loads per plane in flight
     float fx[8], fy[8], fz[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { fx[u] = bx[j + u * VG_LEAF_THREADS]; fy[u] = by[j + u * VG_LEAF_THREADS]; fz[u] = bz[j + u * VG_LEAF_THREADS]; }
+    for (int u = 0; u < 8; u++) { fx[u] = bx[j + u * 64]; fy[u] = by[j + u * 64]; fz[u] = bz[j + u * 64]; }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const double px = (double)fx[u], py = (double)fy[u], pz = (double)fz[u];
@@ -302,7 +304,7 @@ __device__ __forceinline__ void vg_leaf_kernel_body(const float* __restrict__ sx
       s[6] += py * py; s[7] += py * pz; s[8] += pz * pz;
     }
   }
-  for (; j < cnt; j += VG_LEAF_THREADS) {
+  for (; j < cnt; j += 64) {
     const double px = (double)bx[j], py = (double)by[j], pz = (double)bz[j];
     s[0] += px; s[1] += py; s[2] += pz;
     s[3] += px * px; s[4] += px * py; s[5] += px * pz;
@@ -310,23 +312,10 @@ __device__ __forceinline__ void vg_leaf_kernel_body(const float* __restrict__ sx
   }
 #pragma unroll
   for (int k = 0; k < 9; k++) s[k] = wave_sum64(s[k]);
-  if ((tid & 63) == 0) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) s_w[tid >> 6][k] = s[k];
-  }
-  __syncthreads();
-  if (tid != 0) return;
-  double tot[9];
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    double t = s_w[0][k];
-#pragma unroll
-    for (int v = 1; v < VG_LEAF_THREADS / 64; v++) t += s_w[v][k];
-    tot[k] = t;
-  }
+  if (lane != 0) return;
   double mean[3], icov[9];
   bool valid;
-  const int n = leaf_finalize_dev(tot, cnt, min_points, eig_mult, mean, icov, &valid);
+  const int n = leaf_finalize_dev(s, cnt, min_points, eig_mult, mean, icov, &valid);
   leaf_key[cell] = cell;
   leaf_n[cell] = n;
   for (int k = 0; k < 3; k++) mean64[(size_t)cell * 3 + k] = mean[k];
@@ -444,7 +433,7 @@ __global__ __launch_bounds__(256) void vg_scatter_group_kernel(const VgGroup g) 
 }
 __global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_group_kernel(const VgGroup g) {
   const VgMember& M = g.m[blockIdx.y];
-  if ((int)blockIdx.x >= M.ncells) return;
+  if ((int)blockIdx.x * (VG_LEAF_THREADS / 64) >= M.ncells) return;
   vg_leaf_kernel_body(M.sx, M.sy, M.sz, M.start, M.ncells, 6, 0.01, M.rec, M.mean64, M.icov64, M.leaf_key, M.leaf_n, M.cell_slot, (int)blockIdx.x);
 }
 
@@ -539,7 +528,7 @@ int ndt_build_grid_dense(const DeviceCloud& cloud, float leaf, VoxelGridDev& gri
   hipLaunchKernelGGL(vg_cellscan_kernel, dim3(1), dim3(1024), 0, stream, total, C, start, grid.cell_rank.p);
   hipLaunchKernelGGL(vg_scatter_kernel, dim3(nblk), dim3(256), (size_t)C * 8, stream, cloud.x(), cloud.y(), cloud.z(), n, keys, blkoff,
                      start, C, sx, sy, sz, grid.sorted_idx.p);
-  hipLaunchKernelGGL(vg_leaf_kernel, dim3(ncells), dim3(VG_LEAF_THREADS), 0, stream, sx, sy, sz, start, ncells, 6, 0.01, grid.rec.p,
+  hipLaunchKernelGGL(vg_leaf_kernel, dim3((ncells + VG_LEAF_THREADS / 64 - 1) / (VG_LEAF_THREADS / 64)), dim3(VG_LEAF_THREADS), 0, stream, sx, sy, sz, start, ncells, 6, 0.01, grid.rec.p,
                      grid.mean64.p, grid.icov64.p, grid.leaf_key.p, grid.leaf_n.p, grid.cell_slot.p);
   LSR_HIP(hipGetLastError());
   grid.n_leaves = ncells;  // leaf arrays are indexed by cell; empty cells carry leaf_key = -1
@@ -672,7 +661,7 @@ int ndt_build_grids_dense_group(TargetBuildJob* const* jobs, int count, hipStrea
     hipLaunchKernelGGL(vg_scan_group_kernel, dim3((maxC + 31) / 32, ng), dim3(256), 0, stream, grp);
     hipLaunchKernelGGL(vg_cellscan_group_kernel, dim3(ng), dim3(1024), 0, stream, grp);
     hipLaunchKernelGGL(vg_scatter_group_kernel, dim3(max_nblk, ng), dim3(256), (size_t)maxC * 8, stream, grp);
-    hipLaunchKernelGGL(vg_leaf_group_kernel, dim3(max_cells, ng), dim3(VG_LEAF_THREADS), 0, stream, grp);
+    hipLaunchKernelGGL(vg_leaf_group_kernel, dim3((max_cells + VG_LEAF_THREADS / 64 - 1) / (VG_LEAF_THREADS / 64), ng), dim3(VG_LEAF_THREADS), 0, stream, grp);
   }
   LSR_HIP(hipGetLastError());
   return LSR_OK;
