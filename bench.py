@@ -627,7 +627,7 @@ def gicp_leg(gc, dev_index, tstream, torch, synth):
             s["k6_correspondences"] = {"hbm_bytes_per_outer_iteration": int(k6["bytes"]), "kernel_us_per_outer_iteration": float(k6["us"]),
                                        "achieved_gb_per_s": k6["bytes"] / (k6["us"] * 1e-6) / 1e9,
                                        "frac_of_hbm_peak": k6["bytes"] / (k6["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                       "bound": "latency (dependent cell probes of a wave-per-point search)", "source": pg.get("source")}
+                                       "bound": "latency (dependent cell probes of the sixteen-lane seeded search; one launch per outer iteration)", "source": pg.get("source")}
     except (OSError, ValueError, KeyError):
         pass
     return s

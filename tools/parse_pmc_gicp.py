@@ -5,8 +5,8 @@ the same runs give the launch durations (median over launches that did work: lau
 import collections, csv, glob, json, os, re, sys
 
 root, tag = sys.argv[1], sys.argv[2]
-KERNELS = ("gicp_knn_wave_kernel", "gicp_cov_from_nbr_kernel", "gicp_corr_search_kernel", "gicp_corr_ball_kernel", "gicp_corr_pairs_kernel",
-           "gicp_step_kernel")
+KERNELS = ("gicp_knn_wave_kernel", "gicp_cov_from_nbr_kernel", "gicp_corr_seeded_kernel", "gicp_corr_search_kernel", "gicp_corr_ball_kernel",
+           "gicp_corr_pairs_kernel", "gicp_step_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
@@ -49,10 +49,12 @@ for k in KERNELS:
     lines.append(f"| `{k}` | {len(c.get('FETCH_SIZE', []))} | {us if us is None else round(us, 2)} | {f_kb:.1f} | {w_kb:.1f} | {b} | "
                  f"{'' if not us else round(b / (us * 1e-6) / 1e9, 1)} | {q.get('SQ_INSTS_VALU')} | {'' if wait is None else round(wait, 2)} | "
                  f"{'' if hit is None else round(hit, 3)} |")
-k6 = [out["kernels"][k] for k in ("gicp_corr_ball_kernel", "gicp_corr_search_kernel", "gicp_corr_pairs_kernel") if k in out["kernels"]]
+# K6 = one launch per outer iteration since round 4 (gicp_corr_seeded_kernel); the three-launch form only under LSR_GICP_CORR_FUSED=0
+k6_names = ("gicp_corr_seeded_kernel",) if "gicp_corr_seeded_kernel" in out["kernels"] else ("gicp_corr_ball_kernel", "gicp_corr_search_kernel", "gicp_corr_pairs_kernel")
+k6 = [out["kernels"][k] for k in k6_names if k in out["kernels"]]
 if k6:
-    out["k6_per_outer_iteration"] = {"bytes": sum(x["bytes_per_launch"] for x in k6), "us": sum(x["us"] or 0 for x in k6)}
-    lines += ["", f"K6 (seeded ball search + general search of the deferred points + pair records) per outer iteration: "
+    out["k6_per_outer_iteration"] = {"bytes": sum(x["bytes_per_launch"] for x in k6), "us": sum(x["us"] or 0 for x in k6), "kernels": list(k6_names)}
+    lines += ["", f"K6 (seeded search + the points it cannot serve + pair records: {' + '.join(k6_names)}) per outer iteration: "
               f"{out['k6_per_outer_iteration']['bytes'] / 1e6:.2f} MB of HBM traffic in {out['k6_per_outer_iteration']['us']:.1f} us of kernels."]
 open(os.path.join(root, f"{tag}_pmc_gicp.md"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(root, "pmc_gicp_latest.json"), "w"), indent=1)
