@@ -72,7 +72,7 @@ typedef enum lsr_key {
   /* tuning (NO effect on results: every NDT derivative kernel returns the same bits — the sum of a pass is defined on the
      input, csrc/ndt.hip: canon): */
   LSR_NDT_WORKGROUP = 40,             /* lane kernel: threads per workgroup (512, 1024); quad kernel: source points per
-                                         workgroup (64, 128; four lanes each); 0 = automatic */
+                                         workgroup (64, 128; four lanes each); 0 = automatic (512 / 128) */
   LSR_NDT_TABLE_MODE = 41,            /* where the pass reads leaf records: -1 = automatic, 0 = dense global table,
                                          1 = compact global table, 2 = whole table staged in LDS (when it fits), 3 = per
                                          workgroup the box of cells its tile-ordered points touch staged in LDS (dense tables
@@ -93,10 +93,13 @@ typedef enum lsr_key {
 } lsr_key;
 /* Environment presets read when an object is created: LSR_NDT_WORKGROUP, LSR_NDT_TABLE_MODE, LSR_NDT_QUAD, LSR_GRID_BUILDER,
  * LSR_WAIT_MODE (the keys above); LSR_NDT_WIDEN=0 keeps the launches of a candidate set at their first geometry (default: widened
- * as members finish).  Diagnostic A/B switches read once per process, all with bit-identical results
+ * as members finish); LSR_NDT_CHAINS=1|2|3 fixes the number of independent launch chains a candidate set runs as (default: two
+ * from six members on, each on a stream verified to run concurrently with the object's own; LSR_DEBUG_STREAMS=1 prints what the
+ * verification found).  Diagnostic A/B switches read once per process, all with bit-identical results
  * (tests/test_gicp_gpu.py::test_search_and_chain_variants_give_identical_results): LSR_NN_COOP=0 (per-thread neighbour
  * walks instead of one wave per query), LSR_GICP_FUSED=0 (accumulate + update launch pairs instead of the fused
- * Gauss-Newton step), LSR_GICP_BALL=0 (general correspondence search on every outer iteration), LSR_FIT_GROUP_FORM=0|1|2 (fitness
+ * Gauss-Newton step), LSR_GICP_BALL=0 (general correspondence search on every outer iteration), LSR_GICP_CORR_FUSED=0 (seeded
+ * search, general search and pair records as three launches per outer iteration instead of one), LSR_FIT_GROUP_FORM=0|1|2 (fitness
  * search of a candidate set: one wave per query / four lanes + tail / sixteen lanes seeded by the own cell + tail, the default). */
 
 typedef struct lsr_result {

@@ -175,22 +175,28 @@ __device__ __forceinline__ void nn_refine_body(const RefineMember& M, const int 
     atomicAdd(&s_cnt[(fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6)], 1u);
   }
   __syncthreads();
-  // exclusive scan of the 512 counts on the first 256 threads: two per thread + Hillis-Steele over the 256 pair sums
-  const int t2 = tid & 255;
-  const unsigned int c0 = s_cnt[2 * t2], c1 = s_cnt[2 * t2 + 1];
-  if (tid < 256) s_part[tid] = c0 + c1;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const unsigned int v = (tid < 256 && tid >= off) ? s_part[tid - off] : 0u;
-    __syncthreads();
-    if (tid < 256) s_part[tid] += v;
-    __syncthreads();
+  // exclusive scan of the 512 counts: two per thread, a wave scan over the 64 pair sums of a wave, the four wave totals through
+  // LDS — one barrier (a Hillis-Steele scan over the 256 pair sums took seventeen)
+  static_assert(NN_REFINE_THREADS == 256, "four waves, two counters per thread");
+  const unsigned int c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+  unsigned int incl = c0 + c1;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned int v = __shfl_up(incl, d, 64);
+    if ((tid & 63) >= d) incl += v;
   }
-  if (tid < 256) {
-    const unsigned int base = s_part[tid] - (c0 + c1);
+  if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+  __syncthreads();
+  {
+    unsigned int before = 0u;
+    for (int v = 0; v < (tid >> 6); v++) before += s_part[v];
+    incl += before;
+  }
+  {
+    const unsigned int base = incl - (c0 + c1);
     s_off[2 * tid] = base;
     s_off[2 * tid + 1] = base + c0;
-    if (tid == 255) s_off[FINE_PER_BLOCK] = s_part[255];
+    if (tid == 255) s_off[FINE_PER_BLOCK] = incl;
     s_cnt[2 * tid] = 0u;       // becomes the cursor of the scatter
     s_cnt[2 * tid + 1] = 0u;
   }
