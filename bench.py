@@ -897,8 +897,8 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
 
 def cfg4_chain_roofline(lib, regs, hs, nloc, G, srcs, fptr):
     """The fed-chip roofline: the shared launch chain of the candidate set on its own — targets and sources
-    resident, lsr_align_batch with the lead object's profiling on: hipEvents on the chain's stream from the state upload to the
-    launch that raises the last `done`.  Algorithmic bytes = sum over members of passes x (N x 12 + pairs x 40)
+    resident, lsr_align_batch with the lead object's profiling on: hipEvents on the lead's stream from before the state uploads
+    to the point where it has joined the set's launch chains (a set of six or more members runs as two chains on two streams).  Algorithmic bytes = sum over members of passes x (N x 12 + pairs x 40)
     + launches x workgroups x 256; priced against 8 TB/s.  The whole chain is priced, its thin tail (few members still running)
     included — the launches in which all 64 members are active run at the `full_load` figure of profiles/r04_*cfg4*."""
     from lidarslam_ros2_amd import _capi
@@ -918,12 +918,13 @@ def cfg4_chain_roofline(lib, regs, hs, nloc, G, srcs, fptr):
     alg = sum(e * (n * 12 + p * 40) for (e, p), n in zip(per, n_pts)) + prof["deriv_launches"] * 512 * 256
     ms = prof["deriv_ms_total"]
     achieved = alg / (ms * 1e-3) / 1e9
-    return {"kernel": "ndt_eval_lane_kernel<7, LDS table, 512> (one lane per point, shared launch chain of the set)",
+    return {"kernel": "ndt_eval_lane_kernel<7, LDS table, 512> (one lane per point, the set's two launch chains)",
             "members": nloc, "launches": prof["deriv_launches"], "member_passes": member_passes, "chain_ms": ms,
             "us_per_member_pass": 1e3 * ms / member_passes, "algorithmic_bytes": alg, "bound": "valu (lds-gather)", "priced_against": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "mean_valid_pairs_per_point": sum(p for _, p in per) / max(1, sum(n_pts)),
-            "note": "hipEvents on the chain's stream around the whole chain (state upload -> last done), best of 3; bytes per SURVEY.md 8d"}
+            "note": "hipEvents on the lead object's stream around the set's launch chains as production runs them (two chains on two streams: "
+                    "before the state uploads -> both chains joined), best of 3; bytes per SURVEY.md 8d"}
 
 
 def cfg4_projected_8gpu(lib, dev_index, regs, tgts, srcs, G, t_set, fptr):

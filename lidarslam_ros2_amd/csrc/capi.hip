@@ -482,7 +482,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   if ((st = lead->h_prob.reserve(B))) return st;
   // larger sets run as several independent launch chains (run_ndt_feeder), each on a stream of its own that starts behind
   // everything the lead's stream holds at this point (the members' builds and uploads) and does its own state uploads
-  int n_chains = lead->profile ? 1 : ndt_chain_count(B);
+  int n_chains = ndt_chain_count(B);
   if (B > 1 && (st = ensure_aux_streams(lead))) return st;   // once per lead handle
   n_chains = std::min(n_chains, 1 + lead->n_chain_streams);
   int chain_first[5] = {0, B, B, B, B};
@@ -538,6 +538,9 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     lead->h_state.p[2 * b].token = lead->h_state.p[2 * b + 1].token = (int)token;
   }
   const auto t0 = std::chrono::steady_clock::now();
+  // profiling brackets: a set is timed from before its state uploads (every chain does its own) to the point where the lead's stream
+  // has joined every chain; a single registration from after its one-launch initialisation, as before
+  if (lead->profile && B > 1) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   if (B == 1) {  // problem and state in the kernel arguments (no SDMA copy, no memset)
     if ((st = ndt_init_single(lead->h_state.p[0], lead->d_state.p, lead->d_bins.p, lead->stream))) return st;
   } else {
@@ -548,7 +551,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
       LSR_HIP(hipMemsetAsync(lead->d_bins.p + b0 * NDT_NBANKS * NDT_BANK_WORDS, 0, sizeof(long long) * nb * NDT_NBANKS * NDT_BANK_WORDS, chain_streams[c]));
     }
   }
-  if (lead->profile) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
+  if (lead->profile && B == 1) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
   // A candidate set is scored right after it is registered (graph_based_slam_component.cpp:230-231): the neighbour grids that
   // getFitnessScore needs are refined from the voxel order NOW, on a side stream, under the launch chain — the chain is a
   // sequence of short dependent launches that does not fill the chip, the refinement is one wide launch per 16 targets.
