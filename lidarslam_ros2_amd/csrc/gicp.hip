@@ -611,6 +611,32 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// The GN_NRED sums of one wave through an LDS tile instead of GN_NRED x 12 shuffles: every lane parks its accumulators (fourteen
+// at a time), lane (value k, half h) adds 32 of them left to right, the two halves meet in one shuffle — a fixed order.
+// tile: GN_TILE_ROWS x GN_TILE_PITCH doubles private to the wave; out[k] = the wave's sum of value k (written by lane 2k).
+constexpr int GN_TILE_ROWS = 14, GN_TILE_PITCH = 66;
+static_assert(GN_NRED == 2 * GN_TILE_ROWS, "two rounds of GN_TILE_ROWS values");
+__device__ __forceinline__ void wave_sums_tile(const double* acc, double* tile, double* out, const int lane) {
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+#pragma unroll
+    for (int k = 0; k < GN_TILE_ROWS; k++) tile[k * GN_TILE_PITCH + lane] = acc[r * GN_TILE_ROWS + k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2 * GN_TILE_ROWS) {
+      const int k = lane >> 1, h = lane & 1;
+      const double* row = tile + k * GN_TILE_PITCH + 32 * h;
+      double v = row[0];
+#pragma unroll
+      for (int j = 1; j < 32; j++) v += row[j];
+      const double other = __shfl_xor(v, 1, 64);
+      if (h == 0) out[r * GN_TILE_ROWS + k] = v + other;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // K7: one Gauss-Newton accumulation pass at the state's x.
 __global__ __launch_bounds__(GN_THREADS) void gicp_gn_kernel(const float* __restrict__ ox, const float* __restrict__ oy,
                                                              const float* __restrict__ oz, int n, const PairRec* __restrict__ pairs,
@@ -621,6 +647,7 @@ __global__ __launch_bounds__(GN_THREADS) void gicp_gn_kernel(const float* __rest
     if (O->outer_done || (!(ph & 1) && O->corr_mark != ph)) return;  // nothing to accumulate until fresh pairs exist
   }
   __shared__ double s_red[GN_THREADS / 64][GN_NRED];
+  __shared__ double s_tile[GN_THREADS / 64][GN_TILE_ROWS * GN_TILE_PITCH];
   float T[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) T[k] = S->T[k];
@@ -670,11 +697,7 @@ __global__ __launch_bounds__(GN_THREADS) void gicp_gn_kernel(const float* __rest
     acc[27] += J[0][2] * MJ[0][2] + J[1][2] * MJ[1][2] + J[2][2] * MJ[2][2];
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < GN_NRED; k++) {
-    const double v = wave_sum_d(acc[k]);
-    if (lane == 0) s_red[wid][k] = v;
-  }
+  wave_sums_tile(acc, s_tile[wid], s_red[wid], lane);
   __syncthreads();
   if (threadIdx.x < GN_NRED) {
     double v = s_red[0][threadIdx.x];
@@ -1032,6 +1055,7 @@ __global__ __launch_bounds__(GN_THREADS) void gicp_step_kernel(IterBlock* __rest
   __shared__ double s_grp[8][32];
   __shared__ double s_sum[32];
   __shared__ double s_red[GN_THREADS / 64][GN_NRED];
+  __shared__ double s_tile[GN_THREADS / 64][GN_TILE_ROWS * GN_TILE_PITCH];
   __shared__ int s_do;
   IterBlock& Bk = *reinterpret_cast<IterBlock*>(s_raw);
   const int t = threadIdx.x;
@@ -1162,11 +1186,7 @@ __global__ __launch_bounds__(GN_THREADS) void gicp_step_kernel(IterBlock* __rest
     acc[27] += J[0][2] * MJ[0][2] + J[1][2] * MJ[1][2] + J[2][2] * MJ[2][2];
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < GN_NRED; k++) {
-    const double v = wave_sum_d(acc[k]);
-    if (lane == 0) s_red[wid][k] = v;
-  }
+  wave_sums_tile(acc, s_tile[wid], s_red[wid], lane);
   __syncthreads();
   if (threadIdx.x < GN_NRED) {
     double v = s_red[0][threadIdx.x];
