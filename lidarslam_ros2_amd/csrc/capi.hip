@@ -346,12 +346,12 @@ int ensure_aux_streams(lsr_handle lead) {
   return LSR_OK;
 }
 
-// how many independent launch chains a set of B registrations runs as (env LSR_NDT_CHAINS = 1..4 forces it for B >= 2*chains)
+// how many independent launch chains a set of B registrations runs as (env LSR_NDT_CHAINS = 1..3 forces it for B >= 2*chains; at most two verified chain streams exist next to the lead's own)
 int ndt_chain_count(int B) {
   static const int forced = [] { const char* e = std::getenv("LSR_NDT_CHAINS"); return e ? std::atoi(e) : 0; }();
   // measured (cfg-4 sets, align stage, 1 -> 2 chains, 512-thread workgroups): 4 members +13 %, 6 members 0 %, 8 / 12 / 16 members
   // -3 / -9 / -13 %; with 1024-thread workgroups 24 / 32 / 48 / 64 members -17 / -10 / -10 / -9 %
-  int n = forced > 0 ? std::min(forced, 4) : (B >= 6 ? 2 : 1);
+  int n = forced > 0 ? std::min(forced, 3) : (B >= 6 ? 2 : 1);
   while (n > 1 && B < 2 * n) n--;
   return n;
 }
