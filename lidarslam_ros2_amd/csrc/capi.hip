@@ -317,28 +317,49 @@ int ensure_aux_streams(lsr_handle lead) {
   int st;
   if ((st = words.reserve(2))) return st;
   std::vector<hipStream_t> rejected, found;
+  // The first stream found becomes the SIDE stream (grid refinement, fitness searches: wide launches that are in no hurry), created
+  // with the lowest priority so that its workgroups do not take compute units from the launch chains' short dependent launches
+  // (round 5 trace of an 8-candidate share: the refinement of 8 neighbour grids, enqueued next to the first chain launches,
+  // stretched them from 15 to 40 us).  LSR_SIDE_PRIORITY=0 creates it like the others (A/B switch).
+  static const bool side_low = [] { const char* e = std::getenv("LSR_SIDE_PRIORITY"); return !(e && e[0] == '0'); }();
+  int prio_least = 0, prio_greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
   for (int tries = 0; tries < 10 && (int)found.size() < 3; tries++) {
     hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+    const bool want_low = side_low && found.empty() && prio_least != prio_greatest;
+    if ((want_low ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) break;
     bool ok = streams_run_concurrently(lead->stream, s, words.p) == 1;
     for (size_t c = 0; ok && c < found.size(); c++) ok = streams_run_concurrently(found[c], s, words.p) == 1;
     if (ok) found.push_back(s); else rejected.push_back(s);
   }
   for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
   (void)hipStreamSynchronize(lead->stream);
+  // from here on a failure must not leak what was found (and must not leave half of it on the handle: the next call probes again)
+  auto give_up = [&](const char* what) {
+    for (hipStream_t s : found) if (s) (void)hipStreamDestroy(s);
+    if (found.empty() && lead->side_stream) (void)hipStreamDestroy(lead->side_stream);
+    lead->side_stream = nullptr;
+    for (int c = 0; c < 3; c++) {
+      lead->chain_stream[c] = nullptr;
+      if (lead->chain_ev[c]) { (void)hipEventDestroy(lead->chain_ev[c]); lead->chain_ev[c] = nullptr; }
+    }
+    lead->n_chain_streams = 0;
+    set_last_error(std::string("auxiliary streams of a batch lead: ") + what);
+    return LSR_ERR_HIP;
+  };
   size_t k = 0;
   if (!found.empty()) lead->side_stream = found[k++];
-  else LSR_HIP(hipStreamCreateWithFlags(&lead->side_stream, hipStreamNonBlocking));
+  else if (hipStreamCreateWithFlags(&lead->side_stream, hipStreamNonBlocking) != hipSuccess) return give_up("no side stream");
   lead->n_chain_streams = 0;
   for (; k < found.size(); k++) {
     hipEvent_t ev = nullptr;
     if (lead->n_chain_streams < 3 && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
       lead->chain_stream[lead->n_chain_streams] = found[k]; lead->chain_ev[lead->n_chain_streams] = ev; lead->n_chain_streams++;
-    } else (void)hipStreamDestroy(found[k]);
+    } else { (void)hipStreamDestroy(found[k]); found[k] = nullptr; }
   }
-  if (!lead->side_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_ev, hipEventDisableTiming));
-  if (!lead->side_fork_ev) LSR_HIP(hipEventCreateWithFlags(&lead->side_fork_ev, hipEventDisableTiming));
-  if (!lead->chain_fork_ev) LSR_HIP(hipEventCreateWithFlags(&lead->chain_fork_ev, hipEventDisableTiming));
+  if (!lead->side_ev && hipEventCreateWithFlags(&lead->side_ev, hipEventDisableTiming) != hipSuccess) return give_up("event");
+  if (!lead->side_fork_ev && hipEventCreateWithFlags(&lead->side_fork_ev, hipEventDisableTiming) != hipSuccess) return give_up("event");
+  if (!lead->chain_fork_ev && hipEventCreateWithFlags(&lead->chain_fork_ev, hipEventDisableTiming) != hipSuccess) return give_up("event");
   lead->chain_probed = true;
   if (std::getenv("LSR_DEBUG_STREAMS"))
     fprintf(stderr, "[lidarslam_reg] aux streams of handle %p: %zu verified concurrent, %zu rejected, %d chain stream(s)\n", (void*)lead,
@@ -477,9 +498,14 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   for (int b = 1; b < B; b++)
     if ((st = order_lead_after(lead->stream, hs[b]))) return st;
   if ((st = lead->d_state.reserve(2 * (size_t)B))) return st;
-  if ((st = lead->h_state.reserve(2 * (size_t)B))) return st;
   if ((st = lead->d_prob.reserve(B))) return st;
-  if ((st = lead->h_prob.reserve(B))) return st;
+  {  // pinned, mapped: a set's init launch reads the members' records straight out of these arrays (ndt_init_batch)
+    const NdtState* hs0 = lead->h_state.p; const NdtProblem* hp0 = lead->h_prob.p;
+    if ((st = lead->h_state.reserve(2 * (size_t)B, hipHostMallocMapped))) return st;
+    if ((st = lead->h_prob.reserve(B, hipHostMallocMapped))) return st;
+    if (lead->h_state.p != hs0 || !lead->h_state_dev) LSR_HIP(hipHostGetDevicePointer((void**)&lead->h_state_dev, lead->h_state.p, 0));
+    if (lead->h_prob.p != hp0 || !lead->h_prob_dev) LSR_HIP(hipHostGetDevicePointer((void**)&lead->h_prob_dev, lead->h_prob.p, 0));
+  }
   // larger sets run as several independent launch chains (run_ndt_feeder), each on a stream of its own that starts behind
   // everything the lead's stream holds at this point (the members' builds and uploads) and does its own state uploads
   int n_chains = ndt_chain_count(B);
@@ -487,9 +513,28 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   n_chains = std::min(n_chains, 1 + lead->n_chain_streams);
   int chain_first[5] = {0, B, B, B, B};
   hipStream_t chain_streams[4] = {lead->stream, nullptr, nullptr, nullptr};
+  // Every way out of this function after the fork joins the chain streams back into the lead's stream: whatever follows there (the
+  // next align's state upload, a release of the banks) stays behind launches, sorts and uploads still queued on a chain stream.
+  struct ChainJoin {
+    lsr_handle lead; int n = 1; bool joined = false;
+    bool join() {   // false: a stream had to be drained by the host instead
+      if (joined) return true;
+      joined = true;
+      bool ok = true;
+      for (int c = 1; c < n; c++)
+        if (hipEventRecord(lead->chain_ev[c - 1], lead->chain_stream[c - 1]) != hipSuccess ||
+            hipStreamWaitEvent(lead->stream, lead->chain_ev[c - 1], 0) != hipSuccess) {
+          (void)hipStreamSynchronize(lead->chain_stream[c - 1]);
+          ok = false;
+        }
+      return ok;
+    }
+    ~ChainJoin() { (void)join(); }
+  } chain_join{lead};
   if (n_chains > 1) {
     LSR_HIP(hipEventRecord(lead->chain_fork_ev, lead->stream));
     for (int c = 0; c <= n_chains; c++) chain_first[c] = (int)((long)B * c / n_chains);
+    chain_join.n = n_chains;
     for (int c = 1; c < n_chains; c++) {
       chain_streams[c] = lead->chain_stream[c - 1];
       LSR_HIP(hipStreamWaitEvent(chain_streams[c], lead->chain_fork_ev, 0));
@@ -544,11 +589,10 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   if (B == 1) {  // problem and state in the kernel arguments (no SDMA copy, no memset)
     if ((st = ndt_init_single(lead->h_state.p[0], lead->d_state.p, lead->d_bins.p, lead->stream))) return st;
   } else {
-    for (int c = 0; c < n_chains; c++) {
+    for (int c = 0; c < n_chains; c++) {   // one launch per chain: problem records + initial states out of the pinned arrays, banks cleared
       const size_t b0 = (size_t)chain_first[c], nb = (size_t)(chain_first[c + 1] - chain_first[c]);
-      LSR_HIP(hipMemcpyAsync(lead->d_prob.p + b0, lead->h_prob.p + b0, sizeof(NdtProblem) * nb, hipMemcpyHostToDevice, chain_streams[c]));
-      LSR_HIP(hipMemcpyAsync(lead->d_state.p + 2 * b0, lead->h_state.p + 2 * b0, sizeof(NdtState) * 2 * nb, hipMemcpyHostToDevice, chain_streams[c]));
-      LSR_HIP(hipMemsetAsync(lead->d_bins.p + b0 * NDT_NBANKS * NDT_BANK_WORDS, 0, sizeof(long long) * nb * NDT_NBANKS * NDT_BANK_WORDS, chain_streams[c]));
+      if ((st = ndt_init_batch(lead->h_prob_dev + b0, lead->h_state_dev + 2 * b0, lead->d_prob.p + b0, lead->d_state.p + 2 * b0,
+                               lead->d_bins.p + b0 * NDT_NBANKS * NDT_BANK_WORDS, (int)nb, chain_streams[c]))) return st;
     }
   }
   if (lead->profile && B == 1) LSR_HIP(hipEventRecord(lead->ev0, lead->stream));
@@ -598,8 +642,12 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   auto eager_dispatch = [&](bool all) -> int {
     for (int b = 0; b < B; b++)
       if (eager_ok[b] && !eager_queued[b] && __atomic_load_n(&MB[b].done, __ATOMIC_ACQUIRE) == token) { eager_queued[b] = 1; eager_ready.push_back(b); }
-    // a launch group serves up to 12 members: wait for a full group while the chain is still running
-    while (!eager_ready.empty() && (all || eager_ready.size() >= 12)) {
+    // a launch group serves up to 12 members.  A large set waits for a full group while its chains are running (they fill the chip:
+    // few wide searches disturb them less than many narrow ones); a small set is a chain of short launches on a mostly idle chip
+    // — a share of 8 candidates of an 8-GPU node —, so a member is searched as soon as it has finished (round 5: the searches of
+    // such a set were all enqueued after the chain, 0.15-0.35 ms of a 1.0-1.2 ms share)
+    const size_t group_min = (B >= 48) ? 12 : (size_t)std::max(1, B / 8);
+    while (!eager_ready.empty() && (all || eager_ready.size() >= group_min)) {
       const int n = (int)std::min<size_t>(12, eager_ready.size());
       std::vector<FitJob> jobs;
       for (int k = 0; k < n; k++) {
@@ -618,29 +666,23 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   st = run_ndt_feeder(lead, lead->d_prob.p, lead->h_prob.p, cfg, min_evals, hard_cap, token, &launches, eager ? &poll_hook : nullptr,
                       (!cfg.quad && lane_widen_enabled()) ? nb_full : 0, n_chains, chain_first, chain_streams);
   // whatever follows on the lead's stream (the next align's uploads, a release of the banks) stays behind the chains' queued launches
-  for (int c = 1; c < n_chains; c++) {
-    if (hipEventRecord(lead->chain_ev[c - 1], lead->chain_stream[c - 1]) != hipSuccess ||
-        hipStreamWaitEvent(lead->stream, lead->chain_ev[c - 1], 0) != hipSuccess) {
-      (void)hipStreamSynchronize(lead->chain_stream[c - 1]);
-      if (!st) { set_last_error("joining a launch chain failed"); st = LSR_ERR_HIP; }
-    }
-  }
+  if (!chain_join.join() && !st) { set_last_error("joining a launch chain failed"); st = LSR_ERR_HIP; }
   if (eager && !st) st = eager_dispatch(true);
-  if (prefetched || eager) {
-    // the side stream's work — grid refinement, searches — ends here: every later use of the grids and of the members' scratch
-    // (any stream, any call) then needs no ordering against it
-    if (eager) (void)hipEventRecord(lead->side_ev, lead->side_stream);
-    if (hipEventSynchronize(lead->side_ev) != hipSuccess && !st) { set_last_error("side-stream work of the candidate set failed"); st = LSR_ERR_HIP; }
-    if (st && prefetched) for (int b = 0; b < B; b++) if (hs[b]->target) hs[b]->target->has_hash = false;
-  }
   if (eager) {
-    for (int b = 0; b < B; b++) {
+    (void)hipEventRecord(lead->side_ev, lead->side_stream);   // behind the last search
+    for (int b = 0; b < B; b++) {   // every score travels through its member's host mailbox: polled, not synchronised for
       if (!eager_sent[b]) continue;
       double v = 0;
-      const int fst = nn_fitness_end(hs[b]->scratch, lead->side_stream, &v);   // already in the mailbox
+      const int fst = nn_fitness_end(hs[b]->scratch, lead->side_stream, &v);
       if (fst && !st) st = fst;
       if (!fst) fitness_out[b] = v;
     }
+  }
+  if (prefetched || eager) {
+    // the side stream's work — grid refinement, searches — ends here: every later use of the grids and of the members' scratch
+    // (any stream, any call) then needs no ordering against it (after the polls above only a kernel epilogue is left to wait for)
+    if (hipEventSynchronize(lead->side_ev) != hipSuccess && !st) { set_last_error("side-stream work of the candidate set failed"); st = LSR_ERR_HIP; }
+    if (st && prefetched) for (int b = 0; b < B; b++) if (hs[b]->target) hs[b]->target->has_hash = false;
   }
   if (st) return st;
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -762,22 +804,31 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   return LSR_OK;
 }
 
+// Streams and events of one handle object (the public handle and the worker objects lsr_search_loop(top_k > 1) keeps in h->aux: a
+// worker that led a batch owns a side stream, chain streams and their events just like a public handle).
+static void release_handle_streams(lsr_handle h) {
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
+  if (h->side_ev) { (void)hipEventDestroy(h->side_ev); h->side_ev = nullptr; }
+  if (h->chain_fork_ev) { (void)hipEventDestroy(h->chain_fork_ev); h->chain_fork_ev = nullptr; }
+  for (int c = 0; c < 3; c++) {
+    if (h->chain_stream[c]) { (void)hipStreamSynchronize(h->chain_stream[c]); (void)hipStreamDestroy(h->chain_stream[c]); h->chain_stream[c] = nullptr; }
+    if (h->chain_ev[c]) { (void)hipEventDestroy(h->chain_ev[c]); h->chain_ev[c] = nullptr; }
+  }
+  h->n_chain_streams = 0;
+  if (h->side_fork_ev) { (void)hipEventDestroy(h->side_fork_ev); h->side_fork_ev = nullptr; }
+  if (h->ev0) { (void)hipEventDestroy(h->ev0); h->ev0 = nullptr; }
+  if (h->ev1) { (void)hipEventDestroy(h->ev1); h->ev1 = nullptr; }
+  if (h->own_stream && h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
+}
+
 int lsr_destroy(lsr_handle h) {
   if (!h) return LSR_OK;
   DeviceGuard guard(h->device);
-  (void)hipStreamSynchronize(h->stream);
-  if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
-  if (h->side_ev) (void)hipEventDestroy(h->side_ev);
-  if (h->chain_fork_ev) (void)hipEventDestroy(h->chain_fork_ev);
-  for (int c = 0; c < 3; c++) {
-    if (h->chain_stream[c]) { (void)hipStreamSynchronize(h->chain_stream[c]); (void)hipStreamDestroy(h->chain_stream[c]); }
-    if (h->chain_ev[c]) (void)hipEventDestroy(h->chain_ev[c]);
-  }
-  if (h->side_fork_ev) (void)hipEventDestroy(h->side_fork_ev);
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (auto& w : h->aux)   // the workers first: their launches may still read buffers the handle owns
+    if (w) { release_handle_streams(w.get()); w->target.reset(); }
+  release_handle_streams(h);
   h->target.reset();
-  if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return LSR_OK;
 }
@@ -1718,9 +1769,9 @@ int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int co
   if (st) return st;
   if (h->target->grid.ncells == 0) { set_last_error("the input target holds no finite point"); return LSR_ERR_NO_TARGET; }
   if ((st = h->d_state.reserve(2))) return st;
-  if ((st = h->h_state.reserve(2))) return st;
+  if ((st = h->h_state.reserve(2, hipHostMallocMapped))) return st;
   if ((st = h->d_prob.reserve(1))) return st;
-  if ((st = h->h_prob.reserve(1))) return st;
+  if ((st = h->h_prob.reserve(1, hipHostMallocMapped))) return st;
   NdtLaunchCfg cfg;
   cfg.neighborhood = h->ndt.neighborhood;
   {

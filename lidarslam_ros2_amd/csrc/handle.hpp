@@ -57,6 +57,8 @@ struct lsr_handle_s {
   DevBuf<NdtProblem> d_prob;
   PinBuf<NdtState> h_state;
   PinBuf<NdtProblem> h_prob;
+  const NdtState* h_state_dev = nullptr;   // device views of the two pinned arrays (the chain's init launch reads them, ndt_init_batch)
+  const NdtProblem* h_prob_dev = nullptr;
   PinBuf<lsr::NdtMailbox> mailbox;        // host-coherent, mapped: progress + result of a single registration
   lsr::NdtMailbox* d_mailbox = nullptr;   // device view of mailbox.p
   unsigned int align_token = 0;

@@ -1672,6 +1672,34 @@ int ndt_init_single(const NdtState& st, NdtState* d_state2, long long* d_bins, h
   return LSR_OK;
 }
 
+// The same for the members of a candidate set: workgroup b takes member b.  Until round 5 a chain started with two host-to-device
+// copies and a memset (three blit launches, ~25 us on the stream and three runtime calls on the host per chain).
+namespace {
+__global__ __launch_bounds__(256) void ndt_init_batch_kernel(const NdtProblem* __restrict__ src_probs, const NdtState* __restrict__ src_states,
+                                                             NdtProblem* __restrict__ d_probs, NdtState* __restrict__ d_states,
+                                                             long long* __restrict__ d_bins) {
+  static_assert(sizeof(NdtProblem) % 4 == 0 && sizeof(NdtState) % 16 == 0, "copied as words / uint4");
+  const int b = blockIdx.x;
+  constexpr int STATE_Q = (int)(sizeof(NdtState) / 16);
+  const uint4* ss = reinterpret_cast<const uint4*>(src_states + 2 * (size_t)b);
+  uint4* ds = reinterpret_cast<uint4*>(d_states + 2 * (size_t)b);
+  for (int k = threadIdx.x; k < 2 * STATE_Q; k += 256) ds[k] = ss[k];
+  const unsigned int* sp = reinterpret_cast<const unsigned int*>(src_probs + b);
+  unsigned int* dp = reinterpret_cast<unsigned int*>(d_probs + b);
+  for (int k = threadIdx.x; k < (int)(sizeof(NdtProblem) / 4); k += 256) dp[k] = sp[k];
+  uint4* zb = reinterpret_cast<uint4*>(d_bins + (size_t)b * NDT_NBANKS * NDT_BANK_WORDS);
+  for (int k = threadIdx.x; k < NDT_NBANKS * NDT_BANK_WORDS / 2; k += 256) zb[k] = make_uint4(0u, 0u, 0u, 0u);
+}
+}  // namespace
+
+int ndt_init_batch(const NdtProblem* src_probs, const NdtState* src_states, NdtProblem* d_probs, NdtState* d_states, long long* d_bins,
+                   int n, hipStream_t stream) {
+  if (n <= 0) return LSR_OK;
+  hipLaunchKernelGGL(ndt_init_batch_kernel, dim3(n), dim3(256), 0, stream, src_probs, src_states, d_probs, d_states, d_bins);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
 template <int NOFF, int TAB, int PTS>
 static int launch_quad_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq) {
   static bool allowed[2][64] = {};

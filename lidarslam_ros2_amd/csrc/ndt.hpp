@@ -192,6 +192,11 @@ int ndt_sort_source(const DeviceCloud& src, const float* T12, const VoxelGridDev
 // One small launch that writes the initial state (passed in the kernel arguments) into both state buffers and clears the
 // quad kernel's accumulator banks (d_bins nullable).
 int ndt_init_single(const NdtState& st, NdtState* d_state2, long long* d_bins, hipStream_t stream);
+// Start of a candidate set's launch chain: ONE launch copies the members' problem records and initial states out of the
+// lead's pinned host arrays (read by the device over PCIe: ~2.3 KB per member) and clears their accumulator banks.
+// src_probs / src_states: device views of the pinned arrays (hipHostGetDevicePointer); n members; states are pairs.
+int ndt_init_batch(const NdtProblem* src_probs, const NdtState* src_states, NdtProblem* d_probs, NdtState* d_states, long long* d_bins,
+                   int n, hipStream_t stream);
 // Host: controller state at the entry of computeTransformation (guess nullable = identity).
 void ndt_fill_initial_state(NdtState& st, const float* guess16, const NdtParamsHost& prm, int n_points);
 // Fill a diagnostic request on the host (lsr_ndt_derivatives).

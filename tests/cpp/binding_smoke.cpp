@@ -6,7 +6,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <limits>
 #include <memory>
+#include <vector>
 
 using Cloud = pcl::PointCloud<pcl::PointXYZI>;
 using Reg = Gfx950Registration<pcl::PointXYZI, pcl::PointXYZI>;
@@ -39,5 +41,24 @@ int main() {
               ndt->getFitnessScore());
   std::printf("KDTREE builds=%d points_indexed=%zu\n", pcl::search::KdTree<pcl::PointXYZI>::builds(),
               pcl::search::KdTree<pcl::PointXYZI>::points_indexed());
+  // the call the reference makes (graph_based_slam_component.cpp:231): NON-virtual, on the base pointer.  PCL's own loop runs,
+  // over the stand-in tree the binding installed: one device search, the same score as the derived call, no empty-index search.
+  const double through_base = registration_->getFitnessScore();
+  const double again = registration_->getFitnessScore();               // the walk restarts; no second device search is needed
+  const double derived = ndt->getFitnessScore();
+  std::printf("BASE_FITNESS base=%.9g again=%.9g derived=%.9g unindexed_searches=%zu\n", through_base, again, derived,
+              pcl::search::KdTree<pcl::PointXYZI>::unindexed_searches());
+  // ... and after a new align the cached search is stale: the next base-pointer call searches again at the new pose
+  Eigen::Matrix4f G = Eigen::Matrix4f::Identity(); G.m[12] = 0.05f;
+  registration_->align(output, G);
+  std::printf("BASE_FITNESS_AFTER_ALIGN base=%.9g derived=%.9g\n", registration_->getFitnessScore(), ndt->getFitnessScore());
+  // a search that is NOT that walk is refused: 0 neighbours, distance FLT_MAX
+  {
+    pcl::Indices idx(1); std::vector<float> d2(1);
+    pcl::PointXYZI far{1.0e6f, 1.0e6f, 1.0e6f, 1.f, 0, 0, 0, 0};
+    struct Peek : pcl::Registration<pcl::PointXYZI, pcl::PointXYZI> { using pcl::Registration<pcl::PointXYZI, pcl::PointXYZI>::tree_; };
+    const int found = (registration_.get()->*(&Peek::tree_))->nearestKSearch(far, 1, idx, d2);
+    std::printf("FOREIGN_SEARCH found=%d d2_is_max=%d\n", found, (int)(d2[0] == std::numeric_limits<float>::max()));
+  }
   return 0;
 }

@@ -16,6 +16,7 @@
 #include <vector>
 
 #define PCL_ERROR(...) std::fprintf(stderr, __VA_ARGS__)
+#define PCL_WARN(...) std::fprintf(stderr, __VA_ARGS__)
 
 namespace Eigen {
 struct Matrix4f {   // column-major 4x4 float, as Eigen::Matrix4f
@@ -41,13 +42,25 @@ struct PointCloud {
   std::size_t size() const { return points.size(); }
 };
 
+using Indices = std::vector<int>;   // pcl::Indices (PCL 1.12: std::vector<index_t>, index_t = int)
+
 namespace search {
 template <typename PointT>
-struct KdTree {   // pcl::search::KdTree<PointT>: setInputCloud is the O(M log M) FLANN build
+struct KdTree {   // pcl::search::KdTree<PointT>: setInputCloud is the O(M log M) FLANN build, nearestKSearch virtual (pcl::search::Search)
   using Ptr = std::shared_ptr<KdTree<PointT>>;
+  virtual ~KdTree() = default;
   static int& builds() { static int n = 0; return n; }
   static std::size_t& points_indexed() { static std::size_t n = 0; return n; }
-  void setInputCloud(const typename PointCloud<PointT>::ConstPtr& cloud) { builds()++; points_indexed() += cloud ? cloud->size() : 0; }
+  static std::size_t& unindexed_searches() { static std::size_t n = 0; return n; }
+  void setInputCloud(const typename PointCloud<PointT>::ConstPtr& cloud) { builds()++; points_indexed() += cloud ? cloud->size() : 0; indexed_ = true; }
+  // The stand-in indexes nothing, so it can only say what PCL would have done: a search on a tree that never saw a cloud
+  // (force_no_recompute and a caller that stayed on the base pointer) is a null index in FLANN — counted here, outputs untouched.
+  virtual int nearestKSearch(const PointT&, int, Indices&, std::vector<float>&) const {
+    if (!indexed_) unindexed_searches()++;
+    return 0;
+  }
+ private:
+  bool indexed_ = false;
 };
 }  // namespace search
 
@@ -81,7 +94,25 @@ class Registration {
   void setRANSACIterations(int n) { ransac_iterations_ = n; }
   Eigen::Matrix4f getFinalTransformation() { return final_transformation_; }
   bool hasConverged() const { return converged_; }
-  double getFitnessScore(double = std::numeric_limits<double>::max()) { return -1.0; }   // NON-virtual in PCL (host FLANN search)
+  // NON-virtual in PCL (registration.hpp): transforms input_ by final_transformation_ and asks tree_ for the nearest target
+  // point of every source point, one nearestKSearch per point; the mean of the squared distances <= max_range
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) {
+    double fitness_score = 0.0;
+    if (!input_) return std::numeric_limits<double>::max();
+    const float* M = final_transformation_.data();
+    Indices nn_indices(1);
+    std::vector<float> nn_dists(1);
+    int nr = 0;
+    for (const PointSource& p : input_->points) {
+      PointSource q = p;   // pcl::transformPointCloud: xyz only
+      q.x = M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12];
+      q.y = M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13];
+      q.z = M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14];
+      tree_->nearestKSearch(q, 1, nn_indices, nn_dists);
+      if (nn_dists[0] <= max_range) { fitness_score += nn_dists[0]; nr++; }
+    }
+    return nr > 0 ? fitness_score / nr : std::numeric_limits<double>::max();
+  }
   void align(PointCloudSource& output) { align(output, Eigen::Matrix4f::Identity()); }
   void align(PointCloudSource& output, const Eigen::Matrix4f& guess) {
     if (!initCompute()) return;

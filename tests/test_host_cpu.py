@@ -358,6 +358,33 @@ def test_pcl_binding_never_builds_a_host_kdtree_over_the_target(tmp_path):
     assert "KDTREE builds=0 points_indexed=0" in out, out
 
 
+@pytest.mark.gpu
+def test_pcl_binding_answers_getFitnessScore_left_on_the_base_pointer(tmp_path):
+    """VERDICT r04 #7 / ADVICE r04 (medium): pcl::Registration::getFitnessScore is NOT virtual.  The reference's own call sites
+    (graph_based_slam_component.cpp:231, scanmatcher_component.cpp:376) go through the base pointer; with force_no_recompute the
+    base class's tree_ never sees a cloud, so a call site a maintainer forgot to edit would search an empty FLANN index.  The
+    binding installs Gfx950FitnessTree as tree_: PCL's own loop (the stand-in's getFitnessScore mirrors registration.hpp: transform
+    input_, one nearestKSearch per point) is answered from ONE device search.  Asserted: the base-pointer score equals the derived
+    call's, twice in a row and again after a new align; no search ever reached an un-indexed kd-tree; a search that is not that
+    walk is refused with 0 neighbours and distance FLT_MAX (a fitness built from it cannot pass a loop gate)."""
+    import re
+    import subprocess
+
+    run = subprocess.run([_build_binding(tmp_path)], capture_output=True, text=True, timeout=120)
+    out = run.stdout
+    m = re.search(r"BASE_FITNESS base=(\S+) again=(\S+) derived=(\S+) unindexed_searches=(\d+)", out)
+    assert m, out
+    base, again, derived, unindexed = float(m.group(1)), float(m.group(2)), float(m.group(3)), int(m.group(4))
+    assert unindexed == 0, out
+    assert derived > 0 and abs(base - derived) <= 1e-6 * derived and abs(again - derived) <= 1e-6 * derived, out
+    m2 = re.search(r"BASE_FITNESS_AFTER_ALIGN base=(\S+) derived=(\S+)", out)
+    assert m2, out
+    b2, d2 = float(m2.group(1)), float(m2.group(2))
+    assert d2 > 0 and abs(b2 - d2) <= 1e-6 * d2, out
+    assert "FOREIGN_SEARCH found=0 d2_is_max=1" in out, out
+    assert "called through pcl::Registration*" in run.stderr and "not getFitnessScore's walk" in run.stderr, run.stderr
+
+
 def test_c_abi_argument_validation_needs_no_device():
     """Error conventions of the boundary: status codes, never an exception or a crash — checked on
     the paths that do not need a device (null handles, invalid method, status strings)."""
