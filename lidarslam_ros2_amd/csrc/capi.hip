@@ -246,10 +246,13 @@ bool lane_widen_enabled() {
   return on;
 }
 
-bool hash_from_grid_possible(lsr_handle h) {
-  // A/B switch (env LSR_NN_FROM_GRID=0: always build the neighbour grid from the cloud); read once
+// A/B switch (env LSR_NN_FROM_GRID=0: always build the neighbour grid from the cloud); read once
+bool hash_from_grid_enabled() {
   static const bool enabled = [] { const char* e = getenv("LSR_NN_FROM_GRID"); return !(e && e[0] == '0'); }();
-  if (!enabled) return false;
+  return enabled;
+}
+bool hash_from_grid_possible(lsr_handle h) {
+  if (!hash_from_grid_enabled()) return false;
   const TargetData& t = *h->target;
   return h->method == LSR_METHOD_NDT && t.has_grid && t.grid.has_sorted && t.grid.ncells > 0 && t.grid.sorted_n == t.cloud.n;
 }
@@ -317,17 +320,12 @@ int ensure_aux_streams(lsr_handle lead) {
   int st;
   if ((st = words.reserve(2))) return st;
   std::vector<hipStream_t> rejected, found;
-  // The first stream found becomes the SIDE stream (grid refinement, fitness searches: wide launches that are in no hurry), created
-  // with the lowest priority so that its workgroups do not take compute units from the launch chains' short dependent launches
-  // (round 5 trace of an 8-candidate share: the refinement of 8 neighbour grids, enqueued next to the first chain launches,
-  // stretched them from 15 to 40 us).  LSR_SIDE_PRIORITY=0 creates it like the others (A/B switch).
-  static const bool side_low = [] { const char* e = std::getenv("LSR_SIDE_PRIORITY"); return !(e && e[0] == '0'); }();
-  int prio_least = 0, prio_greatest = 0;
-  if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
+  // (Round 5 measured a lowest-priority side stream — hipStreamCreateWithPriority — for the grid refinement and the fitness searches:
+  // the chain launches were disturbed just the same and the side work itself was starved: align + fitness of an 8-candidate share
+  // 1.26-1.38 ms against 0.76-0.95 ms.  Not used.)
   for (int tries = 0; tries < 10 && (int)found.size() < 3; tries++) {
     hipStream_t s = nullptr;
-    const bool want_low = side_low && found.empty() && prio_least != prio_greatest;
-    if ((want_low ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) break;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
     bool ok = streams_run_concurrently(lead->stream, s, words.p) == 1;
     for (size_t c = 0; ok && c < found.size(); c++) ok = streams_run_concurrently(found[c], s, words.p) == 1;
     if (ok) found.push_back(s); else rejected.push_back(s);
@@ -642,11 +640,11 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
   auto eager_dispatch = [&](bool all) -> int {
     for (int b = 0; b < B; b++)
       if (eager_ok[b] && !eager_queued[b] && __atomic_load_n(&MB[b].done, __ATOMIC_ACQUIRE) == token) { eager_queued[b] = 1; eager_ready.push_back(b); }
-    // a launch group serves up to 12 members.  A large set waits for a full group while its chains are running (they fill the chip:
-    // few wide searches disturb them less than many narrow ones); a small set is a chain of short launches on a mostly idle chip
-    // — a share of 8 candidates of an 8-GPU node —, so a member is searched as soon as it has finished (round 5: the searches of
-    // such a set were all enqueued after the chain, 0.15-0.35 ms of a 1.0-1.2 ms share)
-    const size_t group_min = (B >= 48) ? 12 : (size_t)std::max(1, B / 8);
+    // a launch group serves up to 12 members: wait for a full group while the chain is still running.  (Round 5 measured groups of
+    // ONE for small sets — a share of 8 candidates, whose chain leaves the chip idle half of the time —: a search is a wide launch
+    // of long-lived waves, the chain's workgroups queue behind them for wave slots and LDS, launches of 15 us took 40-80 us, and the
+    // share got slower, not faster: 0.757 / 0.949 ms against 0.710 / 0.928 ms for align + fitness of two shares.)
+    const size_t group_min = 12;
     while (!eager_ready.empty() && (all || eager_ready.size() >= group_min)) {
       const int n = (int)std::min<size_t>(12, eager_ready.size());
       std::vector<FitJob> jobs;
@@ -1069,6 +1067,10 @@ int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const
     jobs.push_back(TargetBuildJob{d_aos, stride_bytes, counts[b], &t->cloud, (float)h->ndt.resolution, &t->grid, &h->scratch, 0});
   }
   if (!jobs.empty() && (st = ndt_targets_ingest(jobs.data(), (int)jobs.size(), lead_stream))) return fail(st);
+  // (Round 5 measured forking the neighbour-grid refinement of a small set onto the lead's side stream right after the scatter, under
+  // the leaf sums and the host's work between the calls, instead of next to the first launches of the align chain: the refinement and
+  // the leaf sums slow each other down — target + source stage of an 8-candidate share 0.44 ms against 0.28 ms, align 0.03-0.05 ms
+  // faster, the share 0.14-0.17 ms slower.  Not done.)
   // stage 1: the rest of every build
   if (!jobs.empty() && (st = ndt_targets_build_begin(jobs.data(), (int)jobs.size(), lead_stream))) return fail(st);
   for (int b = 0; b < count; b++)

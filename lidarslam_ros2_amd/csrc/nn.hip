@@ -846,7 +846,11 @@ int nn_fitness_begin_group(const FitJob* jobs, int count, hipStream_t stream) {
     if (ball_form) {
       hipLaunchKernelGGL(fit_zero_work_group_kernel, dim3(1), dim3(ng), 0, stream, grp);
       hipLaunchKernelGGL(nn1_ball_group_kernel, dim3((unsigned)(((long)max_n * 16 + 255) / 256), ng), dim3(256), 0, stream, grp);
-      hipLaunchKernelGGL(nn1_list_group_kernel, dim3(256, ng), dim3(256), 0, stream, grp);
+      // the rest (one wave per query, a stride loop over the member's work list): a member whose scan leaves the submap puts
+      // thousands of queries there, each a walk of 10-30 us; a small group gives such a member more waves (round 5: a share of 8
+      // with one such member spent 114 us here on 1 024 waves per member; the answers do not depend on the geometry)
+      const unsigned list_wgs = ng <= 8 ? 1024u : 256u;
+      hipLaunchKernelGGL(nn1_list_group_kernel, dim3(list_wgs, ng), dim3(256), 0, stream, grp);
     } else if (quad_form) {
       hipLaunchKernelGGL(fit_zero_work_group_kernel, dim3(1), dim3(ng), 0, stream, grp);
       hipLaunchKernelGGL(nn1_quad_group_kernel, dim3((unsigned)(((long)max_n * 4 + NN_THREADS - 1) / NN_THREADS), ng), dim3(NN_THREADS), 0, stream, grp);

@@ -234,6 +234,8 @@ def test_cfg4_hard_candidates_match_the_cpu_fixture(pool):
 # fp32 operation order pinned (ndt_point.hpp) and the canonical sums (ndt.hip: canon) every candidate is within 5e-5 m of the CPU
 # result on BOTH paths — which are now one path: the staged batch and the one-by-one loop return the same bits.
 BAR_T, BAR_R = 1e-3, 1e-4          # north_star: <= 1e-3 m translation, <= 1e-4 rad rotation
+TIGHT_IT_SLACK = 16         # Newton iterations a tight (eps 1e-6) registration may differ from the CPU fixture by (measured max: 13)
+TIGHT_IT_MISMATCHES = 12    # candidates of the 64 whose tight iteration count may differ at all (measured: 7)
 
 
 def _fit_tol(dt, ang, fit):
@@ -320,9 +322,12 @@ def test_cfg4_staged_batch_and_one_by_one_return_the_same_bits(cfg4_runs, eps):
 def test_cfg4_all_64_candidates_match_the_cpu_fixture_tight(cfg4_all, cfg4_runs, batched):
     """Tight mode (transformation_epsilon 1e-6, max_iterations 100): both sides reach the optimum of their candidate, so EVERY
     one of the 64 must agree inside the north_star bar — the ill-conditioned ones (18, 21, 34) included — with the fitness score
-    at that pose equal to 1e-4.  Iteration counts are NOT compared here: at a 1e-6 step threshold the loop stops on the
+    at that pose equal to 1e-4.  Iteration counts are BOUNDED here, not equal: at a 1e-6 step threshold the loop stops on the
     noise floor of the line search (the CPU emulation of the GPU's arithmetic, tests/ndt_host_emu.py, and the oracle differ
-    by up to a dozen iterations there while ending 1e-4 m apart at most); they are compared at eps 0.01, where they are equal."""
+    by up to a dozen iterations there while ending 1e-4 m apart at most).  Measured on MI355X (rounds 4 and 5): 57 of 64 equal,
+    the others off by 1, 1, 1, 2, 2, 2 and 13 — so at most TIGHT_IT_SLACK iterations on any candidate and at most
+    TIGHT_IT_MISMATCHES candidates that differ at all; a controller that wanders fails both.  At eps 0.01
+    the counts are compared for equality (next test)."""
     fx, fxt, cases = cfg4_all
     finals, its, fits = cfg4_runs[(1e-6, batched)]
     bad, rows = {}, []
@@ -330,10 +335,13 @@ def test_cfg4_all_64_candidates_match_the_cpu_fixture_tight(cfg4_all, cfg4_runs,
         dt, ang = pose_delta(finals[c], fxt["final_tight"][c])
         fit_rel = abs(fits[c] - fxt["fitness_tight"][c]) / fxt["fitness_tight"][c]
         rows.append([c, dt, ang, float(fit_rel), int(its[c]), int(fxt["iterations_tight"][c])])
-        if dt > BAR_T or ang > BAR_R or fit_rel > _fit_tol(dt, ang, fxt["fitness_tight"][c]) or its[c] > 102:
+        if (dt > BAR_T or ang > BAR_R or fit_rel > _fit_tol(dt, ang, fxt["fitness_tight"][c]) or its[c] > 102 or
+                abs(int(its[c]) - int(fxt["iterations_tight"][c])) > TIGHT_IT_SLACK):
             bad[c] = (dt, ang, fit_rel, its[c], int(fxt["iterations_tight"][c]))
     _dump("cfg4_parity_tight_%s.json" % ("batch" if batched else "single"), rows)
     assert not bad, bad
+    differ = [r[0] for r in rows if r[4] != r[5]]
+    assert len(differ) <= TIGHT_IT_MISMATCHES, differ
 
 
 @pytest.mark.parametrize("batched", [True, False], ids=["staged-batch", "one-by-one"])
