@@ -345,6 +345,32 @@ def cfg_scan_stream(n_scans: int, seed: int = 0, pool=None, world: World | None 
     return out
 
 
+def cfg_frontend_drive(n_scans: int, seed: int = 0, pool=None, world: World | None = None) -> dict:
+    """The frontend's input over a drive (scanmatcher_component.cpp:296-356,436-481): the cfg-1/2 map of ten keyframes (each
+    VoxelGrid(0.1)-filtered in its OWN sensor frame, with its pose) followed by n_scans RAW scans — as the sensor delivers them: no
+    range filter, no VoxelGrid, ~147k points — taken every 0.5 m further along the trajectory, so that a frontend with
+    trans_for_mapupdate = 1.5 m updates its map on every third scan.  Returns {frames, frame_poses, scans [(n,3) f32 sensor frame],
+    truths [4x4 f64], guess0 (pose of the last keyframe)}."""
+    base = cfg_ndt_30k(seed=seed, pool=pool, keep_parts=True, world=world)
+    sensor = vlp32()
+    sensor = Sensor(sensor.n_beams, sensor.elev_min_deg, sensor.elev_max_deg, sensor.n_azimuth * 3, sensor.range_noise,
+                    sensor.max_range, sensor.min_range)
+    world = world or make_world()
+    x_last = 1.5 * 9
+    xs = [x_last + 0.5 * (1 + j) for j in range(n_scans)]
+    poses = [trajectory_pose(x) for x in xs]
+    sargs = (sensor.n_beams, sensor.elev_min_deg, sensor.elev_max_deg, sensor.n_azimuth, sensor.range_noise, sensor.max_range,
+             sensor.min_range)
+    jobs = [(world, sargs, T) for T in poses]
+    geo = pool.map(_geometry_job, jobs) if pool is not None else [_geometry_job(j) for j in jobs]
+    scans = []
+    for j, (keep, t) in enumerate(geo):
+        rng = np.random.default_rng([WORLD_SEED, 60607, seed, j])
+        scans.append(raycast_noise(sensor, keep, t, rng))
+    return {"frames": base.frames, "frame_poses": base.frame_poses, "scans": scans, "truths": [np.asarray(P, np.float64) for P in poses],
+            "guess0": np.asarray(trajectory_pose(x_last), np.float64)}
+
+
 def cfg_gicp_30k(seed: int = 0, pool=None) -> RegistrationCase:
     """cfg 3: same source; target additionally VoxelGrid(0.2) (scanmatcher_component.cpp:309-315)."""
     return make_case(sensor=vlp32(), n_keyframes=10, vg_map=0.1, vg_input=0.2, n_source=30000, vg_target=0.2,
