@@ -1,0 +1,396 @@
+// Stable LSD radix sort of (uint32 key, int32 value) pairs for the sizes this library sorts — a 147k-point scan before
+// pcl::VoxelGrid (N1: scanmatcher_component.cpp:324-328, every scan), a map-side cloud (:443-447), the keys of a target whose voxel
+// index space is too large for one counting sort — built from the stages of the dense voxel-grid builder (grid_dense.hip): per
+// workgroup LDS histogram of the digit -> per digit exclusive scan over the workgroups -> stable scatter (which scans the digit
+// totals itself).
+// Three passes of 10 bits order a 28-bit leaf index (three launches each); rocPRIM's sort, which this replaces on these paths, spends a dozen
+// dependent launches of 5-10 us each on the same 147k keys (profiles/r04_rocprofv3_bench_stats.md: merge_sort_block_merge x 523).
+//
+// Stability does not lean on the order in which the LDS unit serves the lanes of one atomic instruction (the dense builder's
+// scatter does; its consumers only need a FIXED order): the lanes of a wave that hold the same digit find each other with one
+// ballot per digit bit, rank themselves by lane number, and ONE lane per group draws the group's offset from the wave's packed
+// 16-bit counter — blocks, waves, steps and lanes are all in input order, so equal keys keep their input order, which is what
+// makes the second pass correct and what pcl::VoxelGrid's float centroid (points of a leaf summed in ascending index) needs.
+//
+// The tail of N1 lives here too: the heads of the runs of equal keys are counted per workgroup, scanned by one workgroup (which
+// also reports the number of runs to the host mailbox), and every head then sums its run — three launches instead of rocPRIM's
+// run_length_encode + exclusive_scan + a publishing launch.
+#include "handle.hpp"
+#include "sort.hpp"
+
+namespace lsr {
+
+namespace {
+
+constexpr int RS_THREADS = 256;
+
+// TRANSPOSED: the counters are written digit-major, hist[d * row_pitch + workgroup] (row_pitch = workgroups rounded up to 8), so that
+// the fused scatter's thread reads the whole row of its digit with a few 16-byte loads
+template <int STEPS, bool TRANSPOSED>
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned int* __restrict__ keys, int n, int shift, unsigned int mask,
+                                                             int C, unsigned short* __restrict__ hist, int row_pitch) {
+  extern __shared__ unsigned int s_hist[];  // [C]
+  const int tid = threadIdx.x;
+  for (int k = tid; k < C; k += RS_THREADS) s_hist[k] = 0u;
+  __syncthreads();
+  const int base = blockIdx.x * (RS_THREADS * STEPS);
+  unsigned int kk[STEPS];
+#pragma unroll
+  for (int j = 0; j < STEPS; j++) {
+    const int i = base + j * RS_THREADS + tid;
+    kk[j] = (i < n) ? keys[i] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < STEPS; j++) {
+    const int i = base + j * RS_THREADS + tid;
+    if (i < n) atomicAdd(&s_hist[(kk[j] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  if (TRANSPOSED) {
+    for (int k = tid; k < C; k += RS_THREADS) hist[(size_t)k * row_pitch + blockIdx.x] = (unsigned short)s_hist[k];
+  } else {
+    unsigned short* row = hist + (size_t)blockIdx.x * C;
+    for (int k = tid; k < C; k += RS_THREADS) row[k] = (unsigned short)s_hist[k];   // <= RS_THREADS * STEPS <= 4096
+  }
+}
+
+// per digit: exclusive scan of the workgroup histograms + digit total (the dense builder's vg_scan, restated for this file's tables)
+constexpr int RS_SCAN_SEGS = 8;
+__global__ __launch_bounds__(256) void rs_scan_kernel(const unsigned short* __restrict__ hist, int nblk, int C,
+                                                      unsigned int* __restrict__ blkoff, unsigned int* __restrict__ total) {
+  __shared__ unsigned int s_seg[RS_SCAN_SEGS][32];
+  const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + cl;
+  const int per = (nblk + RS_SCAN_SEGS - 1) / RS_SCAN_SEGS;
+  const int b0 = seg * per, b1 = min(nblk, b0 + per);
+  unsigned int sum = 0u;
+  if (k < C)
+    for (int b = b0; b < b1; b++) sum += hist[(size_t)b * C + k];
+  s_seg[seg][cl] = sum;
+  __syncthreads();
+  unsigned int run = 0u;
+  for (int s2 = 0; s2 < seg; s2++) run += s_seg[s2][cl];
+  if (k < C) {
+    for (int b = b0; b < b1; b++) { const unsigned int c = hist[(size_t)b * C + k]; blkoff[(size_t)b * C + k] = run; run += c; }
+    if (seg == RS_SCAN_SEGS - 1) total[k] = run;
+  }
+}
+
+// Stable scatter of one pass.  Wave w of workgroup b owns the points [b * chunk + w * chunk / 4, + chunk / 4) and walks them in
+// STEPS steps of 64 consecutive points; s_c[d] packs four 16-bit counters (one per wave): per-wave counts of digit d, then their
+// exclusive prefix over the waves, then the running offset of each wave.
+// Where a workgroup's points of digit d start in the output = (number of keys with a smaller digit) + (keys of digit d in the
+// workgroups before this one).  FUSED (few workgroups: a scan): every workgroup forms both sums ITSELF from the histogram rows
+// of the pass — nblk x C counters, read coalesced, thread t owning the digits t, t + 256, ... — so a pass is two launches
+// (histogram, scatter).  Otherwise (a map: hundreds of rows) rs_scan has prefixed the rows (blkoff) and totalled the digits and the
+// workgroup only scans the C totals.
+constexpr int RS_MAX_BITS = 11, RS_MAX_C = 1 << RS_MAX_BITS, RS_OWN = RS_MAX_C / RS_THREADS;
+constexpr int RS_FUSED_MAX_BLOCKS = 256;
+template <int STEPS, bool FUSED>
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned int* __restrict__ keys, const int* __restrict__ vals, int n,
+                                                                int shift, unsigned int mask, int bits,
+                                                                const unsigned int* __restrict__ blkoff, const unsigned int* __restrict__ total,
+                                                                const unsigned short* __restrict__ hist, int row_pitch, int nblk,
+                                                                int C, unsigned int* __restrict__ keys_out, int* __restrict__ vals_out) {
+  extern __shared__ unsigned long long s_c[];  // [C]
+  __shared__ unsigned int s_start[RS_MAX_C];   // absolute output position of this workgroup's first key of every digit
+  __shared__ unsigned int s_wsum[RS_THREADS / 64];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  for (int k = tid; k < C; k += RS_THREADS) s_c[k] = 0ull;
+  {
+    unsigned int tot[RS_OWN], below[RS_OWN];   // of the digits u * 256 + tid
+#pragma unroll
+    for (int u = 0; u < RS_OWN; u++) { tot[u] = 0u; below[u] = 0u; }
+    if (FUSED) {
+      const int me = (int)blockIdx.x;
+      const int own = (C + RS_THREADS - 1) / RS_THREADS;   // digit slices this workgroup's threads own: uniform
+#pragma unroll
+      for (int u = 0; u < RS_OWN; u++) {
+        if (u < own) {   // uniform branch: the loads below carry no per-lane condition, eight rows are in flight at a time
+          const int d = u * RS_THREADS + tid;
+          const bool dv = d < C;
+          // digit-major rows (rs_hist_kernel<.., true>): nblk counters of this digit, contiguous, 16-byte aligned
+          const uint4* row = reinterpret_cast<const uint4*>(hist + (size_t)(dv ? d : 0) * row_pitch);
+          unsigned int t = 0u, bl = 0u;
+          for (int b8 = 0; b8 < row_pitch / 8; b8 += 4) {   // four 16-byte loads (32 counters) in flight (sixteen were measured: slower)
+            uint4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = (b8 + k < row_pitch / 8) ? row[b8 + k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const unsigned int wv[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const int b = (b8 + k) * 8 + 2 * e;
+                const unsigned int lo = (b < nblk) ? (wv[e] & 0xFFFFu) : 0u, hi = (b + 1 < nblk) ? (wv[e] >> 16) : 0u;   // row padding holds no count
+                t += lo + hi;
+                bl += ((b < me) ? lo : 0u) + ((b + 1 < me) ? hi : 0u);
+              }
+            }
+          }
+          tot[u] = dv ? t : 0u;
+          below[u] = dv ? bl : 0u;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < RS_OWN; u++) {
+        const int d = u * RS_THREADS + tid;
+        if (d < C) { tot[u] = total[d]; below[u] = blkoff[(size_t)blockIdx.x * C + d]; }
+      }
+    }
+    // exclusive scan of tot[] in digit order: slice u = digits [256 u, 256 u + 255], one workgroup scan per slice, carry across slices
+    unsigned int carry = 0u;
+    for (int u = 0; u < RS_OWN && u * RS_THREADS < C; u++) {
+      unsigned int inc = tot[u];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int x = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += x;
+      }
+      __syncthreads();   // s_wsum of the previous slice has been read
+      if (lane == 63) s_wsum[w] = inc;
+      __syncthreads();
+      unsigned int run = carry + inc - tot[u];
+      for (int k = 0; k < w; k++) run += s_wsum[k];
+      const int d = u * RS_THREADS + tid;
+      if (d < C) s_start[d] = run + below[u];
+      carry += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    }
+  }
+  const int base_i = blockIdx.x * (RS_THREADS * STEPS) + w * (64 * STEPS) + lane;
+  unsigned int key[STEPS];
+  int val[STEPS];
+#pragma unroll
+  for (int j = 0; j < STEPS; j++) {
+    const int i = base_i + j * 64;
+    const bool in = i < n;
+    key[j] = in ? keys[i] : 0u;
+    val[j] = in ? (vals ? vals[i] : i) : 0;
+  }
+  __syncthreads();
+  const int sh = 16 * w;
+#pragma unroll
+  for (int j = 0; j < STEPS; j++)
+    if (base_i + j * 64 < n) atomicAdd(&s_c[(key[j] >> shift) & mask], 1ull << sh);
+  __syncthreads();
+  for (int k = tid; k < C; k += RS_THREADS) {
+    const unsigned long long v = s_c[k];
+    const unsigned long long c0 = v & 0xFFFFull, c1 = (v >> 16) & 0xFFFFull, c2 = (v >> 32) & 0xFFFFull;
+    s_c[k] = (c0 << 16) | ((c0 + c1) << 32) | ((c0 + c1 + c2) << 48);
+  }
+  unsigned int absb[STEPS];
+#pragma unroll
+  for (int j = 0; j < STEPS; j++) {
+    const unsigned int d = (key[j] >> shift) & mask;
+    absb[j] = (base_i + j * 64 < n) ? s_start[d] : 0u;
+  }
+  __syncthreads();
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));   // lanes below this one
+#pragma unroll
+  for (int j = 0; j < STEPS; j++) {
+    const bool in = base_i + j * 64 < n;
+    const unsigned int d = (key[j] >> shift) & mask;
+    // the lanes of this step that hold the same digit: one ballot per digit bit
+    unsigned long long peers = __ballot(in);
+    for (int b = 0; b < bits; b++) {
+      const bool one = ((d >> b) & 1u) != 0u;
+      const unsigned long long bal = __ballot(one);
+      peers &= one ? bal : ~bal;
+    }
+    if (in) {
+      const int rank = __popcll(peers & lt), cnt = __popcll(peers);
+      const int leader = __ffsll((long long)peers) - 1;
+      unsigned int off = 0u;
+      if (rank == 0) {
+        const unsigned long long old = atomicAdd(&s_c[d], (unsigned long long)cnt << sh);
+        off = (unsigned int)(old >> sh) & 0xFFFFu;
+      }
+      off = (unsigned int)__shfl((int)off, leader, 64);
+      const unsigned int pos = absb[j] + off + (unsigned int)rank;
+      keys_out[pos] = key[j];
+      vals_out[pos] = val[j];
+    }
+  }
+}
+
+// ---- runs of equal keys in the sorted sequence ---------------------------------------------------------------------------
+constexpr int RUN_CHUNK = 256;   // keys per workgroup: one per thread (a head's loop over its run is the long pole: keep it one per lane)
+__device__ __forceinline__ bool is_head(const unsigned int* __restrict__ keys, int i) { return i == 0 || keys[i] != keys[i - 1]; }
+
+__global__ __launch_bounds__(256) void rs_heads_count_kernel(const unsigned int* __restrict__ keys, int n, int* __restrict__ block_heads) {
+  __shared__ int s_w[4];
+  const int i = blockIdx.x * RUN_CHUNK + threadIdx.x;
+  int c = (i < n && is_head(keys, i)) ? 1 : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_heads[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// one workgroup: exclusive scan of the per-workgroup head counts; the total goes to the host mailbox (value + token)
+__global__ __launch_bounds__(1024) void rs_heads_scan_kernel(const int* __restrict__ block_heads, int nblocks, int* __restrict__ block_base,
+                                                             BuildMailbox* __restrict__ mb, unsigned int token) {
+  __shared__ int s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (nblocks + 1023) / 1024;
+  const int b0 = tid * per, b1 = min(nblocks, b0 + per);
+  int cnt = 0;
+  for (int b = b0; b < b1; b++) cnt += block_heads[b];
+  int inc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += v;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < wave; w++) wbase += s_w[w];
+  int run = wbase + inc - cnt;
+  for (int b = b0; b < b1; b++) { const int t = block_heads[b]; block_base[b] = run; run += t; }
+  if (tid == 1023) {
+    mb->value = run;   // == total: thread 1023 owns the last (possibly empty) slice
+    __threadfence_system();
+    __hip_atomic_store(&mb->value_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// every head sums its run: FLOAT accumulators, points in ascending index (the sort is stable) — the very additions
+// pcl::CentroidPoint performs; output ordered by key; the run of the sentinel key (non-finite points, always last) is dropped
+__global__ __launch_bounds__(256) void rs_centroid_kernel(const unsigned int* __restrict__ keys, const int* __restrict__ order, int n,
+                                                          const int* __restrict__ block_base, unsigned int sentinel,
+                                                          const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                          const float* __restrict__ w /*nullable*/, float* __restrict__ ox,
+                                                          float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ ow) {
+  __shared__ int s_w[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * RUN_CHUNK + threadIdx.x;
+  const bool head = (i < n) && is_head(keys, i);
+  const unsigned long long heads = __ballot(head);
+  if (lane == 0) s_w[wave] = __popcll(heads);
+  __syncthreads();
+  if (!head) return;
+  int r = block_base[blockIdx.x] + __popcll(heads & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+  for (int k = 0; k < wave; k++) r += s_w[k];
+  const unsigned int k = keys[i];
+  if (k == sentinel) return;
+  float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+  int j = i;
+  // the additions are a chain by definition (float, in index order); the gathers that feed them are not: four points in flight
+  for (; j + 3 < n && keys[j + 3] == k; j += 4) {   // sorted keys: keys[j + 3] == k implies the three before it
+    const int p0 = order[j], p1 = order[j + 1], p2 = order[j + 2], p3 = order[j + 3];
+    const float x0 = x[p0], y0 = y[p0], z0 = z[p0], x1 = x[p1], y1 = y[p1], z1 = z[p1];
+    const float x2 = x[p2], y2 = y[p2], z2 = z[p2], x3 = x[p3], y3 = y[p3], z3 = z[p3];
+    sx += x0; sy += y0; sz += z0; sx += x1; sy += y1; sz += z1; sx += x2; sy += y2; sz += z2; sx += x3; sy += y3; sz += z3;
+    if (w) { const float w0 = w[p0], w1 = w[p1], w2 = w[p2], w3 = w[p3]; sw += w0; sw += w1; sw += w2; sw += w3; }
+  }
+  for (; j < n && keys[j] == k; j++) {
+    const int pi = order[j];
+    sx += x[pi]; sy += y[pi]; sz += z[pi];
+    if (w) sw += w[pi];
+  }
+  const float m = (float)(j - i);
+  ox[r] = sx / m; oy[r] = sy / m; oz[r] = sz / m;
+  if (ow) ow[r] = w ? sw / m : 0.f;
+}
+
+struct LsdPlan { int passes, bits, steps, nblk, C; size_t table_bytes; };
+LsdPlan lsd_plan(size_t n, int end_bit) {
+  LsdPlan P;
+  end_bit = std::max(1, std::min(32, end_bit));
+  // digits of at most 11 bits: every pass is three launches (histogram, scan over the workgroups, scatter) whose table work —
+  // zeroing, prefixing and scanning C counters per workgroup — stays small next to the points (14-bit digits, 16 384 counters per
+  // 1 024-point workgroup, were measured first: 33 us per pass of a 147k-point scan, most of it tables)
+  P.passes = (end_bit + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  P.bits = (end_bit + P.passes - 1) / P.passes;
+  P.C = 1 << P.bits;
+  P.steps = (n <= 600000) ? 4 : 16;   // a scan: many small workgroups (one 147k-point scan = 144 of them); a map: fewer tables
+  const int chunk = RS_THREADS * P.steps;
+  P.nblk = (int)((n + chunk - 1) / chunk);
+  // [total C | blkoff nblk*C] u32, [hist nblk*C] u16
+  P.table_bytes = ((size_t)P.C + (size_t)P.nblk * P.C) * 4 + (size_t)(P.nblk + 8) * P.C * 2 + 64;
+  return P;
+}
+
+}  // namespace
+
+int sort_pairs_u32_lsd(unsigned int* key_a, unsigned int* key_b, int* val_a /*nullable: iota*/, int* val_a_buf, int* val_b, size_t n, int end_bit,
+                       DevBuf<char>& temp, hipStream_t stream, bool* result_in_b) {
+  *result_in_b = false;
+  if (n == 0) return LSR_OK;
+  if (n > (size_t)INT32_MAX / 2) { set_last_error("lsd sort: too many keys"); return LSR_ERR_INVALID_ARGUMENT; }
+  const LsdPlan P = lsd_plan(n, end_bit);
+  int st = temp.reserve(P.table_bytes);
+  if (st) return st;
+  unsigned int* total = reinterpret_cast<unsigned int*>(temp.p);
+  unsigned int* blkoff = total + P.C;
+  unsigned short* hist = reinterpret_cast<unsigned short*>((reinterpret_cast<uintptr_t>(blkoff + (size_t)P.nblk * P.C) + 15) & ~(uintptr_t)15);
+  const unsigned int mask = (unsigned int)(P.C - 1);
+  const unsigned int* kin = key_a;
+  const int* vin = val_a;
+  unsigned int* kout = key_b;
+  int* vout = val_b;
+  const bool fused = P.nblk <= RS_FUSED_MAX_BLOCKS;
+  const int row_pitch = (P.nblk + 7) & ~7;   // digit-major histogram rows of the fused form (the padding is never read as a count)
+
+  for (int p = 0; p < P.passes; p++) {
+    const int shift = p * P.bits;
+#define LSR_RS_HIST(S, T) \
+  hipLaunchKernelGGL((rs_hist_kernel<S, T>), dim3(P.nblk), dim3(RS_THREADS), (size_t)P.C * 4, stream, kin, (int)n, shift, mask, P.C, hist, row_pitch)
+    if (P.steps == 4) { if (fused) LSR_RS_HIST(4, true); else LSR_RS_HIST(4, false); }
+    else { if (fused) LSR_RS_HIST(16, true); else LSR_RS_HIST(16, false); }
+#undef LSR_RS_HIST
+    if (!fused) hipLaunchKernelGGL(rs_scan_kernel, dim3((P.C + 31) / 32), dim3(256), 0, stream, hist, P.nblk, P.C, blkoff, total);
+#define LSR_RS_SCATTER(S, F)                                                                                                             \
+  hipLaunchKernelGGL((rs_scatter_kernel<S, F>), dim3(P.nblk), dim3(RS_THREADS), (size_t)P.C * 8, stream, kin, vin, (int)n, shift, mask, P.bits, \
+                     blkoff, total, hist, row_pitch, P.nblk, P.C, kout, vout)
+    if (P.steps == 4) { if (fused) LSR_RS_SCATTER(4, true); else LSR_RS_SCATTER(4, false); }
+    else { if (fused) LSR_RS_SCATTER(16, true); else LSR_RS_SCATTER(16, false); }
+#undef LSR_RS_SCATTER
+    // ping-pong: the next pass reads what this one wrote
+    const bool wrote_b = (kout == key_b);
+    kin = kout; vin = vout;
+    kout = wrote_b ? key_a : key_b;
+    vout = wrote_b ? val_a_buf : val_b;
+    *result_in_b = wrote_b;
+  }
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+int sorted_runs_begin(const unsigned int* keys_sorted, size_t n, int* block_heads, int* block_base, BuildScratch& sc, hipStream_t stream,
+                      unsigned int* token_out) {
+  int st = sc.ensure_mailbox();
+  if (st) return st;
+  unsigned int token = ++sc.token;
+  if (token == 0) token = ++sc.token;
+  const int nblocks = (int)((n + RUN_CHUNK - 1) / RUN_CHUNK);
+  hipLaunchKernelGGL(rs_heads_count_kernel, dim3(nblocks), dim3(256), 0, stream, keys_sorted, (int)n, block_heads);
+  hipLaunchKernelGGL(rs_heads_scan_kernel, dim3(1), dim3(1024), 0, stream, block_heads, nblocks, block_base, sc.d_mb, token);
+  LSR_HIP(hipGetLastError());
+  *token_out = token;
+  return LSR_OK;
+}
+
+int sorted_runs_count(BuildScratch& sc, hipStream_t stream, unsigned int token, int* n_runs) {
+  int st = wait_mailbox_word(&sc.mb.p->value_token, token, stream, sc.wait_mode, "run count");
+  if (st) return st;
+  *n_runs = sc.mb.p->value;
+  return LSR_OK;
+}
+
+int sorted_runs_centroids(const unsigned int* keys_sorted, const int* order, size_t n, const int* block_base, unsigned int sentinel,
+                          const float* x, const float* y, const float* z, const float* w, float* ox, float* oy, float* oz, float* ow,
+                          hipStream_t stream) {
+  const int nblocks = (int)((n + RUN_CHUNK - 1) / RUN_CHUNK);
+  hipLaunchKernelGGL(rs_centroid_kernel, dim3(nblocks), dim3(256), 0, stream, keys_sorted, order, (int)n, block_base, sentinel, x, y, z, w, ox,
+                     oy, oz, ow);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+size_t sorted_runs_blocks(size_t n) { return (n + RUN_CHUNK - 1) / RUN_CHUNK; }
+
+}  // namespace lsr

@@ -2185,7 +2185,10 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
     min_b[k] = (int)floorf(mn[k] * inv_leaf);
     div_b[k] = (int)floorf(mx[k] * inv_leaf) - min_b[k] + 1;
   }
-  if ((st = sc.words.reserve(32 + 7 * (size_t)n + 16))) return st;
+  // A/B switch (env LSR_VG_SORT=rocprim: the rocPRIM radix sort + run_length_encode + scan path of rounds 1-4); read once
+  static const bool use_rocprim = [] { const char* e = getenv("LSR_VG_SORT"); return e && e[0] == 'r'; }();
+  const size_t nrb = sorted_runs_blocks((size_t)n);
+  if ((st = sc.words.reserve(32 + 7 * (size_t)n + 2 * nrb + 16))) return st;
   unsigned int* key_in = sc.words.p + 32;
   unsigned int* key_out = key_in + n;
   int* val_in = (int*)(key_out + n);
@@ -2194,10 +2197,27 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
   int* run_cnt = (int*)(run_key + n);
   int* run_off = run_cnt + n;
   int* d_nruns = run_off + n;
+  int* block_heads = d_nruns + 8;
+  int* block_base = block_heads + nrb;
   const unsigned int sentinel = (unsigned int)((int64_t)div_b[0] * div_b[1] * div_b[2]);  // one past the last leaf index
   hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
                      min_b[0], min_b[1], min_b[2], div_b[0], div_b[0] * div_b[1], sentinel, key_in, val_in, (uint4*)nullptr, (size_t)0,
                      (int*)nullptr, (size_t)0, (int*)nullptr);
+  if (!use_rocprim) {
+    // hand-written stable LSD sort (two passes for a 28-bit leaf index) + run heads + centroids: lsd_sort.hip
+    bool in_b = false;
+    if ((st = sort_pairs_u32_lsd(key_in, key_out, nullptr, val_in, val_out, (size_t)n, bits_for(sentinel), sc.temp, stream, &in_b))) return st;
+    const unsigned int* ks = in_b ? key_out : key_in;
+    const int* vs = in_b ? val_out : val_in;
+    unsigned int token = 0;
+    if ((st = sorted_runs_begin(ks, (size_t)n, block_heads, block_base, sc, stream, &token))) return st;
+    int n_runs = 0;
+    if ((st = sorted_runs_count(sc, stream, token, &n_runs))) return st;   // host mailbox: no D2H copy, no stream sync
+    const int n_out = n_runs - ((n_finite < (unsigned int)n) ? 1 : 0);     // minus the sentinel run
+    if ((st = out.resize(n_out, cloud.has_i))) return st;
+    return sorted_runs_centroids(ks, vs, (size_t)n, block_base, sentinel, cloud.x(), cloud.y(), cloud.z(), cloud.i(), out.x(), out.y(), out.z(),
+                                 out.i(), stream);
+  }
   if ((st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), sc.temp, stream))) return st;
   if ((st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
   int n_runs = 0;

@@ -169,3 +169,60 @@ def test_pointcloud2_stand_alone_filter_and_bad_layouts(O, scan):
         with pytest.raises(_capi.RegistrationError) as ei:
             r.setInputSourcePointCloud2(payload, 10, step, offs, 0.0, 100.0, 0.2)
         assert ei.value.status == -1
+
+
+# ---- the hand-written stable LSD radix sort behind N1 (csrc/lsd_sort.hip) ------------------------------------------------
+def _dense_cloud(n, extent, seed):
+    """n points: half of them uniform in a box of `extent`, half piled into a few leaves (hot digits in both passes)."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-extent, extent, (n // 2, 3)).astype(np.float32)
+    a[:, 2] *= 0.1
+    hot = rng.uniform(-1.0, 1.0, (n - n // 2, 3)).astype(np.float32) * np.float32(0.3)
+    pts = np.concatenate([a, hot])
+    return pts[rng.permutation(n)]
+
+
+@pytest.mark.parametrize("n,extent,leaf,what", [
+    (147443, 95.0, 0.2, "a raw scan: two passes, 1024-point workgroups"),
+    (700001, 95.0, 0.2, "a map-side cloud: 4096-point workgroups, ragged tail"),
+    (90000, 60.0, 0.05, "30-bit leaf index: three passes of 10 bits"),
+    (300000, 100.0, 0.08, "29-bit leaf index on 300k points"),
+    (5000, 2.0, 0.5, "a handful of leaves: one short pass, every wave full of equal digits"),
+    (63, 2.0, 0.5, "less than one wave"),
+])
+def test_lsd_sort_path_is_bit_identical_to_the_oracle(O, n, extent, leaf, what):
+    """pcl::VoxelGrid on the device through the hand-written LSD sort: same leaf set, same leaf-index order, float centroids
+    bit-identical (the sums of a leaf run over its points in ascending index — only a STABLE sort gives that)."""
+    from lidarslam_ros2_amd import NormalDistributionsTransform
+
+    pts = _dense_cloud(n, extent, seed=n)
+    pts[::977] = np.nan                                   # non-finite points: the sentinel run, dropped
+    r = NormalDistributionsTransform(device=0)
+    got = r.voxelGridFilter(synth.as_pointxyzi(pts), leaf)
+    ref = O.voxel_grid_filter(pts, leaf)
+    assert got.shape == ref.shape, what
+    assert np.array_equal(got, ref), what
+
+
+def test_lsd_sort_path_equals_the_rocprim_path():
+    """A/B: the same filter through rocPRIM's radix sort + run_length_encode + scan (LSR_VG_SORT=rocprim, rounds 1-4) in a child
+    process: bit-identical output."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = ("import numpy as np, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from lidarslam_ros2_amd import NormalDistributionsTransform, synth\n"
+            "rng = np.random.default_rng(11)\n"
+            "pts = rng.uniform(-60, 60, (200000, 3)).astype(np.float32); pts[:, 2] *= 0.05\n"
+            "out = NormalDistributionsTransform(device=0).voxelGridFilter(synth.as_pointxyzi(pts), 0.25)\n"
+            "np.save(sys.argv[1], out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for name, env in (("lsd", {}), ("rocprim", {"LSR_VG_SORT": "rocprim"})):
+            path = os.path.join(d, name + ".npy")
+            subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, **env), timeout=300)
+            outs.append(np.load(path))
+    assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
