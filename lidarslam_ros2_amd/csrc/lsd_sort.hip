@@ -104,32 +104,36 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned i
     if (FUSED) {
       const int me = (int)blockIdx.x;
       const int own = (C + RS_THREADS - 1) / RS_THREADS;   // digit slices this workgroup's threads own: uniform
+      const int nq = row_pitch / 8;                        // 16-byte pieces per digit-major row (row_pitch is a multiple of 32: no tail)
 #pragma unroll
-      for (int u = 0; u < RS_OWN; u++) {
-        if (u < own) {   // uniform branch: the loads below carry no per-lane condition, eight rows are in flight at a time
-          const int d = u * RS_THREADS + tid;
-          const bool dv = d < C;
-          // digit-major rows (rs_hist_kernel<.., true>): nblk counters of this digit, contiguous, 16-byte aligned
-          const uint4* row = reinterpret_cast<const uint4*>(hist + (size_t)(dv ? d : 0) * row_pitch);
-          unsigned int t = 0u, bl = 0u;
-          for (int b8 = 0; b8 < row_pitch / 8; b8 += 4) {   // four 16-byte loads (32 counters) in flight (sixteen were measured: slower)
-            uint4 q[4];
+      for (int u0 = 0; u0 < RS_OWN; u0 += 2) {
+        if (u0 < own) {   // uniform: the rows of two slices are read side by side, eight unconditional 16-byte loads in flight
+          const int d0 = u0 * RS_THREADS + tid, d1 = d0 + RS_THREADS;
+          const bool v0 = d0 < C, v1 = (u0 + 1 < own) && d1 < C;
+          const uint4* r0 = reinterpret_cast<const uint4*>(hist + (size_t)(v0 ? d0 : 0) * row_pitch);
+          const uint4* r1 = reinterpret_cast<const uint4*>(hist + (size_t)(v1 ? d1 : 0) * row_pitch);
+          unsigned int t0 = 0u, t1 = 0u, l0 = 0u, l1 = 0u;
+          for (int b8 = 0; b8 < nq; b8 += 4) {
+            uint4 q0[4], q1[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) q[k] = (b8 + k < row_pitch / 8) ? row[b8 + k] : make_uint4(0u, 0u, 0u, 0u);
+            for (int k = 0; k < 4; k++) { q0[k] = r0[b8 + k]; q1[k] = r1[b8 + k]; }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-              const unsigned int wv[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+              const unsigned int w0[4] = {q0[k].x, q0[k].y, q0[k].z, q0[k].w}, w1[4] = {q1[k].x, q1[k].y, q1[k].z, q1[k].w};
 #pragma unroll
               for (int e = 0; e < 4; e++) {
                 const int b = (b8 + k) * 8 + 2 * e;
-                const unsigned int lo = (b < nblk) ? (wv[e] & 0xFFFFu) : 0u, hi = (b + 1 < nblk) ? (wv[e] >> 16) : 0u;   // row padding holds no count
-                t += lo + hi;
-                bl += ((b < me) ? lo : 0u) + ((b + 1 < me) ? hi : 0u);
+                const bool in0 = b < nblk, in1 = b + 1 < nblk, be0 = b < me, be1 = b + 1 < me;   // the row padding holds no count
+                const unsigned int a_lo = in0 ? (w0[e] & 0xFFFFu) : 0u, a_hi = in1 ? (w0[e] >> 16) : 0u;
+                const unsigned int c_lo = in0 ? (w1[e] & 0xFFFFu) : 0u, c_hi = in1 ? (w1[e] >> 16) : 0u;
+                t0 += a_lo + a_hi; t1 += c_lo + c_hi;
+                l0 += (be0 ? a_lo : 0u) + (be1 ? a_hi : 0u);
+                l1 += (be0 ? c_lo : 0u) + (be1 ? c_hi : 0u);
               }
             }
           }
-          tot[u] = dv ? t : 0u;
-          below[u] = dv ? bl : 0u;
+          tot[u0] = v0 ? t0 : 0u; below[u0] = v0 ? l0 : 0u;
+          if (u0 + 1 < RS_OWN) { tot[u0 + 1] = v1 ? t1 : 0u; below[u0 + 1] = v1 ? l1 : 0u; }
         }
       }
     } else {
@@ -306,11 +310,12 @@ LsdPlan lsd_plan(size_t n, int end_bit) {
   P.passes = (end_bit + RS_MAX_BITS - 1) / RS_MAX_BITS;
   P.bits = (end_bit + P.passes - 1) / P.passes;
   P.C = 1 << P.bits;
-  P.steps = (n <= 600000) ? 4 : 16;   // a scan: many small workgroups (one 147k-point scan = 144 of them); a map: fewer tables
+  P.steps = (n <= 600000) ? 8 : 16;   // a scan: 2048-point workgroups (72 for a 147k-point scan: every workgroup reads the whole table of
+                                      // the pass; 1024-point workgroups were measured: 16 us per scatter, 9 of them reading 144 rows)
   const int chunk = RS_THREADS * P.steps;
   P.nblk = (int)((n + chunk - 1) / chunk);
   // [total C | blkoff nblk*C] u32, [hist nblk*C] u16
-  P.table_bytes = ((size_t)P.C + (size_t)P.nblk * P.C) * 4 + (size_t)(P.nblk + 8) * P.C * 2 + 64;
+  P.table_bytes = ((size_t)P.C + (size_t)P.nblk * P.C) * 4 + (size_t)(P.nblk + 32) * P.C * 2 + 64;
   return P;
 }
 
@@ -333,20 +338,20 @@ int sort_pairs_u32_lsd(unsigned int* key_a, unsigned int* key_b, int* val_a /*nu
   unsigned int* kout = key_b;
   int* vout = val_b;
   const bool fused = P.nblk <= RS_FUSED_MAX_BLOCKS;
-  const int row_pitch = (P.nblk + 7) & ~7;   // digit-major histogram rows of the fused form (the padding is never read as a count)
+  const int row_pitch = (P.nblk + 31) & ~31;   // digit-major histogram rows of the fused form (the padding is never read as a count)
 
   for (int p = 0; p < P.passes; p++) {
     const int shift = p * P.bits;
 #define LSR_RS_HIST(S, T) \
   hipLaunchKernelGGL((rs_hist_kernel<S, T>), dim3(P.nblk), dim3(RS_THREADS), (size_t)P.C * 4, stream, kin, (int)n, shift, mask, P.C, hist, row_pitch)
-    if (P.steps == 4) { if (fused) LSR_RS_HIST(4, true); else LSR_RS_HIST(4, false); }
+    if (P.steps == 8) { if (fused) LSR_RS_HIST(8, true); else LSR_RS_HIST(8, false); }
     else { if (fused) LSR_RS_HIST(16, true); else LSR_RS_HIST(16, false); }
 #undef LSR_RS_HIST
     if (!fused) hipLaunchKernelGGL(rs_scan_kernel, dim3((P.C + 31) / 32), dim3(256), 0, stream, hist, P.nblk, P.C, blkoff, total);
 #define LSR_RS_SCATTER(S, F)                                                                                                             \
   hipLaunchKernelGGL((rs_scatter_kernel<S, F>), dim3(P.nblk), dim3(RS_THREADS), (size_t)P.C * 8, stream, kin, vin, (int)n, shift, mask, P.bits, \
                      blkoff, total, hist, row_pitch, P.nblk, P.C, kout, vout)
-    if (P.steps == 4) { if (fused) LSR_RS_SCATTER(4, true); else LSR_RS_SCATTER(4, false); }
+    if (P.steps == 8) { if (fused) LSR_RS_SCATTER(8, true); else LSR_RS_SCATTER(8, false); }
     else { if (fused) LSR_RS_SCATTER(16, true); else LSR_RS_SCATTER(16, false); }
 #undef LSR_RS_SCATTER
     // ping-pong: the next pass reads what this one wrote
