@@ -1331,7 +1331,7 @@ typedef __attribute__((address_space(1))) const float GlbFloat;
 typedef __attribute__((address_space(1))) const int GlbInt;
 
 template <int NOFF, int TAB, int THREADS, bool BYVAL>
-__global__ __launch_bounds__(THREADS) void ndt_eval_lane_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void ndt_eval_lane_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq,
                                                                 const int nb, const int tab_bytes) {
   constexpr int NWAVES = THREADS / 64;
   constexpr int NT = (NOFF + 3) / 4;                // neighbours per partial sum
@@ -1523,7 +1523,8 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_lane_kernel(const NdtProblem
     // so skipping it changes no bit
     bool nb_any[NOFF];
 #pragma unroll
-    for (int o = 0; o < NOFF; o++) nb_any[o] = __ballot(nb_ok[o]) != 0ull;
+    for (int o = 0; o < NOFF; o++) nb_any[o] = __builtin_amdgcn_ballot_w64(nb_ok[o]) != 0ull;   // the i1 itself: __ballot(int) takes the
+                                                                                                 // predicate through a VGPR (v_cndmask 0/1 + v_cmp_ne per neighbour)
 
     // the four partial sums of the point in the quad kernel's order: partial q takes neighbours q, q + 4, q + 8, ...;
     // halves (0, 1) and (2, 3) are summed first, then the two halves
@@ -1569,12 +1570,15 @@ __global__ __launch_bounds__(THREADS) void ndt_eval_lane_kernel(const NdtProblem
       }
     }
     // S = {score, #pairs, A0..2, E00, E01, E02, E11, E12, E22}
+    // A point without a valid pair contributes zeros.  Its sums S are all zero already; its coordinates are replaced by zeros so
+    // that every product below is +-0 whatever the input held (a NaN point has no pair either): the terms come out +-0, the chunk
+    // sums and their integer pieces are the same bits as with an explicit "else: zeros" — which cost a branch whose two sides the
+    // compiler merged with 60 register moves per point (round 5, ISA of round 4's kernel)
     float o[29];
-    if (S[1] != 0.f) {
-      point_terms(hess, px, py, pz, S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8], S[9], S[10], L->jang, L->hang, o);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 29; k++) o[k] = 0.f;
+    {
+      const bool any_pair = S[1] != 0.f;
+      const float qx = any_pair ? px : 0.f, qy = any_pair ? py : 0.f, qz = any_pair ? pz : 0.f;
+      point_terms(hess, qx, qy, qz, S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8], S[9], S[10], L->jang, L->hang, o);
     }
     // ---- the chunk's canonical sums -> this workgroup's exact bins
     if (!hess) {
