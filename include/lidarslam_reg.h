@@ -72,7 +72,9 @@ typedef enum lsr_key {
   /* tuning (NO effect on results: every NDT derivative kernel returns the same bits — the sum of a pass is defined on the
      input, csrc/ndt.hip: canon): */
   LSR_NDT_WORKGROUP = 40,             /* lane kernel: threads per workgroup (512, 1024); quad kernel: source points per
-                                         workgroup (64, 128; four lanes each); 0 = automatic (512 / 128) */
+                                         workgroup (64, 128; four lanes each); 0 = automatic (512 / 128).  256 (the default of
+                                         the rounds 1-3 kernel) is accepted and means automatic; as an environment preset an
+                                         unknown value is reported on stderr and ignored */
   LSR_NDT_TABLE_MODE = 41,            /* where the pass reads leaf records: -1 = automatic, 0 = dense global table,
                                          1 = compact global table, 2 = whole table staged in LDS (when it fits), 3 = per
                                          workgroup the box of cells its tile-ordered points touch staged in LDS (dense tables

@@ -773,7 +773,11 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   h->ndt.resolution = 1.0; h->ndt.step_size = 0.1; h->ndt.outlier_ratio = 0.55; h->ndt.trans_eps = 0.1;
   h->ndt.max_iterations = 35; h->ndt.neighborhood = LSR_DIRECT7; h->ndt.d1_sign = 1;
   // tuning defaults may be preset from the environment (A/B runs without touching the caller)
-  if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 512 || v == 1024) h->ndt_threads = v; }
+  if (const char* e = std::getenv("LSR_NDT_WORKGROUP")) {
+    const int v = std::atoi(e);
+    if (v == 64 || v == 128 || v == 512 || v == 1024) h->ndt_threads = v;
+    else if (v != 0) fprintf(stderr, "[lidarslam_reg] LSR_NDT_WORKGROUP=%d ignored: 64 / 128 (quad kernel, points) or 512 / 1024 (lane kernel, threads)\n", v);
+  }
   if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 3) h->ndt_table_mode = v; }
   if (const char* e = std::getenv("LSR_NDT_QUAD")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_quad = v; }
   if (const char* e = std::getenv("LSR_NDT_SORT")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_sort = v; }
@@ -884,6 +888,11 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
     case LSR_HESSIAN_D1_SIGN: h->ndt.d1_sign = (v >= 0) ? 1 : -1; return LSR_OK;
     case LSR_PROFILE: h->profile = v ? 1 : 0; return LSR_OK;
     case LSR_NDT_WORKGROUP:
+      if (v == 256) {   // rounds 1-3: the one-lane kernel's workgroup size (then the default).  That kernel is gone: automatic, said once.
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "[lidarslam_reg] LSR_NDT_WORKGROUP = 256 is a geometry of an earlier kernel: using the automatic choice (0)\n"); }
+        h->ndt_threads = 0; return LSR_OK;
+      }
       if (v != 0 && v != 64 && v != 128 && v != 512 && v != 1024) { set_last_error("NDT workgroup key must be 0 (auto), 64 / 128 (quad kernel: points) or 512 / 1024 (lane kernel: threads)"); return LSR_ERR_INVALID_ARGUMENT; }
       h->ndt_threads = v; return LSR_OK;
     case LSR_NDT_TABLE_MODE:

@@ -40,6 +40,8 @@ struct PointCloud {
   using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
   std::vector<PointT> points;
   std::size_t size() const { return points.size(); }
+  const PointT& operator[](std::size_t i) const { return points[i]; }
+  PointT& operator[](std::size_t i) { return points[i]; }
 };
 
 using Indices = std::vector<int>;   // pcl::Indices (PCL 1.12: std::vector<index_t>, index_t = int)

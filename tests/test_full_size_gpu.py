@@ -209,7 +209,10 @@ def test_cfg4_hard_candidates_match_the_cpu_fixture(pool):
     from lidarslam_ros2_amd import align_batch
     from lidarslam_ros2_amd.registration import fitness_score_batch, set_input_target_batch
 
-    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_candidates_oracle.npz"))
+    from golden_fixtures import load_golden
+
+    fx, origin = load_golden("cfg4_candidates_oracle")
+    print("[golden] cfg-4 hard candidates held to the %s fixture" % origin)
     hard = [11, 30, 43, 48]
     cases = [synth.cfg_loop_candidate(c, pool=pool) for c in hard]
     regs = [make_ndt(5.0, 0.01, 100) for _ in hard]
@@ -263,7 +266,10 @@ def cfg4_all(pool):
     import os
 
     here = os.path.dirname(os.path.abspath(__file__))
-    fx = np.load(os.path.join(here, "golden", "cfg4_candidates_oracle.npz"))
+    from golden_fixtures import load_golden
+
+    fx, origin = load_golden("cfg4_candidates_oracle")   # eps 0.01: the reference's own dump (oracle/ref_recipe) when there is one
+    print("[golden] all 64 cfg-4 candidates held to the %s fixture" % origin)
     fxt = np.load(os.path.join(here, "golden", "cfg4_candidates_oracle_tight.npz"))
     cases = pool.map(synth.cfg_loop_candidate, range(64), chunksize=1)
     return fx, fxt, cases

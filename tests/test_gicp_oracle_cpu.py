@@ -180,7 +180,10 @@ def test_oracle_reproduces_the_gicp_golden_fixture():
     Integer work bit-exact; floating point to the last few ulps (thread count and summation order are fixed)."""
     import os
 
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "gicp_small_golden.npz"))
+    from golden_fixtures import load_golden
+
+    gold, origin = load_golden("gicp_small_golden")
+    print("[golden] the GICP oracle is checked against the %s fixture" % origin)
     case = synth.small_case(n_source=int(gold["n_source"]), n_keyframes=int(gold["n_keyframes"]))
     assert case.target.shape[0] == int(gold["n_target_raw"]) and np.array_equal(case.source, gold["source"])
     tgt = O.voxel_grid_filter(case.target, float(gold["leaf"]))

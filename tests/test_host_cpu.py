@@ -385,6 +385,23 @@ def test_pcl_binding_answers_getFitnessScore_left_on_the_base_pointer(tmp_path):
     assert "called through pcl::Registration*" in run.stderr and "not getFitnessScore's walk" in run.stderr, run.stderr
 
 
+def test_reference_dumper_is_well_formed():
+    """oracle/ref_recipe/dump_fixtures.cpp — the program that, on a machine with PCL 1.12 and a checkout of rsasaki0109/ndt_omp_ros2,
+    dumps the REFERENCE's own numbers for every committed fixture (README there) — compiled with -fsyntax-only against stand-in
+    pcl / pclomp headers (tests/cpp/mock), and the recipe's Python steps parse: the one-command pin cannot rot unnoticed."""
+    import ast
+    import subprocess
+
+    rec = os.path.join(ROOT, "oracle", "ref_recipe")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "tests", "cpp", "mock"),
+                           os.path.join(rec, "dump_fixtures.cpp")])
+    for f in ("export_inputs.py", "import_results.py"):
+        ast.parse(open(os.path.join(rec, f)).read())
+    cm = open(os.path.join(rec, "CMakeLists.txt")).read()
+    assert "dump_fixtures.cpp" in cm and "src/pclomp" in cm
+    assert "ref:" in open(os.path.join(ROOT, "oracle", "Makefile")).read()
+
+
 def test_c_abi_argument_validation_needs_no_device():
     """Error conventions of the boundary: status codes, never an exception or a crash — checked on
     the paths that do not need a device (null handles, invalid method, status strings)."""

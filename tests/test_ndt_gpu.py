@@ -197,7 +197,10 @@ def test_gpu_matches_the_committed_golden_fixture():
     path against the fixture itself, independent of the oracle library being rebuilt identically on this box."""
     import os
 
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ndt_small_golden.npz"))
+    from golden_fixtures import load_golden
+
+    gold, origin = load_golden("ndt_small_golden")   # the reference's own dump (oracle/ref_recipe) when there is one
+    print("[golden] the HIP path is held to the %s fixture" % origin)
     case = synth.small_case(n_source=int(gold["n_source"]), n_keyframes=int(gold["n_keyframes"]))
     assert case.target.shape[0] == int(gold["n_target"]) and np.array_equal(case.source, gold["source"])
     res = float(gold["res"])

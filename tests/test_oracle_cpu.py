@@ -223,7 +223,10 @@ def test_nn_oracle_exact_vs_bruteforce():
 def test_oracle_reproduces_golden():
     """tests/golden/ndt_small_golden.npz was written by tests/golden/make_golden.py from this oracle;
     it pins the oracle (and the GPU tests' expectations) against silent drift."""
-    gold = np.load(GOLDEN)
+    from golden_fixtures import load_golden
+
+    gold, origin = load_golden("ndt_small_golden")   # the reference's own dump when oracle/ref_recipe has produced one
+    print("[golden] test_oracle_reproduces_golden checks the oracle against the %s fixture" % origin)
     case = synth.small_case(n_source=int(gold["n_source"]), n_keyframes=int(gold["n_keyframes"]))
     assert np.array_equal(case.source, gold["source"]) and np.array_equal(case.guess, gold["guess"])
     assert case.target.shape[0] == int(gold["n_target"])
@@ -233,6 +236,37 @@ def test_oracle_reproduces_golden():
     assert np.allclose(g, gold["grad"], rtol=1e-10, atol=1e-9) and np.allclose(H, gold["hess"], rtol=1e-10, atol=1e-7)
     r = O.ndt_align(grid, case.source, case.guess, resolution=float(gold["res"]), trans_eps=0.01, num_threads=1)
     assert np.allclose(r["final"], gold["final_eps001"], atol=1e-6) and r["iterations"] == int(gold["iters_eps001"])
+
+
+def test_fixture_loader_prefers_a_reference_dump(tmp_path, monkeypatch):
+    """tests/golden_fixtures.py: a `ref_<name>.npz` (what oracle/ref_recipe writes from the REFERENCE's own pclomp code) wins over the
+    oracle's `<name>.npz`, arrays the dump does not hold fall back to the oracle fixture, and the import step of the recipe writes the
+    schema the tests read.  Exercised with the oracle's own numbers routed through the recipe's JSON -> npz step."""
+    import json
+    import subprocess
+    import sys
+
+    from golden_fixtures import load_golden
+
+    gold = np.load(GOLDEN)
+    monkeypatch.setenv("LSR_GOLDEN_DIR", str(tmp_path))
+    g0, origin0 = load_golden("ndt_small_golden")
+    assert origin0 == "oracle" and float(g0["score"]) == float(gold["score"])
+    col = lambda M: np.asarray(M, np.float64).T.reshape(-1).tolist()   # the dumper prints Eigen's column-major storage
+    res = {"ndt_small": {"score": float(gold["score"]) + 1.0, "grad": gold["grad"].tolist(), "hess": gold["hess"].reshape(-1).tolist(),
+                         "final_eps001": col(gold["final_eps001"]), "iters_eps001": int(gold["iters_eps001"]),
+                         "final_tight": col(gold["final_tight"]), "iters_tight": int(gold["iters_tight"]),
+                         "leaf_idx": gold["leaf_idx"].tolist(), "leaf_n": gold["leaf_n"].tolist(),
+                         "min_b": gold["min_b"].tolist(), "max_b": gold["max_b"].tolist()}}
+    rj = tmp_path / "results.json"
+    rj.write_text(json.dumps(res))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "oracle", "ref_recipe", "import_results.py"), str(rj), str(tmp_path)])
+    g1, origin1 = load_golden("ndt_small_golden")
+    assert origin1 == "reference"
+    assert float(g1["score"]) == float(gold["score"]) + 1.0                       # the dump's value, not the oracle's
+    assert np.array_equal(g1["final_eps001"], gold["final_eps001"]) and int(g1["iters_tight"]) == int(gold["iters_tight"])
+    assert np.array_equal(g1["source"], gold["source"]) and float(g1["res"]) == float(gold["res"])   # inputs: from the oracle fixture
 
 
 # ---- loop-closure gate (SURVEY.md 8f N3) ---------------------------------------------------------
