@@ -81,14 +81,17 @@ int device_cus(int device) {
 
 // Workgroups per registration.  Every workgroup of a pass pays the fixed head of the launch (totals of the previous pass,
 // controller step, next request: 2.5-4 us) before it evaluates a point, so a pass never launches more workgroups than the
-// chip holds at once — 2048 threads per CU: two 512-thread workgroups of the quad kernel (128 points each) or of the lane
-// kernel, one of its 1024-thread workgroups — and lets each of them walk several batches of points instead.
+// chip holds at once — two 512-thread workgroups of the quad kernel (128 points each) or of the lane kernel per CU, one of its
+// 1024-thread workgroups — and lets each of them walk several batches of points instead.
 // `threads`: THREADS per workgroup; `points`: source points a workgroup takes per trip (quad kernel: threads / 4).
 constexpr int NDT_QUAD_BATCH_MAX = 1;
 constexpr int NDT_LANE_SINGLE_MIN = 65536;   // source points from which a single registration uses the lane kernel
 int ndt_resident_wgs(int device, int threads) {
   static const int wgs_per_cu = [] { const char* e = std::getenv("LSR_NDT_WGS_PER_CU"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 0; }();
-  return device_cus(device) * (wgs_per_cu ? wgs_per_cu : std::max(1, 2048 / std::max(64, threads)));
+  // two 512-thread workgroups per CU (128 VGPRs per lane: four waves per SIMD; the lane kernel's LDS table + staging tiles fit twice),
+  // one of 1024 threads.  (Until round 5 this returned 2048 / threads = 4 for 512: more workgroups than are ever co-resident, each of
+  // them paying the head.  Measured on the 64-candidate chain: 1.46 ms with 4, 1.46 ms with 2, 2.04 ms with 1.)
+  return device_cus(device) * (wgs_per_cu ? wgs_per_cu : (threads >= 1024 ? 1 : 2));
 }
 int ndt_nblocks(size_t n, int device, int batch, int threads, int points) {
   int nb = (int)((n + points - 1) / points);

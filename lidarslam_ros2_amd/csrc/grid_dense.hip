@@ -175,29 +175,30 @@ __global__ __launch_bounds__(256) void vg_scan_kernel(const unsigned short* __re
 // one workgroup: exclusive scan over the cells -> start[0..C] (start[C] = n)
 __device__ __forceinline__ void vg_cellscan_kernel_body(const unsigned int* __restrict__ total, int C, unsigned int* __restrict__ start,
                                                         unsigned int* __restrict__ rank /*nullable*/, const int blk_x) {
-  __shared__ unsigned int s_s[1024], s_o[1024];
-  const int tid = threadIdx.x;
+  // counts and occupancy flags of a thread's slice, a scan inside every wave (shuffles), one barrier, the waves' totals added up by
+  // every thread (until round 5: a Hillis-Steele scan over 1024 LDS words, twenty barriers of sixteen waves each: 6.2 -> 4.7 us)
+  __shared__ unsigned int s_ws[16], s_wo[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (C + 1023) / 1024;
   const int c0 = tid * per, c1 = min(C, c0 + per);
   unsigned int cnt = 0u, occ = 0u;
   for (int c = c0; c < c1; c++) { const unsigned int t = total[c]; cnt += t; occ += (t != 0u); }
-  s_s[tid] = cnt;
-  s_o[tid] = occ;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const unsigned int v = (tid >= off) ? s_s[tid - off] : 0u, w = (tid >= off) ? s_o[tid - off] : 0u;
-    __syncthreads();
-    s_s[tid] += v;
-    s_o[tid] += w;
-    __syncthreads();
+  unsigned int ic = cnt, io = occ;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned int v = __shfl_up(ic, d, 64), w = __shfl_up(io, d, 64);
+    if (lane >= d) { ic += v; io += w; }
   }
-  unsigned int run = s_s[tid] - cnt, rrun = s_o[tid] - occ;
+  if (lane == 63) { s_ws[wave] = ic; s_wo[wave] = io; }
+  __syncthreads();
+  unsigned int run = ic - cnt, rrun = io - occ, all = 0u;
+  for (int w = 0; w < 16; w++) { if (w < wave) { run += s_ws[w]; rrun += s_wo[w]; } all += s_ws[w]; }
   for (int c = c0; c < c1; c++) {
     const unsigned int t = total[c];
     start[c] = run; run += t;
     if (rank) { rank[c] = rrun; rrun += (t != 0u); }   // rank of the cell among the cells that hold points (the sentinel bin counts too: it is last)
   }
-  if (tid == 1023) start[C] = s_s[1023];
+  if (tid == 1023) start[C] = all;
 }
 __global__ __launch_bounds__(1024) void vg_cellscan_kernel(const unsigned int* __restrict__ total, int C, unsigned int* __restrict__ start,
                                                            unsigned int* __restrict__ rank) {
@@ -266,7 +267,10 @@ __global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict
 }
 
 // K1 + K2, one WAVE per grid cell: lane l sums the cell's points l + 64*t (cell order = point order), the lanes are combined by a
-// fixed butterfly, lane 0 finalises the leaf (leaf_finalize_dev).  Dense record layout
+// fixed butterfly, lane 0 finalises the leaf (leaf_finalize_dev).  (Round 5 measured summing the cells of >= 2048 points with the
+// whole workgroup — sums defined on 256 virtual lanes so that both forms return the same bits, four accumulator sets per lane in the
+// wave form, predicated batches instead of serial tails: bit-exact, and slower: 25 us against 22 us for one 661k-point target,
+// 0.28 ms against 0.25 ms for the targets of an 8-candidate share.  The large cells are not what this kernel waits for.)  Dense record layout
 // (record of cell c at rec[4c]); empty cells are written as zero records.
 constexpr int VG_LEAF_THREADS = 256;
 __device__ __forceinline__ void vg_leaf_kernel_body(const float* __restrict__ sx, const float* __restrict__ sy,

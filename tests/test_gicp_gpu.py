@@ -43,12 +43,6 @@ def test_covariances_match_oracle(O, case):
         # every regularised covariance has eigenvalues (eps, 1, 1)
         w = np.linalg.eigvalsh(cov)
         assert np.allclose(w, [1e-3, 1, 1], atol=1e-9)
-        # exact same 20 neighbours; eigenvectors of the same fp64 matrix by two Jacobi codes.  The plane
-        # normal of a near-isotropic neighbourhood is ill-conditioned, so compare the bulk tightly and the
-        # worst case loosely.
-        err = np.abs(cov - ref).max(axis=(1, 2))
-        assert np.quantile(err, 0.99) < 1e-6
-        assert err.max() < 1e-2
         # BEFORE the regularisation there is nothing ill-conditioned: same neighbours, same FLOAT products summed in
         # double in the same order -> the sample covariances agree to fp64 rounding (a few ulps of the k-term sums of
         # squared coordinates ~1e4 m^2: 1e-11 absolute, 1e-10 allowed)
@@ -56,6 +50,12 @@ def test_covariances_match_oracle(O, case):
         raw_ref = O.gicp_raw_covariances(O.NearestNeighbour(pts, 1.0), pts)
         assert np.abs(raw - raw_ref).max() < 1e-10
         assert np.abs(raw - np.swapaxes(raw, 1, 2)).max() == 0.0     # symmetric by construction
+        # AFTER it: exact same 20 neighbours, eigenvectors of the same fp64 matrix by the same cyclic Jacobi sweep (rotation order
+        # (0,1) (0,2) (1,2), same angle formula) written two ways.  U diag(1, 1, eps) U^T = I - (1 - eps) n n^T depends only on the
+        # normal n, the eigenvector of the smallest eigenvalue, and n is as well determined as that eigenvalue is separated from the
+        # next one: a rounding error of a few 1e-16 in the matrix turns n by ~1e-15 / gap, gap = (l1 - l0) / l2.  The bar follows
+        # the conditioning of every single neighbourhood (VERDICT r04 #6b: no more "99 % below 1e-6, the rest below 1e-2")
+        _assert_cov_close(cov, ref, raw)
 
 
 def test_plane_covariance_is_diag_in_plane_frame(O):
@@ -127,11 +127,26 @@ def test_too_few_points_and_no_correspondences(O, case):
     assert np.allclose(g.getFinalTransformation(), np.eye(4))
 
 
-def _assert_cov_close(cov, ref):
-    # same neighbours, eigenvectors of the same fp64 matrix by two Jacobi codes (see test_covariances_match_oracle)
+def _assert_cov_close(cov, ref, raw):
+    """Regularised GICP covariances against the oracle's, each held to the conditioning of ITS neighbourhood:
+    |cov - ref| <= 1e-9 + 2e-14 / gap with gap = (l1 - l0) / l2 of the sample covariance `raw` (a well separated normal: 1e-9; a gap
+    of 1e-6: 2e-8; ...).  Neighbourhoods whose two smallest eigenvalues coincide to 2e-12 of the largest (points along a pole or an
+    edge: the normal is free within a plane and the bar would exceed 1e-2) are counted — they must be rare — and only required to be
+    valid answers: eigenvalues (eps, 1, 1) is asserted by the caller, and the chosen normal must lie in the near-null space."""
     err = np.abs(cov - ref).max(axis=(1, 2))
-    assert np.quantile(err, 0.99) < 1e-6
-    assert err.max() < 1e-2
+    lam = np.linalg.eigvalsh(raw)                                  # ascending; raw is symmetric by construction
+    lam = np.abs(lam); lam.sort(axis=1)                            # the regularisation orders by |eigenvalue|
+    gap = (lam[:, 1] - lam[:, 0]) / np.maximum(lam[:, 2], 1e-300)
+    allowed = 1e-9 + 2e-14 / np.maximum(gap, 1e-300)
+    degenerate = allowed > 1e-2
+    assert degenerate.mean() <= 0.01, ("degenerate neighbourhoods", int(degenerate.sum()), cov.shape[0])
+    bad = np.nonzero(~degenerate & (err > allowed))[0]
+    assert bad.size == 0, [(int(i), float(err[i]), float(allowed[i]), float(gap[i])) for i in bad[:5]]
+    for i in np.nonzero(degenerate)[0]:                            # any unit vector of the near-null plane is a right answer
+        n = np.linalg.eigh(np.eye(3) - cov[i])[1][:, -1]           # I - cov = (1 - eps) n n^T
+        assert float(n @ raw[i] @ n) <= lam[i, 1] * (1 + 1e-6) + 1e-12, i
+    print("GICP covariances: %d of %d neighbourhoods degenerate (gap < 2e-12), worst error elsewhere %.2e" %
+          (int(degenerate.sum()), cov.shape[0], float(err[~degenerate].max()) if (~degenerate).any() else 0.0))
 
 
 @pytest.mark.parametrize("k", [5, 10, 32])
@@ -148,7 +163,7 @@ def test_covariances_other_k(O, k):
     g.setInputSource(src)
     cov = g.covariances("source")
     ref = O.gicp_covariances(O.NearestNeighbour(src), src, k=k, num_threads=min(16, O.max_threads()))
-    _assert_cov_close(cov, ref)
+    _assert_cov_close(cov, ref, g.covariances("source", raw=True))
 
 
 def test_k_correspondences_range():
@@ -178,8 +193,8 @@ def test_covariances_isolated_outliers_take_the_cooperative_path(O):
     g.setInputSource(pts)
     cov = g.covariances("source")
     ref = O.gicp_covariances(O.NearestNeighbour(pts), pts, num_threads=min(16, O.max_threads()))
-    _assert_cov_close(cov, ref)
-    _assert_cov_close(g.covariances("target"), ref)
+    _assert_cov_close(cov, ref, g.covariances("source", raw=True))
+    _assert_cov_close(g.covariances("target"), ref, g.covariances("target", raw=True))
 
 
 _VARIANT_CODE = r"""
