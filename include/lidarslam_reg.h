@@ -280,6 +280,13 @@ int lsr_comm_unique_id(void* id128);
 /* every rank: ncclCommInitRank on device_id (id128 may be NULL when world == 1) */
 int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_comm* out);
 int lsr_comm_destroy(lsr_comm c);
+/* "N keyframes vs. one submap" across ranks: the rank `root` holds the target cloud — the submap
+ * scanmatcher_component.cpp:449-464 assembles and :307 hands to registration_->setInputTarget — and every rank of the communicator
+ * ends up with it as the input target of its handle `h`: one ncclBroadcast of the records (device to device over xGMI, behind a
+ * 16-byte header with the point count), then the same voxel grid built on every rank.  pts / stride_bytes / n / on_device are read on
+ * the root only.  COLLECTIVE: every rank calls it; a one-rank communicator created without an id hands the cloud straight to
+ * lsr_set_input_target.  Reference call it generalises: registration_->setInputTarget(targeted_cloud_ptr), one node, one object. */
+int lsr_set_input_target_bcast(lsr_comm c, lsr_handle h, const void* pts, size_t stride_bytes, size_t n, int on_device, int root);
 /* local_handles / local_guesses: this rank's share (local_count = lsr_shard_range count), targets and sources already
  * set; with_fitness != 0 adds getFitnessScore() per registration (graph_based_slam_component.cpp:231).
  * all_records: global_count entries, in batch order, identical on every rank. */

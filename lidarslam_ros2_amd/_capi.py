@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
     "lsr_debug_angle_tables", "lsr_set_input_source_pc2", "lsr_get_source_pc2", "lsr_voxel_grid_filter_pc2", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
     "lsr_shard_plan", "lsr_align_batch_planned", "lsr_align_fitness_batch",
-    "lsr_set_input_target_batch", "lsr_set_input_source_batch", "lsr_get_fitness_score_batch",
+    "lsr_set_input_target_batch", "lsr_set_input_source_batch", "lsr_get_fitness_score_batch", "lsr_set_input_target_bcast",
 ]
 
 
@@ -144,6 +144,7 @@ def load() -> C.CDLL:
     L.lsr_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.lsr_comm_destroy.argtypes = [vp]
     L.lsr_align_batch_sharded.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, fp, C.c_int, C.POINTER(ShardRecord)]
+    L.lsr_set_input_target_bcast.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
     L.lsr_align_fitness_batch.argtypes = [C.POINTER(vp), C.c_int, fp, fp, C.POINTER(Result), C.c_double, dp]
     i32p = C.POINTER(C.c_int32)
     L.lsr_shard_plan.argtypes = [C.c_int, dp, C.c_int, i32p, i32p, i32p]

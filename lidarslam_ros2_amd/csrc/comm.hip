@@ -19,6 +19,7 @@ typedef int (*fn_get_unique_id)(UniqueId*);
 typedef int (*fn_comm_init_rank)(void** comm, int nranks, UniqueId id, int rank);
 typedef int (*fn_comm_destroy)(void* comm);
 typedef int (*fn_all_gather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream);
+typedef int (*fn_broadcast)(const void* send, void* recv, size_t count, int dtype, int root, void* comm, hipStream_t stream);
 typedef const char* (*fn_get_error_string)(int);
 
 struct Rccl {
@@ -27,6 +28,7 @@ struct Rccl {
   fn_comm_init_rank comm_init_rank = nullptr;
   fn_comm_destroy comm_destroy = nullptr;
   fn_all_gather all_gather = nullptr;
+  fn_broadcast broadcast = nullptr;   // optional (lsr_set_input_target_bcast); absent in no RCCL this library has met
   fn_get_error_string get_error_string = nullptr;
 };
 
@@ -43,6 +45,7 @@ Rccl* rccl() {
     r.comm_init_rank = (fn_comm_init_rank)dlsym(r.lib, "ncclCommInitRank");
     r.comm_destroy = (fn_comm_destroy)dlsym(r.lib, "ncclCommDestroy");
     r.all_gather = (fn_all_gather)dlsym(r.lib, "ncclAllGather");
+    r.broadcast = (fn_broadcast)dlsym(r.lib, "ncclBroadcast");
     r.get_error_string = (fn_get_error_string)dlsym(r.lib, "ncclGetErrorString");
     if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather) { dlclose(r.lib); r.lib = nullptr; }
   });
@@ -68,6 +71,8 @@ struct lsr_comm_s {
   // records to the all-gather instead of leaving the collective.
   lsr::DevBuf<lsr_shard_record> d_send, d_recv;
   size_t armed = 0;   // records of d_send currently holding the invalid pattern
+  lsr::DevBuf<unsigned char> d_cloud;          // lsr_set_input_target_bcast: the broadcast target's records on this rank
+  lsr::DevBuf<unsigned long long> d_header;    // ... and its {point count, stride} header
 };
 constexpr size_t COMM_PREALLOC = 1024;
 
@@ -283,6 +288,44 @@ int lsr_align_batch_planned(lsr_comm c, lsr_handle* local_handles, int local_cou
     return LSR_ERR_HIP;
   }
   return finish(LSR_OK);
+}
+
+// "N keyframes vs. one submap" across ranks (ncclBroadcast of the target, voxel table built redundantly per rank): the
+// root holds the submap (scanmatcher_component.cpp:449-464 assembles it; :307 hands it to the registration object), every rank
+// registers its own share of the scans against it.  Two broadcasts on the communicator's stream — a 16-byte header {points, stride},
+// then the records, device to device over xGMI — and every rank builds the same voxel grid from the same bytes (lsr_set_input_target
+// on the handle).  A one-rank communicator hands the cloud straight through.  Collective: every rank of the communicator calls it.
+int lsr_set_input_target_bcast(lsr_comm c, lsr_handle h, const void* pts, size_t stride_bytes, size_t n, int on_device, int root) {
+  if (!c || !h || root < 0 || root >= c->world) { lsr::set_last_error("bad broadcast-target arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  const bool is_root = (c->rank == root);
+  if (is_root && ((n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0)) {
+    // the root still has to enter the collective: it announces an empty cloud, every rank then fails alike
+    n = 0; stride_bytes = 12; pts = nullptr;
+    lsr::set_last_error("broadcast target: the root's cloud is ill-formed (null pointer or bad stride)");
+  }
+  const bool collective = !(c->world == 1 && !c->comm);
+  if (!collective)
+    return on_device ? lsr_set_input_target_device(h, pts, stride_bytes, n) : lsr_set_input_target(h, pts, stride_bytes, n);
+  Rccl* r = rccl();
+  if (!r || !c->comm || !r->broadcast) { lsr::set_last_error("communicator has no RCCL broadcast"); return LSR_ERR_NOT_IMPLEMENTED; }
+  lsr::DeviceGuard guard(c->device);
+  if (!guard.ok) { lsr::set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
+  int st;
+  if ((st = c->d_header.reserve(2))) return st;
+  unsigned long long header[2] = {(unsigned long long)n, (unsigned long long)stride_bytes};
+  if (is_root) LSR_HIP(hipMemcpyAsync(c->d_header.p, header, sizeof(header), hipMemcpyHostToDevice, c->stream));
+  int rc = r->broadcast(c->d_header.p, c->d_header.p, sizeof(header), /*ncclUint8*/ 1, root, c->comm, c->stream);
+  if (rc) return rccl_fail("ncclBroadcast (header)", rc);
+  LSR_HIP(hipMemcpyAsync(header, c->d_header.p, sizeof(header), hipMemcpyDeviceToHost, c->stream));
+  LSR_HIP(hipStreamSynchronize(c->stream));
+  const size_t count = (size_t)header[0], stride = (size_t)header[1], bytes = count * stride;
+  if (count == 0) { lsr::set_last_error("broadcast target: the root announced an empty cloud"); return LSR_ERR_NO_TARGET; }
+  if ((st = c->d_cloud.reserve(bytes))) return st;   // (a rank that cannot allocate leaves its peers in the second broadcast: there is no abort in the C ABI)
+  if (is_root) LSR_HIP(hipMemcpyAsync(c->d_cloud.p, pts, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  rc = r->broadcast(c->d_cloud.p, c->d_cloud.p, bytes, /*ncclUint8*/ 1, root, c->comm, c->stream);
+  if (rc) return rccl_fail("ncclBroadcast (cloud)", rc);
+  LSR_HIP(hipStreamSynchronize(c->stream));   // the handle reads the records on ITS stream
+  return lsr_set_input_target_device(h, c->d_cloud.p, stride, count);
 }
 
 // the static block partition is the plan { order = identity, rank_first = lsr_shard_range }

@@ -150,6 +150,53 @@ def register_sharded(n_items: int, register_local: Callable[[Sequence[int]], Lis
     return [unpack_record(table[i]) for i in range(n_items)]
 
 
+def broadcast_target(reg, cloud, src: int = 0, device=None):
+    """"N keyframes vs. one submap" across ranks: rank `src` holds the target cloud — (n, c>=3) fp32, what
+    scanmatcher_component.cpp:307 hands to registration_->setInputTarget — and every rank sets it as the input target of its own
+    registration object.  Two torch.distributed broadcasts (shape, then the records: "nccl" = RCCL over xGMI on GPUs, "gloo" in the
+    CPU tests); the voxel grid is built redundantly per rank.  Returns the cloud as this rank received it.  Without an initialised
+    process group (one rank) the cloud goes straight through."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if reg is not None:
+            reg.setInputTarget(cloud)
+        return cloud
+    rank = dist.get_rank()
+    shape = torch.zeros(2, dtype=torch.int64)
+    if rank == src:
+        a = np.ascontiguousarray(np.asarray(cloud, np.float32))
+        shape[0], shape[1] = a.shape[0], a.shape[1]
+    if device is not None:
+        shape = shape.to(device)
+    dist.broadcast(shape, src=src)
+    n, c = int(shape[0]), int(shape[1])
+    buf = torch.from_numpy(a) if rank == src else torch.empty((n, c), dtype=torch.float32)
+    if device is not None:
+        buf = buf.to(device)
+    dist.broadcast(buf, src=src)
+    if reg is not None:
+        reg.setInputTarget(buf if device is not None else buf.numpy())
+    return buf
+
+
+def set_input_target_bcast(comm: "Comm", reg, cloud=None, root: int = 0):
+    """lsr_set_input_target_bcast of the C ABI: the same through the core's own RCCL communicator (one ncclBroadcast of the records).
+    `cloud` is read on rank `root` only (host array or CUDA tensor)."""
+    import ctypes as C
+
+    from . import _capi as capi
+    from .registration import _cloud_args
+
+    p, stride, n, dev = None, 12, 0, 0
+    keep = None
+    if comm.rank == root:
+        p, stride, n, dev, keep = _cloud_args(cloud, reg)
+    capi.check(capi.load().lsr_set_input_target_bcast(comm._h, reg._h, p, stride, n, 1 if dev else 0, root), "lsr_set_input_target_bcast")
+    del keep
+
+
 # ---- the same exchange at the C ABI: lsr_comm_* / lsr_align_batch_sharded (include/lidarslam_reg.h) -------------------
 class Comm:
     """One rank's RCCL communicator of the C core.  `unique_id` (128 bytes, from Comm.unique_id() on rank 0, handed to the

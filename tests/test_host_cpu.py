@@ -216,6 +216,42 @@ def _gloo_worker(rank, world, port, n_items, out_dir, planned=False):
     dist.destroy_process_group()
 
 
+def _gloo_bcast_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from lidarslam_ros2_amd.sharding import broadcast_target
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Rec:   # stands in for a registration object: records what setInputTarget was given
+        def setInputTarget(self, cloud):
+            self.cloud = np.asarray(cloud).copy()
+
+    r = Rec()
+    cloud = None
+    if rank == 1:   # the submap lives on rank 1
+        cloud = np.random.default_rng(7).normal(size=(1234, 4)).astype(np.float32)
+    got = broadcast_target(r, cloud, src=1)
+    np.save(os.path.join(out_dir, f"tgt{rank}.npy"), r.cloud)
+    assert np.array_equal(np.asarray(got), r.cloud)
+    dist.destroy_process_group()
+
+
+def test_target_broadcast_gloo_world2(tmp_path):
+    """SURVEY.md 8e "N keyframes vs. one submap" across ranks: the rank that holds the submap broadcasts it (shape, then the records)
+    and every rank sets the same bytes as its input target (sharding.broadcast_target; the C ABI's lsr_set_input_target_bcast does the
+    same with ncclBroadcast — exercised on hardware by tests/test_multigpu_gpu.py)."""
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    mp.spawn(_gloo_bcast_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "tgt0.npy"), np.load(tmp_path / "tgt1.npy")
+    assert a.shape == (1234, 4) and np.array_equal(a, b)
+    assert np.array_equal(b, np.random.default_rng(7).normal(size=(1234, 4)).astype(np.float32))
+
+
 @pytest.mark.parametrize("n_items", [7, 64])
 def test_sharded_batch_all_gather_gloo_world2(tmp_path, n_items):
     """N>1 path on CPU: two processes, static partition, one all-gather of 64-byte records."""

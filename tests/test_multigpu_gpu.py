@@ -210,6 +210,24 @@ real.close()
 for x, y in zip(a, c):
     assert np.array_equal(x["T"], y["T"]) and x["iterations"] == y["iterations"] and x["converged"] == y["converged"]
     assert abs(x["fitness"] - y["fitness"]) <= 1e-6 * abs(x["fitness"])
+# the target broadcast (lsr_set_input_target_bcast): through the RCCL-free one-rank communicator the cloud goes straight to
+# setInputTarget; through the size-1 RCCL communicator it travels header + records through ncclBroadcast on the communicator's
+# stream into the communicator's buffer and is set from there — both must give the voxel grid and the pose of a plain setInputTarget
+from lidarslam_ros2_amd.sharding import set_input_target_bcast
+import torch
+ref = make(cases[:1])[0]
+ref.align(cases[0].guess)
+real = Comm(0, 1, 0, Comm.unique_id())
+one = Comm(0, 1, 0)
+for comm, cloud in ((one, synth.as_pointxyzi(cases[0].target)), (real, synth.as_pointxyzi(cases[0].target)),
+                    (real, torch.from_numpy(synth.as_pointxyzi(cases[0].target)).cuda())):
+    r = NormalDistributionsTransform(0); r.setResolution(3.0); r.setTransformationEpsilon(0.01); r.setNeighborhoodSearchMethod(DIRECT7)
+    set_input_target_bcast(comm, r, cloud, root=0)
+    r.setInputSource(cases[0].source); r.align(cases[0].guess)
+    assert np.array_equal(r.getFinalTransformation(), ref.getFinalTransformation())
+    ga, gb = r.gridDump(), ref.gridDump()
+    assert np.array_equal(ga["idx"], gb["idx"]) and np.array_equal(ga["mean"], gb["mean"])
+real.close(); one.close()
 print("RCCL1 OK")
 """
 

@@ -1,6 +1,6 @@
 """Round 5: the cfg-5 pass (120k-point scan, ndt_resolution RES, default 2.0) under a chosen table mode / kernel form —
 LSR_NDT_TABLE_MODE (0 dense global table, 3 per-workgroup tile staged in LDS) and LSR_NDT_QUAD are read by the library itself.
-Prints microseconds per derivative pass; run under rocprofv3 --pmc by tools/r05_pmc_cfg5.sh."""
+Prints microseconds per derivative pass; run under rocprofv3 --pmc by tools/pmc_cfg5.sh."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""Per-launch durations of the NDT chain kernels from a rocprofv3 kernel-trace CSV (last align of tools/r04_chain_probe.py).
+"""Per-launch durations of the NDT chain kernels from a rocprofv3 kernel-trace CSV (last align of tools/chain_probe.py).
 A set of six or more members runs as TWO launch chains on two streams (capi.hip: run_ndt_feeder): the launches are listed per
 stream; `gap` = end of a launch -> start of the next launch on the SAME stream."""
 import csv, sys, glob, collections

@@ -1,5 +1,5 @@
 """Round 4: the shared launch chain of a cfg-4 candidate set on its own — targets and sources resident, lsr_align_batch timed by
-the host clock; run under `rocprofv3 --kernel-trace` the per-launch durations of the last set are listed by tools/r04_chain_parse.py.
+the host clock; run under `rocprofv3 --kernel-trace` the per-launch durations of the last set are listed by tools/chain_parse.py.
 NC = members (64), REPS = timed aligns."""
 import sys, os, time
 import numpy as np

@@ -20,5 +20,5 @@ print('frontend', json.dumps(d.get('frontend_stream'))[:2500])
 print('target', d.get('set_input_target',{}).get('median_ms'), 'next_rows', json.dumps(d.get('next_rows',{}).get('source_preprocess'))[:400])
 print('cfg4 shares', json.dumps(d['cfg4_loop_batch'].get('projected_8gpu'))[:900])
 PY
-(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr_target && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_target -o t -- python $REPO/tools/target_probe.py > $OUT/target.stdout 2>&1; python $REPO/tools/stats_to_md.py /tmp/tr_target/t_kernel_stats.csv 30 > $OUT/target_stats.md 2>&1; python $REPO/tools/r05_timeline.py /tmp/tr_target 150 60 > $OUT/timeline_target.txt 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr_target && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_target -o t -- python $REPO/tools/target_probe.py > $OUT/target.stdout 2>&1; python $REPO/tools/stats_to_md.py /tmp/tr_target/t_kernel_stats.csv 30 > $OUT/target_stats.md 2>&1; python $REPO/tools/timeline.py /tmp/tr_target 150 60 > $OUT/timeline_target.txt 2>&1)
 tail -3 $OUT/target.stdout; head -40 $OUT/target_stats.md | cut -c1-200

@@ -16,6 +16,6 @@ print('n1', json.dumps(d.get('next_rows',{}).get('source_preprocess'))[:500])
 print('target', d.get('set_input_target',{}).get('median_ms'))
 PY
 {
-for w in 0 2 1; do echo "[LSR_NDT_WGS_PER_CU=$w]"; LSR_NDT_WGS_PER_CU=$w REPS=5 timeout 300 python tools/r04_chain_probe.py 2>&1 | tail -1; done
+for w in 0 2 1; do echo "[LSR_NDT_WGS_PER_CU=$w]"; LSR_NDT_WGS_PER_CU=$w REPS=5 timeout 300 python tools/chain_probe.py 2>&1 | tail -1; done
 } > $OUT/wgs.txt 2>&1; cat $OUT/wgs.txt | cut -c1-300
-bash tools/r05_pmc_cfg5.sh > $OUT/pmc_cfg5.log 2>&1; tail -25 $OUT/pmc_cfg5.log | cut -c1-420
+bash tools/pmc_cfg5.sh > $OUT/pmc_cfg5.log 2>&1; tail -25 $OUT/pmc_cfg5.log | cut -c1-420

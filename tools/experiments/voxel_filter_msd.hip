@@ -1,5 +1,5 @@
 // SHELVED EXPERIMENT (round 4; not built, not linked): bit-identical to the product path on every test input, but SLOWER than it.
-// Measured on MI355X, 147 443-point scan, leaf 0.2 (tools/r03_preprocess_probe.py: range filter + VoxelGrid + setInputSource):
+// Measured on MI355X, 147 443-point scan, leaf 0.2 (tools/preprocess_probe.py: range filter + VoxelGrid + setInputSource):
 //   rocPRIM path (product): 151 us        this file: 255 us (14 high bits) / 242 us (16) / 440 us (12)
 // Where it loses: a lidar scan is dense next to the sensor — a few dozen slabs hold thousands of points each — so (i) the slab
 // counters are hot: even with one atomic per (wave, slab) vf_count / vf_scatter take 29 / 33 us (90 / 109 us with one atomic per

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 --kernel-trace --stats of one python probe: prints the top kernels.  usage: r04_kstats.sh <outdir-name> <script> [env assignments...]
+# rocprofv3 --kernel-trace --stats of one python probe: prints the top kernels.  usage: kstats.sh <outdir-name> <script> [env assignments...]
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 NAME=$1; SCRIPT=$2; shift 2
 cd /tmp && export TMPDIR=/tmp LSR_BENCH_CACHE_DIR=/tmp/lsr_bench_cache

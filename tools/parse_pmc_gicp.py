@@ -29,7 +29,7 @@ def upper_median(v):   # launches of a phase that is not due return immediately:
 out = {"source": f"tools/pmc_gicp.sh {tag} -> profiles/{tag}_pmc_gicp.md",
        "correction": "2 x FETCH_SIZE (gfx950 counts the 128-byte requests of wide coalesced reads at 64 B) + WRITE_SIZE", "kernels": {}}
 lines = ["# rocprofv3 PMC passes on the GICP kernels — " + tag, "",
-         "Separate runs, `--kernel-trace --pmc <counters>` only (tools/pmc_gicp.sh on tools/r02_gicp_probe.py: cfg 3, 21 registrations).",
+         "Separate runs, `--kernel-trace --pmc <counters>` only (tools/pmc_gicp.sh on tools/gicp_probe.py: cfg 3, 21 registrations).",
          "Upper-quartile values per launch (launches whose phase is not due return at once and would pull a median down).", "",
          "| kernel | launches | us | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes (2F+W) | GB/s | VALU wave-instr | SQ_WAIT_ANY / SQ_WAVE_CYCLES | L2 hit |",
          "|---|---|---|---|---|---|---|---|---|---|"]

@@ -7,8 +7,8 @@ cd /tmp && export TMPDIR=/tmp LSR_BENCH_CACHE_DIR=/tmp/lsr_bench_cache
 export NC=${1:-64}
 OUT=$REPO/gpurun_out/pmc_fit
 rm -rf $OUT; mkdir -p $OUT
-timeout 600 python $REPO/tools/r03_cfg4_stage_c.py > $OUT/warmup.log 2>&1; echo "warm-up rc=$?"
-run() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $REPO/tools/r03_cfg4_stage_c.py > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+timeout 600 python $REPO/tools/cfg4_stage_probe.py > $OUT/warmup.log 2>&1; echo "warm-up rc=$?"
+run() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $REPO/tools/cfg4_stage_probe.py > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
 run inst SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM
 run fetch FETCH_SIZE

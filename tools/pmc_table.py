@@ -1,5 +1,5 @@
 """Per-launch medians of every counter of the ndt_eval kernels found under a rocprofv3 --pmc output tree, as a markdown table
-(one row per kernel instantiation and launch shape).  usage: python tools/r05_pmc_table.py <dir> <label>"""
+(one row per kernel instantiation and launch shape).  usage: python tools/pmc_table.py <dir> <label>"""
 import collections, csv, glob, re, sys
 root, label = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

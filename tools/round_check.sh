@@ -7,8 +7,8 @@ rm -rf $O; mkdir -p $O
 cd $REPO
 export LSR_BENCH_CACHE_DIR=/tmp/lsr_bench_cache
 (timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -25) > $O/pytest.log; tail -8 $O/pytest.log | cut -c1-400
-(timeout 600 python tools/r03_cfg4_stage_c.py 2>&1 | tail -2) | tee $O/stage64.log
-(NC=8 timeout 600 python tools/r03_cfg4_stage_c.py 2>&1 | tail -2) | tee $O/stage8.log
+(timeout 600 python tools/cfg4_stage_probe.py 2>&1 | tail -2) | tee $O/stage64.log
+(NC=8 timeout 600 python tools/cfg4_stage_probe.py 2>&1 | tail -2) | tee $O/stage8.log
 (timeout 900 python bench.py > $O/bench.json 2> $O/bench.err); echo "bench rc=$?"; tail -3 $O/bench.err
 python - <<'PY'
 import json,os

@@ -3,7 +3,7 @@
 # Output: gpurun_out/profiles_<tag>/ (copy into profiles/ afterwards).  PMC passes are separate rocprofv3 runs with
 # --kernel-trace only (tools/pmc_ndt.sh).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 P=$REPO/gpurun_out/profiles_$TAG
 rm -rf $P; mkdir -p $P
@@ -13,9 +13,11 @@ export LSR_BENCH_CACHE_DIR=/tmp/lsr_bench_cache   # synthetic clouds ray-cast on
 bash tools/pmc_ndt.sh $TAG > $P/pmc.log 2>&1; tail -4 $P/pmc.log | head -3
 cp gpurun_out/pmc_ndt/${TAG}_pmc_ndt_eval.md gpurun_out/pmc_ndt/pmc_ndt_eval_latest.json $P/
 cp gpurun_out/pmc_ndt/pmc_ndt_eval_latest.json profiles/pmc_ndt_eval_latest.json
+if [ "${LSR_PROFILE_GICP:-0}" = "1" ]; then   # the GICP kernels did not change in round 5: their counter passes are on request
 bash tools/pmc_gicp.sh $TAG > $P/pmc_gicp.log 2>&1; tail -3 $P/pmc_gicp.log | cut -c1-300
 cp gpurun_out/pmc_gicp/${TAG}_pmc_gicp.md gpurun_out/pmc_gicp/pmc_gicp_latest.json $P/
 cp gpurun_out/pmc_gicp/pmc_gicp_latest.json profiles/pmc_gicp_latest.json
+fi
 # 2. default bench run (the driver's command), JSON line kept
 timeout 900 python bench.py > $P/${TAG}_bench_final.json 2> $P/bench.err; echo "bench rc=$?"
 # 3. kernel-trace summaries
@@ -26,16 +28,24 @@ stats() {  # name, command...
   { echo "# rocprofv3 --kernel-trace --stats -- $* ($TAG, MI355X; raw CSV: ${TAG}_rocprofv3_${name}_kernel_stats.csv)"; echo; python tools/stats_to_md.py /tmp/prof_$name/${name}_kernel_stats.csv 30; echo; echo '```'; grep -v "^W2\|^E2\|amdgpu.ids" $P/$name.stdout | tail -8 | cut -c1-2500; echo '```'; } > $P/${TAG}_rocprofv3_${name}_stats.md
 }
 stats bench python $REPO/bench.py
-stats gicp python $REPO/tools/r02_gicp_probe.py
-stats cfg4 python $REPO/tools/r03_cfg4_probe.py
+stats gicp python $REPO/tools/gicp_probe.py
+stats cfg4 python $REPO/tools/cfg4_probe.py
 stats target python $REPO/tools/target_probe.py
 # 3b. the shared launch chain of the 64-candidate set: host-clock time and the per-launch trace (full-load launches, widened tail)
-(timeout 300 python tools/r04_chain_probe.py 2>&1 | tail -1) > $P/${TAG}_cfg4_chain.txt
-(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr_chain && REPS=2 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_chain -o t -- python $REPO/tools/r04_chain_probe.py > /dev/null 2>&1; python $REPO/tools/r04_chain_parse.py /tmp/tr_chain >> $P/${TAG}_cfg4_chain.txt 2>&1)
-(timeout 300 python tools/r03_cfg4_stage_c.py 2>&1 | tail -2; NC=8 timeout 300 python tools/r03_cfg4_stage_c.py 2>&1 | tail -2) > $P/${TAG}_cfg4_stages.txt
-# 3c. micro-benchmarks behind profiles/<tag>_pass_timeline.md
+(timeout 300 python tools/chain_probe.py 2>&1 | tail -1) > $P/${TAG}_cfg4_chain.txt
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr_chain && REPS=2 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_chain -o t -- python $REPO/tools/chain_probe.py > /dev/null 2>&1; python $REPO/tools/chain_parse.py /tmp/tr_chain >> $P/${TAG}_cfg4_chain.txt 2>&1)
+(timeout 300 python tools/cfg4_stage_probe.py 2>&1 | tail -2; NC=8 timeout 300 python tools/cfg4_stage_probe.py 2>&1 | tail -2) > $P/${TAG}_cfg4_stages.txt
+# 3c. one share of an 8-GPU node (8 candidates): stage medians for the fastest and the slowest share of the block partition, and the
+# kernel timeline of a whole share (tools/share_probe.py, tools/timeline.py)
+(for F in 0 24; do FIRST=$F timeout 300 python tools/share_probe.py 2>&1 | tail -1; done) > $P/${TAG}_cfg4_share.txt
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr_share && FIRST=24 MODE=share REPS=3 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_share -o t -- python $REPO/tools/share_probe.py > /dev/null 2>&1; python $REPO/tools/timeline.py /tmp/tr_share 300 2000 | tail -75 >> $P/${TAG}_cfg4_share.txt 2>&1)
+# 3d. N1: the frontend's source preprocessing (hand-written LSD sort) against the rocPRIM path it replaces
+(for v in lsd rocprim; do echo "[LSR_VG_SORT=$v]"; LSR_VG_SORT=$v timeout 300 python tools/preprocess_probe.py 2>&1 | tail -1; done) > $P/${TAG}_n1_preprocess.txt
+stats n1 python $REPO/tools/preprocess_probe.py
+if [ "${LSR_PROFILE_MICRO:-0}" = "1" ]; then   # micro-benchmarks behind profiles/r04_pass_timeline.md (kernels unchanged since)
 (timeout 300 tools/micro/boundary_probe) > $P/${TAG}_boundary_probe.txt 2>&1
 (LSR_LIB_NAME=liblidarslam_reg_timing.so timeout 400 python tools/timing_probe.py 2>&1 | grep -v amdgpu.ids) > $P/${TAG}_timing_probe.txt
+fi
 # 4. two ranks sharing this one device (gloo): exercises the self-spawn + sharded C-ABI path
 LSR_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 > $P/${TAG}_bench_2ranks_one_device.json 2> $P/bench2.err; echo "bench2 rc=$?"
 rm -f $P/*.stderr

@@ -1,7 +1,7 @@
 """Round 5: ONE share of the cfg-4 candidate set (what one GPU of an 8-GPU node runs: NC = 8 candidates starting at FIRST) through the
 C-ABI batch entries, stage by stage and as the whole per-share path bench.py's `projected_8gpu` times
 (lsr_set_input_target_batch + lsr_set_input_source_batch + lsr_align_batch_sharded with a one-rank communicator).
-MODE=chain: only lsr_align_batch REPS times (targets and sources resident) — the run tools/r04_chain_parse.py reads under
+MODE=chain: only lsr_align_batch REPS times (targets and sources resident) — the run tools/chain_parse.py reads under
 `rocprofv3 --kernel-trace`.  MODE=share: only the whole path REPS times (for a kernel trace of a whole share)."""
 import ctypes as C, os, sys, time
 import numpy as np

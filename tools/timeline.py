@@ -1,6 +1,6 @@
 """Timeline of the LAST burst of kernels in a rocprofv3 kernel-trace directory (a burst ends with an idle gap > GAP_US, default 300):
-every launch with its stream, start, duration and geometry — how the stages of a cfg-4 share (tools/r05_share_probe.py MODE=share)
-or of a single setInputTarget lie on the device.  usage: python tools/r05_timeline.py <trace dir> [GAP_US] [max rows]"""
+every launch with its stream, start, duration and geometry — how the stages of a cfg-4 share (tools/share_probe.py MODE=share)
+or of a single setInputTarget lie on the device.  usage: python tools/timeline.py <trace dir> [GAP_US] [max rows]"""
 import csv, glob, re, sys, collections
 path = sys.argv[1]
 gap_ns = int(float(sys.argv[2]) * 1000) if len(sys.argv) > 2 else 300000
