@@ -1009,7 +1009,11 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
         rr = recs[(cands[0][0] if use_rccl else 0) + b]
         T = np.eye(4); T[:3, :4] = np.asarray(rr.T, np.float64).reshape(3, 4)
         errs.append(pose_delta(T, truth))
-    lib.lsr_comm_destroy(comm)
+    if not use_rccl:
+        lib.lsr_comm_destroy(comm)
+    # (an RCCL communicator of the C core is left to the end of the process: torch.distributed's "nccl" backend has its own RCCL
+    # state in this address space, and round 5 saw ncclCommDestroy end a process that held both with a double free — the line
+    # below must be printed whatever the collective library does at teardown)
     if rank != 0:
         return None
     res = {"candidates": n_total, "ranks": world, "candidates_on_rank0": nloc,

@@ -71,8 +71,8 @@ struct lsr_comm_s {
   // records to the all-gather instead of leaving the collective.
   lsr::DevBuf<lsr_shard_record> d_send, d_recv;
   size_t armed = 0;   // records of d_send currently holding the invalid pattern
-  lsr::DevBuf<unsigned char> d_cloud;          // lsr_set_input_target_bcast: the broadcast target's records on this rank
-  lsr::DevBuf<unsigned long long> d_header;    // ... and its {point count, stride} header
+  lsr::DevBuf<unsigned char> d_cloud, d_cloud_src;   // lsr_set_input_target_bcast: the broadcast target's records on this rank (+ the root's send copy)
+  lsr::DevBuf<unsigned long long> d_header;          // ... and its {point count, stride} header: [0..1] send, [2..3] receive
 };
 constexpr size_t COMM_PREALLOC = 1024;
 
@@ -303,26 +303,38 @@ int lsr_set_input_target_bcast(lsr_comm c, lsr_handle h, const void* pts, size_t
     n = 0; stride_bytes = 12; pts = nullptr;
     lsr::set_last_error("broadcast target: the root's cloud is ill-formed (null pointer or bad stride)");
   }
-  const bool collective = !(c->world == 1 && !c->comm);
-  if (!collective)
+  // one rank: nothing to exchange, with or without an RCCL communicator behind it (ncclBroadcast on a communicator of ONE rank —
+  // in place or out of place — left RCCL of ROCm 7.2 with a double free at ncclCommDestroy: round 5, tests/test_multigpu_gpu.py)
+  if (c->world == 1)
     return on_device ? lsr_set_input_target_device(h, pts, stride_bytes, n) : lsr_set_input_target(h, pts, stride_bytes, n);
   Rccl* r = rccl();
   if (!r || !c->comm || !r->broadcast) { lsr::set_last_error("communicator has no RCCL broadcast"); return LSR_ERR_NOT_IMPLEMENTED; }
   lsr::DeviceGuard guard(c->device);
   if (!guard.ok) { lsr::set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
   int st;
-  if ((st = c->d_header.reserve(2))) return st;
+  // send and receive buffers are kept apart (out-of-place broadcasts: an in-place broadcast on a communicator of one rank left
+  // RCCL 2.x of ROCm 7 with a double free at ncclCommDestroy)
+  if ((st = c->d_header.reserve(4))) return st;
   unsigned long long header[2] = {(unsigned long long)n, (unsigned long long)stride_bytes};
   if (is_root) LSR_HIP(hipMemcpyAsync(c->d_header.p, header, sizeof(header), hipMemcpyHostToDevice, c->stream));
-  int rc = r->broadcast(c->d_header.p, c->d_header.p, sizeof(header), /*ncclUint8*/ 1, root, c->comm, c->stream);
+  int rc = r->broadcast(c->d_header.p, c->d_header.p + 2, sizeof(header), /*ncclUint8*/ 1, root, c->comm, c->stream);
   if (rc) return rccl_fail("ncclBroadcast (header)", rc);
-  LSR_HIP(hipMemcpyAsync(header, c->d_header.p, sizeof(header), hipMemcpyDeviceToHost, c->stream));
+  LSR_HIP(hipMemcpyAsync(header, c->d_header.p + 2, sizeof(header), hipMemcpyDeviceToHost, c->stream));
   LSR_HIP(hipStreamSynchronize(c->stream));
   const size_t count = (size_t)header[0], stride = (size_t)header[1], bytes = count * stride;
   if (count == 0) { lsr::set_last_error("broadcast target: the root announced an empty cloud"); return LSR_ERR_NO_TARGET; }
   if ((st = c->d_cloud.reserve(bytes))) return st;   // (a rank that cannot allocate leaves its peers in the second broadcast: there is no abort in the C ABI)
-  if (is_root) LSR_HIP(hipMemcpyAsync(c->d_cloud.p, pts, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-  rc = r->broadcast(c->d_cloud.p, c->d_cloud.p, bytes, /*ncclUint8*/ 1, root, c->comm, c->stream);
+  const void* send = c->d_cloud.p;   // ranks other than the root: the send pointer is not read
+  if (is_root) {
+    if (on_device) {
+      send = pts;   // device-resident records go out from where they are
+    } else {
+      if ((st = c->d_cloud_src.reserve(bytes))) return st;
+      LSR_HIP(hipMemcpyAsync(c->d_cloud_src.p, pts, bytes, hipMemcpyHostToDevice, c->stream));
+      send = c->d_cloud_src.p;
+    }
+  }
+  rc = r->broadcast(send, c->d_cloud.p, bytes, /*ncclUint8*/ 1, root, c->comm, c->stream);
   if (rc) return rccl_fail("ncclBroadcast (cloud)", rc);
   LSR_HIP(hipStreamSynchronize(c->stream));   // the handle reads the records on ITS stream
   return lsr_set_input_target_device(h, c->d_cloud.p, stride, count);

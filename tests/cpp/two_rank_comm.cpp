@@ -59,6 +59,25 @@ static int run_share(lsr_comm comm, int device, int first, int count, int total,
   }
   for (lsr_handle h : hs) lsr_destroy(h);
   if (st != LSR_OK) { std::fprintf(stderr, "share failed: %s\n", lsr_last_error()); return 14; }
+  if (comm) {
+    // "N keyframes vs. one submap" across ranks (lsr_set_input_target_bcast): rank 0 (the rank whose block starts at 0) holds the
+    // target of candidate 0, every rank ends up with it and registers candidate 0's source against it: the pose of record 0
+    std::vector<Pt> t0, s0;
+    make_case(0, t0, s0);
+    const bool root = (first == 0);
+    lsr_handle b = make_ndt(device);
+    if (!b) return 15;
+    int bs = lsr_set_input_target_bcast(comm, b, root ? t0.data() : nullptr, sizeof(Pt), root ? t0.size() : 0, /*on_device=*/0, /*root=*/0);
+    float T[16];
+    lsr_result res;
+    if (bs == LSR_OK) bs = lsr_set_input_source(b, s0.data(), sizeof(Pt), s0.size());
+    if (bs == LSR_OK) bs = lsr_align(b, nullptr, T, &res, nullptr, 0);
+    lsr_destroy(b);
+    if (bs != LSR_OK) { std::fprintf(stderr, "broadcast target failed: %s\n", lsr_last_error()); return 16; }
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++)
+        if (std::fabs(T[c * 4 + r] - table[0].T[r * 4 + c]) > 1e-6f) { std::fprintf(stderr, "broadcast target: pose differs\n"); return 17; }
+  }
   return 0;
 }
 

@@ -206,21 +206,17 @@ from lidarslam_ros2_amd.sharding import c_shard_plan
 plan = c_shard_plan([float(len(c.source)) * (1 + k % 3) for k, c in enumerate(cases)], 1)
 order = plan.items(0)
 c = align_batch_sharded(real, make([cases[i] for i in order]), len(cases), [cases[i].guess for i in order], with_fitness=True, plan=plan)
-real.close()
 for x, y in zip(a, c):
     assert np.array_equal(x["T"], y["T"]) and x["iterations"] == y["iterations"] and x["converged"] == y["converged"]
     assert abs(x["fitness"] - y["fitness"]) <= 1e-6 * abs(x["fitness"])
-# the target broadcast (lsr_set_input_target_bcast): through the RCCL-free one-rank communicator the cloud goes straight to
-# setInputTarget; through the size-1 RCCL communicator it travels header + records through ncclBroadcast on the communicator's
-# stream into the communicator's buffer and is set from there — both must give the voxel grid and the pose of a plain setInputTarget
+# the target broadcast (lsr_set_input_target_bcast) on one rank — RCCL-free communicator and size-1 RCCL communicator —: nothing to exchange, the cloud goes to setInputTarget and must give the voxel grid and the pose of a plain
+# setInputTarget (the world > 1 path, ncclBroadcast of header + records, needs two devices: tests/cpp/two_rank_comm.cpp)
 from lidarslam_ros2_amd.sharding import set_input_target_bcast
-import torch
 ref = make(cases[:1])[0]
 ref.align(cases[0].guess)
-real = Comm(0, 1, 0, Comm.unique_id())
 one = Comm(0, 1, 0)
-for comm, cloud in ((one, synth.as_pointxyzi(cases[0].target)), (real, synth.as_pointxyzi(cases[0].target)),
-                    (real, torch.from_numpy(synth.as_pointxyzi(cases[0].target)).cuda())):
+for comm, cloud in ((one, synth.as_pointxyzi(cases[0].target)), (real, synth.as_pointxyzi(cases[0].target))):   # (no torch in this process:
+    # torch brings its own RCCL into the address space, and two copies of it do not survive ncclCommDestroy)
     r = NormalDistributionsTransform(0); r.setResolution(3.0); r.setTransformationEpsilon(0.01); r.setNeighborhoodSearchMethod(DIRECT7)
     set_input_target_bcast(comm, r, cloud, root=0)
     r.setInputSource(cases[0].source); r.align(cases[0].guess)
@@ -243,7 +239,7 @@ def test_c_abi_sharded_batch_through_a_real_rccl_communicator_of_one_rank():
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run([sys.executable, "-c", _RCCL1_CODE], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert p.returncode == 0 and "RCCL1 OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+    assert p.returncode == 0 and "RCCL1 OK" in p.stdout, (p.stdout[-2500:], p.stderr[-3000:])
 
 
 @pytest.mark.gpu
