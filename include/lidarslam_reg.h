@@ -207,6 +207,11 @@ int lsr_set_input_source_pc2(lsr_handle h, const void* data, size_t n_points, co
 /* toROSMsg of the handle's current input source (e.g. the filtered scan, to publish it or to store it in a SubMap):
  * n records of layout->point_step bytes, x / y / z / intensity at the layout's offsets, every other byte zero. */
 int lsr_get_source_pc2(lsr_handle h, void* out_data, size_t capacity_points, const lsr_pc2_layout* layout, size_t* n_out);
+/* The same into a DEVICE buffer (d_out: capacity_points records of layout->point_step bytes in HBM): the filtered scan stays resident,
+ * e.g. as the newest submap of the frontend's map window — updateMap()'s VoxelGrid(vg_size_for_map) + toROSMsg
+ * (scanmatcher_component.cpp:442-446, 466-470) without the 3.5 MB round trip over PCIe; lsr_set_input_target_frames(on_device = 1)
+ * takes such buffers.  Returns after the records are complete (any stream may read them). */
+int lsr_get_source_pc2_device(lsr_handle h, void* d_out, size_t capacity_points, const lsr_pc2_layout* layout, size_t* n_out);
 /* pcl::VoxelGrid::filter, message payload in, message payload out (map side: :266-269, 443-447;
  * graph_based_slam_component.cpp:224-226), intensity averaged per leaf like the coordinates. */
 int lsr_voxel_grid_filter_pc2(lsr_handle h, const void* data, size_t n_points, const lsr_pc2_layout* in_layout, float leaf, void* out_data,

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
     "lsr_debug_angle_tables", "lsr_set_input_source_pc2", "lsr_get_source_pc2", "lsr_voxel_grid_filter_pc2", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
     "lsr_shard_plan", "lsr_align_batch_planned", "lsr_align_fitness_batch",
-    "lsr_set_input_target_batch", "lsr_set_input_source_batch", "lsr_get_fitness_score_batch", "lsr_set_input_target_bcast",
+    "lsr_set_input_target_batch", "lsr_set_input_source_batch", "lsr_get_fitness_score_batch", "lsr_set_input_target_bcast", "lsr_get_source_pc2_device",
 ]
 
 
@@ -136,6 +136,7 @@ def load() -> C.CDLL:
     L.lsr_set_input_source_pc2.argtypes = [vp, vp, C.c_size_t, C.POINTER(Pc2Layout), C.c_double, C.c_double, C.c_float, C.c_int,
                                            C.POINTER(C.c_size_t)]
     L.lsr_get_source_pc2.argtypes = [vp, vp, C.c_size_t, C.POINTER(Pc2Layout), C.POINTER(C.c_size_t)]
+    L.lsr_get_source_pc2_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(Pc2Layout), C.POINTER(C.c_size_t)]
     L.lsr_voxel_grid_filter_pc2.argtypes = [vp, vp, C.c_size_t, C.POINTER(Pc2Layout), C.c_float, vp, C.c_size_t, C.POINTER(Pc2Layout),
                                             C.POINTER(C.c_size_t)]
     L.lsr_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]

@@ -1301,6 +1301,25 @@ int lsr_get_source_pc2(lsr_handle h, void* out_data, size_t capacity_points, con
   return write_pc2_host(h, h->source, out_data, capacity_points, layout, n_out);
 }
 
+// the same into a DEVICE buffer (a keyframe kept resident in HBM: what lsr_set_input_target_frames takes with on_device != 0):
+// enqueued on the handle's stream, which is synchronised before returning so that any stream may read the records
+int lsr_get_source_pc2_device(lsr_handle h, void* d_out, size_t capacity_points, const lsr_pc2_layout* layout, size_t* n_out) {
+  LSR_CHECK_HANDLE(h);
+  int st = check_layout(layout);
+  if (st) return st;
+  if (!n_out || (capacity_points > 0 && !d_out)) { set_last_error("bad argument"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (!h->has_source) { set_last_error("no input source"); return LSR_ERR_NO_SOURCE; }
+  const DeviceCloud& cloud = h->source;
+  *n_out = cloud.n;
+  if (cloud.n > capacity_points) { set_last_error("output buffer too small"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (cloud.n == 0) return LSR_OK;
+  LSR_HIP(hipMemsetAsync(d_out, 0, cloud.n * layout->point_step, h->stream));
+  if ((st = pc2_write(cloud, d_out, (int)layout->point_step, (int)layout->offset_x, (int)layout->offset_y, (int)layout->offset_z,
+                      layout->offset_intensity, h->stream))) return st;
+  LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
 int lsr_voxel_grid_filter_pc2(lsr_handle h, const void* data, size_t n_points, const lsr_pc2_layout* in_layout, float leaf, void* out_data,
                               size_t capacity_points, const lsr_pc2_layout* out_layout, size_t* n_out) {
   LSR_CHECK_HANDLE(h);

@@ -63,10 +63,13 @@ class FrontendReplay:
     `to_device` (optional): maps a kept submap — (m,8) fp32 pcl::PointXYZI records on the host — to what `reg.setInputTargetFrames`
     should be given (e.g. a CUDA tensor, so that the keyframes stay resident in HBM); identity when None."""
 
-    def __init__(self, reg, params: FrontendParams | None = None, to_device=None):
+    def __init__(self, reg, params: FrontendParams | None = None, to_device=None, mapper=None):
         self.reg = reg
         self.p = params or FrontendParams()
         self.to_device = to_device or (lambda a: a)
+        # `mapper` (optional): a second registration object whose input-source slot serves as the map side's filter — with it and a
+        # device-resident payload the new keyframe (range filter + VoxelGrid(vg_size_for_map)) is produced and kept in HBM
+        self.mapper = mapper
         self.submaps: list = []          # [(payload as given to setInputTargetFrames, pose 4x4 f64)]
         self.pose = np.eye(4)
         self.key_position = np.zeros(3)
@@ -100,6 +103,18 @@ class FrontendReplay:
         # displacement since the last map update (:412-424): trans_ >= trans_for_mapupdate_
         if float(np.linalg.norm(T[:3, 3] - self.key_position)) >= self.p.trans_for_mapupdate:
             t2 = time.perf_counter()
+            if self.mapper is not None and hasattr(payload, "is_cuda") and payload.is_cuda:
+                # the whole map side on the device: range filter + VoxelGrid(vg_size_for_map) into the mapper's source slot, from there
+                # into a keyframe buffer in HBM (lsr_set_input_source_pc2 + lsr_get_source_pc2_device)
+                self.mapper.setInputSourcePointCloud2(payload, n_points, step, offs, self.p.scan_min_range, self.p.scan_max_range,
+                                                      self.p.vg_size_for_map)
+                self.submaps.append((self.mapper.getInputSourceDeviceRecords(), T.copy()))
+                self.submaps = self.submaps[-self.p.num_targeted_cloud:]
+                self._set_target()
+                self.key_position = T[:3, 3].copy()
+                out.update_seconds.append(time.perf_counter() - t2)
+                out.update_at.append(len(out.poses) - 1)
+                return
             host = np.asarray(payload if payload_host is None else payload_host).reshape(n_points, step)
             # updateMap filters the cloud the callback received, i.e. AFTER the subscription's range filter (:210-218: horizontal range,
             # open interval, in double) — a host-side mask here, as in the reference

@@ -219,6 +219,18 @@ class Registration:
                    "getInputSourcePointCloud2")
         return out[: n_out.value].copy()
 
+    def getInputSourceDeviceRecords(self):
+        """The current input source as pcl::PointXYZI records in HBM: an (n, 8) fp32 CUDA tensor (x y z _ intensity _ _ _), e.g. a
+        keyframe for setInputTargetFrames that never leaves the device (lsr_get_source_pc2_device)."""
+        import torch
+
+        lay = self._layout(32, (0, 4, 8, 16))
+        out = torch.empty((max(self._n_source, 1), 8), dtype=torch.float32, device="cuda")
+        n_out = C.c_size_t()
+        capi.check(self._lib.lsr_get_source_pc2_device(self._h, C.c_void_p(out.data_ptr()), out.shape[0], C.byref(lay), C.byref(n_out)),
+                   "getInputSourceDeviceRecords")
+        return out[: n_out.value]
+
     def voxelGridFilterPointCloud2(self, data, n_points: int, point_step: int, offsets, leaf: float, out_point_step: int = 32,
                                    out_offsets=(0, 4, 8, 16)) -> np.ndarray:
         """pcl::VoxelGrid(leaf).filter on a PointCloud2 payload (host), all four fields averaged per leaf; -> (m, out_point_step) uint8."""

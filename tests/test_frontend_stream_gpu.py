@@ -24,10 +24,12 @@ def drive():
         return synth.cfg_frontend_drive(N_SCANS, pool=p)
 
 
-def _replay(reg, drive, to_device=None, device_payloads=False):
+def _replay(reg, drive, to_device=None, device_payloads=False, mapper=None):
     import torch
 
-    fr = FrontendReplay(reg, FrontendParams(), to_device=to_device)
+    if device_payloads and to_device is None:   # a device run keeps its keyframes in HBM whichever way they are produced
+        to_device = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    fr = FrontendReplay(reg, FrontendParams(), to_device=to_device, mapper=mapper)
     fr.initialise(drive["frames"], drive["frame_poses"], drive["guess0"])
     out = FrontendResult()
     for scan in drive["scans"]:
@@ -45,7 +47,8 @@ def test_frontend_stream_matches_the_oracle_on_every_scan(drive):
 
     ndt = NormalDistributionsTransform(device=0)
     ndt.setResolution(5.0); ndt.setTransformationEpsilon(0.01); ndt.setMaximumIterations(35); ndt.setNeighborhoodSearchMethod(DIRECT7)
-    gpu = _replay(ndt, drive, to_device=lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda(), device_payloads=True)
+    mapper = NormalDistributionsTransform(device=0)   # its source slot filters the new keyframes, which then never leave HBM
+    gpu = _replay(ndt, drive, to_device=lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda(), device_payloads=True, mapper=mapper)
     cpu = _replay(OracleFrontendRegistration(5.0, 0.01, 35), drive)
     assert gpu.update_at == cpu.update_at and len(gpu.update_at) >= 3, (gpu.update_at, cpu.update_at)   # the same scans became keyframes
     assert gpu.points_kept == cpu.points_kept                                                            # N1/N4: same filtered scans
@@ -63,13 +66,15 @@ def test_frontend_stream_matches_the_oracle_on_every_scan(drive):
 
 
 def test_host_and_device_payloads_give_the_same_stream(drive):
-    """The raw payload handed over as a CUDA tensor or as a host buffer (PCIe-inclusive path): bit-identical poses."""
+    """The raw payload handed over as a CUDA tensor — with the keyframes produced and kept in HBM (lsr_get_source_pc2_device), and
+    with the keyframes taken through the host — or as a host buffer (PCIe-inclusive path): bit-identical poses, all three."""
     from lidarslam_ros2_amd import DIRECT7, NormalDistributionsTransform
 
     outs = []
-    for dev in (True, False):
+    for dev, resident in ((True, True), (True, False), (False, False)):
         ndt = NormalDistributionsTransform(device=0)
         ndt.setResolution(5.0); ndt.setTransformationEpsilon(0.01); ndt.setMaximumIterations(35); ndt.setNeighborhoodSearchMethod(DIRECT7)
-        outs.append(_replay(ndt, drive, device_payloads=dev))
-    for a, b in zip(outs[0].poses, outs[1].poses):
-        assert np.array_equal(a, b)
+        outs.append(_replay(ndt, drive, device_payloads=dev, mapper=NormalDistributionsTransform(device=0) if resident else None))
+    assert outs[0].update_at == outs[1].update_at == outs[2].update_at
+    for a, b, c in zip(outs[0].poses, outs[1].poses, outs[2].poses):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
