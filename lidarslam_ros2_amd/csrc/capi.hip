@@ -646,7 +646,10 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     // a launch group serves up to 12 members: wait for a full group while the chain is still running.  (Round 5 measured groups of
     // ONE for small sets — a share of 8 candidates, whose chain leaves the chip idle half of the time —: a search is a wide launch
     // of long-lived waves, the chain's workgroups queue behind them for wave slots and LDS, launches of 15 us took 40-80 us, and the
-    // share got slower, not faster: 0.757 / 0.949 ms against 0.710 / 0.928 ms for align + fitness of two shares.)
+    // share got slower, not faster: 0.757 / 0.949 ms against 0.710 / 0.928 ms for align + fitness of two shares.  Bounding the searches
+    // and the grid refinement to 256 / 512 / 1024 resident workgroups (stride loops) so that the chain always finds its slots made it
+    // worse still — 1.22 / 0.99 / 0.78 ms against 0.68 for the first share: refinement + searches are ~0.4 ms of full-chip work, at a
+    // fraction of the chip they outlast the 0.5 ms chain and the tail is paid at the reduced rate.)
     const size_t group_min = 12;
     while (!eager_ready.empty() && (all || eager_ready.size() >= group_min)) {
       const int n = (int)std::min<size_t>(12, eager_ready.size());

@@ -79,5 +79,6 @@ for it in range(REPS + 2):
 tw = [whole() for _ in range(REPS + 2)][2:]
 ev = [int(r.n_evaluations) for r in res]; its = [int(r.iterations) for r in res]
 print("share x%d first %d | median ms: " % (N, FIRST) + " | ".join("%s %.3f" % (k, 1e3 * np.median(v)) for k, v in T.items()) +
-      " | align+fitness (one call) %.3f | whole path best %.3f median %.3f | passes %s iterations %s" %
-      (1e3 * np.median(tf[2:]), 1e3 * min(tw), 1e3 * float(np.median(tw)), ev, its), flush=True)
+      " | align+fitness (one call) %.3f | whole path best %.3f median %.3f | passes %s iterations %s | fitness bits %s" %
+      (1e3 * np.median(tf[2:]), 1e3 * min(tw), 1e3 * float(np.median(tw)), ev, its,
+       "%016x" % (int(np.bitwise_xor.reduce(np.frombuffer(np.array(list(fit), np.float64).tobytes(), np.uint64)))), ), flush=True)
