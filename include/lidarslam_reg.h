@@ -89,15 +89,21 @@ typedef enum lsr_key {
   LSR_NDT_QUAD = 44,                  /* single NDT registrations: 1 = quad kernel (four lanes per source point on every CU:
                                          lowest latency for a 30k-point scan), 0 = lane kernel (one lane per point: what candidate
                                          sets use), -1 = automatic (quad below 65 536 source points, lane from there on) */
-  LSR_NDT_SORT = 45                   /* order the source by voxel tile of its guess-moved points at the start of align():
+  LSR_NDT_SORT = 45,                  /* order the source by voxel tile of its guess-moved points at the start of align():
                                          -1 = automatic (tile table mode only), 0 = never (the tile mode then falls back to the
                                          global table), 1 = also when the records are gathered from the global table */
+  LSR_VOXEL_FILTER_FORM = 46          /* read-only (lsr_get_i32): which form the last VoxelGrid filter on this object took:
+                                         0 = none yet, 1 = grid dimensions worked out on the host (one wait for the bounding box,
+                                         one for the leaf count), 2 = on the device (one wait: from the second
+                                         lsr_set_input_source_pc2 / _frontend of an object on), 3 = the device form came back
+                                         flagged (more key bits than planned, or an index overflow) and the host form ran */
 } lsr_key;
 /* Environment presets read when an object is created: LSR_NDT_WORKGROUP, LSR_NDT_TABLE_MODE, LSR_NDT_QUAD, LSR_GRID_BUILDER,
  * LSR_WAIT_MODE (the keys above); LSR_NDT_WIDEN=0 keeps the launches of a candidate set at their first geometry (default: widened
  * as members finish); LSR_NDT_CHAINS=1|2|3 fixes the number of independent launch chains a candidate set runs as (default: two
  * from six members on, each on a stream verified to run concurrently with the object's own; LSR_DEBUG_STREAMS=1 prints what the
- * verification found).  Diagnostic A/B switches read once per process, all with bit-identical results
+ * verification found).  Diagnostic A/B switches read once per process, all with bit-identical results (LSR_VG_DEVICE_DIMS=0: the
+ * VoxelGrid filter always works out its grid dimensions on the host)
  * (tests/test_gicp_gpu.py::test_search_and_chain_variants_give_identical_results): LSR_NN_COOP=0 (per-thread neighbour
  * walks instead of one wave per query), LSR_GICP_FUSED=0 (accumulate + update launch pairs instead of the fused
  * Gauss-Newton step), LSR_GICP_BALL=0 (general correspondence search on every outer iteration), LSR_GICP_CORR_FUSED=0 (seeded

@@ -66,6 +66,23 @@ int upload_cloud(lsr_handle h, const void* pts, size_t stride, size_t n, bool on
   return deinterleave(d_aos, stride, n, out, h->stream);
 }
 
+// A PointCloud2 payload (or strided xyz records: a payload without intensity) -> SoA planes through pc2_ingest: ONE launch that also applies
+// the frontend's range filter (do_range) and leaves the bounding-box records for what follows
+int ingest_pc2(lsr_handle h, const void* data, size_t n, const lsr_pc2_layout* L, bool on_device, bool do_range, double rmin, double rmax,
+               DeviceCloud& out) {
+  if (n > 0 && !data) { set_last_error("null PointCloud2 data"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (n > (size_t)INT32_MAX / 2) { set_last_error("cloud too large"); return LSR_ERR_INVALID_ARGUMENT; }
+  const void* d = data;
+  if (!on_device && n > 0) {
+    int st = h->staging.reserve(n * L->point_step);
+    if (st) return st;
+    LSR_HIP(hipMemcpyAsync(h->staging.p, data, n * L->point_step, hipMemcpyHostToDevice, h->stream));
+    d = h->staging.p;
+  }
+  return pc2_ingest(d, (int)L->point_step, (int)L->offset_x, (int)L->offset_y, (int)L->offset_z, L->offset_intensity, n, do_range, rmin, rmax,
+                    out, h->scratch, h->stream);
+}
+
 // Workgroups per registration.  A single registration spreads one point per thread over as many CUs as
 // it can (latency); a batch wants ~4 resident workgroups per CU in total and lets every thread stride
 // over several points, which amortises the reduction and the partial-row traffic (throughput).
@@ -940,6 +957,7 @@ int lsr_get_i32(lsr_handle h, int key, int* v) {
     case LSR_NDT_SORT: *v = h->ndt_sort; return LSR_OK;
     case LSR_GRID_BUILDER: *v = h->scratch.force_sort_path ? 1 : 0; return LSR_OK;
     case LSR_WAIT_MODE: *v = h->scratch.wait_mode; return LSR_OK;
+    case LSR_VOXEL_FILTER_FORM: *v = h->scratch.vg_form; return LSR_OK;
     default: set_last_error("unknown i32 key"); return LSR_ERR_INVALID_ARGUMENT;
   }
 }
@@ -1203,9 +1221,12 @@ int lsr_set_input_source_frontend(lsr_handle h, const void* pts, size_t stride_b
                                   double scan_max_range, float vg_size_for_input, int on_device, size_t* n_out) {
   LSR_CHECK_HANDLE(h);
   if (!(vg_size_for_input > 0)) { set_last_error("leaf size must be > 0"); return LSR_ERR_INVALID_ARGUMENT; }
-  int st = upload_cloud(h, pts, stride_bytes, n, on_device != 0, h->raw);
+  if (stride_bytes < 12 || (stride_bytes % 4) != 0) { set_last_error("stride_bytes must be a multiple of 4 and >= 12"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (n > 0 && !pts) { set_last_error("null point pointer"); return LSR_ERR_INVALID_ARGUMENT; }
+  // strided xyz records are a PointCloud2 payload without an intensity field: the same one-launch ingest
+  const lsr_pc2_layout rec_layout{(uint32_t)stride_bytes, 0u, 4u, 8u, -1};
+  int st = ingest_pc2(h, pts, n, &rec_layout, on_device != 0, true, scan_min_range, scan_max_range, h->raw);
   if (st) return st;
-  if ((st = range_mask(h->raw, scan_min_range, scan_max_range, h->stream))) return st;
   if ((st = voxel_grid_filter(h->raw, vg_size_for_input, h->source, h->scratch, h->stream))) return st;
   h->has_source = true;
   h->source_cov_valid = false;
@@ -1249,19 +1270,6 @@ int check_layout(const lsr_pc2_layout* L) {
 }
 
 // payload -> SoA planes (+ intensity) on the device
-int read_pc2(lsr_handle h, const void* data, size_t n, const lsr_pc2_layout* L, bool on_device, DeviceCloud& out) {
-  if (n > 0 && !data) { set_last_error("null PointCloud2 data"); return LSR_ERR_INVALID_ARGUMENT; }
-  if (n > (size_t)INT32_MAX / 2) { set_last_error("cloud too large"); return LSR_ERR_INVALID_ARGUMENT; }
-  const void* d = data;
-  if (!on_device && n > 0) {
-    int st = h->staging.reserve(n * L->point_step);
-    if (st) return st;
-    LSR_HIP(hipMemcpyAsync(h->staging.p, data, n * L->point_step, hipMemcpyHostToDevice, h->stream));
-    d = h->staging.p;
-  }
-  return pc2_read(d, (int)L->point_step, (int)L->offset_x, (int)L->offset_y, (int)L->offset_z, L->offset_intensity, n, out, h->stream);
-}
-
 // SoA planes -> host payload (bytes outside the four fields are zero)
 int write_pc2_host(lsr_handle h, const DeviceCloud& cloud, void* out_data, size_t capacity, const lsr_pc2_layout* L, size_t* n_out) {
   *n_out = cloud.n;
@@ -1285,8 +1293,8 @@ int lsr_set_input_source_pc2(lsr_handle h, const void* data, size_t n_points, co
   int st = check_layout(layout);
   if (st) return st;
   if (!(vg_size_for_input > 0)) { set_last_error("leaf size must be > 0"); return LSR_ERR_INVALID_ARGUMENT; }
-  if ((st = read_pc2(h, data, n_points, layout, on_device != 0, h->raw))) return st;
-  if ((st = range_mask(h->raw, scan_min_range, scan_max_range, h->stream))) return st;
+  // payload -> planes + range filter + bounding-box records in one launch; the voxel filter behind it reads the records on the device
+  if ((st = ingest_pc2(h, data, n_points, layout, on_device != 0, true, scan_min_range, scan_max_range, h->raw))) return st;
   if ((st = voxel_grid_filter(h->raw, vg_size_for_input, h->source, h->scratch, h->stream))) return st;
   h->has_source = true;
   h->source_cov_valid = false;
@@ -1330,7 +1338,7 @@ int lsr_voxel_grid_filter_pc2(lsr_handle h, const void* data, size_t n_points, c
   if (st) return st;
   if ((st = check_layout(out_layout))) return st;
   if (!(leaf > 0) || !n_out) { set_last_error("bad argument"); return LSR_ERR_INVALID_ARGUMENT; }
-  if ((st = read_pc2(h, data, n_points, in_layout, false, h->raw))) return st;
+  if ((st = ingest_pc2(h, data, n_points, in_layout, false, false, 0.0, 0.0, h->raw))) return st;
   if ((st = voxel_grid_filter(h->raw, leaf, h->filtered, h->scratch, h->stream))) return st;
   return write_pc2_host(h, h->filtered, out_data, capacity_points, out_layout, n_out);
 }

@@ -102,8 +102,19 @@ struct DeviceCloud {
   mutable bool bbox_valid = false;
   mutable float bbox_mn[3] = {0, 0, 0}, bbox_mx[3] = {0, 0, 0};
   mutable unsigned int bbox_finite = 0;
+  // the pass that wrote this cloud left its per-workgroup bounding-box records behind (pc2_ingest): in the scratch's host mailbox
+  // (cloud_bbox_end collects them, no bbox launch) and in device memory (voxel_grid_filter's device-side dimensions)
+  mutable bool bbox_enqueued = false;
+  // fewer points than the planes were laid out for: the planes stay where they are (a kernel that was enqueued before the count
+  // was known has written them at this pitch)
+  int shrink(size_t count) {
+    if (count > n) return LSR_ERR_INVALID_ARGUMENT;
+    n = count;
+    return LSR_OK;
+  }
   int resize(size_t count, bool with_intensity = false) {
     bbox_valid = false;
+    bbox_enqueued = false;
     size_t pt = (count + 63) & ~size_t(63);
     if (pt == 0) pt = 64;
     int st = buf.reserve(4 * pt);   // room for the intensity plane whether or not this cloud uses it
@@ -185,8 +196,13 @@ struct BuildMailbox {
   unsigned int value_token;
   double fit_sum, fit_cnt;
   unsigned int fit_token;
-  unsigned int pad[3];
+  // voxel_grid_filter with device-side dimensions: what the host needs next to `value` (= runs of equal keys), same token
+  unsigned int vg_flags;      // VG_FLAG_*
+  unsigned int vg_finite;     // finite points of the input
+  unsigned int vg_bits;       // bits of the largest key (the next call on this scratch plans its sort with it)
 };
+constexpr unsigned int VG_FLAG_OVERFLOW = 1u;   // leaf index space beyond int32 (PCL: "Leaf size is too small for the input dataset")
+constexpr unsigned int VG_FLAG_REPLAN = 2u;     // the keys need more bits than the sort was planned for: run again with exact dimensions
 
 // How a host thread waits on a mailbox word (lsr_set_i32(LSR_WAIT_MODE)): a ROS2 MultiThreadedExecutor runs two
 // registration objects side by side (lidarslam/src/lidarslam.cpp:12-17), and a spinning wait pins one core per align.
@@ -209,6 +225,9 @@ struct BuildScratch {
   bool grid_pending = false;       // a dense voxel-grid build whose result has not been read from the mailbox yet
   unsigned int grid_token = 0;
   unsigned int fit_token = 0;      // an enqueued fitness reduction (0: none)
+  DevBuf<unsigned long long> bbox_dev;   // device copy of the bounding-box records of the last pc2_ingest ([BBOX_MAX_PARTS][8])
+  int vg_bits_hint = 0;            // key bits of the last voxel_grid_filter on this scratch (0: none yet)
+  int vg_form = 0;                 // which form that filter took (LSR_VOXEL_FILTER_FORM)
   int ensure_mailbox();
 };
 

@@ -234,8 +234,10 @@ __global__ __launch_bounds__(256) void rs_heads_count_kernel(const unsigned int*
 }
 
 // one workgroup: exclusive scan of the per-workgroup head counts; the total goes to the host mailbox (value + token)
+// dims (nullable): {sentinel, finite points, VG_FLAG_*, key bits} left by leaf_key_dims_kernel — handed to the host with the count
 __global__ __launch_bounds__(1024) void rs_heads_scan_kernel(const int* __restrict__ block_heads, int nblocks, int* __restrict__ block_base,
-                                                             BuildMailbox* __restrict__ mb, unsigned int token) {
+                                                             BuildMailbox* __restrict__ mb, unsigned int token,
+                                                             const unsigned int* __restrict__ dims) {
   __shared__ int s_w[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (nblocks + 1023) / 1024;
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(1024) void rs_heads_scan_kernel(const int* __restri
   for (int b = b0; b < b1; b++) { const int t = block_heads[b]; block_base[b] = run; run += t; }
   if (tid == 1023) {
     mb->value = run;   // == total: thread 1023 owns the last (possibly empty) slice
+    if (dims) { mb->vg_finite = dims[1]; mb->vg_flags = dims[2]; mb->vg_bits = dims[3]; }
     __threadfence_system();
     __hip_atomic_store(&mb->value_token, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -264,7 +267,8 @@ __global__ __launch_bounds__(1024) void rs_heads_scan_kernel(const int* __restri
 // every head sums its run: FLOAT accumulators, points in ascending index (the sort is stable) — the very additions
 // pcl::CentroidPoint performs; output ordered by key; the run of the sentinel key (non-finite points, always last) is dropped
 __global__ __launch_bounds__(256) void rs_centroid_kernel(const unsigned int* __restrict__ keys, const int* __restrict__ order, int n,
-                                                          const int* __restrict__ block_base, unsigned int sentinel,
+                                                          const int* __restrict__ block_base, unsigned int sentinel_arg,
+                                                          const unsigned int* __restrict__ sentinel_dev /*nullable: dims[0]*/,
                                                           const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                           const float* __restrict__ w /*nullable*/, float* __restrict__ ox,
                                                           float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ ow) {
@@ -279,6 +283,7 @@ __global__ __launch_bounds__(256) void rs_centroid_kernel(const unsigned int* __
   int r = block_base[blockIdx.x] + __popcll(heads & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
   for (int k = 0; k < wave; k++) r += s_w[k];
   const unsigned int k = keys[i];
+  const unsigned int sentinel = sentinel_dev ? *sentinel_dev : sentinel_arg;
   if (k == sentinel) return;
   float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
   int j = i;
@@ -366,14 +371,14 @@ int sort_pairs_u32_lsd(unsigned int* key_a, unsigned int* key_b, int* val_a /*nu
 }
 
 int sorted_runs_begin(const unsigned int* keys_sorted, size_t n, int* block_heads, int* block_base, BuildScratch& sc, hipStream_t stream,
-                      unsigned int* token_out) {
+                      unsigned int* token_out, const unsigned int* dims_dev) {
   int st = sc.ensure_mailbox();
   if (st) return st;
   unsigned int token = ++sc.token;
   if (token == 0) token = ++sc.token;
   const int nblocks = (int)((n + RUN_CHUNK - 1) / RUN_CHUNK);
   hipLaunchKernelGGL(rs_heads_count_kernel, dim3(nblocks), dim3(256), 0, stream, keys_sorted, (int)n, block_heads);
-  hipLaunchKernelGGL(rs_heads_scan_kernel, dim3(1), dim3(1024), 0, stream, block_heads, nblocks, block_base, sc.d_mb, token);
+  hipLaunchKernelGGL(rs_heads_scan_kernel, dim3(1), dim3(1024), 0, stream, block_heads, nblocks, block_base, sc.d_mb, token, dims_dev);
   LSR_HIP(hipGetLastError());
   *token_out = token;
   return LSR_OK;
@@ -388,10 +393,10 @@ int sorted_runs_count(BuildScratch& sc, hipStream_t stream, unsigned int token, 
 
 int sorted_runs_centroids(const unsigned int* keys_sorted, const int* order, size_t n, const int* block_base, unsigned int sentinel,
                           const float* x, const float* y, const float* z, const float* w, float* ox, float* oy, float* oz, float* ow,
-                          hipStream_t stream) {
+                          hipStream_t stream, const unsigned int* sentinel_dev) {
   const int nblocks = (int)((n + RUN_CHUNK - 1) / RUN_CHUNK);
-  hipLaunchKernelGGL(rs_centroid_kernel, dim3(nblocks), dim3(256), 0, stream, keys_sorted, order, (int)n, block_base, sentinel, x, y, z, w, ox,
-                     oy, oz, ow);
+  hipLaunchKernelGGL(rs_centroid_kernel, dim3(nblocks), dim3(256), 0, stream, keys_sorted, order, (int)n, block_base, sentinel, sentinel_dev,
+                     x, y, z, w, ox, oy, oz, ow);
   LSR_HIP(hipGetLastError());
   return LSR_OK;
 }

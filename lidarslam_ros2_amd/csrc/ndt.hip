@@ -1903,6 +1903,70 @@ __global__ __launch_bounds__(256) void leaf_key_kernel(const float* __restrict__
   val[i] = i;
 }
 
+// The same keys with the grid dimensions worked out ON THE DEVICE from the bounding-box records the ingest pass left in device memory
+// (pc2_ingest): every workgroup folds the (<= 256) records itself — the arithmetic is voxel_grid_filter's host code, operation for
+// operation — and workgroup 0 leaves {sentinel, finite points, VG_FLAG_*, key bits} in dims[0..3] for the kernels behind the sort.
+// The host never sees the box: it enqueues key + sort + run heads + centroids without a wait in between.
+__global__ __launch_bounds__(256) void leaf_key_dims_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ z, int n, float inv_leaf,
+                                                            const unsigned long long* __restrict__ parts, int nparts, int planned_bits,
+                                                            unsigned int* __restrict__ key, unsigned int* __restrict__ dims) {
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  __shared__ unsigned int s_cnt[4];
+  const int tid = threadIdx.x, w = tid >> 6;
+  // the point first: its loads are in flight while the records are folded
+  const int i = blockIdx.x * 256 + tid;
+  const float px = (i < n) ? x[i] : NAN, py = (i < n) ? y[i] : NAN, pz = (i < n) ? z[i] : NAN;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  unsigned int cnt = 0;
+  if (tid < nparts) {
+    const unsigned long long* P = parts + (size_t)tid * 8;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mn[k] = __uint_as_float((unsigned int)P[k]); mx[k] = __uint_as_float((unsigned int)P[3 + k]); }
+    cnt = (unsigned int)P[6];
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], m, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], m, 64)); }
+    cnt += __shfl_xor(cnt, m, 64);
+  }
+  if ((tid & 63) == 0) {
+    for (int k = 0; k < 3; k++) { s_mn[w][k] = mn[k]; s_mx[w][k] = mx[k]; }
+    s_cnt[w] = cnt;
+  }
+  __syncthreads();
+  const unsigned int n_finite = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  int mb[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
+  unsigned int sentinel = 0u, flags = 0u;
+  int bits = 1;
+  if (n_finite != 0u) {
+    long long vol = 1;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float lo = fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k]));
+      const float hi = fmaxf(fmaxf(s_mx[0][k], s_mx[1][k]), fmaxf(s_mx[2][k], s_mx[3][k]));
+      vol *= (long long)((hi - lo) * inv_leaf) + 1;
+      mb[k] = (int)floorf(lo * inv_leaf);
+      dv[k] = (int)floorf(hi * inv_leaf) - mb[k] + 1;
+    }
+    if (vol > (long long)INT32_MAX) flags |= VG_FLAG_OVERFLOW;
+    sentinel = (unsigned int)((long long)dv[0] * dv[1] * dv[2]);
+    while (bits < 32 && (sentinel >> bits) != 0u) bits++;
+    if (bits > planned_bits) flags |= VG_FLAG_REPLAN;
+  }
+  if (blockIdx.x == 0 && tid == 0) { dims[0] = sentinel; dims[1] = n_finite; dims[2] = flags; dims[3] = (unsigned int)bits; }
+  if (i >= n) return;
+  unsigned int k = sentinel;
+  if (flags == 0u && isfinite(px) && isfinite(py) && isfinite(pz)) {
+    const int i0 = (int)(floorf(px * inv_leaf) - (float)mb[0]);
+    const int i1 = (int)(floorf(py * inv_leaf) - (float)mb[1]);
+    const int i2 = (int)(floorf(pz * inv_leaf) - (float)mb[2]);
+    k = (unsigned int)(i0 + i1 * dv[0] + i2 * (dv[0] * dv[1]));
+  }
+  key[i] = k;
+}
+
 // K1: one wave per leaf; lanes stride the leaf's points (stable-sorted => ascending point index),
 // fp64 sums, fixed butterfly order => deterministic.  sums[leaf][9] = {Sx,Sy,Sz,Sxx,Sxy,Sxz,Syy,Syz,Szz}
 __global__ __launch_bounds__(256) void leaf_sum_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -2046,6 +2110,7 @@ int transform_to_strided(const DeviceCloud& src, const float* d_T16, void* d_out
 // Two halves, so that a batch of builds can enqueue every bounding-box pass before waiting for the first one.
 int cloud_bbox_begin(const DeviceCloud& cloud, BuildScratch& sc, hipStream_t stream) {
   const int n = (int)cloud.n;
+  if (n > 0 && !cloud.bbox_valid && cloud.bbox_enqueued && sc.bbox_parts > 0) return LSR_OK;   // pc2_ingest wrote the records already
   sc.bbox_parts = 0;
   if (n <= 0 || cloud.bbox_valid) return LSR_OK;
   int st = sc.ensure_mailbox();
@@ -2093,6 +2158,7 @@ int cloud_bbox_end(const DeviceCloud& cloud, float* mn, float* mx, unsigned int*
     for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], v[k]); hi[k] = std::fmax(hi[k], v[3 + k]); }
   }
   sc.bbox_parts = 0;
+  cloud.bbox_enqueued = false;
   *n_finite = cnt;
   if (cnt) for (int k = 0; k < 3; k++) { mn[k] = lo[k]; mx[k] = hi[k]; }
   cloud.bbox_valid = true;
@@ -2145,39 +2211,73 @@ __global__ __launch_bounds__(256) void leaf_centroid_kernel(const float* __restr
 }
 }  // namespace
 
-// N4: the frontend's min-max range filter (scanmatcher_component.cpp:210-218): keep p iff
-// scan_min_range < sqrt(x^2 + y^2) < scan_max_range (double arithmetic, as pow(p.x, 2.0) promotes).
-// Rejected points are overwritten with NaN in the handle's private copy, so the voxel filter that
-// follows drops them exactly like non-finite input.
-namespace {
-__global__ __launch_bounds__(256) void range_mask_kernel(float* __restrict__ x, const float* __restrict__ y, int n, double rmin,
-                                                         double rmax) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double px = (double)x[i], py = (double)y[i];
-  const double r = sqrt(px * px + py * py);
-  if (!(rmin < r && r < rmax)) x[i] = __int_as_float(0x7FC00000);
-}
-}  // namespace
-
-int range_mask(DeviceCloud& cloud, double rmin, double rmax, hipStream_t stream) {
-  if (cloud.n == 0) return LSR_OK;
-  hipLaunchKernelGGL(range_mask_kernel, dim3((unsigned)((cloud.n + 255) / 256)), dim3(256), 0, stream, cloud.x(), cloud.y(),
-                     (int)cloud.n, rmin, rmax);
-  LSR_HIP(hipGetLastError());
-  return LSR_OK;
-}
-
 int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, BuildScratch& sc, hipStream_t stream) {
   const int n = (int)cloud.n;
   out.n = 0;
   if (n == 0) return out.resize(0, cloud.has_i);
+  int st;
+  // A/B switches, read once: LSR_VG_SORT=rocprim — the rocPRIM radix sort + run_length_encode + scan path of rounds 1-4;
+  // LSR_VG_DEVICE_DIMS=0 — always work out the grid dimensions on the host
+  static const bool use_rocprim = [] { const char* e = getenv("LSR_VG_SORT"); return e && e[0] == 'r'; }();
+  static const bool device_dims = [] { const char* e = getenv("LSR_VG_DEVICE_DIMS"); return !(e && e[0] == '0'); }();
+  const float inv_leaf = 1.0f / leaf;
+  const size_t nrb = sorted_runs_blocks((size_t)n);
+  if ((st = sc.words.reserve(32 + 7 * (size_t)n + 2 * nrb + 16))) return st;
+  unsigned int* dims_dev = sc.words.p + 16;   // {sentinel, finite points, flags, key bits} of the device-side form
+  unsigned int* key_in = sc.words.p + 32;
+  unsigned int* key_out = key_in + n;
+  int* val_in = (int*)(key_out + n);
+  int* val_out = val_in + n;
+  unsigned int* run_key = (unsigned int*)(val_out + n);
+  int* run_cnt = (int*)(run_key + n);
+  int* run_off = run_cnt + n;
+  int* d_nruns = run_off + n;
+  int* block_heads = d_nruns + 8;
+  int* block_base = block_heads + nrb;
+
+  // ---- device-side dimensions: the pass that wrote `cloud` left its bounding-box records in device memory (pc2_ingest) and an earlier
+  // call on this scratch says how many key bits such a cloud needs -> key (folds the records itself), sort, run heads and centroids are
+  // enqueued back to back; the host waits ONCE, for {runs, finite points, flags}.  A cloud that needs more bits than planned (or whose
+  // index space overflows) comes back flagged and takes the host-side form below, which also renews the hint.
+  if (!use_rocprim && device_dims && cloud.bbox_enqueued && !cloud.bbox_valid && sc.bbox_parts > 0 && sc.bbox_dev.p && sc.vg_bits_hint > 0) {
+    const int planned_bits = sc.vg_bits_hint;
+    hipLaunchKernelGGL(leaf_key_dims_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
+                       sc.bbox_dev.p, sc.bbox_parts, planned_bits, key_in, dims_dev);
+    bool in_b = false;
+    if ((st = sort_pairs_u32_lsd(key_in, key_out, nullptr, val_in, val_out, (size_t)n, planned_bits, sc.temp, stream, &in_b))) return st;
+    const unsigned int* ks = in_b ? key_out : key_in;
+    const int* vs = in_b ? val_out : val_in;
+    unsigned int token = 0;
+    if ((st = sorted_runs_begin(ks, (size_t)n, block_heads, block_base, sc, stream, &token, dims_dev))) return st;
+    // the centroids do not wait for the count: the planes are laid out for n runs, the cloud shrinks to what was found
+    if ((st = out.resize((size_t)n, cloud.has_i))) return st;
+    if ((st = sorted_runs_centroids(ks, vs, (size_t)n, block_base, 0u, cloud.x(), cloud.y(), cloud.z(), cloud.i(), out.x(), out.y(), out.z(),
+                                    out.i(), stream, dims_dev))) return st;
+    int n_runs = 0;
+    if ((st = sorted_runs_count(sc, stream, token, &n_runs))) return st;
+    const unsigned int flags = sc.mb.p->vg_flags, n_finite = sc.mb.p->vg_finite;
+    if (flags == 0u) {
+      sc.vg_form = 2;
+      sc.bbox_parts = 0;            // the records are spent
+      cloud.bbox_enqueued = false;
+      // the plan follows the clouds: up at once (the host form does that), down only when a cloud needs clearly fewer bits — a stream
+      // whose index space hovers around a power of two would otherwise be flagged every other scan; an empty cloud says nothing
+      const int needed = (int)sc.mb.p->vg_bits;
+      if (n_finite > 0u && needed > 0 && needed <= sc.vg_bits_hint - 3) sc.vg_bits_hint = needed;
+      return out.shrink((size_t)(n_runs - ((n_finite < (unsigned int)n) ? 1 : 0)));   // minus the sentinel run
+    }
+    // flagged: the centroid launch may still be writing `out` — the host-side form below runs behind it on the same stream
+    out.n = 0;
+    sc.vg_form = 3;
+  } else {
+    sc.vg_form = 1;
+  }
+
   float mn[3], mx[3];
   unsigned int n_finite = 0;
-  int st = cloud_bbox(cloud, mn, mx, &n_finite, sc, stream);
+  st = cloud_bbox(cloud, mn, mx, &n_finite, sc, stream);
   if (st) return st;
   if (n_finite == 0) return out.resize(0, cloud.has_i);
-  const float inv_leaf = 1.0f / leaf;
   int64_t d[3];
   for (int k = 0; k < 3; k++) d[k] = (int64_t)((mx[k] - mn[k]) * inv_leaf) + 1;
   if (d[0] * d[1] * d[2] > (int64_t)INT32_MAX) {  // PCL: "Leaf size is too small for the input dataset"
@@ -2189,38 +2289,26 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
     min_b[k] = (int)floorf(mn[k] * inv_leaf);
     div_b[k] = (int)floorf(mx[k] * inv_leaf) - min_b[k] + 1;
   }
-  // A/B switch (env LSR_VG_SORT=rocprim: the rocPRIM radix sort + run_length_encode + scan path of rounds 1-4); read once
-  static const bool use_rocprim = [] { const char* e = getenv("LSR_VG_SORT"); return e && e[0] == 'r'; }();
-  const size_t nrb = sorted_runs_blocks((size_t)n);
-  if ((st = sc.words.reserve(32 + 7 * (size_t)n + 2 * nrb + 16))) return st;
-  unsigned int* key_in = sc.words.p + 32;
-  unsigned int* key_out = key_in + n;
-  int* val_in = (int*)(key_out + n);
-  int* val_out = val_in + n;
-  unsigned int* run_key = (unsigned int*)(val_out + n);
-  int* run_cnt = (int*)(run_key + n);
-  int* run_off = run_cnt + n;
-  int* d_nruns = run_off + n;
-  int* block_heads = d_nruns + 8;
-  int* block_base = block_heads + nrb;
   const unsigned int sentinel = (unsigned int)((int64_t)div_b[0] * div_b[1] * div_b[2]);  // one past the last leaf index
+  sc.vg_bits_hint = bits_for(sentinel);
   hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
                      min_b[0], min_b[1], min_b[2], div_b[0], div_b[0] * div_b[1], sentinel, key_in, val_in, (uint4*)nullptr, (size_t)0,
                      (int*)nullptr, (size_t)0, (int*)nullptr);
   if (!use_rocprim) {
-    // hand-written stable LSD sort (two passes for a 28-bit leaf index) + run heads + centroids: lsd_sort.hip
+    // hand-written stable LSD sort (three passes for a 27-bit leaf index) + run heads + centroids: lsd_sort.hip
     bool in_b = false;
     if ((st = sort_pairs_u32_lsd(key_in, key_out, nullptr, val_in, val_out, (size_t)n, bits_for(sentinel), sc.temp, stream, &in_b))) return st;
     const unsigned int* ks = in_b ? key_out : key_in;
     const int* vs = in_b ? val_out : val_in;
     unsigned int token = 0;
     if ((st = sorted_runs_begin(ks, (size_t)n, block_heads, block_base, sc, stream, &token))) return st;
+    // the centroids do not wait for the count either (planes laid out for n runs; shrunk below)
+    if ((st = out.resize((size_t)n, cloud.has_i))) return st;
+    if ((st = sorted_runs_centroids(ks, vs, (size_t)n, block_base, sentinel, cloud.x(), cloud.y(), cloud.z(), cloud.i(), out.x(), out.y(), out.z(),
+                                    out.i(), stream))) return st;
     int n_runs = 0;
     if ((st = sorted_runs_count(sc, stream, token, &n_runs))) return st;   // host mailbox: no D2H copy, no stream sync
-    const int n_out = n_runs - ((n_finite < (unsigned int)n) ? 1 : 0);     // minus the sentinel run
-    if ((st = out.resize(n_out, cloud.has_i))) return st;
-    return sorted_runs_centroids(ks, vs, (size_t)n, block_base, sentinel, cloud.x(), cloud.y(), cloud.z(), cloud.i(), out.x(), out.y(), out.z(),
-                                 out.i(), stream);
+    return out.shrink((size_t)(n_runs - ((n_finite < (unsigned int)n) ? 1 : 0)));     // minus the sentinel run
   }
   if ((st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), sc.temp, stream))) return st;
   if ((st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
@@ -2259,17 +2347,6 @@ int interleave(const DeviceCloud& in, void* d_out, size_t stride_bytes, hipStrea
 // pcl::fromROSMsg (scanmatcher_component.cpp:201-202) reads x / y / z / intensity wherever the message's fields put them;
 // pcl::toROSMsg (:279,284; SubMap.msg:4) writes pcl::PointXYZI's layout.  Offsets are in bytes inside a point_step record.
 namespace {
-__global__ __launch_bounds__(256) void pc2_read_kernel(const unsigned char* __restrict__ data, int step, int ox, int oy, int oz, int oi,
-                                                       int n, float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
-                                                       float* __restrict__ w) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned char* rec = data + (size_t)i * step;
-  x[i] = *reinterpret_cast<const float*>(rec + ox);
-  y[i] = *reinterpret_cast<const float*>(rec + oy);
-  z[i] = *reinterpret_cast<const float*>(rec + oz);
-  if (w) w[i] = (oi >= 0) ? *reinterpret_cast<const float*>(rec + oi) : 0.f;
-}
 __global__ __launch_bounds__(256) void pc2_write_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                         const float* __restrict__ w, int n, unsigned char* __restrict__ data, int step,
                                                         int ox, int oy, int oz, int oi) {
@@ -2283,13 +2360,97 @@ __global__ __launch_bounds__(256) void pc2_write_kernel(const float* __restrict_
 }
 }  // namespace
 
-int pc2_read(const void* d_data, int step, int ox, int oy, int oz, int oi, size_t n, DeviceCloud& out, hipStream_t stream) {
+namespace {
+// payload -> planes, the frontend's range filter and the bounding box of what is left in ONE pass (until round 5 three launches —
+// read, range mask, bounding box — and two more trips over the planes).
+//   range filter (N4, scanmatcher_component.cpp:210-218): keep p iff scan_min_range < sqrt(x^2 + y^2) < scan_max_range (double
+//   arithmetic, as pow(p.x, 2.0) promotes); a rejected point gets a NaN x in the handle's private copy, so the voxel filter that
+//   follows drops it exactly like non-finite input.
+//   bounding box: the workgroup records go to the host mailbox (cloud_bbox_end folds them as it folds bbox_kernel's) and, the same
+//   words, to device memory for voxel_grid_filter's device-side dimensions.
+__global__ __launch_bounds__(256) void pc2_ingest_kernel(const unsigned char* __restrict__ data, int step, int ox, int oy, int oz, int oi,
+                                                         int n, float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
+                                                         float* __restrict__ w, int do_range, double rmin, double rmax,
+                                                         unsigned long long* __restrict__ parts_dev, BuildMailbox* __restrict__ mb,
+                                                         unsigned int token) {
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  unsigned int cnt = 0;
+  const int step_pts = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * step_pts) {  // four records per trip in flight
+    float p[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * step_pts;
+      if (i < n) {
+        const unsigned char* rec = data + (size_t)i * step;
+        p[u][0] = *reinterpret_cast<const float*>(rec + ox);
+        p[u][1] = *reinterpret_cast<const float*>(rec + oy);
+        p[u][2] = *reinterpret_cast<const float*>(rec + oz);
+        p[u][3] = (w && oi >= 0) ? *reinterpret_cast<const float*>(rec + oi) : 0.f;
+      } else {
+        p[u][0] = p[u][1] = p[u][2] = NAN; p[u][3] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * step_pts;
+      if (i >= n) continue;
+      if (do_range) {
+        const double px = (double)p[u][0], py = (double)p[u][1];
+        const double r = sqrt(px * px + py * py);
+        if (!(rmin < r && r < rmax)) p[u][0] = __int_as_float(0x7FC00000);
+      }
+      x[i] = p[u][0]; y[i] = p[u][1]; z[i] = p[u][2];
+      if (w) w[i] = p[u][3];
+      if (!(isfinite(p[u][0]) && isfinite(p[u][1]) && isfinite(p[u][2]))) continue;
+      cnt++;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], p[u][k]); mx[k] = fmaxf(mx[k], p[u][k]); }
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], m, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], m, 64)); }
+    cnt += __shfl_xor(cnt, m, 64);
+  }
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  __shared__ unsigned int s_cnt[4];
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 3; k++) { s_mn[wv][k] = mn[k]; s_mx[wv][k] = mx[k]; }
+    s_cnt[wv] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < BBOX_GRANULES) {
+    const int k = threadIdx.x;
+    unsigned int bits;
+    if (k < 3) bits = __float_as_uint(fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k])));
+    else if (k < 6) bits = __float_as_uint(fmaxf(fmaxf(s_mx[0][k - 3], s_mx[1][k - 3]), fmaxf(s_mx[2][k - 3], s_mx[3][k - 3])));
+    else bits = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const unsigned long long g = ((unsigned long long)token << 32) | bits;
+    parts_dev[(size_t)blockIdx.x * 8 + k] = g;
+    __hip_atomic_store(&mb->part[blockIdx.x].g[k], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+}  // namespace
+
+int pc2_ingest(const void* d_data, int step, int ox, int oy, int oz, int oi, size_t n, bool do_range, double rmin, double rmax,
+               DeviceCloud& out, BuildScratch& sc, hipStream_t stream) {
   int st = out.resize(n, oi >= 0);
   if (st) return st;
   if (n == 0) return LSR_OK;
-  hipLaunchKernelGGL(pc2_read_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const unsigned char*)d_data, step, ox, oy, oz,
-                     oi, (int)n, out.x(), out.y(), out.z(), out.i());
+  if ((st = sc.ensure_mailbox())) return st;
+  if ((st = sc.bbox_dev.reserve((size_t)BBOX_MAX_PARTS * 8))) return st;
+  unsigned int token = ++sc.token;
+  if (token == 0) token = ++sc.token;
+  const int nb = std::max(1, std::min((int)((n + 1023) / 1024), BBOX_MAX_PARTS));
+  hipLaunchKernelGGL(pc2_ingest_kernel, dim3(nb), dim3(256), 0, stream, (const unsigned char*)d_data, step, ox, oy, oz, oi, (int)n, out.x(),
+                     out.y(), out.z(), out.i(), do_range ? 1 : 0, rmin, rmax, sc.bbox_dev.p, sc.d_mb, token);
   LSR_HIP(hipGetLastError());
+  sc.bbox_parts = nb;
+  sc.bbox_token = token;
+  out.bbox_enqueued = true;
   return LSR_OK;
 }
 

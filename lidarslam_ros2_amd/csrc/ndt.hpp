@@ -210,11 +210,13 @@ void ndt_fill_align_constants(NdtState& st, const NdtParamsHost& prm, int n_poin
 int publish_device_int(const int* d_value, BuildScratch& sc, hipStream_t stream, int* out);
 // N4: PointCloud2 payload (float32 fields at byte offsets ox/oy/oz/oi inside point_step records; oi < 0: no intensity)
 // <-> SoA planes, device to device.
-int pc2_read(const void* d_data, int step, int ox, int oy, int oz, int oi, size_t n, DeviceCloud& out, hipStream_t stream);
 int pc2_write(const DeviceCloud& in, void* d_data, int step, int ox, int oy, int oz, int oi, hipStream_t stream);
+// payload -> planes + the frontend's range filter (do_range) + the bounding-box pass in one launch; the box records wait in sc (host mailbox and
+// device memory) for cloud_bbox_end / voxel_grid_filter
+int pc2_ingest(const void* d_data, int step, int ox, int oy, int oz, int oi, size_t n, bool do_range, double rmin, double rmax,
+               DeviceCloud& out, BuildScratch& sc, hipStream_t stream);
 // N1: pcl::VoxelGrid::filter on the device (centroid per leaf, leaf-index order).
 int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, BuildScratch& sc, hipStream_t stream);
-int range_mask(DeviceCloud& cloud, double rmin, double rmax, hipStream_t stream);
 int interleave(const DeviceCloud& in, void* d_out, size_t stride_bytes, hipStream_t stream);
 
 // Transform cloud by a column-major 4x4 into a strided device buffer (align()'s `output`).

@@ -21,11 +21,11 @@ int sort_pairs_u32_lsd(unsigned int* key_a, unsigned int* key_b, int* val_a, int
 // runs travels to the host through sc's mailbox (sorted_runs_count polls it).  sorted_runs_blocks(n) = ints each table needs.
 size_t sorted_runs_blocks(size_t n);
 int sorted_runs_begin(const unsigned int* keys_sorted, size_t n, int* block_heads, int* block_base, BuildScratch& sc, hipStream_t stream,
-                      unsigned int* token_out);
+                      unsigned int* token_out, const unsigned int* dims_dev = nullptr);   // dims_dev: see leaf_key_dims_kernel (ndt.hip)
 int sorted_runs_count(BuildScratch& sc, hipStream_t stream, unsigned int token, int* n_runs);
 // pcl::VoxelGrid's centroid of every run (float sums, ascending point index; all fields): out[r] for run r in key order; the run
 // of `sentinel` (always last) is skipped
 int sorted_runs_centroids(const unsigned int* keys_sorted, const int* order, size_t n, const int* block_base, unsigned int sentinel,
                           const float* x, const float* y, const float* z, const float* w, float* ox, float* oy, float* oz, float* ow,
-                          hipStream_t stream);
+                          hipStream_t stream, const unsigned int* sentinel_dev = nullptr);   // sentinel_dev: the sentinel lives on the device
 }  // namespace lsr

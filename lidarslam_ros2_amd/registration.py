@@ -210,6 +210,11 @@ class Registration:
         self._n_source = int(n_out.value)
         return self._n_source
 
+    def voxelFilterForm(self) -> int:
+        """Which form the last VoxelGrid filter on this object took (LSR_VOXEL_FILTER_FORM): 1 = grid dimensions on the host, 2 = on the
+        device (one host wait per scan), 3 = the device form came back flagged and the host form ran; 0 = none yet."""
+        return self._geti(capi.VOXEL_FILTER_FORM)
+
     def getInputSourcePointCloud2(self, point_step: int = 32, offsets=(0, 4, 8, 16)) -> np.ndarray:
         """pcl::toROSMsg of the current input source: (n, point_step) uint8 records (default: pcl::PointXYZI's layout)."""
         lay = self._layout(point_step, offsets)

@@ -171,6 +171,83 @@ def test_pointcloud2_stand_alone_filter_and_bad_layouts(O, scan):
         assert ei.value.status == -1
 
 
+def test_device_side_grid_dimensions_give_the_same_filter(O):
+    """From the second scan of an object on, the VoxelGrid filter behind lsr_set_input_source_pc2 / _frontend works out its grid
+    dimensions on the DEVICE (one host wait per scan instead of two): same leaf set, same order, bit-identical centroids — through
+    clouds that need as many key bits as the last one, more (the sort was planned too short: flagged, host form), fewer, a scan the
+    range filter rejects completely, a leaf size whose index space overflows (PCL's error), and back."""
+    from lidarslam_ros2_amd import NormalDistributionsTransform, _capi
+
+    step, offs = 32, (0, 4, 8, 16)
+    r = NormalDistributionsTransform(device=0)
+    assert r.voxelFilterForm() == 0
+
+    def run(n, extent, seed, leaf, rmin=0.0, rmax=1.0e4):
+        pts = _dense_cloud(n, extent, seed)
+        pts[::613] = np.nan
+        inten = np.random.default_rng(seed).uniform(0, 255, n).astype(np.float32)
+        got_n = r.setInputSourcePointCloud2(_pc2_payload(pts, inten, step, offs), n, step, offs, rmin, rmax, leaf)
+        rr = np.sqrt(pts[:, 0].astype(np.float64) ** 2 + pts[:, 1].astype(np.float64) ** 2)
+        keep = (rmin < rr) & (rr < rmax)                                  # NaN x: rejected here, dropped there
+        ref = O.voxel_grid_filter_xyzi(np.c_[pts[keep], inten[keep]].astype(np.float32), leaf, 3) if keep.any() else np.zeros((0, 4), np.float32)
+        assert got_n == ref.shape[0], (n, extent, seed, leaf, r.voxelFilterForm())
+        if got_n:
+            f = r.getInputSourcePointCloud2().view(np.float32).reshape(got_n, 8)
+            assert np.array_equal(f[:, :3], ref[:, :3]) and np.array_equal(f[:, 4], ref[:, 3]), (n, extent, seed, leaf, r.voxelFilterForm())
+        return r.voxelFilterForm()
+
+    assert run(60000, 40.0, 1, 0.2) == 1               # first scan of the object: dimensions on the host
+    assert run(60000, 40.0, 2, 0.2) == 2               # same extent: device form
+    assert run(61000, 39.0, 3, 0.2) == 2
+    assert run(147443, 95.0, 4, 0.2) == 3              # a larger index space than the sort was planned for: flagged, host form ran
+    assert run(147443, 95.0, 5, 0.2) == 2              # ... which renewed the plan
+    assert run(30000, 10.0, 6, 0.2) == 2               # fewer bits than planned: still ordered by the whole key
+    assert run(30000, 10.0, 7, 0.2, rmin=1.0e5, rmax=2.0e5) == 2 and r.getInputSourcePointCloud2().shape[0] == 0   # nothing passes the range filter
+    assert run(30000, 10.0, 8, 0.2, rmin=2.0, rmax=9.0) == 2
+    with pytest.raises(_capi.RegistrationError) as ei:  # PCL: "Leaf size is too small for the input dataset"
+        run(30000, 95.0, 9, 1.0e-4)
+    assert ei.value.status == -7 and r.voxelFilterForm() == 3   # LSR_ERR_INDEX_OVERFLOW
+    assert run(60000, 40.0, 10, 0.2) in (2, 3)
+    assert run(60000, 40.0, 11, 0.2) == 2
+    # strided xyz records (lsr_set_input_source_frontend) take the same path
+    pts = _dense_cloud(50000, 40.0, 12)
+    n1 = r.setInputSourceFrontend(synth.as_pointxyzi(pts), 1.0, 35.0, 0.2)
+    rr = np.sqrt(pts[:, 0].astype(np.float64) ** 2 + pts[:, 1].astype(np.float64) ** 2)
+    ref = O.voxel_grid_filter(pts[(1.0 < rr) & (rr < 35.0)], 0.2)
+    assert n1 == ref.shape[0] and r.voxelFilterForm() == 2
+    assert np.array_equal(r.getInputSourcePointCloud2().view(np.float32).reshape(n1, 8)[:, :3], ref)
+
+
+def test_device_side_grid_dimensions_equal_the_host_form():
+    """A/B in child processes: LSR_VG_DEVICE_DIMS=0 keeps every scan on the host-dimension form; the scans of a short stream come out
+    bit-identical either way."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = ("import numpy as np, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from lidarslam_ros2_amd import NormalDistributionsTransform, synth\n"
+            "r = NormalDistributionsTransform(device=0)\n"
+            "outs, forms = [], []\n"
+            "for k in range(4):\n"
+            "    rng = np.random.default_rng(20 + k)\n"
+            "    pts = rng.uniform(-70, 70, (120000, 3)).astype(np.float32); pts[:, 2] *= 0.05\n"
+            "    n = r.setInputSourceFrontend(synth.as_pointxyzi(pts), 0.5, 60.0, 0.2)\n"
+            "    outs.append(r.getInputSourcePointCloud2()); forms.append(r.voxelFilterForm())\n"
+            "np.savez(sys.argv[1], forms=np.array(forms), **{'o%%d' %% k: o for k, o in enumerate(outs)})\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for name, env in (("device", {}), ("host", {"LSR_VG_DEVICE_DIMS": "0"})):
+            path = os.path.join(d, name + ".npz")
+            subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, **env), timeout=300)
+            res.append(dict(np.load(path)))
+    assert list(res[0]["forms"]) == [1, 2, 2, 2] and list(res[1]["forms"]) == [1, 1, 1, 1]
+    for k in range(4):
+        assert np.array_equal(res[0]["o%d" % k], res[1]["o%d" % k])
+
+
 # ---- the hand-written stable LSD radix sort behind N1 (csrc/lsd_sort.hip) ------------------------------------------------
 def _dense_cloud(n, extent, seed):
     """n points: half of them uniform in a box of `extent`, half piled into a few leaves (hot digits in both passes)."""

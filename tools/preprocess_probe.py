@@ -16,4 +16,5 @@ for _ in range(5): n = r.setInputSourceFrontend(raw, 0.1, 100.0, 0.2)
 ts = []
 for _ in range(40):
     t0 = time.perf_counter(); n = r.setInputSourceFrontend(raw, 0.1, 100.0, 0.2); ts.append(time.perf_counter() - t0)
-print("preprocess: %d -> %d points, median %.1f us p10 %.1f | LSR_SORT_ONESWEEP_FROM=%s" % (raw.shape[0], n, 1e6 * np.median(ts), 1e6 * np.percentile(ts, 10), os.environ.get("LSR_SORT_ONESWEEP_FROM", "-")), flush=True)
+print("preprocess: %d -> %d points, median %.1f us p10 %.1f | voxel filter form %d (2 = grid dimensions on the device) | LSR_VG_DEVICE_DIMS=%s LSR_VG_SORT=%s" %
+      (raw.shape[0], n, 1e6 * np.median(ts), 1e6 * np.percentile(ts, 10), r.voxelFilterForm(), os.environ.get("LSR_VG_DEVICE_DIMS", "-"), os.environ.get("LSR_VG_SORT", "-")), flush=True)
