@@ -83,7 +83,7 @@ struct Backend {
 // ---- §3c: PointCloud2 payloads ----------------------------------------------------------------------------------------
 void pc2_sites(lsr_handle h, const mock::PointCloud2* msg, uint32_t off_x, uint32_t off_y, uint32_t off_z, int32_t off_intensity,
                double scan_min_range_, double scan_max_range_, float vg_size_for_input_, const void* in, size_t n_in, float leaf, void* out,
-               size_t capacity) {
+               size_t capacity, void* d_keyframe) {
   // [snippet: pc2]
   lsr_pc2_layout L = {msg->point_step, off_x, off_y, off_z, off_intensity /* -1: none */};   // from msg->fields
   // range filter [min,max] + VoxelGrid(leaf) + setInputSource in one call, cloud stays in HBM (replaces :201-218,324-329)
@@ -94,6 +94,8 @@ void pc2_sites(lsr_handle h, const mock::PointCloud2* msg, uint32_t off_x, uint3
   size_t n_out; lsr_voxel_grid_filter_pc2(h, in, n_in, &L, leaf, out, capacity, &L, &n_out);
   // the current (filtered) source as a PointCloud2 payload (toROSMsg direction)
   lsr_get_source_pc2(h, out, capacity, &L, &n_out);
+  // ... or into a DEVICE buffer: a keyframe that never leaves HBM (what lsr_set_input_target_frames takes with on_device = 1)
+  lsr_get_source_pc2_device(h, d_keyframe, capacity, &L, &n_out);
   // [end snippet]
 }
 
