@@ -1907,16 +1907,12 @@ __global__ __launch_bounds__(256) void leaf_key_kernel(const float* __restrict__
 // (pc2_ingest): every workgroup folds the (<= 256) records itself — the arithmetic is voxel_grid_filter's host code, operation for
 // operation — and workgroup 0 leaves {sentinel, finite points, VG_FLAG_*, key bits} in dims[0..3] for the kernels behind the sort.
 // The host never sees the box: it enqueues key + sort + run heads + centroids without a wait in between.
-__global__ __launch_bounds__(256) void leaf_key_dims_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                            const float* __restrict__ z, int n, float inv_leaf,
-                                                            const unsigned long long* __restrict__ parts, int nparts, int planned_bits,
-                                                            unsigned int* __restrict__ key, unsigned int* __restrict__ dims) {
+// dims folded from the records of the ingest pass by ALL 256 threads of a workgroup (one barrier inside)
+struct VgDims { int mb[3], dv[3]; unsigned int sentinel, flags, n_finite; int bits; };
+__device__ __forceinline__ VgDims vg_fold_dims(const unsigned long long* __restrict__ parts, int nparts, float inv_leaf, int planned_bits) {
   __shared__ float s_mn[4][3], s_mx[4][3];
   __shared__ unsigned int s_cnt[4];
   const int tid = threadIdx.x, w = tid >> 6;
-  // the point first: its loads are in flight while the records are folded
-  const int i = blockIdx.x * 256 + tid;
-  const float px = (i < n) ? x[i] : NAN, py = (i < n) ? y[i] : NAN, pz = (i < n) ? z[i] : NAN;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   unsigned int cnt = 0;
   if (tid < nparts) {
@@ -1936,35 +1932,80 @@ __global__ __launch_bounds__(256) void leaf_key_dims_kernel(const float* __restr
     s_cnt[w] = cnt;
   }
   __syncthreads();
-  const unsigned int n_finite = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-  int mb[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
-  unsigned int sentinel = 0u, flags = 0u;
-  int bits = 1;
-  if (n_finite != 0u) {
+  VgDims D;
+  D.n_finite = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  for (int k = 0; k < 3; k++) { D.mb[k] = 0; D.dv[k] = 0; }
+  D.sentinel = 0u; D.flags = 0u; D.bits = 1;
+  if (D.n_finite != 0u) {
     long long vol = 1;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const float lo = fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k]));
       const float hi = fmaxf(fmaxf(s_mx[0][k], s_mx[1][k]), fmaxf(s_mx[2][k], s_mx[3][k]));
       vol *= (long long)((hi - lo) * inv_leaf) + 1;
-      mb[k] = (int)floorf(lo * inv_leaf);
-      dv[k] = (int)floorf(hi * inv_leaf) - mb[k] + 1;
+      D.mb[k] = (int)floorf(lo * inv_leaf);
+      D.dv[k] = (int)floorf(hi * inv_leaf) - D.mb[k] + 1;
     }
-    if (vol > (long long)INT32_MAX) flags |= VG_FLAG_OVERFLOW;
-    sentinel = (unsigned int)((long long)dv[0] * dv[1] * dv[2]);
-    while (bits < 32 && (sentinel >> bits) != 0u) bits++;
-    if (bits > planned_bits) flags |= VG_FLAG_REPLAN;
+    if (vol > (long long)INT32_MAX) D.flags |= VG_FLAG_OVERFLOW;
+    D.sentinel = (unsigned int)((long long)D.dv[0] * D.dv[1] * D.dv[2]);
+    while (D.bits < 32 && (D.sentinel >> D.bits) != 0u) D.bits++;
+    if (D.bits > planned_bits) D.flags |= VG_FLAG_REPLAN;
   }
-  if (blockIdx.x == 0 && tid == 0) { dims[0] = sentinel; dims[1] = n_finite; dims[2] = flags; dims[3] = (unsigned int)bits; }
-  if (i >= n) return;
-  unsigned int k = sentinel;
-  if (flags == 0u && isfinite(px) && isfinite(py) && isfinite(pz)) {
-    const int i0 = (int)(floorf(px * inv_leaf) - (float)mb[0]);
-    const int i1 = (int)(floorf(py * inv_leaf) - (float)mb[1]);
-    const int i2 = (int)(floorf(pz * inv_leaf) - (float)mb[2]);
-    k = (unsigned int)(i0 + i1 * dv[0] + i2 * (dv[0] * dv[1]));
+  return D;
+}
+__device__ __forceinline__ unsigned int vg_key(const VgDims& D, float inv_leaf, float px, float py, float pz) {
+  if (D.flags != 0u || !(isfinite(px) && isfinite(py) && isfinite(pz))) return D.sentinel;
+  const int i0 = (int)(floorf(px * inv_leaf) - (float)D.mb[0]);
+  const int i1 = (int)(floorf(py * inv_leaf) - (float)D.mb[1]);
+  const int i2 = (int)(floorf(pz * inv_leaf) - (float)D.mb[2]);
+  return (unsigned int)(i0 + i1 * D.dv[0] + i2 * (D.dv[0] * D.dv[1]));
+}
+
+__global__ __launch_bounds__(256) void leaf_key_dims_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ z, int n, float inv_leaf,
+                                                            const unsigned long long* __restrict__ parts, int nparts, int planned_bits,
+                                                            unsigned int* __restrict__ key, unsigned int* __restrict__ dims) {
+  const int tid = threadIdx.x;
+  // the point first: its loads are in flight while the records are folded
+  const int i = blockIdx.x * 256 + tid;
+  const float px = (i < n) ? x[i] : NAN, py = (i < n) ? y[i] : NAN, pz = (i < n) ? z[i] : NAN;
+  const VgDims D = vg_fold_dims(parts, nparts, inv_leaf, planned_bits);
+  if (blockIdx.x == 0 && tid == 0) { dims[0] = D.sentinel; dims[1] = D.n_finite; dims[2] = D.flags; dims[3] = (unsigned int)D.bits; }
+  if (i < n) key[i] = vg_key(D, inv_leaf, px, py, pz);
+}
+
+// The same on the sort's 2048-key workgroups, counting the keys' FIRST digit on the way (lsd_first_hist_plan: the table the first pass
+// of sort_pairs_u32_lsd reads) — the sort then starts with its scatter: one launch less, and the records are folded by an eighth of
+// the workgroups.
+__global__ __launch_bounds__(256) void leaf_key_dims_hist_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                 const float* __restrict__ z, int n, float inv_leaf,
+                                                                 const unsigned long long* __restrict__ parts, int nparts, int planned_bits,
+                                                                 unsigned int* __restrict__ key, unsigned int* __restrict__ dims,
+                                                                 unsigned int mask, int C, unsigned short* __restrict__ hist, int row_pitch) {
+  extern __shared__ unsigned int s_hist[];  // [C]
+  const int tid = threadIdx.x;
+  for (int k = tid; k < C; k += 256) s_hist[k] = 0u;
+  const int base = blockIdx.x * 2048;
+  float px[8], py[8], pz[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = base + j * 256 + tid;
+    const bool in = i < n;
+    px[j] = in ? x[i] : NAN; py[j] = in ? y[i] : NAN; pz[j] = in ? z[i] : NAN;
   }
-  key[i] = k;
+  const VgDims D = vg_fold_dims(parts, nparts, inv_leaf, planned_bits);   // its barrier also orders the zeroing above before the counts below
+  if (blockIdx.x == 0 && tid == 0) { dims[0] = D.sentinel; dims[1] = D.n_finite; dims[2] = D.flags; dims[3] = (unsigned int)D.bits; }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = base + j * 256 + tid;
+    if (i < n) {
+      const unsigned int k = vg_key(D, inv_leaf, px[j], py[j], pz[j]);
+      key[i] = k;
+      atomicAdd(&s_hist[k & mask], 1u);
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < C; k += 256) hist[(size_t)k * row_pitch + blockIdx.x] = (unsigned short)s_hist[k];
 }
 
 // K1: one wave per leaf; lanes stride the leaf's points (stable-sorted => ascending point index),
@@ -2241,10 +2282,16 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
   // index space overflows) comes back flagged and takes the host-side form below, which also renews the hint.
   if (!use_rocprim && device_dims && cloud.bbox_enqueued && !cloud.bbox_valid && sc.bbox_parts > 0 && sc.bbox_dev.p && sc.vg_bits_hint > 0) {
     const int planned_bits = sc.vg_bits_hint;
-    hipLaunchKernelGGL(leaf_key_dims_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
-                       sc.bbox_dev.p, sc.bbox_parts, planned_bits, key_in, dims_dev);
+    LsdFirstHist fh;
+    if ((st = lsd_first_hist_plan((size_t)n, planned_bits, sc.temp, &fh))) return st;
+    if (fh.usable)   // the key kernel counts the first digit on the sort's own workgroups: the sort starts with its scatter
+      hipLaunchKernelGGL(leaf_key_dims_hist_kernel, dim3(fh.nblk), dim3(256), (size_t)fh.C * 4, stream, cloud.x(), cloud.y(), cloud.z(), n,
+                         inv_leaf, sc.bbox_dev.p, sc.bbox_parts, planned_bits, key_in, dims_dev, fh.mask, fh.C, fh.hist, fh.row_pitch);
+    else
+      hipLaunchKernelGGL(leaf_key_dims_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
+                         sc.bbox_dev.p, sc.bbox_parts, planned_bits, key_in, dims_dev);
     bool in_b = false;
-    if ((st = sort_pairs_u32_lsd(key_in, key_out, nullptr, val_in, val_out, (size_t)n, planned_bits, sc.temp, stream, &in_b))) return st;
+    if ((st = sort_pairs_u32_lsd(key_in, key_out, nullptr, val_in, val_out, (size_t)n, planned_bits, sc.temp, stream, &in_b, fh.usable))) return st;
     const unsigned int* ks = in_b ? key_out : key_in;
     const int* vs = in_b ? val_out : val_in;
     unsigned int token = 0;

@@ -16,7 +16,12 @@ int exclusive_scan_i32(const int* in, int* out, size_t n, DevBuf<char>& temp, hi
 // *result_in_b says where the sorted pairs ended up.  temp holds the histogram tables.
 struct BuildScratch;
 int sort_pairs_u32_lsd(unsigned int* key_a, unsigned int* key_b, int* val_a, int* val_a_buf, int* val_b, size_t n, int end_bit,
-                       DevBuf<char>& temp, hipStream_t stream, bool* result_in_b);
+                       DevBuf<char>& temp, hipStream_t stream, bool* result_in_b, bool first_hist_done = false);
+// The first pass's histogram table as that call will lay it out in temp: digit-major uint16 rows hist[digit * row_pitch + workgroup],
+// workgroup = 2048 consecutive keys (key i of workgroup b: b * 2048 + i), digit = key & mask.  A kernel that produces the keys may fill
+// it and pass first_hist_done = true (only when `usable`).
+struct LsdFirstHist { unsigned short* hist = nullptr; int row_pitch = 0, C = 0, nblk = 0; unsigned int mask = 0; bool usable = false; };
+int lsd_first_hist_plan(size_t n, int end_bit, DevBuf<char>& temp, LsdFirstHist* out);
 // Runs of equal keys of a sorted sequence: heads counted per 256-key block (block_heads), scanned into block_base; the number of
 // runs travels to the host through sc's mailbox (sorted_runs_count polls it).  sorted_runs_blocks(n) = ints each table needs.
 size_t sorted_runs_blocks(size_t n);

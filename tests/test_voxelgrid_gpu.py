@@ -209,6 +209,8 @@ def test_device_side_grid_dimensions_give_the_same_filter(O):
     assert ei.value.status == -7 and r.voxelFilterForm() == 3   # LSR_ERR_INDEX_OVERFLOW
     assert run(60000, 40.0, 10, 0.2) in (2, 3)
     assert run(60000, 40.0, 11, 0.2) == 2
+    assert run(610001, 95.0, 13, 0.2) in (2, 3)        # beyond the fused sort's 256 workgroups: key kernel and histogram stay two launches
+    assert run(610001, 95.0, 14, 0.2) == 2
     # strided xyz records (lsr_set_input_source_frontend) take the same path
     pts = _dense_cloud(50000, 40.0, 12)
     n1 = r.setInputSourceFrontend(synth.as_pointxyzi(pts), 1.0, 35.0, 0.2)
