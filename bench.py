@@ -836,13 +836,22 @@ def next_rows_leg(case, dev_index, tstream, torch, synth, args):
             t0 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t0)
         return med(ts), r
 
-    t_dev, n_kept = timed(lambda: ndt.setInputSourceFrontend(raw_dev, rmin, rmax, leaf))
-    t_pc2_dev, n_kept2 = timed(lambda: ndt.setInputSourcePointCloud2(payload_dev, n_raw, 32, (0, 4, 8, 16), rmin, rmax, leaf))
-    t_pc2_host, _ = timed(lambda: ndt.setInputSourcePointCloud2(payload_host, n_raw, 32, (0, 4, 8, 16), rmin, rmax, leaf))
+    # the filtered-source entries return when the caller's buffer has been read and the count is known; the centroid launch may still
+    # be running (a following align starts under it).  Timed here to the END of the device work: a device synchronisation inside the clock
+    def done(v):
+        torch.cuda.synchronize()
+        return v
+
+    t_dev, n_kept = timed(lambda: done(ndt.setInputSourceFrontend(raw_dev, rmin, rmax, leaf)))
+    t_pc2_dev, n_kept2 = timed(lambda: done(ndt.setInputSourcePointCloud2(payload_dev, n_raw, 32, (0, 4, 8, 16), rmin, rmax, leaf)))
+    t_pc2_host, _ = timed(lambda: done(ndt.setInputSourcePointCloud2(payload_host, n_raw, 32, (0, 4, 8, 16), rmin, rmax, leaf)))
+    t_pc2_ret, _ = timed(lambda: ndt.setInputSourcePointCloud2(payload_dev, n_raw, 32, (0, 4, 8, 16), rmin, rmax, leaf))
+    torch.cuda.synchronize()
     t_get, back = timed(lambda: ndt.getInputSourcePointCloud2())
     bytes_n1 = n_raw * 16 + int(n_kept) * 16
     out["source_preprocess"] = {"raw_points": n_raw, "points_kept": int(n_kept), "pc2_points_kept": int(n_kept2),
                                 "ms_device_records": t_dev, "ms_device_pointcloud2_payload": t_pc2_dev,
+                                "ms_device_payload_call_returns": t_pc2_ret,
                                 "ms_host_pointcloud2_payload_pcie_inclusive": t_pc2_host, "ms_get_source_pointcloud2_to_host": t_get,
                                 "algorithmic_GBps_device_payload": bytes_n1 / (t_pc2_dev * 1e-3) / 1e9,
                                 "what": "range filter [0, 100 m] + VoxelGrid(0.2) incl. intensity + setInputSource (N1 + N4)"}

@@ -165,7 +165,10 @@ int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const
  * everything enqueued on the producer so far (event record + hipStreamWaitEvent, no host wait); buffers produced on the
  * handle's own stream or already complete need nothing.  (2) setInputTarget-type calls return after the read has
  * completed; lsr_set_input_source_device returns with the read ENQUEUED: keep the buffer alive and unmodified until the
- * next lsr_align / lsr_align_batch / lsr_get_fitness_score on this handle has returned (or synchronise its stream). */
+ * next lsr_align / lsr_align_batch / lsr_get_fitness_score on this handle has returned (or synchronise its stream).
+ * (3) lsr_set_input_source_filtered / _frontend / _pc2 return when the caller's buffer (host or device) has been read and the
+ * number of points kept is known; the last kernel of the filter may still be running on the handle's stream, where every later
+ * call on the handle is enqueued behind it (a lsr_align right after it starts under it).  LSR_SOURCE_SYNC=1 makes them wait. */
 int lsr_wait_stream(lsr_handle h, void* producer_stream);
 /* Submap assembly fused with setInputTarget: frame f (strided xyz, counts[f] points) is moved by poses16[16*f ..]
  * (column-major 4x4, pcl::transformPointCloud's fp32 arithmetic) and the frames are concatenated in order — what

@@ -1199,6 +1199,18 @@ int lsr_set_input_source_batch(lsr_handle* handles, int count, const void* const
   return LSR_OK;
 }
 
+// How the filtered-source entries return.  voxel_grid_filter has polled a mailbox word written by a kernel that runs BEHIND the pass
+// that read the caller's buffer (the run count; the bounding box when no point is finite): the caller's buffer — host or device — has
+// been consumed and may be reused.  What can still be running is the centroid launch, which reads and writes buffers the object owns;
+// everything that uses the source afterwards is enqueued on the object's stream (or orders itself behind it: order_lead_after), so
+// the call does not wait for it — the align that follows in the frontend loop starts under it (env LSR_SOURCE_SYNC=1: wait, as until
+// round 5).
+static int finish_source_call(lsr_handle h) {
+  static const bool wait = [] { const char* e = std::getenv("LSR_SOURCE_SYNC"); return e && e[0] == '1'; }();
+  if (wait) LSR_HIP(hipStreamSynchronize(h->stream));
+  return LSR_OK;
+}
+
 // pcl::VoxelGrid::filter + registration_->setInputSource, without the cloud leaving HBM
 // (scanmatcher_component.cpp:324-329)
 int lsr_set_input_source_filtered(lsr_handle h, const void* pts, size_t stride_bytes, size_t n, float leaf, int on_device,
@@ -1211,8 +1223,7 @@ int lsr_set_input_source_filtered(lsr_handle h, const void* pts, size_t stride_b
   h->has_source = true;
   h->source_cov_valid = false;
   if (n_out) *n_out = h->source.n;
-  LSR_HIP(hipStreamSynchronize(h->stream));
-  return LSR_OK;
+  return finish_source_call(h);
 }
 
 // The frontend's whole per-scan preprocessing in one call, on the device: min-max range filter
@@ -1231,8 +1242,7 @@ int lsr_set_input_source_frontend(lsr_handle h, const void* pts, size_t stride_b
   h->has_source = true;
   h->source_cov_valid = false;
   if (n_out) *n_out = h->source.n;
-  LSR_HIP(hipStreamSynchronize(h->stream));
-  return LSR_OK;
+  return finish_source_call(h);
 }
 
 // pcl::VoxelGrid::filter as a stand-alone device operation (host in, host out)
@@ -1299,8 +1309,7 @@ int lsr_set_input_source_pc2(lsr_handle h, const void* data, size_t n_points, co
   h->has_source = true;
   h->source_cov_valid = false;
   if (n_out) *n_out = h->source.n;
-  LSR_HIP(hipStreamSynchronize(h->stream));
-  return LSR_OK;
+  return finish_source_call(h);
 }
 
 int lsr_get_source_pc2(lsr_handle h, void* out_data, size_t capacity_points, const lsr_pc2_layout* layout, size_t* n_out) {
