@@ -158,6 +158,7 @@ struct RefineMember {
   int *coarse_block, *block_off, *fine_start; float4* packed; int* order;
 };
 struct RefineGroup { RefineMember m[LSR_GROUP]; };
+constexpr int NN_REFINE_KEEP = 6;         // points a thread keeps in registers between the two passes over its voxel (1 536 per voxel)
 constexpr int NN_REFINE_THREADS = 256;    // (1024 threads per voxel were measured slower on 64 x 661k-point windows: 258 vs 214 us per group of 16)
 __device__ __forceinline__ void nn_refine_body(const RefineMember& M, const int cell) {
   __shared__ unsigned int s_cnt[FINE_PER_BLOCK], s_off[FINE_PER_BLOCK + 1], s_part[256];
@@ -170,7 +171,24 @@ __device__ __forceinline__ void nn_refine_body(const RefineMember& M, const int 
   const int b = (int)M.rank[cell];
   for (int k = tid; k < FINE_PER_BLOCK; k += NN_REFINE_THREADS) s_cnt[k] = 0u;
   __syncthreads();
-  for (unsigned int j = beg + tid; j < end; j += NN_REFINE_THREADS) {
+  // A voxel of the 661k-point submap holds ~1 000 points: four or five per thread.  The first NN_REFINE_KEEP of a thread stay in
+  // registers between the counting pass and the scatter (coordinates, original index, fine cell): the scatter reads nothing twice
+  // (the second trip over the planes was a quarter of this kernel's traffic).  The atomics are issued in the same order as before —
+  // per thread in ascending point index —, so the layout of a fine cell does not change.
+  float kx[NN_REFINE_KEEP], ky[NN_REFINE_KEEP], kz[NN_REFINE_KEEP];
+  int ki[NN_REFINE_KEEP], kf[NN_REFINE_KEEP];
+#pragma unroll
+  for (int u = 0; u < NN_REFINE_KEEP; u++) {
+    const unsigned int j = beg + tid + u * NN_REFINE_THREADS;
+    kf[u] = -1;
+    if (j < end) {
+      kx[u] = M.sx[j]; ky[u] = M.sy[j]; kz[u] = M.sz[j]; ki[u] = M.sidx[j];
+      const int fx = (int)floorf(kx[u] * M.inv_cell) - M.o0, fy = (int)floorf(ky[u] * M.inv_cell) - M.o1, fz = (int)floorf(kz[u] * M.inv_cell) - M.o2;
+      kf[u] = (fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6);
+      atomicAdd(&s_cnt[kf[u]], 1u);
+    }
+  }
+  for (unsigned int j = beg + tid + NN_REFINE_KEEP * NN_REFINE_THREADS; j < end; j += NN_REFINE_THREADS) {
     const int fx = (int)floorf(M.sx[j] * M.inv_cell) - M.o0, fy = (int)floorf(M.sy[j] * M.inv_cell) - M.o1, fz = (int)floorf(M.sz[j] * M.inv_cell) - M.o2;
     atomicAdd(&s_cnt[(fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6)], 1u);
   }
@@ -207,7 +225,15 @@ __device__ __forceinline__ void nn_refine_body(const RefineMember& M, const int 
     M.block_off[b] = (int)beg;
     M.block_off[b + 1] = (int)end;  // the next occupied voxel (if any) rewrites the same value
   }
-  for (unsigned int j = beg + tid; j < end; j += NN_REFINE_THREADS) {
+#pragma unroll
+  for (int u = 0; u < NN_REFINE_KEEP; u++) {
+    if (kf[u] >= 0) {
+      const unsigned int pos = beg + s_off[kf[u]] + atomicAdd(&s_cnt[kf[u]], 1u);
+      M.packed[pos] = make_float4(kx[u], ky[u], kz[u], __int_as_float(ki[u]));
+      M.order[pos] = ki[u];
+    }
+  }
+  for (unsigned int j = beg + tid + NN_REFINE_KEEP * NN_REFINE_THREADS; j < end; j += NN_REFINE_THREADS) {
     const float px = M.sx[j], py = M.sy[j], pz = M.sz[j];
     const int fx = (int)floorf(px * M.inv_cell) - M.o0, fy = (int)floorf(py * M.inv_cell) - M.o1, fz = (int)floorf(pz * M.inv_cell) - M.o2;
     const int fine = (fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6);

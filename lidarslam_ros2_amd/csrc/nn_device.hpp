@@ -373,11 +373,21 @@ __device__ __forceinline__ void scan_cell_group16(const NNGridView& G, const flo
   if (blk >= 0) {
     const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((fq[1] & 7) << 3) | ((fq[2] & 7) << 6)) + (fq[0] & 7);
     const int end = fs[1];
-    for (int f = fs[0] + gl; f < end; f += 16) {
-      const float4 pt = G.p[f];
-      const float d = dist2_rn(q[0], q[1], q[2], pt.x, pt.y, pt.z);
-      const int oi = __float_as_int(pt.w);
-      if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+    for (int f = fs[0] + gl; f < end; f += 32) {   // two points per lane and trip, both loads in flight
+      const bool in1 = f + 16 < end;
+      const float4 p0 = G.p[f];
+      float4 p1 = p0;
+      if (in1) p1 = G.p[f + 16];
+      {
+        const float d = dist2_rn(q[0], q[1], q[2], p0.x, p0.y, p0.z);
+        const int oi = __float_as_int(p0.w);
+        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+      }
+      if (in1) {
+        const float d = dist2_rn(q[0], q[1], q[2], p1.x, p1.y, p1.z);
+        const int oi = __float_as_int(p1.w);
+        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+      }
     }
   }
   row16_best(bd, bi);
@@ -416,20 +426,33 @@ __device__ __forceinline__ void scan_cells_group16(const NNGridView& G, const fl
     incl += row16_i<DPP_ROW_SHR + 8, true>(incl);
     const int excl = incl - len;
     const int total = row16_i<DPP_ROW_NEWBCAST + 15, false>(incl);
-    for (int t0 = 0; t0 < total; t0 += 16) {
-      const int f = t0 + gl;
-      int sl = 0;   // the slot that holds flat position f: the largest lane whose exclusive offset is <= f
+    // thirty-two candidates per trip, two per lane: both loads are in flight before either is compared (a query's candidates are a
+    // few dozen points; the trips are a chain of L2 / HBM round trips — the minimum over a total order does not care in which order
+    // it meets them)
+    for (int t0 = 0; t0 < total; t0 += 32) {
+      const int f0 = t0 + gl, f1 = t0 + 16 + gl;
+      int sl0 = 0, sl1 = 0;   // the slot that holds flat position f: the largest lane whose exclusive offset is <= f
 #pragma unroll
       for (int step = 8; step >= 1; step >>= 1) {
-        const int cand = sl + step;
-        const int o = __shfl(excl, cand, 16);
-        if (o <= f) sl = cand;
+        const int c0 = sl0 + step, c1 = sl1 + step;
+        const int o0 = __shfl(excl, c0, 16), o1 = __shfl(excl, c1, 16);
+        if (o0 <= f0) sl0 = c0;
+        if (o1 <= f1) sl1 = c1;
       }
-      const int sb = __shfl(beg, sl, 16), so = __shfl(excl, sl, 16);
-      if (f < total) {
-        const float4 pt = G.p[sb + (f - so)];
-        const float d = dist2_rn(q[0], q[1], q[2], pt.x, pt.y, pt.z);
-        const int oi = __float_as_int(pt.w);
+      const int sb0 = __shfl(beg, sl0, 16), so0 = __shfl(excl, sl0, 16);
+      const int sb1 = __shfl(beg, sl1, 16), so1 = __shfl(excl, sl1, 16);
+      const bool in0 = f0 < total, in1 = f1 < total;
+      float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+      if (in0) p0 = G.p[sb0 + (f0 - so0)];
+      if (in1) p1 = G.p[sb1 + (f1 - so1)];
+      if (in0) {
+        const float d = dist2_rn(q[0], q[1], q[2], p0.x, p0.y, p0.z);
+        const int oi = __float_as_int(p0.w);
+        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+      }
+      if (in1) {
+        const float d = dist2_rn(q[0], q[1], q[2], p1.x, p1.y, p1.z);
+        const int oi = __float_as_int(p1.w);
         if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
       }
     }
