@@ -176,8 +176,11 @@ def test_device_side_grid_dimensions_give_the_same_filter(O):
     dimensions on the DEVICE (one host wait per scan instead of two): same leaf set, same order, bit-identical centroids — through
     clouds that need as many key bits as the last one, more (the sort was planned too short: flagged, host form), fewer, a scan the
     range filter rejects completely, a leaf size whose index space overflows (PCL's error), and back."""
+    import os
     from lidarslam_ros2_amd import NormalDistributionsTransform, _capi
 
+    if os.environ.get("LSR_VG_SORT", "").startswith("r") or os.environ.get("LSR_VG_DEVICE_DIMS", "") == "0":
+        pytest.skip("an A/B switch of this process keeps the filter on the host-dimension form")
     step, offs = 32, (0, 4, 8, 16)
     r = NormalDistributionsTransform(device=0)
     assert r.voxelFilterForm() == 0
@@ -228,6 +231,8 @@ def test_device_side_grid_dimensions_equal_the_host_form():
     import sys
     import tempfile
 
+    if os.environ.get("LSR_VG_SORT", "").startswith("r") or os.environ.get("LSR_VG_DEVICE_DIMS", "") == "0":
+        pytest.skip("an A/B switch of this process keeps the filter on the host-dimension form")
     code = ("import numpy as np, sys\n"
             "sys.path.insert(0, %r)\n"
             "from lidarslam_ros2_amd import NormalDistributionsTransform, synth\n"
