@@ -226,7 +226,8 @@ struct BuildScratch {
   unsigned int grid_token = 0;
   unsigned int fit_token = 0;      // an enqueued fitness reduction (0: none)
   DevBuf<unsigned long long> bbox_dev;   // device copy of the bounding-box records of the last pc2_ingest ([BBOX_MAX_PARTS][8])
-  int vg_bits_hint = 0;            // key bits of the last voxel_grid_filter on this scratch (0: none yet)
+  int vg_bits_hint = 0;            // key bits of the last voxel_grid_filter on this scratch (0: none yet) ...
+  float vg_hint_leaf = 0.f;        // ... and the leaf size it was for: another leaf size is another index space
   int vg_form = 0;                 // which form that filter took (LSR_VOXEL_FILTER_FORM)
   int ensure_mailbox();
 };

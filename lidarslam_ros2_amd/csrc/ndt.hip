@@ -2280,7 +2280,8 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
   // call on this scratch says how many key bits such a cloud needs -> key (folds the records itself), sort, run heads and centroids are
   // enqueued back to back; the host waits ONCE, for {runs, finite points, flags}.  A cloud that needs more bits than planned (or whose
   // index space overflows) comes back flagged and takes the host-side form below, which also renews the hint.
-  if (!use_rocprim && device_dims && cloud.bbox_enqueued && !cloud.bbox_valid && sc.bbox_parts > 0 && sc.bbox_dev.p && sc.vg_bits_hint > 0) {
+  if (!use_rocprim && device_dims && cloud.bbox_enqueued && !cloud.bbox_valid && sc.bbox_parts > 0 && sc.bbox_dev.p && sc.vg_bits_hint > 0 &&
+      sc.vg_hint_leaf == leaf) {   // (an object that filters at two leaf sizes in turn — scans and keyframes — stays on the host form)
     const int planned_bits = sc.vg_bits_hint;
     LsdFirstHist fh;
     if ((st = lsd_first_hist_plan((size_t)n, planned_bits, sc.temp, &fh))) return st;
@@ -2338,6 +2339,7 @@ int voxel_grid_filter(const DeviceCloud& cloud, float leaf, DeviceCloud& out, Bu
   }
   const unsigned int sentinel = (unsigned int)((int64_t)div_b[0] * div_b[1] * div_b[2]);  // one past the last leaf index
   sc.vg_bits_hint = bits_for(sentinel);
+  sc.vg_hint_leaf = leaf;
   hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv_leaf,
                      min_b[0], min_b[1], min_b[2], div_b[0], div_b[0] * div_b[1], sentinel, key_in, val_in, (uint4*)nullptr, (size_t)0,
                      (int*)nullptr, (size_t)0, (int*)nullptr);

@@ -207,12 +207,18 @@ def test_device_side_grid_dimensions_give_the_same_filter(O):
     assert run(30000, 10.0, 6, 0.2) == 2               # fewer bits than planned: still ordered by the whole key
     assert run(30000, 10.0, 7, 0.2, rmin=1.0e5, rmax=2.0e5) == 2 and r.getInputSourcePointCloud2().shape[0] == 0   # nothing passes the range filter
     assert run(30000, 10.0, 8, 0.2, rmin=2.0, rmax=9.0) == 2
-    with pytest.raises(_capi.RegistrationError) as ei:  # PCL: "Leaf size is too small for the input dataset"
-        run(30000, 95.0, 9, 1.0e-4)
+    with pytest.raises(_capi.RegistrationError) as ei:  # PCL: "Leaf size is too small for the input dataset", found by the device form
+        run(30000, 3000.0, 9, 0.2)
     assert ei.value.status == -7 and r.voxelFilterForm() == 3   # LSR_ERR_INDEX_OVERFLOW
     assert run(60000, 40.0, 10, 0.2) in (2, 3)
     assert run(60000, 40.0, 11, 0.2) == 2
-    assert run(610001, 95.0, 13, 0.2) in (2, 3)        # beyond the fused sort's 256 workgroups: key kernel and histogram stay two launches
+    assert run(60000, 40.0, 15, 0.4) == 1              # another leaf size is another index space: the plan is not carried over
+    assert run(60000, 40.0, 16, 0.4) == 2
+    with pytest.raises(_capi.RegistrationError) as ei:  # the same error from the host form (first scan at this leaf size)
+        run(30000, 95.0, 17, 1.0e-4)
+    assert ei.value.status == -7 and r.voxelFilterForm() == 1
+    assert run(60000, 40.0, 18, 0.4) == 2
+    assert run(610001, 95.0, 13, 0.2) == 1             # (back to leaf 0.2: host form) beyond the fused sort's 256 workgroups: key kernel and histogram stay two launches
     assert run(610001, 95.0, 14, 0.2) == 2
     # strided xyz records (lsr_set_input_source_frontend) take the same path
     pts = _dense_cloud(50000, 40.0, 12)
