@@ -349,6 +349,7 @@ struct FitMember {
   float max_d2; double max_range;
   int* idx; float* d2; double* part; int* work;
   BuildMailbox* mb; unsigned int token; int empty; int fine_rings;
+  int ball_cells;   // widest ball (fine cells per axis) the sixteen-lane search reads itself; wider ones go to the work list
 };
 constexpr int FIT_GROUP = 12;
 constexpr int NN_FITNESS_FINE_RINGS = 0;   // measured on 64 candidate windows (fitness stage): 2.54 ms with 1, 2.39 ms with 0
@@ -469,7 +470,7 @@ __global__ void fit_zero_work_group_kernel(const FitGroup g) { g.m[threadIdx.x].
 constexpr int FIT_BALL_CELLS = 5;
 __device__ __forceinline__ void nn1_ball_body(const NNGridView& G, const float* __restrict__ qx, const float* __restrict__ qy,
                                               const float* __restrict__ qz, int n, const float* __restrict__ T16, int* __restrict__ work,
-                                              int* __restrict__ idx, float* __restrict__ d2, const int t) {
+                                              int* __restrict__ idx, float* __restrict__ d2, const int t, const int ball_cells) {
   const int i = t >> 4, gl = t & 15;
   if (i >= n) return;   // n * 16 threads: a group is never split by this test
   const float x = qx[i], y = qy[i], z = qz[i];
@@ -506,7 +507,7 @@ __device__ __forceinline__ void nn1_ball_body(const NNGridView& G, const float* 
     if (bi == INT_MAX) general = true;   // nothing within a cell of the query: rare for a registered scan
   }
   // ---- 2. the cells of the ball of radius sqrt(bd) around the query hold every point that could beat the seed
-  if (!general && !ball_cell_range(G, q, bd, FIT_BALL_CELLS, lo, hi)) general = true;
+  if (!general && !ball_cell_range(G, q, bd, ball_cells, lo, hi)) general = true;
   if (general) {
     if (gl == 0) work[1 + atomicAdd(work, 1)] = i;
     return;
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) void nn1_list_group_kernel(const FitGroup g) {
 __global__ __launch_bounds__(256) void nn1_ball_group_kernel(const FitGroup g) {
   const FitMember& M = g.m[blockIdx.y];
   if (M.empty) return;
-  nn1_ball_body(M.G, M.qx, M.qy, M.qz, M.n, M.T16, M.work, M.idx, M.d2, blockIdx.x * 256 + threadIdx.x);
+  nn1_ball_body(M.G, M.qx, M.qy, M.qz, M.n, M.T16, M.work, M.idx, M.d2, blockIdx.x * 256 + threadIdx.x, M.ball_cells);
 }
 __global__ __launch_bounds__(NN_THREADS) void nn1_quad_group_kernel(const FitGroup g) {
   const FitMember& M = g.m[blockIdx.y];
@@ -864,6 +865,8 @@ int nn_fitness_begin_group(const FitJob* jobs, int count, hipStream_t stream) {
       M.idx = d_idx; M.d2 = d_d2; M.part = d_part; M.work = d_work;
       M.mb = sc.d_mb; M.token = token;
       M.fine_rings = nn_fitness_fine_rings();
+      static const int ball_cells = [] { const char* e = getenv("LSR_FIT_BALL_CELLS"); const int v = e ? atoi(e) : FIT_BALL_CELLS; return v < 1 ? 1 : v > 8 ? 8 : v; }();
+      M.ball_cells = ball_cells;
       if (!M.empty) { max_blocks = std::max(max_blocks, M.blocks); max_n = std::max(max_n, M.n); }
     }
     static const int form = [] { const char* e = getenv("LSR_FIT_GROUP_FORM"); return e ? atoi(e) : -1; }();   // 0 wave, 1 quad + tail, -1 by size
