@@ -42,6 +42,10 @@ stats target python $REPO/tools/target_probe.py
 # 3d. N1: the frontend's source preprocessing (hand-written LSD sort) against the rocPRIM path it replaces
 (for v in lsd rocprim; do echo "[LSR_VG_SORT=$v]"; LSR_VG_SORT=$v timeout 300 python tools/preprocess_probe.py 2>&1 | tail -1; done) > $P/${TAG}_n1_preprocess.txt
 stats n1 python $REPO/tools/preprocess_probe.py
+# 3e. ONE frontend scan at the reference's settings (payload in HBM -> lsr_set_input_source_pc2 -> lsr_align): host-clock medians and the
+# kernel timeline of a scan (tools/frontend_scan_probe.py, tools/timeline.py)
+(timeout 300 python tools/frontend_scan_probe.py 2>&1 | tail -1) > $P/${TAG}_frontend_scan.txt
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr_fs && REPS=8 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_fs -o t -- python $REPO/tools/frontend_scan_probe.py > /dev/null 2>&1; python $REPO/tools/timeline.py /tmp/tr_fs 800 60 >> $P/${TAG}_frontend_scan.txt 2>&1)
 if [ "${LSR_PROFILE_MICRO:-0}" = "1" ]; then   # micro-benchmarks behind profiles/r04_pass_timeline.md (kernels unchanged since)
 (timeout 300 tools/micro/boundary_probe) > $P/${TAG}_boundary_probe.txt 2>&1
 (LSR_LIB_NAME=liblidarslam_reg_timing.so timeout 400 python tools/timing_probe.py 2>&1 | grep -v amdgpu.ids) > $P/${TAG}_timing_probe.txt
