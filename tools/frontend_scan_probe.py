@@ -1,5 +1,6 @@
 """One frontend scan at the reference's settings — lsr_set_input_source_pc2 (raw 147k-point payload in HBM) + lsr_align (eps 0.01) — a
-few dozen times with a pause between them, for a kernel timeline of ONE scan (tools/timeline.py, GAP_US below the pause)."""
+few dozen times with a pause between them, for a kernel timeline of ONE scan (tools/timeline.py, GAP_US below the pause).  NOPAUSE=1:
+back to back (the next scan's first kernel then queues behind the launches the previous align left in its stream)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +20,8 @@ r.setInputTarget(torch.from_numpy(synth.as_pointxyzi(case.target)).cuda())
 g = np.asarray(case.guess, np.float32)
 ts, ta = [], []
 for _ in range(int(os.environ.get("REPS", "30"))):
-    torch.cuda.synchronize(); time.sleep(0.002)
+    if os.environ.get("NOPAUSE") != "1":
+        torch.cuda.synchronize(); time.sleep(0.002)
     t0 = time.perf_counter(); r.setInputSourcePointCloud2(payload, raw.shape[0], 32, (0, 4, 8, 16), 0.1, 100.0, 0.2); t1 = time.perf_counter(); r.align(g); t2 = time.perf_counter()
     ts.append(t1 - t0); ta.append(t2 - t1)
 print("frontend scan: source %.1f us + align %.1f us = %.1f us (medians; %d Newton iterations)" %
