@@ -130,3 +130,59 @@ def test_objects_driven_from_four_threads_return_what_they_return_alone():
         assert _same(got, alone[3][0]), ("candidate set, round", i)
     for i, got in enumerate(results[1]):                    # rounds continue the alternation the two solo rounds started
         assert _same(got, alone[1][i % 2]), ("backend object, round", i)
+
+
+def test_objects_sharing_one_target_from_three_threads():
+    """N keyframes against ONE submap (lsr_share_target), every keyframe's object on a thread of its own: the lazy builds on the shared
+    target (voxel grid, neighbour grid for getFitnessScore) are behind the target's mutex; every object returns what it returns alone."""
+    from lidarslam_ros2_amd import NormalDistributionsTransform
+
+    base = synth.small_case(n_source=2500, n_keyframes=4, seed=41)
+    world = synth.make_world()
+    owner = NormalDistributionsTransform(device=0)
+    owner.setResolution(5.0)
+    owner.setInputTarget(base.target)
+    sources = [base.source] + [synth.voxel_downsample(synth.raycast(world, synth.Sensor(16, -20.0, 12.0, 600), base.truth, np.random.default_rng(50 + k)), 0.4)
+                               for k in range(2)]
+
+    def make(src):
+        r = NormalDistributionsTransform(device=0)
+        r.setResolution(5.0); r.setTransformationEpsilon(0.01); r.setMaximumIterations(60)
+        r.shareTargetOf(owner)
+
+        def once():
+            r.setInputSource(src)
+            r.align(base.guess)
+            return (np.array(r.getFinalTransformation()), r.getFinalNumIteration(), r.getFitnessScore())
+        return once
+
+    # the solo answers come from objects of their own, so that the threads below meet a target whose lazy builds have NOT run for them
+    alone = [make(s)() for s in sources]
+    owner2 = NormalDistributionsTransform(device=0)
+    owner2.setResolution(5.0)
+    owner2.setInputTarget(base.target)
+    owner_keep, owner = owner, owner2          # fresh target: grid and neighbour grid are built under the threads
+    jobs = [make(s) for s in sources]
+    results = [[] for _ in jobs]
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def run(k):
+        try:
+            start.wait()
+            for _ in range(ROUNDS):
+                results[k].append(jobs[k]())
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    for k in range(len(jobs)):
+        assert len(results[k]) == ROUNDS
+        for i, got in enumerate(results[k]):
+            assert _same(got, alone[k]), ("object", k, "round", i)
+    del owner_keep
