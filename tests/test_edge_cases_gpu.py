@@ -228,3 +228,37 @@ def test_d1_quirk_does_not_move_the_fixed_point(case):
         finals.append(r.getFinalTransformation())
     dt, ang = pose_delta(finals[0], finals[1])
     assert dt <= 1e-3 and ang <= 1e-4
+
+
+def test_objects_are_created_and_destroyed_by_the_hundred(case):
+    """The backend creates and drops registration objects as loop candidates come and go: 100 objects in turn — each sets a target,
+    registers, scores (lazy neighbour grid), every fifth also leads a candidate set (side stream, chain streams, their events) — and is
+    destroyed again (lsr_destroy releases streams, events, pinned mailboxes).  The last object must answer like the first."""
+    import gc
+
+    from lidarslam_ros2_amd import NormalDistributionsTransform
+    from lidarslam_ros2_amd.registration import align_fitness_batch
+
+    first = None
+    for k in range(100):
+        r = NormalDistributionsTransform(device=0)
+        r.setResolution(5.0)
+        r.setTransformationEpsilon(0.01)
+        r.setInputTarget(case.target)
+        r.setInputSource(case.source)
+        r.align(case.guess)
+        got = (np.array(r.getFinalTransformation()), r.getFinalNumIteration(), r.getFitnessScore())
+        if k % 5 == 0:   # a set of two led by this object
+            mate = NormalDistributionsTransform(device=0)
+            mate.setResolution(5.0)
+            mate.setTransformationEpsilon(0.01)
+            mate.setInputTarget(case.target)
+            mate.setInputSource(case.source)
+            finals, _, fit = align_fitness_batch([r, mate], [case.guess, case.guess])
+            assert np.array_equal(finals[0], finals[1]) and fit[0] == fit[1]
+            del mate
+        if first is None:
+            first = got
+        assert np.array_equal(got[0], first[0]) and got[1] == first[1] and got[2] == first[2], k
+        del r
+        gc.collect()
