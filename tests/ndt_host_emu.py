@@ -21,7 +21,9 @@ def build():
     src = os.path.join(ROOT, "tools", "ndt_host_emu", "harness.cpp")
     hdr = os.path.join(ROOT, "lidarslam_ros2_amd", "csrc", "ndt_point.hpp")
     libdir = os.path.join(ROOT, "lidarslam_ros2_amd")
-    out = os.path.join(tempfile.gettempdir(), "lsr_ndt_host_emu_%d" % os.getuid())
+    import hashlib
+    # one build directory per checkout: the library is linked with an rpath into THIS tree
+    out = os.path.join(tempfile.gettempdir(), "lsr_ndt_host_emu_%d_%s" % (os.getuid(), hashlib.sha1(ROOT.encode()).hexdigest()[:10]))
     os.makedirs(out, exist_ok=True)
     so = os.path.join(out, "libndtemu.so")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
