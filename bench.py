@@ -88,6 +88,67 @@ def self_spawn(args) -> int:
     return rc
 
 
+def make_comm(lib, dist, rank, world, dev_index):
+    """The library's communicator for the data-path collectives (csrc/comm.hip): rank 0 draws the 128-byte id, the control plane
+    (gloo) carries it, every rank calls lsr_comm_create.  -> (handle or None, description for config.collective).  Creation runs
+    under a watchdog and the ranks agree on the outcome over gloo: if ANY rank failed, every rank gives its communicator up and the
+    records travel over gloo instead — the line is printed either way and says which it was."""
+    from lidarslam_ros2_amd import _capi
+
+    if dist is None:
+        return None, "none (one rank)"
+    import threading
+
+    box = {}
+
+    def _create():
+        try:
+            ident = (C.c_char * 128)()
+            idb = None
+            if rank == 0:
+                try:
+                    _capi.check(lib.lsr_comm_unique_id(ident), "lsr_comm_unique_id")
+                    idb = bytes(ident)
+                except Exception as e:
+                    box["err"] = repr(e)
+            b = [idb]
+            dist.broadcast_object_list(b, src=0)
+            if b[0] is None:
+                box.setdefault("err", "rank 0 could not draw a unique id")
+                return
+            ident = (C.c_char * 128).from_buffer_copy(b[0])
+            comm = C.c_void_p()
+            _capi.check(lib.lsr_comm_create(ident, rank, world, dev_index, C.byref(comm)), "lsr_comm_create")
+            box["comm"] = comm
+        except Exception as e:
+            box["err"] = repr(e)
+
+    # RCCL prints a version banner on stdout when a communicator is created; stdout must carry exactly one JSON line
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        th = threading.Thread(target=_create, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("LSR_BENCH_COMM_TIMEOUT", "180")))
+        if th.is_alive():
+            box["err"] = "lsr_comm_create did not return within its watchdog time"
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    ok = [None] * world
+    dist.all_gather_object(ok, box.get("err"))
+    errs = [f"rank {r}: {e}" for r, e in enumerate(ok) if e]
+    lib_name = os.environ.get("LSR_RCCL_LIB")
+    kind = f"stand-in collective library {os.path.basename(lib_name)} (ranks share a device; test infrastructure)" if lib_name else "RCCL over xGMI"
+    if errs:
+        if "comm" in box and not any("watchdog" in e for e in errs):
+            lib.lsr_comm_destroy(box["comm"])
+        return None, "gloo all-gather of the records on the host — the library's communicator could not be created: " + "; ".join(errs)[:400]
+    return box["comm"], f"lsr_comm_all_gather_records / lsr_align_batch_sharded / lsr_set_input_target_bcast: ncclAllGather + ncclBroadcast of the library's own communicator ({kind})"
+
+
 def pct(v, q):
     return float(np.percentile(np.asarray(v, np.float64), q))
 
@@ -168,24 +229,33 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = "nccl" if own_device else "gloo"   # RCCL refuses two ranks on one device: shared-device runs gather on the host
-        # RCCL prints a version banner on stdout when the communicator is created; stdout must carry exactly one
-        # JSON line, so C-level stdout is pointed at stderr until the first collective has run.
+        # ONE RCCL client per process (VERDICT r05 #1b): torch.distributed is the CONTROL plane only — barrier, the 128-byte id, the
+        # max-reduce of the clocks, per-rank report objects — and runs on gloo; the data-path collective (the all-gather of the
+        # 64-byte result records, the broadcast of a shared submap) is the library's own communicator (csrc/comm.hip -> RCCL over
+        # xGMI), created once below and destroyed normally at the end.  Round 5 held torch's NCCL process group AND the library's
+        # communicator in one address space and met a double free in ncclCommDestroy.
+        backend = "gloo"
+        # gloo announces its connections on stdout; stdout must carry exactly one JSON line: C-level stdout points at stderr meanwhile
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-            else:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
-            torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
+        if not own_device and not os.environ.get("LSR_RCCL_LIB"):
+            # ranks share a device (LSR_BENCH_FORCE_DIST on a one-GPU box): RCCL refuses that layout; the shared-memory stand-in of
+            # the tests carries the collectives so that comm.hip still runs every world > 1 line (test infrastructure, never timed
+            # for a headline: the line says so in config.collective_library)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from ccl_stub import build_stub
+            if rank == 0:
+                build_stub()
+            dist.barrier()
+            os.environ["LSR_RCCL_LIB"] = build_stub()
 
     from lidarslam_ros2_amd import DIRECT7, NormalDistributionsTransform, _capi
     from lidarslam_ros2_amd.posemath import pose_delta
@@ -194,6 +264,7 @@ def main():
     fptr = C.POINTER(C.c_float)
     res, max_iter = 5.0, 30
     tstream = torch.cuda.current_stream().cuda_stream
+    comm, comm_note = make_comm(lib, dist, rank, world, dev_index)
 
     def make_ndt(eps=0.0, mi=max_iter, resolution=res):
         r = NormalDistributionsTransform(device=dev_index, stream=tstream)
@@ -224,39 +295,48 @@ def main():
     for k in range(args.warmup):
         step(ndt, k % nss)
     torch.cuda.synchronize()
+    rec_np = np.zeros((args.steps, 16), np.float32)   # 64-byte result records (lsr_shard_record): row-major 3x4 | score | iterations | converged | fitness
+    all_np = np.zeros((world, args.steps, 16), np.float32)
+
+    def gather_records():
+        """C1: the pose all-gather of the K records of every rank — the library's communicator (ncclAllGather over xGMI); gloo only
+        if that communicator could not be created (the line then says so)."""
+        if dist is None:
+            return
+        if comm is not None:
+            _capi.check(lib.lsr_comm_all_gather_records(comm, rec_np.ctypes.data_as(C.c_void_p), args.steps, all_np.ctypes.data_as(C.c_void_p)),
+                        "lsr_comm_all_gather_records")
+        else:
+            got = [torch.empty((args.steps, 16)) for _ in range(world)]
+            dist.all_gather(got, torch.from_numpy(rec_np))
+
     if dist is not None:
-        # warm-up of the one collective of the path too: RCCL sets up its all-gather channels on first use
-        w_rec = torch.zeros((args.steps, 16), dtype=torch.float32, device=coll_dev)
-        dist.all_gather([torch.empty_like(w_rec) for _ in range(world)], w_rec)
+        gather_records()   # warm-up of the one collective of the path too: RCCL sets up its all-gather channels on first use
         torch.cuda.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
-    rec_np = np.zeros((args.steps, 16), np.float32)   # 64-byte result records: column-major 4x4, bottom row reused
     lat = np.zeros(args.steps)
     evals = np.zeros(args.steps)   # derivative passes of every timed registration (the scans of the stream differ)
     t0 = time.perf_counter()
     tk = t0
     for k in range(args.steps):
         step(ndt, (args.warmup + k) % nss)
-        rec_np[k] = fin16   # final transformation (column-major) straight into the record
-        rec_np[k, 3] = ndt._last.score
-        rec_np[k, 7] = ndt._last.iterations
-        rec_np[k, 11] = ndt._last.converged
+        rec_np[k, :12] = fin16.reshape(4, 4).T[:3].reshape(12)   # final transformation (column-major 4x4 -> row-major 3x4) into the record
+        rec_np[k, 12] = ndt._last.score
+        rec_np[k, 13] = ndt._last.iterations
+        rec_np[k, 14] = ndt._last.converged
         evals[k] = ndt._last.n_evaluations
         tn = time.perf_counter()
         lat[k] = tn - tk
         tk = tn
-    rec = torch.from_numpy(rec_np).to(coll_dev)
-    if dist is not None:
-        gathered = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(gathered, rec)                                      # C1: pose all-gather (RCCL over xGMI)
+    gather_records()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     last = ndt.last_result
@@ -277,7 +357,7 @@ def main():
                    "voxels_valid": grid["n_valid"], "newton_iterations": last["iterations"],
                    "derivative_passes_per_align": float(evals.mean()), "derivative_passes_last_scan": last["n_evaluations"],
                    "parallelism": f"1 registration stream per GPU x{world}",
-                   "collective_backend": backend, "ranks_share_a_device": not own_device},
+                   "control_plane": backend, "collective": comm_note, "ranks_share_a_device": not own_device},
         "step_latency": lat_stats(lat),
         "last_step_error_vs_truth": {"translation_m": err_t, "rotation_rad": err_r},
         "ndt_iterations_per_s": world * args.steps * last["iterations"] / elapsed,
@@ -304,7 +384,7 @@ def main():
         def _leg():
             try:
                 torch.cuda.set_device(dev_index)   # the current device is per thread
-                box["v"] = run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, torch, synth)
+                box["v"] = run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, comm, torch, synth)
             except Exception as e:  # the headline line must still be printed
                 box["v"] = {"error": repr(e)}
 
@@ -323,6 +403,28 @@ def main():
         else:
             _leg()
             cfg4 = box.get("v")
+
+    # ---- N > 1: the other batch shape, sharded — N keyframes vs ONE submap broadcast from rank 0 (every rank; watchdog as above)
+    sharded_st = None
+    if extras and dist is not None and comm is not None and not cfg4_hung:
+        import threading
+        box2 = {}
+
+        def _leg2():
+            try:
+                torch.cuda.set_device(dev_index)
+                box2["v"] = shared_target_sharded_leg(lib, comm, dist, rank, world, make_ndt, tgt_dev, src_dev, g16, n_src_pts, torch)
+            except Exception as e:
+                box2["v"] = {"error": repr(e)}
+
+        th2 = threading.Thread(target=_leg2, daemon=True)
+        th2.start()
+        th2.join(float(os.environ.get("LSR_BENCH_CFG4_TIMEOUT", "240")))
+        if th2.is_alive():
+            cfg4_hung = True
+            sharded_st = {"error": "the sharded shared-target leg did not finish within its watchdog time"}
+        else:
+            sharded_st = box2.get("v")
 
     stash = {}
     # ---- cfg 5 and cfg 3 on EVERY rank (BASELINE config 5 reads "1 and 8 GPUs"): each rank registers its own workload, the rank-0
@@ -343,6 +445,8 @@ def main():
     if rank == 0:
         if cfg4 is not None:
             out["cfg4_loop_batch"] = cfg4
+        if sharded_st is not None:
+            out["ndt_shared_target_sharded"] = sharded_st
         if extras and not cfg4_hung:
             for name in ("cfg5_dense", "gicp_cfg3"):
                 out[name] = gathered[0].get(name, {})
@@ -357,7 +461,7 @@ def main():
         if world == 1 and extras:
             legs = [("set_input_target", lambda: target_leg(ndt, tgt_dev, case)),
                     ("scan_stream", lambda: stream_leg(args, lib, make_ndt, ndt, stream, src_dev, g16, n_src_pts, torch, synth)),
-                    ("ndt_shared_target_batch", lambda: shared_target_leg(lib, make_ndt, ndt, src_dev, g16, n_src_pts, torch)),
+                    ("ndt_shared_target_batch", lambda: shared_target_leg(lib, make_ndt, ndt, src_dev, g16, n_src_pts, torch, tgt_dev, dev_index)),
                     ("frontend_stream", lambda: frontend_stream_leg(drive, dev_index, tstream, torch, args)),
                     ("loop_gate", lambda: loop_gate_leg(dev_index, tstream, torch, synth, stash)),
                     ("next_rows", lambda: next_rows_leg(case, dev_index, tstream, torch, synth, args))]
@@ -422,6 +526,13 @@ def main():
             out["cfg4_projected_speedup_8_gpus"] = pj["block"]["projected_speedup_8_gpus"]
             if isinstance(pj.get("planned_longest_first"), dict):
                 out["cfg4_max_share_ms_planned"] = pj["planned_longest_first"]["max_share_ms"]
+        # ... and of the other batch shape (N keyframes vs ONE submap: the one that fills a chip; VERDICT r05 #1c)
+        sp = (out.get("ndt_shared_target_batch") or {}).get("sharded_8_projection") if isinstance(out.get("ndt_shared_target_batch"), dict) else None
+        if isinstance(sp, dict) and "projected_speedup_8_gpus" in sp:
+            out["shared_target_scans_total"] = sp["scans_total"]
+            out["shared_target_set_ms_one_gpu"] = min(x for x in (sp["one_gpu_ms_as_8_sets"], sp["one_gpu_ms_as_one_set"]) if x)
+            out["shared_target_max_share_ms"] = sp["max_share_ms"] + sp["xgmi_broadcast_allowance_ms"]
+            out["shared_target_projected_speedup_8_gpus"] = sp["projected_speedup_8_gpus"]
         print(json.dumps(out), flush=True)
 
     if cfg4_hung:
@@ -430,6 +541,8 @@ def main():
         os._exit(0)   # the stuck leg holds a thread inside the collective library: no orderly shutdown is possible
     if dist is not None:
         dist.barrier()
+        if comm is not None:
+            lib.lsr_comm_destroy(comm)   # destroyed normally: this process holds ONE collective-library client
         dist.destroy_process_group()
 
 
@@ -539,7 +652,7 @@ def stream_leg(args, lib, make_ndt, ndt, stream, src_dev, g16, n_src_pts, torch,
     return out
 
 
-def shared_target_leg(lib, make_ndt, owner, src_dev, g16, n_src_pts, torch):
+def shared_target_leg(lib, make_ndt, owner, src_dev, g16, n_src_pts, torch, tgt_dev=None, dev_index=0):
     """north_star's other batch shape — "N keyframes vs. submap" (VERDICT r04 missing #2): the scans of the stream registered against
     the ONE resident 10-frame submap in shared launches.  Every member is its own registration object sharing the owner's target
     (lsr_share_target: one voxel table in HBM, one LDS image); lsr_set_input_source_batch + lsr_align_batch per set.  This is
@@ -599,7 +712,140 @@ def shared_target_leg(lib, make_ndt, owner, src_dev, g16, n_src_pts, torch):
             r.close()
     out["what"] = ("the stream's scans as ONE set against the shared 10-frame submap: lsr_set_input_source_batch + lsr_align_batch per set, "
                    "host clock; chain_ms = hipEvents around the set's launch chains")
+    try:
+        out["sharded_8_projection"] = shared_target_projection(lib, make_ndt, tgt_dev, src_dev, g16, n_src_pts, dev_index)
+    except Exception as e:
+        out["sharded_8_projection"] = {"error": repr(e)}
     return out
+
+
+def shared_target_projection(lib, make_ndt, tgt_dev, src_dev, g16, n_src_pts, dev_index, world=8):
+    """What ONE GPU can say about north_star's ">= 6x batched-scan throughput at 8 GPUs" on the batch shape that fills a chip: 8 x m
+    scans against ONE submap (cfg 2 schedule).  One GPU: setInputTarget once, then all 8 x m scans — as 8 sets of m one after the
+    other AND as one set of 8 x m, whichever is faster.  One of 8 ranks: the submap arrives (lsr_set_input_target_bcast; here
+    lsr_set_input_target_device stands in for broadcast + build: the 21 MB records over xGMI at >= 50 GB/s are ~0.4 ms more, added
+    below as an allowance), the voxel grid is built redundantly per rank, the rank registers ITS m scans
+    (lsr_set_input_source_batch + lsr_align_batch_sharded through a one-rank communicator, records exchanged).  Projection = one-GPU
+    time / share time.  A projection from single-GPU measurements, not a scaling run: bench.py --gpus 8 runs the real thing
+    (ndt_shared_target_sharded)."""
+    from lidarslam_ros2_amd import _capi
+
+    fptr = C.POINTER(C.c_float)
+    m = min(len(src_dev), 55)
+    total = m * world
+    owner = make_ndt(eps=0.0, mi=30)
+    regs = []
+    for _ in range(total):
+        r = make_ndt(eps=0.0, mi=30)
+        regs.append(r)
+    comm = C.c_void_p()
+    _capi.check(lib.lsr_comm_create(None, 0, 1, dev_index, C.byref(comm)), "lsr_comm_create")
+    hs = (C.c_void_p * total)(*[r._h for r in regs])
+    sptr = (C.c_void_p * total)(*[C.c_void_p(src_dev[j % m].data_ptr()) for j in range(total)])
+    scnt = (C.c_size_t * total)(*[n_src_pts] * total)
+    G = np.ascontiguousarray(np.stack([g16[j % m] for j in range(total)]), np.float32)
+    finals = np.zeros((total, 16), np.float32)
+    res = (_capi.Result * total)()
+    recs = (_capi.ShardRecord * total)()
+    n_t = int(tgt_dev.shape[0])
+
+    def set_target():
+        _capi.check(lib.lsr_set_input_target_device(owner._h, C.c_void_p(tgt_dev.data_ptr()), 32, n_t), "lsr_set_input_target_device")
+        for r in regs:
+            r.shareTargetOf(owner)
+
+    def sub(a, k):   # a ctypes / numpy view of members [k*m, (k+1)*m)
+        return (type(a)._type_ * m).from_buffer(a, k * m * C.sizeof(type(a)._type_))
+
+    def one_gpu_sets():
+        t0 = time.perf_counter()
+        set_target()
+        for k in range(world):
+            _capi.check(lib.lsr_set_input_source_batch(sub(hs, k), m, sub(sptr, k), sub(scnt, k), 32, 1), "lsr_set_input_source_batch")
+            _capi.check(lib.lsr_align_batch(sub(hs, k), m, G[k * m:].ctypes.data_as(fptr), finals[k * m:].ctypes.data_as(fptr), sub(res, k)), "lsr_align_batch")
+        return time.perf_counter() - t0
+
+    def one_gpu_whole():
+        t0 = time.perf_counter()
+        set_target()
+        _capi.check(lib.lsr_set_input_source_batch(hs, total, sptr, scnt, 32, 1), "lsr_set_input_source_batch")
+        _capi.check(lib.lsr_align_batch(hs, total, G.ctypes.data_as(fptr), finals.ctypes.data_as(fptr), res), "lsr_align_batch")
+        return time.perf_counter() - t0
+
+    def share(k):
+        t0 = time.perf_counter()
+        set_target()
+        _capi.check(lib.lsr_set_input_source_batch(sub(hs, k), m, sub(sptr, k), sub(scnt, k), 32, 1), "lsr_set_input_source_batch")
+        _capi.check(lib.lsr_align_batch_sharded(comm, sub(hs, k), m, m, G[k * m:].ctypes.data_as(fptr), 0, recs), "lsr_align_batch_sharded")
+        return time.perf_counter() - t0
+
+    one_gpu_sets(); t_sets = min(one_gpu_sets() for _ in range(2))
+    sets_T = finals.copy()
+    try:
+        one_gpu_whole(); t_whole = min(one_gpu_whole() for _ in range(2))
+        whole_same = int(sum(np.array_equal(finals[j], sets_T[j]) for j in range(total)))
+    except Exception as e:   # a set of 440 may exceed what one launch chain takes: the 8-sets form then stands alone
+        t_whole, whole_same = None, repr(e)
+    share(0); t_share = [min(share(k) for _ in range(2)) for k in range(world)]
+    lib.lsr_comm_destroy(comm)
+    for r in regs:
+        r.close()
+    owner.close()
+    xgmi_allowance = (n_t * 32) / 50e9   # the records of the submap, one hop at 50 GB/s (a third of a link's 153 GB/s)
+    t_one = min(t_sets, t_whole) if t_whole else t_sets
+    t_rank = max(t_share) + xgmi_allowance
+    return {"scans_total": total, "scans_per_rank": m, "ranks": world,
+            "one_gpu_ms_as_8_sets": 1e3 * t_sets, "one_gpu_ms_as_one_set": (1e3 * t_whole) if t_whole else None, "one_set_same_bits_as_8_sets": whole_same,
+            "share_ms": [round(1e3 * t, 4) for t in t_share], "max_share_ms": 1e3 * max(t_share), "xgmi_broadcast_allowance_ms": 1e3 * xgmi_allowance,
+            "projected_speedup_8_gpus": t_one / t_rank, "registrations_per_s_one_gpu": total / t_one, "projected_registrations_per_s_8_gpus": total / t_rank,
+            "note": "strong scaling of 8 x m scans vs ONE submap; the share includes the per-rank (redundant) voxel-grid build and the record exchange"}
+
+
+def shared_target_sharded_leg(lib, comm, dist, rank, world, make_ndt, tgt_dev, src_dev, g16, n_src_pts, torch):
+    """N > 1: north_star's "N keyframes vs. submap" sharded across the ranks as SURVEY.md 8e partitions it — rank 0 holds the
+    10-frame submap (scanmatcher_component.cpp:449-464) and broadcasts its records (lsr_set_input_target_bcast: ncclBroadcast over
+    xGMI), every rank builds the voxel grid, shares it among its m registration objects (lsr_share_target) and registers ITS m scans
+    in shared launches; one ncclAllGather of the 64-byte records (lsr_align_batch_sharded) gives every rank all world x m poses.
+    Timed from before the broadcast to after the all-gather, max over ranks.  cfg 2 schedule (30 fixed iterations)."""
+    from lidarslam_ros2_amd import _capi
+
+    fptr = C.POINTER(C.c_float)
+    mt = torch.tensor([min(len(src_dev), 55)], dtype=torch.int64)
+    dist.all_reduce(mt, op=dist.ReduceOp.MIN)   # the same share size on every rank (rank 0's stream is longer: it feeds the latency statistics)
+    m = int(mt.item())
+    owner = make_ndt(eps=0.0, mi=30)
+    regs = [make_ndt(eps=0.0, mi=30) for _ in range(m)]
+    hs = (C.c_void_p * m)(*[r._h for r in regs])
+    sptr = (C.c_void_p * m)(*[C.c_void_p(src_dev[j].data_ptr()) for j in range(m)])
+    scnt = (C.c_size_t * m)(*[n_src_pts] * m)
+    G = np.ascontiguousarray(np.stack(g16[:m]), np.float32)
+    recs = (_capi.ShardRecord * (m * world))()
+    n_t = int(tgt_dev.shape[0])
+
+    def round_():
+        dist.barrier()
+        t0 = time.perf_counter()
+        _capi.check(lib.lsr_set_input_target_bcast(comm, owner._h, C.c_void_p(tgt_dev.data_ptr()) if rank == 0 else None, 32, n_t if rank == 0 else 0, 1, 0),
+                    "lsr_set_input_target_bcast")
+        t1 = time.perf_counter()
+        for r in regs:
+            r.shareTargetOf(owner)
+        _capi.check(lib.lsr_set_input_source_batch(hs, m, sptr, scnt, 32, 1), "lsr_set_input_source_batch")
+        _capi.check(lib.lsr_align_batch_sharded(comm, hs, m, m * world, G.ctypes.data_as(fptr), 0, recs), "lsr_align_batch_sharded")
+        t2 = time.perf_counter()
+        v = torch.tensor([t2 - t0, t1 - t0], dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v[0]), float(v[1])
+
+    round_()
+    best = min((round_() for _ in range(3)), key=lambda x: x[0])
+    conv = int(sum(1 for k in range(m * world) if recs[k].converged > 0.5))
+    for r in regs:
+        r.close()
+    owner.close()
+    return {"scans_total": m * world, "scans_per_rank": m, "ranks": world, "ms_per_round": 1e3 * best[0], "ms_broadcast_and_grid_build": 1e3 * best[1],
+            "registrations_per_s_all_ranks": m * world / best[0], "records_converged": conv,
+            "what": "rank 0's submap by lsr_set_input_target_bcast, m scans per rank in shared launches, one all-gather of world x m records; max over ranks"}
 
 
 def frontend_stream_leg(drive, dev_index, tstream, torch, args):
@@ -914,7 +1160,7 @@ def loop_gate_leg(dev_index, tstream, torch, synth, stash):
                     "+ gate, clouds resident in HBM"}
 
 
-def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, torch, synth):
+def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, world_comm, torch, synth):
     """BASELINE cfg 4 as SURVEY.md §8d defines it: every candidate is its own (target, source, guess) and pays
     setInputTarget + setInputSource + align + getFitnessScore (graph_based_slam_component.cpp:181-231, backend settings
     max_iterations 100, transformation_epsilon 0.01, :64-72).  Candidates are sharded over the ranks (lsr_shard_range) and the
@@ -935,17 +1181,11 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
         guesses.append(np.ascontiguousarray(np.asarray(guess, np.float32).T).reshape(16))
     torch.cuda.synchronize()
     nloc = len(regs)
-    # communicator at the C ABI: ncclUniqueId from rank 0 to everybody through torch.distributed's store
+    # the job's communicator (make_comm) when there is more than one rank; else a one-rank communicator (no RCCL behind it)
     comm = C.c_void_p()
-    use_rccl = (world > 1 and backend == "nccl")
+    use_rccl = (world > 1 and world_comm is not None)
     if use_rccl:
-        ident = (C.c_char * 128)()
-        if rank == 0:
-            _capi.check(lib.lsr_comm_unique_id(ident), "lsr_comm_unique_id")
-        box = [bytes(ident)]
-        dist.broadcast_object_list(box, src=0)
-        ident = (C.c_char * 128).from_buffer_copy(box[0])
-        _capi.check(lib.lsr_comm_create(ident, rank, world, dev_index, C.byref(comm)), "lsr_comm_create")
+        comm = world_comm
     else:
         _capi.check(lib.lsr_comm_create(None, 0, 1, dev_index, C.byref(comm)), "lsr_comm_create")   # one-rank communicator per process
     hs = (C.c_void_p * max(nloc, 1))(*[r._h for r in regs])
@@ -985,8 +1225,8 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
     def sync_max(t):
         if dist is None:
             return t
-        v = torch.tensor([t], dtype=torch.float64, device=("cuda" if backend == "nccl" else "cpu"))
-        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        v = torch.tensor([t], dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)   # control plane (gloo)
         return float(v.item())
 
     one_round(True)   # warm-up (allocations, RCCL channels)
@@ -1026,15 +1266,12 @@ def run_cfg4(args, lib, rank, world, dev_index, tstream, cands, dist, backend, t
         errs.append(pose_delta(T, truth))
     if not use_rccl:
         lib.lsr_comm_destroy(comm)
-    # (an RCCL communicator of the C core is left to the end of the process: torch.distributed's "nccl" backend has its own RCCL
-    # state in this address space, and round 5 saw ncclCommDestroy end a process that held both with a double free — the line
-    # below must be printed whatever the collective library does at teardown)
     if rank != 0:
         return None
     res = {"candidates": n_total, "ranks": world, "candidates_on_rank0": nloc,
            "value": n_total / t_batched, "unit": "registrations/s", "ms_per_candidate_set": 1e3 * t_batched,
            "collective": ("ncclAllGather of 64-byte records (lsr_align_batch_sharded)" if use_rccl else
-                          "none (one rank)" if world == 1 else "per-rank tables only: ranks share a device, RCCL needs one device per rank"),
+                          "none (one rank)" if world == 1 else "per-rank tables only: the library's communicator could not be created"),
            "max_error_vs_truth_rank0": {"translation_m": float(max(e[0] for e in errs)) if errs else None,
                                         "rotation_rad": float(max(e[1] for e in errs)) if errs else None},
            "fitness_rank0": [float(recs[(cands[0][0] if use_rccl else 0) + b].fitness) for b in range(min(nloc, 4))],

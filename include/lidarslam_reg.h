@@ -296,11 +296,22 @@ int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_c
 int lsr_comm_destroy(lsr_comm c);
 /* "N keyframes vs. one submap" across ranks: the rank `root` holds the target cloud — the submap
  * scanmatcher_component.cpp:449-464 assembles and :307 hands to registration_->setInputTarget — and every rank of the communicator
- * ends up with it as the input target of its handle `h`: one ncclBroadcast of the records (device to device over xGMI, behind a
- * 16-byte header with the point count), then the same voxel grid built on every rank.  pts / stride_bytes / n / on_device are read on
- * the root only.  COLLECTIVE: every rank calls it; a one-rank communicator created without an id hands the cloud straight to
- * lsr_set_input_target.  Reference call it generalises: registration_->setInputTarget(targeted_cloud_ptr), one node, one object. */
+ * ends up with it as the input target of its handle `h`: a 16-byte header {points, stride} by ncclBroadcast, one ncclAllGather of a
+ * ready word per rank (the records travel only if every rank can receive them), one ncclBroadcast of the records (device to device
+ * over xGMI), then the same voxel grid built on every rank.  pts / stride_bytes / n / on_device are read on the root only.
+ * COLLECTIVE: every rank calls it, and a rank that fails locally (bad cloud on the root, no memory, a handle on another device than
+ * the communicator) still takes part in every exchange and returns its error afterwards; the other ranks return an error too
+ * (LSR_ERR_NO_TARGET when the root had nothing to send) — no rank waits for one that has left.
+ * ORDERING of a device-resident root cloud (on_device != 0): the records are read on the COMMUNICATOR's stream, which this call
+ * orders behind the handle's stream; the caller orders the handle's stream behind the producer of the records exactly as for
+ * lsr_set_input_target_device — lsr_wait_stream(h, producer_stream) or a synchronisation of its own — and keeps the buffer valid
+ * until the call returns.  A one-rank communicator hands the cloud straight to lsr_set_input_target(_device).
+ * Reference call it generalises: registration_->setInputTarget(targeted_cloud_ptr), one node, one object. */
 int lsr_set_input_target_bcast(lsr_comm c, lsr_handle h, const void* pts, size_t stride_bytes, size_t n, int on_device, int root);
+/* The pose all-gather on its own (BASELINE.json north_star: "RCCL all-gather of the 6-DoF poses"): every rank contributes `count`
+ * 64-byte records — e.g. the scans of its stream, registered one after the other with lsr_align as the frontend does
+ * (scanmatcher_component.cpp:353-356) — and receives all world x count of them, rank-major.  COLLECTIVE, same count on every rank. */
+int lsr_comm_all_gather_records(lsr_comm c, const lsr_shard_record* local, int count, lsr_shard_record* all_records /* world x count */);
 /* local_handles / local_guesses: this rank's share (local_count = lsr_shard_range count), targets and sources already
  * set; with_fitness != 0 adds getFitnessScore() per registration (graph_based_slam_component.cpp:231).
  * all_records: global_count entries, in batch order, identical on every rank. */

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "lsr_debug_angle_tables", "lsr_set_input_source_pc2", "lsr_get_source_pc2", "lsr_voxel_grid_filter_pc2", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
     "lsr_shard_plan", "lsr_align_batch_planned", "lsr_align_fitness_batch",
     "lsr_set_input_target_batch", "lsr_set_input_source_batch", "lsr_get_fitness_score_batch", "lsr_set_input_target_bcast", "lsr_get_source_pc2_device",
+    "lsr_comm_all_gather_records",
 ]
 
 

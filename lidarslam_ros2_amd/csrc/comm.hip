@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -36,9 +38,18 @@ Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
-      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.lib) break;
+    // LSR_RCCL_LIB names the collective library instead (any library exporting the six nccl* entry points used here: a site's own
+    // RCCL build — or tests/cpp/stub_ccl.cpp, which carries the collectives of two PROCESSES sharing ONE device through a shared
+    // memory segment, so that every world > 1 line below executes on a one-GPU box; RCCL itself refuses two ranks on one device)
+    const char* over = std::getenv("LSR_RCCL_LIB");
+    if (over && *over) {
+      r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+      if (!r.lib) { std::fprintf(stderr, "lidarslam_reg: LSR_RCCL_LIB=%s could not be loaded: %s\n", over, dlerror()); return; }
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+      }
     }
     if (!r.lib) return;
     r.get_unique_id = (fn_get_unique_id)dlsym(r.lib, "ncclGetUniqueId");
@@ -65,6 +76,7 @@ struct lsr_comm_s {
   void* comm = nullptr;
   int rank = 0, world = 1, device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;   // orders the communicator's stream behind a handle's (lsr_set_input_target_bcast, device-resident root cloud)
   // Exchange buffers, allocated when the communicator is created (COMM_PREALLOC records per rank: 64 KiB + world x 64 KiB) so
   // that the sharded calls normally allocate nothing.  d_send is kept ARMED: between calls it holds records flagged invalid
   // (converged = -1, NaN), so a call whose upload of its own records fails still contributes well-formed "this share failed"
@@ -72,7 +84,7 @@ struct lsr_comm_s {
   lsr::DevBuf<lsr_shard_record> d_send, d_recv;
   size_t armed = 0;   // records of d_send currently holding the invalid pattern
   lsr::DevBuf<unsigned char> d_cloud, d_cloud_src;   // lsr_set_input_target_bcast: the broadcast target's records on this rank (+ the root's send copy)
-  lsr::DevBuf<unsigned long long> d_header;          // ... and its {point count, stride} header: [0..1] send, [2..3] receive
+  lsr::DevBuf<unsigned long long> d_header;          // ... its {point count, stride} header: [0..1] send, [2..3] receive; [4] this rank's ready word, [8..8+world) all of them
 };
 constexpr size_t COMM_PREALLOC = 1024;
 
@@ -170,8 +182,9 @@ int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_c
     std::memcpy(&id, id128, sizeof(id));
     const int rc = r->comm_init_rank(&c->comm, world, id, rank);
     if (rc) { (void)hipStreamDestroy(c->stream); delete c; return rccl_fail("ncclCommInitRank", rc); }
-    if (c->d_send.reserve(COMM_PREALLOC) || c->d_recv.reserve(COMM_PREALLOC * (size_t)world) || arm_send(c, COMM_PREALLOC)) {
-      (void)r->comm_destroy(c->comm); (void)hipStreamDestroy(c->stream); delete c;
+    if (c->d_send.reserve(COMM_PREALLOC) || c->d_recv.reserve(COMM_PREALLOC * (size_t)world) || c->d_header.reserve(8 + (size_t)world) ||
+        hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess || arm_send(c, COMM_PREALLOC)) {
+      (void)r->comm_destroy(c->comm); (void)hipStreamDestroy(c->stream); if (c->ev) (void)hipEventDestroy(c->ev); delete c;
       return LSR_ERR_HIP;
     }
   }
@@ -185,6 +198,7 @@ int lsr_comm_destroy(lsr_comm c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) { Rccl* r = rccl(); if (r) (void)r->comm_destroy(c->comm); }
   (void)hipStreamDestroy(c->stream);
+  if (c->ev) (void)hipEventDestroy(c->ev);
   delete c;
   return LSR_OK;
 }
@@ -292,52 +306,122 @@ int lsr_align_batch_planned(lsr_comm c, lsr_handle* local_handles, int local_cou
 
 // "N keyframes vs. one submap" across ranks (ncclBroadcast of the target, voxel table built redundantly per rank): the
 // root holds the submap (scanmatcher_component.cpp:449-464 assembles it; :307 hands it to the registration object), every rank
-// registers its own share of the scans against it.  Two broadcasts on the communicator's stream — a 16-byte header {points, stride},
-// then the records, device to device over xGMI — and every rank builds the same voxel grid from the same bytes (lsr_set_input_target
-// on the handle).  A one-rank communicator hands the cloud straight through.  Collective: every rank of the communicator calls it.
+// registers its own share of the scans against it.  Every rank of the communicator calls it, and every rank that has entered the
+// exchange goes through ALL of its collectives whatever fails locally on the way (the C ABI has no abort):
+//   1. ncclBroadcast of a 16-byte header {points, stride} — a root that cannot offer its cloud (ill-formed arguments, no staging
+//      memory) announces zero points and every rank returns LSR_ERR_NO_TARGET alike;
+//   2. every rank reserves room for the records, then ONE ncclAllGather of a ready word per rank: the records travel only if every
+//      rank can receive them (a rank without memory, or whose handle lives on another device than the communicator, says so here
+//      and all ranks return an error instead of some of them waiting in step 3 for a rank that has left);
+//   3. ncclBroadcast of the records, device to device over xGMI, on the communicator's stream — ordered BEHIND the handle's stream
+//      on the root when the records are device resident (the caller orders the handle's stream behind the producer with
+//      lsr_wait_stream, as for every device input; the communicator's stream then waits for an event recorded there);
+//   4. every rank builds the same voxel grid from the same bytes (lsr_set_input_target_device on the handle).
+// A one-rank communicator hands the cloud straight through.
 int lsr_set_input_target_bcast(lsr_comm c, lsr_handle h, const void* pts, size_t stride_bytes, size_t n, int on_device, int root) {
   if (!c || !h || root < 0 || root >= c->world) { lsr::set_last_error("bad broadcast-target arguments"); return LSR_ERR_INVALID_ARGUMENT; }
   const bool is_root = (c->rank == root);
-  if (is_root && ((n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0)) {
-    // the root still has to enter the collective: it announces an empty cloud, every rank then fails alike
-    n = 0; stride_bytes = 12; pts = nullptr;
-    lsr::set_last_error("broadcast target: the root's cloud is ill-formed (null pointer or bad stride)");
-  }
   // one rank: nothing to exchange, with or without an RCCL communicator behind it (ncclBroadcast on a communicator of ONE rank —
   // in place or out of place — left RCCL of ROCm 7.2 with a double free at ncclCommDestroy: round 5, tests/test_multigpu_gpu.py)
-  if (c->world == 1)
+  if (c->world == 1) {
+    if ((n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0) { lsr::set_last_error("broadcast target: the cloud is ill-formed (null pointer or bad stride)"); return LSR_ERR_INVALID_ARGUMENT; }
     return on_device ? lsr_set_input_target_device(h, pts, stride_bytes, n) : lsr_set_input_target(h, pts, stride_bytes, n);
+  }
+  // ---- what is the same on every rank of a job (the library, the communicator's kind) may return at once
   Rccl* r = rccl();
   if (!r || !c->comm || !r->broadcast) { lsr::set_last_error("communicator has no RCCL broadcast"); return LSR_ERR_NOT_IMPLEMENTED; }
   lsr::DeviceGuard guard(c->device);
   if (!guard.ok) { lsr::set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
-  int st;
-  // send and receive buffers are kept apart (out-of-place broadcasts: an in-place broadcast on a communicator of one rank left
-  // RCCL 2.x of ROCm 7 with a double free at ncclCommDestroy)
-  if ((st = c->d_header.reserve(4))) return st;
-  unsigned long long header[2] = {(unsigned long long)n, (unsigned long long)stride_bytes};
-  if (is_root) LSR_HIP(hipMemcpyAsync(c->d_header.p, header, sizeof(header), hipMemcpyHostToDevice, c->stream));
+  // ---- from here on every exit is behind the last collective.  Local failures are remembered and reported afterwards.
+  int local_status = LSR_OK;
+  std::string local_error;
+  auto fail = [&](int st, const std::string& what) { if (!local_status) { local_status = st; local_error = what; } };
+  if (h->device != c->device) fail(LSR_ERR_INVALID_ARGUMENT, "broadcast target: the handle lives on another device than the communicator");
+  unsigned long long header[2] = {0ull, 12ull};
+  const void* send = nullptr;
+  if (is_root) {
+    if ((n > 0 && !pts) || n == 0 || stride_bytes < 12 || (stride_bytes % 4) != 0) {
+      fail(LSR_ERR_INVALID_ARGUMENT, "broadcast target: the root's cloud is empty or ill-formed (null pointer or bad stride)");
+    } else if (on_device) {
+      // device-resident records go out from where they are, once the handle's stream (which the caller has ordered behind their
+      // producer) has reached this point
+      hipError_t e = hipEventRecord(c->ev, h->stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev, 0);
+      if (e != hipSuccess) fail(LSR_ERR_HIP, std::string("broadcast target: stream ordering failed: ") + hipGetErrorString(e));
+      else send = pts;
+    } else {
+      const size_t bytes = n * stride_bytes;
+      if (c->d_cloud_src.reserve(bytes)) fail(LSR_ERR_HIP, "broadcast target: no device memory to stage the root's cloud");
+      else {
+        const hipError_t e = hipMemcpyAsync(c->d_cloud_src.p, pts, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) fail(LSR_ERR_HIP, std::string("broadcast target: staging the root's cloud failed: ") + hipGetErrorString(e));
+        else send = c->d_cloud_src.p;
+      }
+    }
+    if (!local_status) { header[0] = (unsigned long long)n; header[1] = (unsigned long long)stride_bytes; }
+    // (a root that failed announces zero points)
+    (void)hipMemcpyAsync(c->d_header.p, header, sizeof(header), hipMemcpyHostToDevice, c->stream);
+  }
+  // 1. header (send and receive buffers are kept apart: out-of-place collectives throughout)
   int rc = r->broadcast(c->d_header.p, c->d_header.p + 2, sizeof(header), /*ncclUint8*/ 1, root, c->comm, c->stream);
-  if (rc) return rccl_fail("ncclBroadcast (header)", rc);
+  if (rc) return rccl_fail("ncclBroadcast (header)", rc);   // the collective library itself failed: nothing more can be promised
   LSR_HIP(hipMemcpyAsync(header, c->d_header.p + 2, sizeof(header), hipMemcpyDeviceToHost, c->stream));
   LSR_HIP(hipStreamSynchronize(c->stream));
   const size_t count = (size_t)header[0], stride = (size_t)header[1], bytes = count * stride;
-  if (count == 0) { lsr::set_last_error("broadcast target: the root announced an empty cloud"); return LSR_ERR_NO_TARGET; }
-  if ((st = c->d_cloud.reserve(bytes))) return st;   // (a rank that cannot allocate leaves its peers in the second broadcast: there is no abort in the C ABI)
-  const void* send = c->d_cloud.p;   // ranks other than the root: the send pointer is not read
-  if (is_root) {
-    if (on_device) {
-      send = pts;   // device-resident records go out from where they are
-    } else {
-      if ((st = c->d_cloud_src.reserve(bytes))) return st;
-      LSR_HIP(hipMemcpyAsync(c->d_cloud_src.p, pts, bytes, hipMemcpyHostToDevice, c->stream));
-      send = c->d_cloud_src.p;
-    }
+  if (count == 0) {   // every rank reads the same header: all leave here together
+    if (local_status) { lsr::set_last_error(local_error); return local_status; }
+    lsr::set_last_error("broadcast target: the root announced an empty cloud");
+    return LSR_ERR_NO_TARGET;
   }
-  rc = r->broadcast(send, c->d_cloud.p, bytes, /*ncclUint8*/ 1, root, c->comm, c->stream);
+  // 2. can everybody receive?
+  if (!local_status && c->d_cloud.reserve(bytes)) fail(LSR_ERR_HIP, "broadcast target: no device memory for the records on this rank");
+  unsigned long long ready = local_status ? 0ull : 1ull;
+  (void)hipMemcpyAsync(c->d_header.p + 4, &ready, sizeof(ready), hipMemcpyHostToDevice, c->stream);
+  rc = r->all_gather(c->d_header.p + 4, c->d_header.p + 8, sizeof(ready), /*ncclUint8*/ 1, c->comm, c->stream);
+  if (rc) return rccl_fail("ncclAllGather (ready words)", rc);
+  std::vector<unsigned long long> all_ready((size_t)c->world, 0ull);
+  LSR_HIP(hipMemcpyAsync(all_ready.data(), c->d_header.p + 8, sizeof(ready) * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+  LSR_HIP(hipStreamSynchronize(c->stream));
+  int not_ready = -1;
+  for (int rk = 0; rk < c->world; rk++) if (!all_ready[rk] && not_ready < 0) not_ready = rk;
+  if (not_ready >= 0) {   // the same table on every rank: all leave here together
+    if (local_status) { lsr::set_last_error(local_error); return local_status; }
+    lsr::set_last_error("broadcast target: rank " + std::to_string(not_ready) + " cannot receive the records; nothing was sent");
+    return LSR_ERR_HIP;
+  }
+  // 3. the records
+  rc = r->broadcast(is_root ? send : (const void*)c->d_cloud.p, c->d_cloud.p, bytes, /*ncclUint8*/ 1, root, c->comm, c->stream);
   if (rc) return rccl_fail("ncclBroadcast (cloud)", rc);
   LSR_HIP(hipStreamSynchronize(c->stream));   // the handle reads the records on ITS stream
+  // 4. the grid
   return lsr_set_input_target_device(h, c->d_cloud.p, stride, count);
+}
+
+// One all-gather of `count` 64-byte records per rank (the pose all-gather of north_star on its own: the scans of a stream a rank
+// registered one after the other, a share registered through other entries).  all_records: world x count, rank-major.
+int lsr_comm_all_gather_records(lsr_comm c, const lsr_shard_record* local, int count, lsr_shard_record* all_records) {
+  if (!c || count <= 0 || !local || !all_records) { lsr::set_last_error("bad record all-gather arguments"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (c->world == 1 && !c->comm) { std::memcpy(all_records, local, sizeof(lsr_shard_record) * (size_t)count); return LSR_OK; }
+  Rccl* r = rccl();
+  if (!r || !c->comm) { lsr::set_last_error("communicator has no RCCL handle"); return LSR_ERR_NOT_IMPLEMENTED; }
+  lsr::DeviceGuard guard(c->device);
+  if (!guard.ok) { lsr::set_last_error("hipSetDevice failed"); return LSR_ERR_HIP; }
+  int st;
+  if ((size_t)count > c->d_send.cap || (size_t)count * c->world > c->d_recv.cap) {   // before the collective (see invalid_record)
+    if ((st = c->d_send.reserve((size_t)count))) return st;
+    if ((st = c->d_recv.reserve((size_t)count * c->world))) return st;
+  }
+  c->armed = 0;
+  int local_status = LSR_OK;
+  std::string local_error;
+  const hipError_t e = hipMemcpyAsync(c->d_send.p, local, sizeof(lsr_shard_record) * (size_t)count, hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) { local_status = LSR_ERR_HIP; local_error = std::string("upload of the records failed: ") + hipGetErrorString(e); }
+  const int rc = r->all_gather(c->d_send.p, c->d_recv.p, sizeof(lsr_shard_record) * (size_t)count, /*ncclUint8*/ 1, c->comm, c->stream);
+  if (rc) return rccl_fail("ncclAllGather", rc);
+  LSR_HIP(hipMemcpyAsync(all_records, c->d_recv.p, sizeof(lsr_shard_record) * (size_t)count * c->world, hipMemcpyDeviceToHost, c->stream));
+  LSR_HIP(hipStreamSynchronize(c->stream));
+  if (local_status) { lsr::set_last_error(local_error); return local_status; }
+  return LSR_OK;
 }
 
 // the static block partition is the plan { order = identity, rank_first = lsr_shard_range }

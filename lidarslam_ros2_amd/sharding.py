@@ -224,6 +224,19 @@ class Comm:
         capi.check(capi.load().lsr_comm_unique_id(ident), "lsr_comm_unique_id")
         return bytes(ident)
 
+    def all_gather_records(self, local: np.ndarray) -> np.ndarray:
+        """lsr_comm_all_gather_records: `local` = (count, 16) fp32 records of this rank (same count on every rank); returns
+        (world, count, 16), rank-major — the pose all-gather on its own."""
+        import ctypes as C
+
+        from . import _capi as capi
+
+        a = np.ascontiguousarray(np.asarray(local, np.float32).reshape(-1, RECORD_FLOATS))
+        out = np.zeros((self.world, a.shape[0], RECORD_FLOATS), np.float32)
+        capi.check(self._lib.lsr_comm_all_gather_records(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.c_void_p)),
+                   "lsr_comm_all_gather_records")
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.lsr_comm_destroy(self._h)
