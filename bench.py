@@ -190,12 +190,12 @@ def main():
     cache = None
     if os.environ.get("LSR_BENCH_CACHE_DIR"):
         cache = os.path.join(os.environ["LSR_BENCH_CACHE_DIR"],
-                             f"bench3_r{rank}w{world}_s{n_stream}_c{args.candidates}_e{int(extras)}.pkl")
-    drive = None
+                             f"bench4_r{rank}w{world}_s{n_stream}_c{args.candidates}_e{int(extras)}.pkl")
+    drive = drive20 = route_full = None
     if cache and os.path.exists(cache):
         import pickle
         with open(cache, "rb") as f:
-            case, stream, cands, dense, gc, drive = pickle.load(f)
+            case, stream, cands, dense, gc, drive, drive20, route_full = pickle.load(f)
     else:
         with mp.get_context("fork").Pool(nwork) as pool:
             case = synth.cfg_ndt_30k(seed=0, pool=pool, keep_parts=(extras and rank == 0))   # the 10-frame submap (same on every rank) + its own next scan
@@ -205,11 +205,15 @@ def main():
             gc = synth.cfg_gicp_30k(seed=rank, pool=pool) if extras else None
             # the frontend's RAW input over a drive (rank 0, one GPU): ten keyframes + scans every 0.5 m, map update every 1.5 m
             drive = synth.cfg_frontend_drive(max(12, min(args.stream, 60)), seed=0, pool=pool) if (extras and rank == 0 and world == 1) else None
+            # the reference's own shipped parameter sets at full size: the 20-frame window of lidarslam/param/lidarslam.yaml
+            # (24 scans = 8 map updates) and a there-and-back route of full-size submaps for the backend's loop gate
+            drive20 = synth.cfg_frontend_drive(24, seed=0, pool=pool, n_keyframes=20) if (extras and rank == 0 and world == 1) else None
+            route_full = synth.cfg_loop_route_full(pool=pool) if (extras and rank == 0 and world == 1) else None
         if cache:
             import pickle
             os.makedirs(os.path.dirname(cache), exist_ok=True)
             with open(cache + ".tmp", "wb") as f:
-                pickle.dump((case, stream, cands, dense, gc, drive), f, protocol=4)
+                pickle.dump((case, stream, cands, dense, gc, drive, drive20, route_full), f, protocol=4)
             os.replace(cache + ".tmp", cache)
     t_gen = time.perf_counter() - t_gen
 
@@ -463,7 +467,9 @@ def main():
                     ("scan_stream", lambda: stream_leg(args, lib, make_ndt, ndt, stream, src_dev, g16, n_src_pts, torch, synth)),
                     ("ndt_shared_target_batch", lambda: shared_target_leg(lib, make_ndt, ndt, src_dev, g16, n_src_pts, torch, tgt_dev, dev_index)),
                     ("frontend_stream", lambda: frontend_stream_leg(drive, dev_index, tstream, torch, args)),
+                    ("frontend_stream_lidarslam_yaml", lambda: frontend_stream_ref_leg(drive20, dev_index, tstream, torch, args)),
                     ("loop_gate", lambda: loop_gate_leg(dev_index, tstream, torch, synth, stash)),
+                    ("loop_gate_reference_params", lambda: loop_gate_ref_leg(route_full, dev_index, tstream, torch, synth, args)),
                     ("next_rows", lambda: next_rows_leg(case, dev_index, tstream, torch, synth, args))]
             for name, fn in legs:
                 try:
@@ -848,72 +854,211 @@ def shared_target_sharded_leg(lib, comm, dist, rank, world, make_ndt, tgt_dev, s
             "what": "rank 0's submap by lsr_set_input_target_bcast, m scans per rank in shared launches, one all-gather of world x m records; max over ranks"}
 
 
-def frontend_stream_leg(drive, dev_index, tstream, torch, args):
+def frontend_stream_leg(drive, dev_index, tstream, torch, args, res=5.0, params=None, label=None, light=False):
     """The frontend loop as the reference runs it, end to end (VERDICT r04 missing #4): scanmatcher_component.cpp:296-356 per scan,
     :436-481 per map update, replayed by lidarslam_ros2_amd.frontend.FrontendReplay over RAW scans (~147k points each) of a drive with
-    a map update every 1.5 m.  scan_in_to_pose_out = raw PointCloud2 payload -> range filter -> VoxelGrid(0.2) -> setInputSource ->
-    align at the reference's settings; map_update = range filter + VoxelGrid(0.1) of the scan into a keyframe that stays in HBM
-    (lsr_set_input_source_pc2 on a second object + lsr_get_source_pc2_device) + assembly of the last ten submaps + setInputTarget; the
-    variant that takes the keyframe through the host, as the reference stores its submaps, is reported next to it.  The same loop on the CPU oracle gives the parity of
-    the WHOLE sequence: both sides feed on their own previous poses and their own maps."""
+    a map update every 1.5 m.  scan_in_to_pose_out = raw PointCloud2 payload -> range filter -> VoxelGrid(vg_size_for_input) ->
+    setInputSource -> align at the reference's settings; map_update = range filter + VoxelGrid(vg_size_for_map) of the scan into a
+    keyframe that stays in HBM (lsr_set_input_source_pc2 on a second object + lsr_get_source_pc2_device) + assembly of the last
+    num_targeted_cloud submaps + setInputTarget; the variant that takes the keyframe through the host, as the reference stores its
+    submaps, is reported next to it.  `async_map_update` (round 6): the map side on a WORKER THREAD with its own objects and streams
+    (scanmatcher_component.cpp:427-434), the callback takes the finished target over with lsr_share_target (:298-320) — hand-over lag 0
+    (target in place for the very next scan) and 1 (the next scan is registered while the map side runs).  The same loop on the CPU
+    oracle gives the parity of the WHOLE sequence: both sides feed on their own previous poses and their own maps.
+    `res` / `params`: ndt_resolution and the frontend's parameters (default: BASELINE cfg 1/2; `light`: fewer variants)."""
     from lidarslam_ros2_amd import DIRECT7, NormalDistributionsTransform
     from lidarslam_ros2_amd.frontend import FrontendParams, FrontendReplay, FrontendResult, as_pc2_payload
     from lidarslam_ros2_amd.posemath import pose_delta
 
     if drive is None:
         return {"skipped": "workload generated without the drive"}
+    prm = params or FrontendParams()
     hosts = [as_pc2_payload(s) for s in drive["scans"]]
     devs = [torch.from_numpy(h).cuda() for h in hosts]
     torch.cuda.synchronize()
 
-    def make():
-        r = NormalDistributionsTransform(device=dev_index, stream=tstream)
-        r.setResolution(5.0); r.setTransformationEpsilon(0.01); r.setMaximumIterations(35); r.setNeighborhoodSearchMethod(DIRECT7)
+    def make(own_stream=False):
+        # own_stream: True = a stream of the object's own, False = torch's current stream, an integer = that HIP stream
+        st = None if own_stream is True else tstream if own_stream is False else own_stream
+        r = NormalDistributionsTransform(device=dev_index, stream=st)
+        r.setResolution(res); r.setTransformationEpsilon(0.01); r.setMaximumIterations(35); r.setNeighborhoodSearchMethod(DIRECT7)
         return r
 
-    def replay(reg, device_payloads, to_device, mapper=None):
-        fr = FrontendReplay(reg, FrontendParams(), to_device=to_device, mapper=mapper)
+    def replay(reg, device_payloads, to_device, mapper=None, builder=None, async_update=False, swap_lag=0):
+        fr = FrontendReplay(reg, prm, to_device=to_device, mapper=mapper, builder=builder, async_update=async_update, swap_lag=swap_lag)
         fr.initialise(drive["frames"], drive["frame_poses"], drive["guess0"])
-        res = FrontendResult()
+        res_ = FrontendResult()
+        t0 = time.perf_counter()
         for h, d in zip(hosts, devs):
-            fr.receive_cloud(d if device_payloads else h, int(h.shape[0]), res, payload_host=h)
-        return res
+            fr.receive_cloud(d if device_payloads else h, int(h.shape[0]), res_, payload_host=h)
+        fr.finish(res_)
+        res_.wall_seconds = time.perf_counter() - t0
+        return res_
 
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
     reg, mapper = make(), make()
     replay(reg, True, to_dev, mapper)         # first pass: allocations
     g = replay(reg, True, to_dev, mapper)     # keyframes produced and kept in HBM (lsr_get_source_pc2_device)
-    gk = replay(reg, True, to_dev)            # keyframes through the host, as the reference stores its submaps (ROS messages)
-    gh = replay(reg, False, to_dev)           # raw payload from host memory: one ~4.7 MB PCIe copy per scan
     n = len(g.poses)
     errs = [pose_delta(a, t) for a, t in zip(g.poses, drive["truths"])]
     upd = np.asarray(g.update_seconds) * 1e3
-    upd_host = np.asarray(gk.update_seconds) * 1e3
     out = {"scans": n, "raw_points_per_scan": int(np.mean([h.shape[0] for h in hosts])), "points_kept_median": float(np.median(g.points_kept)),
            "map_updates": len(g.update_at), "newton_iterations_median": float(np.median(g.iterations)),
+           "settings": {"ndt_resolution": res, "vg_size_for_input": prm.vg_size_for_input, "vg_size_for_map": prm.vg_size_for_map,
+                        "num_targeted_cloud": prm.num_targeted_cloud, "scan_min_range": prm.scan_min_range, "scan_max_range": prm.scan_max_range,
+                        "trans_for_mapupdate": prm.trans_for_mapupdate, "transformation_epsilon": 0.01, "max_iterations": 35},
            "scan_in_to_pose_out": lat_stats(g.scan_seconds),
-           "scan_in_to_pose_out_host_payload_pcie_inclusive": lat_stats(gh.scan_seconds),
            "map_update_ms": {"median": float(np.median(upd)) if upd.size else None, "p90": pct(upd, 90) if upd.size else None},
-           "map_update_ms_keyframes_through_host": {"median": float(np.median(upd_host)) if upd_host.size else None,
-                                                    "what": "lsr_voxel_grid_filter_pc2 host in / host out (range mask in numpy) + upload of the filtered keyframe, PCIe-inclusive"},
-           "device_and_host_keyframes_same_poses": bool(all(np.array_equal(a, b) for a, b in zip(g.poses, gk.poses))),
-           "ms_per_scan_with_map_update_amortised": 1e3 * (float(np.sum(g.scan_seconds)) + float(np.sum(g.update_seconds))) / n,
+           "ms_per_scan_with_map_update_amortised": 1e3 * g.wall_seconds / n,
            "max_error_vs_truth": {"translation_m": float(max(e[0] for e in errs)), "rotation_rad": float(max(e[1] for e in errs))},
-           "host_payload_same_poses": bool(all(np.array_equal(a, b) for a, b in zip(g.poses, gh.poses))),
            "what": "receiveCloud + updateMap replayed per scan through the C ABI (lsr_set_input_source_pc2, lsr_align, lsr_voxel_grid_filter_pc2, "
-                   "lsr_set_input_target_frames); reference settings: ndt_resolution 5.0, eps 0.01, vg 0.2 / 0.1, trans_for_mapupdate 1.5"}
+                   "lsr_set_input_target_frames); ms_per_scan_with_map_update_amortised = wall clock of the whole drive / scans"}
+    if not light:
+        gk = replay(reg, True, to_dev)            # keyframes through the host, as the reference stores its submaps (ROS messages)
+        gh = replay(reg, False, to_dev)           # raw payload from host memory: one ~4.7 MB PCIe copy per scan
+        upd_host = np.asarray(gk.update_seconds) * 1e3
+        out["scan_in_to_pose_out_host_payload_pcie_inclusive"] = lat_stats(gh.scan_seconds)
+        out["map_update_ms_keyframes_through_host"] = {"median": float(np.median(upd_host)) if upd_host.size else None,
+                                                       "what": "lsr_voxel_grid_filter_pc2 host in / host out (range mask in numpy) + upload of the filtered keyframe, PCIe-inclusive"}
+        out["device_and_host_keyframes_same_poses"] = bool(all(np.array_equal(a, b) for a, b in zip(g.poses, gk.poses)))
+        out["host_payload_same_poses"] = bool(all(np.array_equal(a, b) for a, b in zip(g.poses, gh.poses)))
+    # ---- the map side off the scan path: worker thread + mapper + builder on their own streams, hand-over by lsr_share_target
+    try:
+        # the callback's object stays on the stream the payloads live on (no cross-stream wait per scan); the map side gets its own
+        # and shares ONE (every further hardware queue in use lengthens the dependent launches of all the others: measured, DESIGN.md)
+        map_stream = torch.cuda.Stream(device=dev_index)
+        ms = map_stream.cuda_stream if os.environ.get("LSR_BENCH_ASYNC_MAP_STREAMS", "1") == "1" else True
+        a_reg, a_map, a_bld = make(os.environ.get("LSR_BENCH_ASYNC_REG_STREAM", "torch") == "own"), make(ms), make(ms)
+        asy = {}
+        for lag in (0, 1):
+            ser = replay(a_reg, True, to_dev, a_map, a_bld, False, lag)
+            replay(a_reg, True, to_dev, a_map, a_bld, True, lag)
+            thr = replay(a_reg, True, to_dev, a_map, a_bld, True, lag)
+            sc = np.asarray(thr.scan_seconds) * 1e3
+            if os.environ.get("LSR_BENCH_DUMP_SCANS"):
+                print(f"[scan dump lag {lag}] inline", np.round(np.asarray(g.scan_seconds) * 1e3, 3).tolist(), "\n serial", np.round(np.asarray(ser.scan_seconds) * 1e3, 3).tolist(),
+                      "\n threaded", np.round(sc, 3).tolist(), "\n update_at", thr.update_at, "swap_at", thr.swap_at, "iterations", thr.iterations, file=sys.stderr)
+            on_swap = [sc[j] for j in thr.swap_at if j < len(sc)]
+            off_swap = [sc[j] for j in range(len(sc)) if j not in set(thr.swap_at)]
+            trig = [sc[j] for j in thr.update_at]
+            asy[f"hand_over_lag_{lag}"] = {
+                "scan_in_to_pose_out": lat_stats(thr.scan_seconds),
+                "scan_ms_median_on_hand_over_scans": float(np.median(on_swap)) if on_swap else None,
+                "scan_ms_median_on_other_scans": float(np.median(off_swap)) if off_swap else None,
+                "scan_ms_median_on_scans_that_trigger_an_update": float(np.median(trig)) if trig else None,
+                "hand_over_wait_ms_median": 1e3 * float(np.median(thr.swap_wait_seconds)) if thr.swap_wait_seconds else None,
+                "map_update_on_the_worker_ms_median": 1e3 * float(np.median(thr.update_seconds)) if thr.update_seconds else None,
+                "ms_per_scan_with_map_update_amortised": 1e3 * thr.wall_seconds / n,
+                "serial_replay_same_lag_ms_per_scan_amortised": 1e3 * ser.wall_seconds / n,
+                "same_poses_as_the_serial_replay": bool(all(np.array_equal(x, y) for x, y in zip(thr.poses, ser.poses))),
+                "map_updates": len(thr.update_at)}
+            if lag == 0:
+                asy["hand_over_lag_0"]["same_poses_as_the_inline_replay"] = bool(all(np.array_equal(x, y) for x, y in zip(thr.poses, g.poses)))
+        asy["what"] = ("updateMap on a worker thread (mapper filters the keyframe, builder assembles the window and builds the voxel grid, each on its own "
+                       "stream); the callback's object only registers and takes the finished target over (lsr_share_target).  Back-to-back replay: a 10 Hz "
+                       "sensor leaves 100 ms between scans, here the next scan starts at once — lag 0 therefore waits for the worker, lag 1 overlaps it")
+        out["async_map_update"] = asy
+        a_reg.close(); a_map.close(); a_bld.close()
+    except Exception as e:
+        out["async_map_update"] = {"error": repr(e)}
     if not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from frontend_oracle import OracleFrontendRegistration   # test infrastructure: the checker, outside every timed region
 
+        n_cpu = n if not light else min(n, 9)   # the oracle takes 40-150 ms per scan: a bounded prefix of the drive for the second parameter set
+        hosts_cpu = hosts[:n_cpu]
+        fr = FrontendReplay(OracleFrontendRegistration(res, 0.01, 35), prm)
+        fr.initialise(drive["frames"], drive["frame_poses"], drive["guess0"])
+        c = FrontendResult()
         t0 = time.perf_counter()
-        c = replay(OracleFrontendRegistration(5.0, 0.01, 35), False, None)
+        for h in hosts_cpu:
+            fr.receive_cloud(h, int(h.shape[0]), c, payload_host=h)
         t_cpu = time.perf_counter() - t0
-        d = [pose_delta(a, b) for a, b in zip(g.poses, c.poses)]
-        out["parity_vs_cpu_over_the_stream"] = {"max_translation_m": float(max(x[0] for x in d)), "max_rotation_rad": float(max(x[1] for x in d)),
-                                                "same_keyframes": bool(g.update_at == c.update_at), "same_points_kept": bool(g.points_kept == c.points_kept),
-                                                "same_newton_iterations": bool(g.iterations == c.iterations), "cpu_port_ms_per_scan": 1e3 * t_cpu / n}
+        d = [pose_delta(a, b) for a, b in zip(g.poses[:n_cpu], c.poses)]
+        out["parity_vs_cpu_over_the_stream"] = {"scans_compared": n_cpu, "max_translation_m": float(max(x[0] for x in d)), "max_rotation_rad": float(max(x[1] for x in d)),
+                                                "same_keyframes": bool([u for u in g.update_at if u < n_cpu] == c.update_at), "same_points_kept": bool(g.points_kept[:n_cpu] == c.points_kept),
+                                                "same_newton_iterations": bool(g.iterations[:n_cpu] == c.iterations), "cpu_port_ms_per_scan": 1e3 * t_cpu / n_cpu}
     reg.close(); mapper.close()
+    return out
+
+
+def frontend_stream_ref_leg(drive20, dev_index, tstream, torch, args):
+    """The frontend loop at the parameter set the reference SHIPS (lidarslam/param/lidarslam.yaml:5-17): ndt_resolution 2.0,
+    vg_size_for_input 0.5, vg_size_for_map 0.1, scan range 1.0..200.0 m, num_targeted_cloud 20, trans_for_mapupdate 1.5 — a 20-frame
+    window (~1.3 M target points, dense global voxel table) instead of BASELINE's 10 frames at 5 m."""
+    from lidarslam_ros2_amd.frontend import FrontendParams
+
+    prm = FrontendParams(vg_size_for_input=0.5, vg_size_for_map=0.1, trans_for_mapupdate=1.5, scan_min_range=1.0, scan_max_range=200.0, num_targeted_cloud=20)
+    out = frontend_stream_leg(drive20, dev_index, tstream, torch, args, res=2.0, params=prm, light=True)
+    if isinstance(out, dict):
+        out["parameter_set"] = "lidarslam/param/lidarslam.yaml scan_matcher"
+    return out
+
+
+def loop_gate_ref_leg(route, dev_index, tstream, torch, synth, args):
+    """GraphBasedSlamComponent::searchLoop (graph_based_slam_component.cpp:164-252) at the two parameter sets the reference ships, on a
+    route of FULL-SIZE submaps (one VLP-32 revolution at vg_size_for_map 0.1 each, ~65k points; > 100 m of travel between the two visits
+    of the start): lidarslam/param/lidarslam.yaml:30-41 — NDT, ndt_resolution 1.0, voxel_leaf_size 0.1, threshold 0.7,
+    distance_loop_closure 100, range 20, search_submap_num 2 — and graph_based_slam/param/graphbasedslam.yaml:3-7 — GICP,
+    voxel_leaf_size 0.2, threshold 1.5, distance_loop_closure 30 (range 20 and search_submap_num 3: the node's defaults, :37-40).
+    parity_vs_cpu: the same gate on the CPU oracle (a bounded leg: one search each)."""
+    from lidarslam_ros2_amd import GeneralizedIterativeClosestPoint, LoopClosureParams, NormalDistributionsTransform, SubMap, search_loop
+    from lidarslam_ros2_amd.posemath import pose_delta
+
+    if route is None:
+        return {"skipped": "workload generated without the full-size route"}
+    sms = [SubMap(torch.from_numpy(synth.as_pointxyzi(s["cloud"])).cuda(), s["position"], s["orientation"], s["distance"]) for s in route]
+    torch.cuda.synchronize()
+    sets = {
+        "lidarslam_yaml_ndt": (dict(threshold_loop_closure_score=0.7, distance_loop_closure=100.0, range_of_searching_loop_closure=20.0, search_submap_num=2,
+                                    voxel_leaf_size=0.1), "ndt"),
+        "graphbasedslam_yaml_gicp": (dict(threshold_loop_closure_score=1.5, distance_loop_closure=30.0, range_of_searching_loop_closure=20.0, search_submap_num=3,
+                                          voxel_leaf_size=0.2), "gicp"),
+    }
+    out = {"submaps": len(route), "points_per_submap_median": int(np.median([s["cloud"].shape[0] for s in route])), "route_length_m": float(route[-1]["distance"])}
+    for name, (lp, method) in sets.items():
+        try:
+            if method == "ndt":   # graph_based_slam_component.cpp:64-72
+                back = NormalDistributionsTransform(device=dev_index, stream=tstream)
+                back.setMaximumIterations(100); back.setResolution(1.0); back.setTransformationEpsilon(0.01)
+            else:                 # :74-82
+                back = GeneralizedIterativeClosestPoint(device=dev_index, stream=tstream)
+                back.setMaxCorrespondenceDistance(30); back.setMaximumIterations(100); back.setTransformationEpsilon(1e-8)
+                back.setEuclideanFitnessEpsilon(1e-6); back.setRANSACIterations(0)
+            edges = search_loop(back, sms, LoopClosureParams(**lp))
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                edges = search_loop(back, sms, LoopClosureParams(**lp))
+                ts.append(time.perf_counter() - t0)
+            e = edges[0]
+            truth = np.linalg.inv(route[e.pair_id[0]]["truth"]) @ route[-1]["truth"]
+            et = pose_delta(e.relative_pose, truth)
+            r = {"settings": dict(lp, method=method, **({"ndt_resolution": 1.0} if method == "ndt" else {"max_correspondence_distance": 30.0})),
+                 "ms_per_search": 1e3 * float(np.median(ts[2:])), "edge": list(e.pair_id), "fitness_score": e.fitness_score, "accepted": e.accepted,
+                 "target_points": e.n_target_points, "source_points": int(route[-1]["cloud"].shape[0]), "iterations": e.iterations,
+                 "relative_pose_error_vs_truth": {"translation_m": et[0], "rotation_rad": et[1]}}
+            if not args.no_cpu:
+                from oracle import oracle as O   # the checker, outside every timed region
+
+                t0 = time.perf_counter()
+                if method == "ndt":
+                    ref = O.search_loop(route, **lp, ndt_resolution=1.0, trans_eps=0.01, max_iterations=100, num_threads=min(64, O.max_threads()))
+                else:
+                    ref = O.search_loop(route, **lp, method="gicp", gicp_corr_dist=30.0, gicp_trans_eps=1e-8, max_iterations=100, gicp_solver=0, num_threads=min(64, O.max_threads()))
+                t_cpu = time.perf_counter() - t0
+                o = ref[0]
+                d = pose_delta(e.final_transformation, o["final"])
+                r["parity_vs_cpu"] = {"same_edge": bool(tuple(e.pair_id) == tuple(o["pair_id"])), "same_target_points": bool(e.n_target_points == o["n_target_points"]),
+                                      "same_gate_decision": bool(e.accepted == o["accepted"]), "translation_m": d[0], "rotation_rad": d[1],
+                                      "fitness_rel_diff": abs(e.fitness_score - o["fitness_score"]) / max(abs(o["fitness_score"]), 1e-300),
+                                      "cpu_port_ms_per_search": 1e3 * t_cpu,
+                                      "note": "GICP: the oracle's inner solver is the reference's BFGS, the device runs Gauss-Newton (north_star)" if method == "gicp" else "same schedule"}
+            back.close()
+            out[name] = r
+        except Exception as ex:
+            out[name] = {"error": repr(ex)}
     return out
 
 

@@ -108,7 +108,10 @@ int ndt_resident_wgs(int device, int threads) {
   // two 512-thread workgroups per CU (128 VGPRs per lane: four waves per SIMD; the lane kernel's LDS table + staging tiles fit twice),
   // one of 1024 threads.  (Until round 5 this returned 2048 / threads = 4 for 512: more workgroups than are ever co-resident, each of
   // them paying the head.  Measured on the 64-candidate chain: 1.46 ms with 4, 1.46 ms with 2, 2.04 ms with 1.)
-  return device_cus(device) * (wgs_per_cu ? wgs_per_cu : (threads >= 1024 ? 1 : 2));
+  // Below 512 threads (the quad kernel with 64 points per workgroup: 256 threads, LSR_NDT_WORKGROUP=64) occupancy decides again:
+  // 2048 / threads workgroups fill the same four waves per SIMD (the measurement above covers 512 and 1024 only).
+  const int by_size = threads >= 1024 ? 1 : threads >= 512 ? 2 : 2048 / std::max(64, threads);
+  return device_cus(device) * (wgs_per_cu ? wgs_per_cu : by_size);
 }
 int ndt_nblocks(size_t n, int device, int batch, int threads, int points) {
   int nb = (int)((n + points - 1) / points);
@@ -1364,7 +1367,17 @@ int lsr_share_target(lsr_handle h, lsr_handle owner) {
   LSR_CHECK_HANDLE(h);
   if (!owner || !owner->target) { set_last_error("owner has no target"); return LSR_ERR_NO_TARGET; }
   if (owner->device != h->device) { set_last_error("handles live on different devices"); return LSR_ERR_INVALID_ARGUMENT; }
+  // The frontend's hand-over (scanmatcher_component.cpp:298-320: the target the map thread assembled is taken over at the start of a
+  // callback): the target h held until now goes back to the owner as its SPARE when nobody else holds it, so that the owner's next
+  // setInputTarget recycles its buffers (fresh_target) instead of allocating while h still reads the new one — two TargetData
+  // objects then alternate for the life of the node, no hipMalloc / hipFree per map update.  The caller must not be inside another
+  // call on `owner` at this moment (the hand-over happens after the map thread's job has finished).
+  std::shared_ptr<TargetData> old = h->target;
   h->target = owner->target;
+  if (old && old != owner->target) {
+    if (h->spare_target == old) h->spare_target.reset();
+    if (old.use_count() == 1 && (!owner->spare_target || owner->spare_target == owner->target)) owner->spare_target = old;
+  }
   return LSR_OK;
 }
 

@@ -230,7 +230,11 @@ class Registration:
         import torch
 
         lay = self._layout(32, (0, 4, 8, 16))
-        out = torch.empty((max(self._n_source, 1), 8), dtype=torch.float32, device="cuda")
+        # on the OBJECT's device (not torch's current one), and the object's stream ordered behind whatever torch's stream may
+        # still be doing with the block the caching allocator hands out
+        dev = torch.device("cuda", self._device)
+        out = torch.empty((max(self._n_source, 1), 8), dtype=torch.float32, device=dev)
+        capi.check(self._lib.lsr_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "lsr_wait_stream")
         n_out = C.c_size_t()
         capi.check(self._lib.lsr_get_source_pc2_device(self._h, C.c_void_p(out.data_ptr()), out.shape[0], C.byref(lay), C.byref(n_out)),
                    "getInputSourceDeviceRecords")

@@ -345,18 +345,22 @@ def cfg_scan_stream(n_scans: int, seed: int = 0, pool=None, world: World | None 
     return out
 
 
-def cfg_frontend_drive(n_scans: int, seed: int = 0, pool=None, world: World | None = None) -> dict:
+def cfg_frontend_drive(n_scans: int, seed: int = 0, pool=None, world: World | None = None, n_keyframes: int = 10) -> dict:
     """The frontend's input over a drive (scanmatcher_component.cpp:296-356,436-481): the cfg-1/2 map of ten keyframes (each
     VoxelGrid(0.1)-filtered in its OWN sensor frame, with its pose) followed by n_scans RAW scans — as the sensor delivers them: no
     range filter, no VoxelGrid, ~147k points — taken every 0.5 m further along the trajectory, so that a frontend with
     trans_for_mapupdate = 1.5 m updates its map on every third scan.  Returns {frames, frame_poses, scans [(n,3) f32 sensor frame],
     truths [4x4 f64], guess0 (pose of the last keyframe)}."""
-    base = cfg_ndt_30k(seed=seed, pool=pool, keep_parts=True, world=world)
+    if n_keyframes == 10:
+        base = cfg_ndt_30k(seed=seed, pool=pool, keep_parts=True, world=world)
+    else:   # e.g. the 20-frame window of the reference's lidarslam.yaml (num_targeted_cloud: 20)
+        base = make_case(sensor=vlp32(), n_keyframes=n_keyframes, vg_map=0.1, vg_input=0.2, n_source=30000, seed=seed, world=world,
+                         azimuth_oversample=3, name=f"ndt_30k_vs_{n_keyframes}frame", pool=pool, keep_parts=True)
     sensor = vlp32()
     sensor = Sensor(sensor.n_beams, sensor.elev_min_deg, sensor.elev_max_deg, sensor.n_azimuth * 3, sensor.range_noise,
                     sensor.max_range, sensor.min_range)
     world = world or make_world()
-    x_last = 1.5 * 9
+    x_last = 1.5 * (n_keyframes - 1)
     xs = [x_last + 0.5 * (1 + j) for j in range(n_scans)]
     poses = [trajectory_pose(x) for x in xs]
     sargs = (sensor.n_beams, sensor.elev_min_deg, sensor.elev_max_deg, sensor.n_azimuth, sensor.range_noise, sensor.max_range,
@@ -411,12 +415,13 @@ def as_pointxyzi(pts: np.ndarray) -> np.ndarray:
 # ---- loop-closure route ------------------------------------------------------
 def make_loop_route(spacing: float = 3.0, length: float = 24.0, lane: float = 1.25, sensor: Sensor | None = None,
                     vg_map: float = 0.2, drift: tuple = (0.35, -0.25, 0.04, 0.01), seed: int = 0,
-                    world: World | None = None) -> list:
+                    world: World | None = None, pool=None) -> list:
     """A route that returns to its start, as a lidarslam_msgs/MapArray stand-in: out along the corridor on the lane
     y = -lane, a turn, back on y = +lane, and a final submap next to the first one.  Each submap is one scan
     (VoxelGrid(vg_map), pose-local coordinates) with its ESTIMATED pose; the estimate drifts linearly with travelled
     distance up to `drift` = (dx, dy, dz, dyaw) at the end, which is what a loop edge has to correct.
-    Returns a list of dicts: cloud (n,3) f32, position (3), orientation (x,y,z,w), distance, truth (4x4 f64)."""
+    Returns a list of dicts: cloud (n,3) f32, position (3), orientation (x,y,z,w), distance, truth (4x4 f64).
+    `pool` only parallelises the ray intersections (same clouds)."""
     sensor = sensor or Sensor(32, -25.0, 15.0, 900)
     world = world or make_world()
     rng = np.random.default_rng(WORLD_SEED + 104729 * seed + 5)
@@ -432,13 +437,23 @@ def make_loop_route(spacing: float = 3.0, length: float = 24.0, lane: float = 1.
             dist += math.hypot(x - way[k - 1][0], y - way[k - 1][1])
         out.append(dict(xyyaw=(x, y, yaw), distance=dist))
     total = max(dist, 1e-9)
-    for sm in out:
+    scans = raycast_many(world, sensor, [pose_matrix(sm["xyyaw"][0], sm["xyyaw"][1], 0.0, sm["xyyaw"][2]) for sm in out], rng, pool)
+    for sm, scan in zip(out, scans):
         x, y, yaw = sm.pop("xyyaw")
         T = pose_matrix(x, y, 0.0, yaw)
         f = sm["distance"] / total
         est_yaw = yaw + drift[3] * f
         sm["truth"] = T
-        sm["cloud"] = voxel_downsample(raycast(world, sensor, T, rng), vg_map)
+        sm["cloud"] = voxel_downsample(scan, vg_map)
         sm["position"] = (x + drift[0] * f, y + drift[1] * f, drift[2] * f)
         sm["orientation"] = (0.0, 0.0, math.sin(0.5 * est_yaw), math.cos(0.5 * est_yaw))
     return out
+
+
+def cfg_loop_route_full(pool=None, length: float = 54.0) -> list:
+    """The backend's input at the size the frontend produces it: every submap is a full VLP-32 revolution filtered at
+    vg_size_for_map = 0.1 (~110k points, pose-local), one every 3 m along a there-and-back route long enough for the reference's own
+    gate (lidarslam.yaml: distance_loop_closure 100 m -> > 100 m of travel between the two visits of the start)."""
+    s = vlp32()
+    sensor = Sensor(s.n_beams, s.elev_min_deg, s.elev_max_deg, s.n_azimuth * 3, s.range_noise, s.max_range, s.min_range)
+    return make_loop_route(spacing=3.0, length=length, sensor=sensor, vg_map=0.1, pool=pool)

@@ -341,7 +341,7 @@ def transform_point_cloud(pts: np.ndarray, M) -> np.ndarray:
 def search_loop(submaps, *, threshold_loop_closure_score=1.0, distance_loop_closure=20.0,
                 range_of_searching_loop_closure=20.0, search_submap_num=3, voxel_leaf_size=0.2, top_k=1,
                 method="ndt", ndt_resolution=1.0, trans_eps=0.01, max_iterations=100, step_size=0.1, num_threads=0,
-                gicp_corr_dist=5.0, gicp_trans_eps=1e-8):
+                gicp_corr_dist=5.0, gicp_trans_eps=1e-8, gicp_solver=1):
     """CPU restatement of searchLoop() from `latest_submap` on (graph_based_slam_component.cpp:164-252).
     submaps: sequence of dicts {cloud (n,>=3) f32, position (3), orientation (4, xyzw), distance}.
     Returns one dict per evaluated candidate (nearest first): pair_id, fitness_score, accepted, relative_pose, final."""
@@ -377,7 +377,7 @@ def search_loop(submaps, *, threshold_loop_closure_score=1.0, distance_loop_clos
             nn_s = NearestNeighbour(source)
             r = gicp_align(nn_t, target, gicp_covariances(nn_t, target, num_threads=num_threads), source,
                            gicp_covariances(nn_s, source, num_threads=num_threads), None, max_corr_dist=gicp_corr_dist,
-                           trans_eps=gicp_trans_eps, max_iterations=max_iterations, solver=1, num_threads=num_threads)
+                           trans_eps=gicp_trans_eps, max_iterations=max_iterations, solver=gicp_solver, num_threads=num_threads)   # 1 = Gauss-Newton (the device's), 0 = the reference's BFGS
         fitness = NearestNeighbour(target).fitness_score(source, r["final"], num_threads=num_threads)   # :231
         frm = pose_msg_to_matrix(submaps[id_min]["position"], submaps[id_min]["orientation"])
         to = r["final"].astype(np.float64) @ init                                           # :241-243

@@ -119,3 +119,75 @@ def test_keyframes_go_through_to_device_and_the_mapper_needs_a_device_payload():
     fr.receive_cloud(as_pc2_payload(np.full((6, 3), 5.0, np.float32)), 6, out)         # host payload: the host path, through to_device
     assert out.update_at == [0] and seen[-1] == (6, 8)
     assert reg.targets[-1][0][0][0] == "resident"
+
+
+class ScriptedShared(ScriptedRegistration):
+    """The callback's object of an asynchronous replay: it never builds a target, it takes the builder's over."""
+
+    def __init__(self, poses, log):
+        super().__init__(poses)
+        self.log = log
+
+    def shareTargetOf(self, owner):
+        self.calls.append(("share",))
+        self.log.append(("share", len(owner.targets)))        # which of the builder's targets is in place from here on
+
+    def align(self, guess):
+        super().align(guess)
+        self.log.append(("align", self.k - 1))
+
+
+def _drive(fr, n=9):
+    out = FrontendResult()
+    rng = np.random.default_rng(1)
+    for j in range(n):
+        fr.receive_cloud(as_pc2_payload(rng.uniform(-30, 30, (20, 3)).astype(np.float32)), 20, out)
+    fr.finish(out)
+    return out
+
+
+def test_asynchronous_map_update_runs_on_the_builder_and_is_handed_over_at_the_due_callback():
+    """updateMap on a worker thread (scanmatcher_component.cpp:427-434), the new target taken over at the start of a later callback
+    (:298-320): the callback's object never filters a keyframe or builds a target; with swap_lag = L the target triggered by scan k
+    is in place for scan k + 1 + L — in the asynchronous replay and in the serial one alike; no update is triggered while one is
+    pending (`!mapping_flag_`)."""
+    prm = FrontendParams()
+    frames = [np.full((5, 3), float(k), np.float32) for k in range(12)]
+    frame_poses = [_pose(1.5 * k) for k in range(12)]
+    x0 = 1.5 * 11
+    truth = [_pose(x0 + 0.8 * (j + 1)) for j in range(9)]     # 0.8 m per scan: an update is due after every second scan
+    for lag in (0, 1, 2):
+        logs = []
+        for asynchronous in (True, False):
+            log = []
+            reg = ScriptedShared(truth, log)
+            builder = ScriptedRegistration([])
+            fr = FrontendReplay(reg, prm, builder=builder, async_update=asynchronous, swap_lag=lag)
+            fr.initialise(frames, frame_poses, _pose(x0))
+            out = _drive(fr)
+            assert not any(c[0] in ("target", "map_filter") for c in reg.calls)                 # the callback's object builds nothing
+            assert [c[0] for c in builder.calls].count("target") == 1 + len(out.update_at)       # initial target + one per update
+            assert len(out.update_seconds) == len(out.update_at) == len(out.swap_wait_seconds)
+            logs.append((log, out.update_at, [P.copy() for _, P in fr.submaps]))
+            # the hand-over of update u (triggered after scan k = update_at[u]) comes right before align number k + 1 + lag
+            aligns_before_share = []
+            n_align = 0
+            for e in log[1:]:                   # log[0] is the initial hand-over
+                if e[0] == "align":
+                    n_align += 1
+                else:
+                    aligns_before_share.append(n_align)
+            due = [k + 1 + lag for k in out.update_at]
+            assert aligns_before_share == [min(d, 9) for d in due], (lag, asynchronous, aligns_before_share, due)
+        assert logs[0][0] == logs[1][0] and logs[0][1] == logs[1][1]                              # same schedule, threaded or not
+        assert all(np.array_equal(a, b) for a, b in zip(logs[0][2], logs[1][2]))                  # ... and the same map window at the end
+    # lag 2 with an update due every second scan: the pending flag suppresses triggers (fewer updates than with lag 0)
+    reg = ScriptedShared(truth, [])
+    fr = FrontendReplay(reg, prm, builder=ScriptedRegistration([]), async_update=True, swap_lag=0)
+    fr.initialise(frames, frame_poses, _pose(x0))
+    n0 = len(_drive(fr).update_at)
+    reg = ScriptedShared(truth, [])
+    fr = FrontendReplay(reg, prm, builder=ScriptedRegistration([]), async_update=True, swap_lag=3)
+    fr.initialise(frames, frame_poses, _pose(x0))
+    n3 = len(_drive(fr).update_at)
+    assert n3 < n0
