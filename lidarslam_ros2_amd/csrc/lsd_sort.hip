@@ -54,26 +54,28 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned int*
   }
 }
 
-// per digit: exclusive scan of the workgroup histograms + digit total (the dense builder's vg_scan, restated for this file's tables)
-constexpr int RS_SCAN_SEGS = 8;
-__global__ __launch_bounds__(256) void rs_scan_kernel(const unsigned short* __restrict__ hist, int nblk, int C,
-                                                      unsigned int* __restrict__ blkoff, unsigned int* __restrict__ total) {
-  __shared__ unsigned int s_seg[RS_SCAN_SEGS][32];
-  const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + cl;
-  const int per = (nblk + RS_SCAN_SEGS - 1) / RS_SCAN_SEGS;
-  const int b0 = seg * per, b1 = min(nblk, b0 + per);
-  unsigned int sum = 0u;
-  if (k < C)
-    for (int b = b0; b < b1; b++) sum += hist[(size_t)b * C + k];
-  s_seg[seg][cl] = sum;
-  __syncthreads();
+// per digit: exclusive scan of the workgroup histograms + digit total, from DIGIT-MAJOR rows (hist[d * row_pitch + b], what rs_hist_kernel<S, true> writes), one WAVE per digit: 64 workgroup
+// counts per step through a wave scan — C waves instead of C / 32 workgroups walking nblk rows one after the other (a 2.5 M-key sort:
+// 611 rows; the row walk took 32 us per pass, more than the scatter).  blkoff stays workgroup-major for the scatter's coalesced read.
+__global__ __launch_bounds__(256) void rs_scan_wave_kernel(const unsigned short* __restrict__ hist, int row_pitch, int nblk, int C,
+                                                           unsigned int* __restrict__ blkoff, unsigned int* __restrict__ total) {
+  const int d = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (d >= C) return;
+  const unsigned short* row = hist + (size_t)d * row_pitch;
   unsigned int run = 0u;
-  for (int s2 = 0; s2 < seg; s2++) run += s_seg[s2][cl];
-  if (k < C) {
-    for (int b = b0; b < b1; b++) { const unsigned int c = hist[(size_t)b * C + k]; blkoff[(size_t)b * C + k] = run; run += c; }
-    if (seg == RS_SCAN_SEGS - 1) total[k] = run;
+  for (int b0 = 0; b0 < nblk; b0 += 64) {
+    const int b = b0 + lane;
+    const unsigned int v = (b < nblk) ? row[b] : 0u;
+    unsigned int inc = v;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+      const unsigned int x = __shfl_up(inc, k, 64);
+      if (lane >= k) inc += x;
+    }
+    if (b < nblk) blkoff[(size_t)b * C + d] = run + inc - v;
+    run += __shfl(inc, 63, 64);
   }
+  if (lane == 0) total[d] = run;
 }
 
 // Stable scatter of one pass.  Wave w of workgroup b owns the points [b * chunk + w * chunk / 4, + chunk / 4) and walks them in
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void rs_heads_count_kernel(const unsigned int*
 // dims (nullable): {sentinel, finite points, VG_FLAG_*, key bits} left by leaf_key_dims_kernel — handed to the host with the count
 __global__ __launch_bounds__(1024) void rs_heads_scan_kernel(const int* __restrict__ block_heads, int nblocks, int* __restrict__ block_base,
                                                              BuildMailbox* __restrict__ mb, unsigned int token,
-                                                             const unsigned int* __restrict__ dims) {
+                                                             const unsigned int* __restrict__ dims, int* __restrict__ total_dev /*nullable*/) {
   __shared__ int s_w[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (nblocks + 1023) / 1024;
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(1024) void rs_heads_scan_kernel(const int* __restri
   int run = wbase + inc - cnt;
   for (int b = b0; b < b1; b++) { const int t = block_heads[b]; block_base[b] = run; run += t; }
   if (tid == 1023) {
+    if (total_dev) *total_dev = run;   // for kernels enqueued behind this one that must not wait for the host to learn the count
     mb->value = run;   // == total: thread 1023 owns the last (possibly empty) slice
     if (dims) { mb->vg_finite = dims[1]; mb->vg_flags = dims[2]; mb->vg_bits = dims[3]; }
     __threadfence_system();
@@ -303,6 +306,104 @@ __global__ __launch_bounds__(256) void rs_centroid_kernel(const unsigned int* __
   const float m = (float)(j - i);
   ox[r] = sx / m; oy[r] = sy / m; oz[r] = sz / m;
   if (ow) ow[r] = w ? sw / m : 0.f;
+}
+
+// The runs as a table (what rocPRIM's run_length_encode + exclusive_scan gave the sort-based builders): run r in key order has
+// key run_key[r] and covers the sorted positions [run_off[r], run_off[r + 1]); run_off[number of runs] = n closes the table.
+__global__ __launch_bounds__(256) void rs_runs_table_kernel(const unsigned int* __restrict__ keys, int n, const int* __restrict__ block_base,
+                                                            unsigned int* __restrict__ run_key, int* __restrict__ run_off) {
+  __shared__ int s_w[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * RUN_CHUNK + threadIdx.x;
+  const bool head = (i < n) && is_head(keys, i);
+  const unsigned long long heads = __ballot(head);
+  if (lane == 0) s_w[wave] = __popcll(heads);
+  __syncthreads();
+  if (i >= n) return;
+  int r = block_base[blockIdx.x] + __popcll(heads & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));   // heads before this position
+  for (int k = 0; k < wave; k++) r += s_w[k];
+  if (head) { run_key[r] = keys[i]; run_off[r] = i; }
+  if (i == n - 1) run_off[r + (head ? 1 : 0)] = n;   // r counts the heads BEFORE i: the table has r (+ 1 if i is a head itself) runs
+}
+
+// ---- exclusive scan of an int array of any length: three launches (sums of 4096-element blocks; one workgroup scans the sums;
+// every block scans its elements behind its base) — the device-wide scan of the bucket-built neighbour grid (nn.hip)
+constexpr int XS_THREADS = 256, XS_ITEMS = 16, XS_CHUNK = XS_THREADS * XS_ITEMS;
+__global__ __launch_bounds__(XS_THREADS) void xs_reduce_kernel(const int* __restrict__ in, size_t n, int* __restrict__ block_sum) {
+  __shared__ int s_w[XS_THREADS / 64];
+  const size_t base = (size_t)blockIdx.x * XS_CHUNK;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < XS_ITEMS; j++) {   // coalesced: consecutive threads read consecutive words
+    const size_t i = base + (size_t)j * XS_THREADS + threadIdx.x;
+    s += (i < n) ? in[i] : 0;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(1024) void xs_scan_sums_kernel(int* __restrict__ block_sum, int nblocks) {   // in place: sums -> exclusive bases
+  __shared__ int s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (nblocks + 1023) / 1024;
+  const int b0 = tid * per, b1 = min(nblocks, b0 + per);
+  int cnt = 0;
+  for (int b = b0; b < b1; b++) cnt += block_sum[b];
+  int inc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += v;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int run = inc - cnt;
+  for (int w = 0; w < wave; w++) run += s_w[w];
+  for (int b = b0; b < b1; b++) { const int t = block_sum[b]; block_sum[b] = run; run += t; }
+}
+__global__ __launch_bounds__(XS_THREADS) void xs_apply_kernel(const int* __restrict__ in, size_t n, const int* __restrict__ block_base,
+                                                              int* __restrict__ out) {
+  __shared__ int s_w[XS_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // thread t owns the XS_ITEMS CONSECUTIVE elements [base + t * XS_ITEMS, ...): a thread-local running sum, one wave scan of the
+  // thread totals, one exchange between the four waves (the loads are 64-byte runs per thread: four 16-byte loads)
+  const size_t first = (size_t)blockIdx.x * XS_CHUNK + (size_t)tid * XS_ITEMS;
+  int v[XS_ITEMS];
+  if (first + XS_ITEMS <= n && ((reinterpret_cast<size_t>(in) & 15) == 0)) {
+    const int4* q = reinterpret_cast<const int4*>(in + first);
+#pragma unroll
+    for (int j = 0; j < XS_ITEMS / 4; j++) { const int4 t = q[j]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < XS_ITEMS; j++) v[j] = (first + j < n) ? in[first + j] : 0;
+  }
+  int tot = 0;
+#pragma unroll
+  for (int j = 0; j < XS_ITEMS; j++) tot += v[j];
+  int inc = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int x = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += x;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int run = block_base[blockIdx.x] + inc - tot;
+  for (int w = 0; w < wave; w++) run += s_w[w];
+  if (first + XS_ITEMS <= n && ((reinterpret_cast<size_t>(out) & 15) == 0)) {
+    int4* q = reinterpret_cast<int4*>(out + first);
+#pragma unroll
+    for (int j = 0; j < XS_ITEMS / 4; j++) {
+      int4 t;
+      t.x = run; run += v[4 * j]; t.y = run; run += v[4 * j + 1]; t.z = run; run += v[4 * j + 2]; t.w = run; run += v[4 * j + 3];
+      q[j] = t;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < XS_ITEMS; j++) { if (first + j < n) out[first + j] = run; run += v[j]; }
+  }
 }
 
 struct LsdPlan { int passes, bits, steps, nblk, C; size_t table_bytes; };
@@ -372,10 +473,10 @@ int sort_pairs_u32_lsd(unsigned int* key_a, unsigned int* key_b, int* val_a /*nu
 #define LSR_RS_HIST(S, T) \
   hipLaunchKernelGGL((rs_hist_kernel<S, T>), dim3(P.nblk), dim3(RS_THREADS), (size_t)P.C * 4, stream, kin, (int)n, shift, mask, P.C, hist, row_pitch)
     if (p == 0 && first_hist_done && fused && P.steps == 8) { /* the producer of the keys has counted the first digit (lsd_first_hist_plan) */ }
-    else if (P.steps == 8) { if (fused) LSR_RS_HIST(8, true); else LSR_RS_HIST(8, false); }
-    else { if (fused) LSR_RS_HIST(16, true); else LSR_RS_HIST(16, false); }
+    else if (P.steps == 8) LSR_RS_HIST(8, true);    // digit-major rows in both forms
+    else LSR_RS_HIST(16, true);
 #undef LSR_RS_HIST
-    if (!fused) hipLaunchKernelGGL(rs_scan_kernel, dim3((P.C + 31) / 32), dim3(256), 0, stream, hist, P.nblk, P.C, blkoff, total);
+    if (!fused) hipLaunchKernelGGL(rs_scan_wave_kernel, dim3((P.C * 64 + 255) / 256), dim3(256), 0, stream, hist, row_pitch, P.nblk, P.C, blkoff, total);
 #define LSR_RS_SCATTER(S, F)                                                                                                             \
   hipLaunchKernelGGL((rs_scatter_kernel<S, F>), dim3(P.nblk), dim3(RS_THREADS), (size_t)P.C * 8, stream, kin, vin, (int)n, shift, mask, P.bits, \
                      blkoff, total, hist, row_pitch, P.nblk, P.C, kout, vout)
@@ -394,7 +495,7 @@ int sort_pairs_u32_lsd(unsigned int* key_a, unsigned int* key_b, int* val_a /*nu
 }
 
 int sorted_runs_begin(const unsigned int* keys_sorted, size_t n, int* block_heads, int* block_base, BuildScratch& sc, hipStream_t stream,
-                      unsigned int* token_out, const unsigned int* dims_dev) {
+                      unsigned int* token_out, const unsigned int* dims_dev, int* total_dev) {
   int st = sc.ensure_mailbox();
   if (st) return st;
   unsigned int token = ++sc.token;
@@ -403,7 +504,7 @@ int sorted_runs_begin(const unsigned int* keys_sorted, size_t n, int* block_head
   hipLaunchKernelGGL(rs_heads_count_kernel, dim3(nblocks), dim3(256), 0, stream, keys_sorted, (int)n, block_heads);
   // (one launch for the two — the workgroup that draws the last ticket scans the counts — was measured: 15.3 us against 4.6 + 4.6;
   // 576 atomics on one address and a device-scope fence per workgroup cost more than the launch they save)
-  hipLaunchKernelGGL(rs_heads_scan_kernel, dim3(1), dim3(1024), 0, stream, block_heads, nblocks, block_base, sc.d_mb, token, dims_dev);
+  hipLaunchKernelGGL(rs_heads_scan_kernel, dim3(1), dim3(1024), 0, stream, block_heads, nblocks, block_base, sc.d_mb, token, dims_dev, total_dev);
   LSR_HIP(hipGetLastError());
   *token_out = token;
   return LSR_OK;
@@ -427,5 +528,27 @@ int sorted_runs_centroids(const unsigned int* keys_sorted, const int* order, siz
 }
 
 size_t sorted_runs_blocks(size_t n) { return (n + RUN_CHUNK - 1) / RUN_CHUNK; }
+
+int sorted_runs_table(const unsigned int* keys_sorted, size_t n, const int* block_base, unsigned int* run_key, int* run_off, hipStream_t stream) {
+  if (n == 0) return LSR_OK;
+  const int nblocks = (int)((n + RUN_CHUNK - 1) / RUN_CHUNK);
+  hipLaunchKernelGGL(rs_runs_table_kernel, dim3(nblocks), dim3(256), 0, stream, keys_sorted, (int)n, block_base, run_key, run_off);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
+
+int exclusive_scan_i32_lsd(const int* in, int* out, size_t n, DevBuf<char>& temp, hipStream_t stream) {
+  if (n == 0) return LSR_OK;
+  const size_t nblocks = (n + XS_CHUNK - 1) / XS_CHUNK;
+  if (nblocks > (size_t)INT32_MAX / 2) { set_last_error("exclusive scan: too many elements"); return LSR_ERR_INVALID_ARGUMENT; }
+  int st = temp.reserve(nblocks * sizeof(int) + 64);
+  if (st) return st;
+  int* sums = reinterpret_cast<int*>(temp.p);
+  hipLaunchKernelGGL(xs_reduce_kernel, dim3((unsigned)nblocks), dim3(XS_THREADS), 0, stream, in, n, sums);
+  hipLaunchKernelGGL(xs_scan_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, (int)nblocks);
+  hipLaunchKernelGGL(xs_apply_kernel, dim3((unsigned)nblocks), dim3(XS_THREADS), 0, stream, in, n, sums, out);
+  LSR_HIP(hipGetLastError());
+  return LSR_OK;
+}
 
 }  // namespace lsr

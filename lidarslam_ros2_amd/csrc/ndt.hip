@@ -1900,7 +1900,7 @@ __global__ __launch_bounds__(256) void leaf_key_kernel(const float* __restrict__
     k = (unsigned int)(i0 + i1 * mul1 + i2 * mul2);
   }
   key[i] = k;
-  val[i] = i;
+  if (val) val[i] = i;   // (the hand-written sort numbers the values itself)
 }
 
 // The same keys with the grid dimensions worked out ON THE DEVICE from the bounding-box records the ingest pass left in device memory
@@ -2013,11 +2013,12 @@ __global__ __launch_bounds__(256) void leaf_key_dims_hist_kernel(const float* __
 __global__ __launch_bounds__(256) void leaf_sum_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ z, const int* __restrict__ order,
                                                        const int* __restrict__ run_off, const int* __restrict__ run_cnt,
-                                                       int n_runs, double* __restrict__ sums) {
+                                                       int n_runs, double* __restrict__ sums, const int* __restrict__ n_runs_dev /*nullable*/) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
+  if (n_runs_dev) n_runs = *n_runs_dev;   // launched over an upper bound: the host has not waited for the count
   if (wave >= n_runs) return;
-  const int off = run_off[wave], cnt = run_cnt[wave];
+  const int off = run_off[wave], cnt = run_cnt ? run_cnt[wave] : run_off[wave + 1] - off;   // (a table from sorted_runs_table closes with run_off[n_runs] = n)
   double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 4
   for (int j = lane; j < cnt; j += 64) {  // unrolled: several gathers in flight, additions stay in index order
@@ -2037,14 +2038,16 @@ __global__ __launch_bounds__(256) void leaf_sum_kernel(const float* __restrict__
 
 // K2: one thread per leaf: mean, single-pass covariance, (n-1)/n, eigenvalue clamp, inverse (leaf_finalize_dev).
 __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __restrict__ sums, const unsigned int* __restrict__ run_key,
-                                                            const int* __restrict__ run_cnt, int n_runs, int min_points,
+                                                            const int* __restrict__ run_cnt /*nullable: counts from run_off*/,
+                                                            const int* __restrict__ run_off, int n_runs, int min_points,
                                                             double eig_mult, float4* __restrict__ rec,
                                                             double* __restrict__ mean64, double* __restrict__ icov64,
                                                             int* __restrict__ leaf_key, int* __restrict__ leaf_n,
                                                             int* __restrict__ cell_slot, int* __restrict__ n_valid, int dense,
-                                                            unsigned int sentinel) {
+                                                            unsigned int sentinel, const int* __restrict__ n_runs_dev /*nullable*/) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   bool valid = false;
+  if (n_runs_dev) n_runs = *n_runs_dev;
   if (r < n_runs) {
     const unsigned int key = run_key[r];
     if (key == sentinel) {  // the run of non-finite points: not a leaf
@@ -2052,7 +2055,7 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __rest
       leaf_n[r] = 0;
     } else {
       double mean[3], icov[9];
-      const int n = leaf_finalize_dev(sums + (size_t)r * 9, run_cnt[r], min_points, eig_mult, mean, icov, &valid);
+      const int n = leaf_finalize_dev(sums + (size_t)r * 9, run_cnt ? run_cnt[r] : run_off[r + 1] - run_off[r], min_points, eig_mult, mean, icov, &valid);
       leaf_key[r] = (int)key;
       leaf_n[r] = n;
       for (int k = 0; k < 3; k++) mean64[(size_t)r * 3 + k] = mean[k];
@@ -2697,8 +2700,13 @@ static unsigned int next_token(BuildScratch& sc) {
   return token;
 }
 
-// general key space: stable radix sort (rocPRIM) + run-length encoding; returns with the grid complete
+// general key space (more than VG_DENSE_MAX_CELLS cells: cfg 5's 2 m grid over a 20-frame submap, the reference's own 1.0-2.0 m
+// resolutions): leaf keys -> hand-written stable LSD radix sort (lsd_sort.hip; the points of a leaf stay in ascending index, so the
+// fp64 sums of a leaf are a fixed function of the cloud) -> run heads (count per 256 keys, one-workgroup scan, run table) -> leaf sums
+// -> finalise.  Returns with the grid complete.  LSR_TARGET_SORT=rocprim keeps rounds 1-5's rocPRIM radix sort + run_length_encode +
+// exclusive_scan as the A/B cross-check (same leaves, same sums, bit for bit: tests/test_ndt_gpu.py).
 static int ndt_build_grid_general(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  static const bool use_rocprim = [] { const char* e = std::getenv("LSR_TARGET_SORT"); return e && std::strcmp(e, "rocprim") == 0; }();
   DevBuf<char>& temp = sc.temp;
   DevBuf<unsigned int>& scratch = sc.words;
   DevBuf<double>& sums = sc.sums;
@@ -2712,32 +2720,56 @@ static int ndt_build_grid_general(const DeviceCloud& cloud, float leaf, VoxelGri
   grid.dense = grid.ncells <= ((size_t)4 << 20);
   if (grid.dense && (st = grid.rec.reserve(grid.ncells * 4))) return st;
   const unsigned int sentinel = (unsigned int)grid.ncells;  // non-finite points: one past the last leaf index
-  // scratch carved from one allocation: pad[16] | key_in[n] | key_out[n] | val_in[n] | val_out[n] | run_key[n] | run_cnt[n] | run_off[n] | nruns | nvalid
-  size_t words = 16 + 7 * (size_t)n + 16;
+  // scratch carved from one allocation: pad[16] | key_in[n] | key_out[n] | val_in[n] | val_out[n] | run_key[n+1] | run_cnt[n+1] | run_off[n+1] |
+  // nruns | nvalid | block_heads[nb] | block_base[nb]
+  const size_t nb = sorted_runs_blocks((size_t)n);
+  size_t words = 16 + 7 * (size_t)n + 3 + 16 + 2 * nb;
   if ((st = scratch.reserve(words))) return st;
   unsigned int* key_in = scratch.p + 16;
   unsigned int* key_out = key_in + n;
   int* val_in = (int*)(key_out + n);
   int* val_out = val_in + n;
   unsigned int* run_key = (unsigned int*)(val_out + n);
-  int* run_cnt = (int*)(run_key + n);
-  int* run_off = run_cnt + n;
-  int* d_nruns = run_off + n;
+  int* run_cnt = (int*)(run_key + n + 1);
+  int* run_off = run_cnt + n + 1;
+  int* d_nruns = run_off + n + 1;
   int* d_nvalid = d_nruns + 1;
+  int* block_heads = d_nvalid + 15;
+  int* block_base = block_heads + nb;
 
   hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n,
-                     inv_leaf, grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, sentinel, key_in, val_in,
+                     inv_leaf, grid.min_b[0], grid.min_b[1], grid.min_b[2], mul1, mul2, sentinel, key_in, use_rocprim ? val_in : (int*)nullptr,
                      reinterpret_cast<uint4*>(grid.dense ? grid.rec.p : nullptr), grid.dense ? grid.ncells * 4 : (size_t)0,   // all-ones words are NaN: empty cells answer no lookup
                      grid.cell_slot.p, grid.ncells, d_nvalid);
   // keys live in [0, ncells]: only that many radix bits are sorted
-  st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), temp, stream);
-  if (st) return st;
-  st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, temp, stream);
-  if (st) return st;
-  int n_runs = 0;   // through the host mailbox (one small launch + a poll: no copy engine, no stream synchronisation)
-  if ((st = publish_device_int(d_nruns, sc, stream, &n_runs))) return st;
-  st = exclusive_scan_i32(run_cnt, run_off, n_runs, temp, stream);
-  if (st) return st;
+  int n_runs = 0;
+  const int* order = val_out;
+  const int* counts = run_cnt;
+  const int* n_runs_dev = nullptr;   // non-null: the kernels behind read the run count from the device, the host learns it at the end
+  unsigned int rtoken = 0;
+  // runs <= min(points, cells + 1): with that bound no larger than 1 Mi the leaf buffers are sized by it and the host does not wait
+  // for the count in the middle of the chain (one round trip and ~8 us of idle device less)
+  const size_t run_bound = std::min((size_t)n, grid.ncells + 1);
+  if (use_rocprim) {
+    st = sort_pairs_u32(key_in, key_out, val_in, val_out, n, bits_for(sentinel), temp, stream);
+    if (st) return st;
+    st = run_length_encode_u32(key_out, n, run_key, run_cnt, d_nruns, temp, stream);
+    if (st) return st;
+    // through the host mailbox (one small launch + a poll: no copy engine, no stream synchronisation)
+    if ((st = publish_device_int(d_nruns, sc, stream, &n_runs))) return st;
+    st = exclusive_scan_i32(run_cnt, run_off, n_runs, temp, stream);
+    if (st) return st;
+  } else {
+    bool in_b = false;
+    if ((st = sort_pairs_u32_lsd(key_in, key_out, nullptr, val_in, val_out, (size_t)n, bits_for(sentinel), temp, stream, &in_b))) return st;
+    const unsigned int* ks = in_b ? key_out : key_in;
+    order = in_b ? val_out : val_in;
+    if ((st = sorted_runs_begin(ks, (size_t)n, block_heads, block_base, sc, stream, &rtoken, nullptr, d_nruns))) return st;
+    if ((st = sorted_runs_table(ks, (size_t)n, block_base, run_key, run_off, stream))) return st;   // enqueued before the count is known
+    counts = nullptr;   // run r covers [run_off[r], run_off[r + 1])
+    if (run_bound <= ((size_t)1 << 20)) { n_runs = (int)run_bound; n_runs_dev = d_nruns; }
+    else if ((st = sorted_runs_count(sc, stream, rtoken, &n_runs))) return st;
+  }
 
   st = sums.reserve((size_t)n_runs * 9);
   if (st) return st;
@@ -2746,15 +2778,16 @@ static int ndt_build_grid_general(const DeviceCloud& cloud, float leaf, VoxelGri
   if ((st = grid.icov64.reserve((size_t)n_runs * 9))) return st;
   if ((st = grid.leaf_key.reserve(n_runs))) return st;
   if ((st = grid.leaf_n.reserve(n_runs))) return st;
-  hipLaunchKernelGGL(leaf_sum_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), val_out,
-                     run_off, run_cnt, n_runs, sums.p);
-  hipLaunchKernelGGL(leaf_finalize_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, stream, sums.p, run_key, run_cnt, n_runs,
+  hipLaunchKernelGGL(leaf_sum_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), order,
+                     run_off, counts, n_runs, sums.p, n_runs_dev);
+  hipLaunchKernelGGL(leaf_finalize_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, stream, sums.p, run_key, counts, run_off, n_runs,
                      6, 0.01, grid.rec.p, grid.mean64.p, grid.icov64.p, grid.leaf_key.p, grid.leaf_n.p, grid.cell_slot.p,
-                     d_nvalid, grid.dense ? 1 : 0, sentinel);
+                     d_nvalid, grid.dense ? 1 : 0, sentinel, n_runs_dev);
   LSR_HIP(hipGetLastError());
-  grid.n_leaves = n_runs;  // includes the sentinel run if non-finite points exist (leaf_key = -1)
   if ((st = ndt_pack_lds_table(grid, sc, false, token, stream))) return st;
   if ((st = wait_mailbox_word(&sc.mb.p->done_token, token, stream, sc.wait_mode, "voxel grid build"))) return st;
+  if (n_runs_dev && (st = sorted_runs_count(sc, stream, rtoken, &n_runs))) return st;   // published long before the pack: no wait
+  grid.n_leaves = n_runs;  // includes the sentinel run if non-finite points exist (leaf_key = -1)
   grid.n_valid = sc.mb.p->n_valid;
   grid.lds_bytes = sc.mb.p->lds_bytes;
   grid.lds_map_bytes = sc.mb.p->lds_map_bytes;

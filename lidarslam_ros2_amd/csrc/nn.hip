@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void nn_key_kernel(const float* __restrict__ x
     k = coarse * FINE_PER_BLOCK + (unsigned int)((fx & 7) | ((fy & 7) << 3) | ((fz & 7) << 6));
   }
   key[i] = k;
-  val[i] = i;
+  if (val) val[i] = i;   // (the hand-written sort numbers the values itself)
 }
 
 __global__ __launch_bounds__(256) void nn_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void nn_fine_table_kernel(const unsigned int* 
   if (b >= n_runs) return;
   const unsigned int ck = run_key[b];
   if (ck == 0xFFFFFFFFu) return;  // run of non-finite points (always last)
-  const int beg = run_off[b], end = beg + run_cnt[b];
+  const int beg = run_off[b], end = run_cnt ? beg + run_cnt[b] : run_off[b + 1];   // (sorted_runs_table closes with run_off[n_runs] = n)
   if (lane == 0) {
     coarse_block[ck] = b;
     block_off[b] = beg;
@@ -596,6 +596,12 @@ int transform_append(const void* d_aos, size_t stride_bytes, size_t n, const flo
 
 float nn_pick_cell(size_t, const lsr_handle_s*) { return 0.5f; }
 
+// LSR_NN_SORT=rocprim: rounds 1-5's rocPRIM sort / run_length_encode / scans as the A/B cross-check of the hand-written ones
+static bool nn_use_rocprim() {
+  static const bool v = [] { const char* e = getenv("LSR_NN_SORT"); return e && strcmp(e, "rocprim") == 0; }();
+  return v;
+}
+
 int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, BuildScratch& sc, hipStream_t stream) {
   const int n = (int)cloud.n;
   grid.cell = cell;
@@ -641,9 +647,11 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
     LSR_HIP(hipMemsetAsync(hist, 0, (nkeys + 1) * sizeof(int), stream));
     hipLaunchKernelGGL(nnb_hist_kernel, dim3(nbk), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv, grid.org[0], grid.org[1],
                        grid.org[2], grid.cdim[0], grid.cdim[1], sentinel_b, key, hist);
-    if ((st = exclusive_scan_i32(hist, start, nkeys + 1, sc.temp, stream))) return st;
+    // device-wide exclusive scans: hand-written (lsd_sort.hip: block sums, one-workgroup scan of the sums, block scans); rocPRIM's
+    // behind LSR_NN_SORT=rocprim as the A/B cross-check
+    if ((st = nn_use_rocprim() ? exclusive_scan_i32(hist, start, nkeys + 1, sc.temp, stream) : exclusive_scan_i32_lsd(hist, start, nkeys + 1, sc.temp, stream))) return st;
     hipLaunchKernelGGL(nnb_flag_kernel, dim3((unsigned)((ccells + 255) / 256)), dim3(256), 0, stream, start, (int)ccells, flag);
-    if ((st = exclusive_scan_i32(flag, rank, ccells, sc.temp, stream))) return st;
+    if ((st = nn_use_rocprim() ? exclusive_scan_i32(flag, rank, ccells, sc.temp, stream) : exclusive_scan_i32_lsd(flag, rank, ccells, sc.temp, stream))) return st;
     hipLaunchKernelGGL(nnb_scatter_kernel, dim3(nbk), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, key, sentinel_b, start, hist,
                        grid.packed.p, grid.order.p);
     hipLaunchKernelGGL(nnb_table_kernel, dim3((unsigned)((ccells + 3) / 4)), dim3(256), 0, stream, start, flag, rank, (int)ccells,
@@ -652,38 +660,60 @@ int nn_build_hash(const DeviceCloud& cloud, float cell, HashGridDev& grid, Build
     grid.n_blocks = 1;  // "not empty" (n_finite > 0); the exact count stays on the device, nobody on the host needs it
     return LSR_OK;
   }
-  // scratch: key_in | key_out | val_in | ckey | run_key | run_cnt | run_off | nruns   (n words each)
-  if ((st = sc.words.reserve(32 + 7 * (size_t)n + 16))) return st;
+  // scratch: key_in | key_out | val_in | ckey | run_key (n+1) | run_cnt (n+1) | run_off (n+1) | nruns | block_heads | block_base
+  const size_t nbr = sorted_runs_blocks((size_t)n);
+  if ((st = sc.words.reserve(32 + 7 * (size_t)n + 3 + 16 + 2 * nbr))) return st;
   unsigned int* key_in = sc.words.p + 32;
   unsigned int* key_out = key_in + n;
   int* val_in = (int*)(key_out + n);
   unsigned int* ckey = (unsigned int*)(val_in + n);
   unsigned int* run_key = ckey + n;
-  int* run_cnt = (int*)(run_key + n);
-  int* run_off = run_cnt + n;
-  int* d_nruns = run_off + n;
+  int* run_cnt = (int*)(run_key + n + 1);
+  int* run_off = run_cnt + n + 1;
+  int* d_nruns = run_off + n + 1;
+  int* block_heads = d_nruns + 16;
+  int* block_base = block_heads + nbr;
   if ((st = grid.order.reserve(n))) return st;
   if ((st = grid.packed.reserve(n))) return st;
   if ((st = grid.coarse_block.reserve(ccells))) return st;
   LSR_HIP(hipMemsetAsync(grid.coarse_block.p, 0xFF, ccells * sizeof(int), stream));
   const int nb = (n + 255) / 256;
   const unsigned int sentinel = (unsigned int)(ccells * FINE_PER_BLOCK);
+  const bool rocprim_path = nn_use_rocprim();
   hipLaunchKernelGGL(nn_key_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, inv, grid.org[0],
-                     grid.org[1], grid.org[2], grid.cdim[0], grid.cdim[1], sentinel, key_in, val_in);
+                     grid.org[1], grid.org[2], grid.cdim[0], grid.cdim[1], sentinel, key_in, rocprim_path ? val_in : (int*)nullptr);
   int bits = 1;
   while (bits < 32 && (sentinel >> bits) != 0) bits++;  // only the bits the keys can use are sorted
-  if ((st = sort_pairs_u32(key_in, key_out, val_in, grid.order.p, n, bits, sc.temp, stream))) return st;
+  const unsigned int* ks = key_out;
+  if (rocprim_path) {
+    if ((st = sort_pairs_u32(key_in, key_out, val_in, grid.order.p, n, bits, sc.temp, stream))) return st;
+  } else {
+    // hand-written stable LSD radix sort (lsd_sort.hip); the order lands in grid.order or in val_in, whichever the pass count says
+    bool in_b = false;
+    if ((st = sort_pairs_u32_lsd(key_in, key_out, nullptr, val_in, grid.order.p, (size_t)n, bits, sc.temp, stream, &in_b))) return st;
+    ks = in_b ? key_out : key_in;
+    if (!in_b) LSR_HIP(hipMemcpyAsync(grid.order.p, val_in, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+  }
   hipLaunchKernelGGL(nn_gather_kernel, dim3(nb), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), grid.order.p, n,
                      grid.packed.p);
-  hipLaunchKernelGGL(nn_coarse_key_kernel, dim3(nb), dim3(256), 0, stream, key_out, n, sentinel, ckey);
-  if ((st = run_length_encode_u32(ckey, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
+  hipLaunchKernelGGL(nn_coarse_key_kernel, dim3(nb), dim3(256), 0, stream, ks, n, sentinel, ckey);
   // the number of occupied coarse cells reaches the host through the mailbox (one polled word)
   int n_runs = 0;
-  if ((st = publish_device_int(d_nruns, sc, stream, &n_runs))) return st;
-  if ((st = exclusive_scan_i32(run_cnt, run_off, n_runs, sc.temp, stream))) return st;
+  const int* counts = run_cnt;
+  if (rocprim_path) {
+    if ((st = run_length_encode_u32(ckey, n, run_key, run_cnt, d_nruns, sc.temp, stream))) return st;
+    if ((st = publish_device_int(d_nruns, sc, stream, &n_runs))) return st;
+    if ((st = exclusive_scan_i32(run_cnt, run_off, n_runs, sc.temp, stream))) return st;
+  } else {
+    unsigned int rtoken = 0;
+    if ((st = sorted_runs_begin(ckey, (size_t)n, block_heads, block_base, sc, stream, &rtoken))) return st;
+    if ((st = sorted_runs_table(ckey, (size_t)n, block_base, run_key, run_off, stream))) return st;
+    if ((st = sorted_runs_count(sc, stream, rtoken, &n_runs))) return st;
+    counts = nullptr;
+  }
   if ((st = grid.block_off.reserve((size_t)n_runs + 1))) return st;
   if ((st = grid.fine_start.reserve((size_t)n_runs * FINE_STRIDE))) return st;
-  hipLaunchKernelGGL(nn_fine_table_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream, key_out, run_key, run_off, run_cnt,
+  hipLaunchKernelGGL(nn_fine_table_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream, ks, run_key, run_off, counts,
                      n_runs, grid.coarse_block.p, grid.block_off.p, grid.fine_start.p);
   LSR_HIP(hipGetLastError());
   // no synchronisation here: every consumer of the grid (and of the scratch buffers) is ordered on the same stream

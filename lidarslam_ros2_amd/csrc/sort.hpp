@@ -26,8 +26,14 @@ int lsd_first_hist_plan(size_t n, int end_bit, DevBuf<char>& temp, LsdFirstHist*
 // runs travels to the host through sc's mailbox (sorted_runs_count polls it).  sorted_runs_blocks(n) = ints each table needs.
 size_t sorted_runs_blocks(size_t n);
 int sorted_runs_begin(const unsigned int* keys_sorted, size_t n, int* block_heads, int* block_base, BuildScratch& sc, hipStream_t stream,
-                      unsigned int* token_out, const unsigned int* dims_dev = nullptr);   // dims_dev: see leaf_key_dims_kernel (ndt.hip)
+                      unsigned int* token_out, const unsigned int* dims_dev = nullptr,   // dims_dev: see leaf_key_dims_kernel (ndt.hip)
+                      int* total_dev = nullptr);   // total_dev: the number of runs left in device memory too
 int sorted_runs_count(BuildScratch& sc, hipStream_t stream, unsigned int token, int* n_runs);
+// The runs as a table (enqueue behind sorted_runs_begin; needs no host wait): run r in key order has key run_key[r] and covers the
+// sorted positions [run_off[r], run_off[r + 1]); run_off[number of runs] = n.  run_key / run_off: n + 1 entries.
+int sorted_runs_table(const unsigned int* keys_sorted, size_t n, const int* block_base, unsigned int* run_key, int* run_off, hipStream_t stream);
+// Exclusive scan of an int array of any length (hand-written, three launches); in != out.
+int exclusive_scan_i32_lsd(const int* in, int* out, size_t n, DevBuf<char>& temp, hipStream_t stream);
 // pcl::VoxelGrid's centroid of every run (float sums, ascending point index; all fields): out[r] for run r in key order; the run
 // of `sentinel` (always last) is skipped
 int sorted_runs_centroids(const unsigned int* keys_sorted, const int* order, size_t n, const int* block_base, unsigned int sentinel,

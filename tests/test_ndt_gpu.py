@@ -463,3 +463,42 @@ def test_align_fitness_batch_equals_the_two_calls(case):
             assert r1[k]["iterations"] == r2[k]["iterations"] and r1[k]["converged"] == r2[k]["converged"]
             assert s2[k] == pytest.approx(s1[k], rel=1e-12), (B, k)
             assert b[k].getFitnessScore() == pytest.approx(s1[k], rel=1e-12)      # the objects are left as after the two calls
+
+
+def test_hand_written_sort_builders_equal_the_rocprim_builders(tmp_path):
+    """Round 6: the radix target builder (key spaces beyond the counting sort: cfg 5, the reference's 1-2 m resolutions) and the NN grid
+    builder run on the hand-written LSD sort + run table + scans of csrc/lsd_sort.hip; rocPRIM's sort / run_length_encode / scan stay
+    behind LSR_TARGET_SORT=rocprim / LSR_NN_SORT=rocprim.  Child processes, one per setting: the voxel grids (leaf set, counts, fp64
+    means and inverse covariances), a registration, the NN answers and the GICP covariances are bit-identical."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import numpy as np, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from lidarslam_ros2_amd import NormalDistributionsTransform, GeneralizedIterativeClosestPoint, DIRECT7, synth\n"
+            "case = synth.small_case(n_source=4000, n_keyframes=4, seed=3)\n"
+            "tgt = synth.as_pointxyzi(case.target); tgt[5::89, 1] = np.nan\n"
+            "out = {}\n"
+            "for tag, res, builder in (('r1', 1.0, 0), ('r07', 0.7, 0), ('r5_forced', 5.0, 1)):\n"
+            "    r = NormalDistributionsTransform(device=0); r.setResolution(res); r.setTransformationEpsilon(0.01); r.setNeighborhoodSearchMethod(DIRECT7)\n"
+            "    r.setTuning(grid_builder=builder); r.setInputTarget(tgt); r.setInputSource(case.source); r.align(case.guess)\n"
+            "    d = r.gridDump(); info = r.gridInfo()\n"
+            "    for k in ('idx', 'n', 'mean', 'icov'): out[tag + '_' + k] = d[k]\n"
+            "    out[tag + '_T'] = r.getFinalTransformation(); out[tag + '_leaves'] = np.array([info['n_leaves'], info['n_valid']])\n"
+            "for tag, builder in (('nn_bucket', 0), ('nn_sort', 1)):\n"
+            "    g = GeneralizedIterativeClosestPoint(device=0); g.setTuning(grid_builder=builder); g.setInputTarget(case.target); g.setInputSource(case.source)\n"
+            "    idx, d2 = g.nearestNeighbors(case.guess); g.align(case.guess)\n"
+            "    out[tag + '_idx'] = idx; out[tag + '_d2'] = d2; out[tag + '_T'] = g.getFinalTransformation(); out[tag + '_cov'] = g.covariances('target')\n"
+            "    out[tag + '_fit'] = np.array([g.getFitnessScore()])\n"
+            "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, env in (("hand", {}), ("rocprim", {"LSR_TARGET_SORT": "rocprim", "LSR_NN_SORT": "rocprim"})):
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, **env), timeout=600)
+        outs.append(np.load(path))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 28
+    for k in a.files:
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), k
+    assert int(a["r1_leaves"][0]) > 16383 or int(a["r07_leaves"][0]) > 3000   # the general builder really ran on a large key space
