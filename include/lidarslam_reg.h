@@ -92,11 +92,15 @@ typedef enum lsr_key {
   LSR_NDT_SORT = 45,                  /* order the source by voxel tile of its guess-moved points at the start of align():
                                          -1 = automatic (tile table mode only), 0 = never (the tile mode then falls back to the
                                          global table), 1 = also when the records are gathered from the global table */
-  LSR_VOXEL_FILTER_FORM = 46          /* read-only (lsr_get_i32): which form the last VoxelGrid filter on this object took:
+  LSR_VOXEL_FILTER_FORM = 46,         /* read-only (lsr_get_i32): which form the last VoxelGrid filter on this object took:
                                          0 = none yet, 1 = grid dimensions worked out on the host (one wait for the bounding box,
                                          one for the leaf count), 2 = on the device (one wait: from the second
                                          lsr_set_input_source_pc2 / _frontend of an object on), 3 = the device form came back
                                          flagged (more key bits than planned, or an index overflow) and the host form ran */
+  LSR_NDT_SPLIT = 47                  /* single NDT registrations on the 512-thread lane kernel: 1 = two waves per 64-point chunk (each
+                                         forms one half of the per-point neighbour tree; half the serial chain per wave, twice the waves),
+                                         0 = one wave per chunk, -1 = automatic (= 0: measured on BASELINE cfg 5, the split form is not
+                                         faster — the pass is bound by its fixed latency chain).  Environment preset LSR_NDT_SPLIT */
 } lsr_key;
 /* Environment presets read when an object is created: LSR_NDT_WORKGROUP, LSR_NDT_TABLE_MODE, LSR_NDT_QUAD, LSR_GRID_BUILDER,
  * LSR_WAIT_MODE (the keys above); LSR_NDT_WIDEN=0 keeps the launches of a candidate set at their first geometry (default: widened

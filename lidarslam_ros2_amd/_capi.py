@@ -19,7 +19,7 @@ KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
 (RESOLUTION, TRANSFORMATION_EPSILON, STEP_SIZE, OUTLIER_RATIO, MAX_CORRESPONDENCE_DISTANCE, ROTATION_EPSILON,
  EUCLIDEAN_FITNESS_EPSILON, GICP_EPSILON) = range(8)
 (MAX_ITERATIONS, NEIGHBORHOOD, NUM_THREADS, K_CORRESPONDENCES, MAX_INNER_ITERATIONS, RANSAC_ITERATIONS,
- HESSIAN_D1_SIGN, PROFILE, NDT_WORKGROUP, NDT_TABLE_MODE, GRID_BUILDER, WAIT_MODE, NDT_QUAD, NDT_SORT, VOXEL_FILTER_FORM) = range(32, 47)
+ HESSIAN_D1_SIGN, PROFILE, NDT_WORKGROUP, NDT_TABLE_MODE, GRID_BUILDER, WAIT_MODE, NDT_QUAD, NDT_SORT, VOXEL_FILTER_FORM, NDT_SPLIT) = range(32, 48)
 
 EXPORTED_SYMBOLS = [
     "lsr_version", "lsr_status_string", "lsr_last_error", "lsr_device_count", "lsr_create", "lsr_destroy",

@@ -31,12 +31,47 @@ namespace {
   if (!_guard.ok) {                              \
     set_last_error("hipSetDevice failed");       \
     return LSR_ERR_HIP;                          \
+  }                                              \
+  if ((h)->dep && settle_dep(h)) return LSR_ERR_HIP;
+
+// the object is about to be used on its own: its stream now waits for the group work it was part of (lsr::StreamDep, handle.hpp)
+int settle_dep(lsr_handle h) {
+  if (!h->dep) return LSR_OK;
+  if (h->dep_stream != h->stream && hipStreamWaitEvent(h->stream, h->dep->ev, 0) != hipSuccess) {
+    set_last_error("hipStreamWaitEvent failed (deferred dependency on a group launch)");
+    return LSR_ERR_HIP;
   }
+  h->dep.reset();
+  h->dep_stream = nullptr;
+  return LSR_OK;
+}
+// after group work for `members` has been enqueued on the lead's stream: one event record, the members remember it
+int defer_members_behind(lsr_handle lead, lsr_handle* members, int count) {
+  if (!lead->lead_dep) {
+    auto d = std::make_shared<lsr::StreamDep>();
+    if (hipEventCreateWithFlags(&d->ev, hipEventDisableTiming) != hipSuccess) { set_last_error("hipEventCreate failed"); return LSR_ERR_HIP; }
+    lead->lead_dep = d;
+  }
+  bool any = false;
+  for (int b = 0; b < count; b++) any = any || (members[b] != lead && members[b]->stream != lead->stream);
+  if (!any) return LSR_OK;
+  if (hipEventRecord(lead->lead_dep->ev, lead->stream) != hipSuccess) { set_last_error("hipEventRecord failed"); return LSR_ERR_HIP; }
+  for (int b = 0; b < count; b++)
+    if (members[b] != lead && members[b]->stream != lead->stream) { members[b]->dep = lead->lead_dep; members[b]->dep_stream = lead->stream; }
+  return LSR_OK;
+}
 
 // Make everything `h` still has in flight on its own stream precede what is enqueued on `lead` next (group launches of a
 // candidate set run on the first member's stream).  An idle stream — the usual case — costs one query and no event.
 int order_lead_after(hipStream_t lead, lsr_handle h) {
   if (h->stream == lead) return LSR_OK;
+  if (h->dep) {
+    // everything this member has had enqueued since its last own use went to dep_stream (a group call ordered that stream behind the
+    // member's own one before it started): on the same lead stream there is nothing to order, on another one the event is the order
+    if (h->dep_stream == lead) return LSR_OK;
+    LSR_HIP(hipStreamWaitEvent(lead, h->dep->ev, 0));
+    return LSR_OK;
+  }
   if (hipStreamQuery(h->stream) == hipSuccess) return LSR_OK;
   LSR_HIP(hipEventRecord(h->ev1, h->stream));
   LSR_HIP(hipStreamWaitEvent(lead, h->ev1, 0));
@@ -121,7 +156,7 @@ int ndt_nblocks(size_t n, int device, int batch, int threads, int points) {
 }
 // workgroup geometry of a launch configuration
 int cfg_wg_threads(const NdtLaunchCfg& cfg) { return cfg.quad ? 4 * cfg.threads : cfg.threads; }
-int cfg_wg_points(const NdtLaunchCfg& cfg) { return cfg.threads; }
+int cfg_wg_points(const NdtLaunchCfg& cfg) { return (!cfg.quad && cfg.split) ? cfg.threads / 2 : cfg.threads; }
 
 // LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock; 160 KiB on gfx950): the table modes that
 // stage into LDS are only chosen when their buffers fit, anything else reads the global table.
@@ -211,6 +246,19 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   cfg.lds_bytes = (tab == NDT_TAB_LDS) ? lds_max : (tab == NDT_TAB_TILE ? NDT_TILE_BYTES : 0);
   if (cfg.quad) cfg.threads = (lead->ndt_threads == 64 || lead->ndt_threads == 128) ? lead->ndt_threads : NDT_QUAD_POINTS;  // POINTS per workgroup
   else cfg.threads = lane_threads;
+  // two waves per chunk (ndt.hip: SPLIT) for a single scan whose points, one lane each, leave the chip half empty but whose chunk
+  // pairs still fit it at once: 65 536 .. resident workgroups x 256 points (cfg 5: 120 000 points = 469 workgroups of 512 threads).
+  // LSR_NDT_SPLIT = 0 / 1 (key or environment preset) forces it off / on (on: any single registration that takes the 512-thread lane kernel).
+  cfg.split = 0;
+  if (!cfg.quad && B == 1 && cfg.threads == 512) {
+    const size_t fits = (size_t)ndt_resident_wgs(lead->device, 512) * 256;
+    // measured (cfg 5, 120 000 points, res 2.0 / 1.0): 9.25 / 9.33 us per pass split against 9.14 / 9.08 us with one wave per chunk —
+    // the pass is bound by its fixed chain (boundary, head read, controller: ~5.5 us), not by the point loop the split halves; the
+    // barrier and the second copy of the gathers eat what the shorter per-wave chain gives.  Automatic = off; kept as an A/B form
+    // (same bits: tests/test_ndt_gpu.py) with its counters in profiles/r06_pmc_cfg5.md.
+    (void)fits;
+    cfg.split = lead->ndt_split >= 0 ? lead->ndt_split : 0;
+  }
   // source ordered by voxel tile: always for the tile mode (its boxes are small only then); for global-table gathers on request
   // (LSR_NDT_SORT = 1): neighbouring lanes then read neighbouring records
   cfg.sorted = (tab == NDT_TAB_TILE) || (lead->ndt_sort == 1 && tab != NDT_TAB_LDS);
@@ -369,6 +417,22 @@ int ensure_aux_streams(lsr_handle lead) {
     return LSR_ERR_HIP;
   };
   size_t k = 0;
+  // LSR_SIDE_CUS = K (experiment, VERDICT r05 #2 ii): the side stream — grid refinement, fitness searches of early finishers — is
+  // confined to K compute units (hipExtStreamCreateWithCUMask: the first K bits of the mask; the driver deals the bits of a mask to the
+  // XCDs in turn, so K / 8 CUs of every XCD), the launch chain keeps the rest of the chip to itself
+  static const int side_cus = [] { const char* e = std::getenv("LSR_SIDE_CUS"); return e ? std::atoi(e) : 0; }();
+  if (side_cus > 0) {
+    const int total = device_cus(lead->device);
+    const int words = (total + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0u);
+    for (int c = 0; c < std::min(side_cus, total); c++) mask[c / 32] |= 1u << (c % 32);
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask.data()) != hipSuccess) return give_up("CU-masked side stream");
+    lead->side_stream = s;
+    if (std::getenv("LSR_DEBUG_STREAMS")) {
+      fprintf(stderr, "[lidarslam_reg] side stream confined to %d of %d CUs\n", std::min(side_cus, total), total);
+    }
+  } else
   if (!found.empty()) lead->side_stream = found[k++];
   else if (hipStreamCreateWithFlags(&lead->side_stream, hipStreamNonBlocking) != hipSuccess) return give_up("no side stream");
   lead->n_chain_streams = 0;
@@ -670,7 +734,7 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     // and the grid refinement to 256 / 512 / 1024 resident workgroups (stride loops) so that the chain always finds its slots made it
     // worse still — 1.22 / 0.99 / 0.78 ms against 0.68 for the first share: refinement + searches are ~0.4 ms of full-chip work, at a
     // fraction of the chip they outlast the 0.5 ms chain and the tail is paid at the reduced rate.)
-    const size_t group_min = 12;
+    static const size_t group_min = [] { const char* e = std::getenv("LSR_FIT_GROUP_MIN"); const int v = e ? std::atoi(e) : 12; return (size_t)std::max(1, std::min(12, v)); }();
     while (!eager_ready.empty() && (all || eager_ready.size() >= group_min)) {
       const int n = (int)std::min<size_t>(12, eager_ready.size());
       std::vector<FitJob> jobs;
@@ -807,6 +871,7 @@ int lsr_create(int method, int device_id, void* stream, lsr_handle* out) {
   if (const char* e = std::getenv("LSR_NDT_TABLE_MODE")) { const int v = std::atoi(e); if (v >= -1 && v <= 3) h->ndt_table_mode = v; }
   if (const char* e = std::getenv("LSR_NDT_QUAD")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_quad = v; }
   if (const char* e = std::getenv("LSR_NDT_SORT")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_sort = v; }
+  if (const char* e = std::getenv("LSR_NDT_SPLIT")) { const int v = std::atoi(e); if (v >= -1 && v <= 1) h->ndt_split = v; }
   if (const char* e = std::getenv("LSR_WAIT_MODE")) {   // 0 | 1 | 2 or spin | yield | sleep
     const std::string w(e);
     const int v = (w == "spin") ? 0 : (w == "yield") ? 1 : (w == "sleep") ? 2 : (w.size() == 1 && w[0] >= '0' && w[0] <= '2') ? w[0] - '0' : -1;
@@ -930,6 +995,9 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
     case LSR_NDT_SORT:
       if (v < -1 || v > 1) { set_last_error("NDT source ordering must be -1 (auto), 0 or 1"); return LSR_ERR_INVALID_ARGUMENT; }
       h->ndt_sort = v; return LSR_OK;
+    case LSR_NDT_SPLIT:
+      if (v < -1 || v > 1) { set_last_error("NDT split mode must be -1 (auto), 0 or 1"); return LSR_ERR_INVALID_ARGUMENT; }
+      h->ndt_split = v; return LSR_OK;
     case LSR_GRID_BUILDER:
       if (v < 0 || v > 1) { set_last_error("grid builder must be 0 (auto) or 1 (radix-sort builder)"); return LSR_ERR_INVALID_ARGUMENT; }
       h->scratch.force_sort_path = (v == 1);
@@ -958,6 +1026,7 @@ int lsr_get_i32(lsr_handle h, int key, int* v) {
     case LSR_NDT_TABLE_MODE: *v = h->ndt_table_mode; return LSR_OK;
     case LSR_NDT_QUAD: *v = h->ndt_quad; return LSR_OK;
     case LSR_NDT_SORT: *v = h->ndt_sort; return LSR_OK;
+    case LSR_NDT_SPLIT: *v = h->ndt_split; return LSR_OK;
     case LSR_GRID_BUILDER: *v = h->scratch.force_sort_path ? 1 : 0; return LSR_OK;
     case LSR_WAIT_MODE: *v = h->scratch.wait_mode; return LSR_OK;
     case LSR_VOXEL_FILTER_FORM: *v = h->scratch.vg_form; return LSR_OK;
@@ -1088,6 +1157,7 @@ int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const
     t->n = counts[b];
     h->target = t;
     if (h->method != LSR_METHOD_NDT) {
+      if ((st = settle_dep(h))) return fail(st);   // used on its own stream here
       if ((st = upload_cloud(h, clouds[b], stride_bytes, counts[b], on_device != 0, t->cloud))) return fail(st);
       if ((st = cloud_bbox_begin(t->cloud, h->scratch, h->stream))) return fail(st);
       continue;
@@ -1190,13 +1260,9 @@ int lsr_set_input_source_batch(lsr_handle* handles, int count, const void* const
     jobs[b] = DeinterleaveJob{d_aos, stride_bytes, counts[b], &h->source};
   }
   if ((st = deinterleave_group(jobs.data(), count, lead_stream))) return fail(st);
-  // every member's own stream continues after the shared launch (its next align / fitness call runs there)
-  if (hipEventRecord(handles[0]->ev0, lead_stream) != hipSuccess) { set_last_error("hipEventRecord failed"); return fail(LSR_ERR_HIP); }
-  for (int b = 1; b < count; b++)
-    if (handles[b]->stream != lead_stream && hipStreamWaitEvent(handles[b]->stream, handles[0]->ev0, 0) != hipSuccess) {
-      set_last_error("hipStreamWaitEvent failed");
-      return fail(LSR_ERR_HIP);
-    }
+  // every member's own stream continues after the shared launch (its next align / fitness call runs there): deferred — the members
+  // remember the event, their streams wait for it when they are next used on their own (handle.hpp: StreamDep)
+  if ((st = defer_members_behind(handles[0], handles, count))) return fail(st);
   if (!on_device && hipStreamSynchronize(lead_stream) != hipSuccess) { set_last_error("stream error in the source batch"); return LSR_ERR_HIP; }
   for (int b = 0; b < count; b++) handles[b]->has_source = true;
   return LSR_OK;
@@ -1399,6 +1465,8 @@ int lsr_align_batch(lsr_handle* handles, int batch, const float* guesses, float*
   for (int b = 0; b < batch; b++)
     for (int a = 0; a < b; a++)
       if (handles[a] == handles[b]) { set_last_error("the same object appears twice in the batch"); return LSR_ERR_INVALID_ARGUMENT; }
+  for (int b = 1; b < batch; b++)
+    if (settle_dep(handles[b])) return LSR_ERR_HIP;   // each member runs on its own stream
   return gicp_align_batch(handles, batch, guesses, finals, results);
 }
 
@@ -1540,6 +1608,7 @@ int lsr_get_fitness_score_batch(lsr_handle* handles, int count, double max_range
   int begun = 0;
   for (; begun < (int)single.size(); begun++) {
     lsr_handle h = handles[single[begun]];
+    if ((st = settle_dep(h))) break;   // used on its own stream here
     if ((st = ensure_target_hash(h))) break;
     if ((st = nn_fitness_begin(h->source, h->final_T, h->target->hash, max_range, h->scratch, h->d_T16, h->stream))) break;
   }

@@ -5,6 +5,17 @@
 #include "ndt.hpp"
 #include "nn.hpp"
 
+namespace lsr {
+// A deferred stream dependency (round 6): the group launches of a candidate set run on the FIRST member's stream; instead of making
+// every other member's own stream wait for them right away (one hipStreamWaitEvent per member and call, and one query + record + wait
+// per member at the next group call: ~110 us of host time per share of eight), the members only remember the event.  A member's own
+// stream waits for it when the member is next used on its own (LSR_CHECK_HANDLE); a group call on the SAME lead stream needs nothing.
+struct StreamDep {
+  hipEvent_t ev = nullptr;
+  ~StreamDep() { if (ev) (void)hipEventDestroy(ev); }
+};
+}  // namespace lsr
+
 struct lsr_handle_s {
   using NdtParamsHost = lsr::NdtParamsHost; using GicpParamsHost = lsr::GicpParamsHost; using TargetData = lsr::TargetData;
   using DeviceCloud = lsr::DeviceCloud; using HashGridDev = lsr::HashGridDev; using BuildScratch = lsr::BuildScratch;
@@ -16,6 +27,9 @@ struct lsr_handle_s {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // profiling brackets (LSR_PROFILE)
+  std::shared_ptr<lsr::StreamDep> dep;        // pending: `stream` must wait for dep->ev before this object's next launch of its own
+  hipStream_t dep_stream = nullptr;           // ... the (lead) stream that event was recorded on
+  std::shared_ptr<lsr::StreamDep> lead_dep;   // as the lead of a set: the event its members are handed
   // side stream of a batch lead: the neighbour grids of a candidate set are refined there while the shared NDT launch chain
   // runs on `stream` (align_ndt_batch); created on first use
   hipStream_t side_stream = nullptr;
@@ -35,6 +49,7 @@ struct lsr_handle_s {
   int ndt_threads = 0;       // LSR_NDT_WORKGROUP: 0 = automatic; quad kernel: 64 / 128 points, lane kernel: 512 / 1024 threads
   int ndt_table_mode = -1;   // LSR_NDT_TABLE_MODE: -1 = automatic, else lsr::NdtTableMode
   int ndt_quad = -1;         // LSR_NDT_QUAD: -1 = automatic (single registrations: four lanes per point), 0 = lane kernel, 1 = four
+  int ndt_split = -1;        // LSR_NDT_SPLIT: -1 = automatic, 0 / 1 = one / two waves per chunk in the 512-thread lane kernel (single registrations)
   int ndt_sort = -1;         // LSR_NDT_SORT: -1 = automatic (tile mode only), 0 = never, 1 = also for global-table gathers
 
   std::shared_ptr<TargetData> target;

@@ -1330,16 +1330,26 @@ typedef __attribute__((address_space(1))) const v4f GlbV4;
 typedef __attribute__((address_space(1))) const float GlbFloat;
 typedef __attribute__((address_space(1))) const int GlbInt;
 
-template <int NOFF, int TAB, int THREADS, bool BYVAL>
+//  SPLIT (round 6; single scans that do not fill the chip with one lane per point: cfg 5's 120k points are 1.8 waves per SIMD, 73 % of
+//      their cycles waiting on the dependent gather -> exp -> weight chain of seven neighbours one after the other): TWO WAVES per
+//      canonical chunk.  Wave 2p takes the point's partial sums 0 and 1 (neighbours 0, 4, 1, 5), wave 2p + 1 partial sums 2 and 3
+//      (neighbours 2, 6, 3) — the two HALVES of the canonical per-point tree (p0 + p1) + (p2 + p3) — the odd wave parks its half in its
+//      staging tile, one workgroup barrier, the even wave adds the halves, forms the point's terms and reduces the chunk as before.
+//      Same bits (the association is the canonical one), half the serial chain per wave, twice the waves: a workgroup covers
+//      THREADS / 2 points per trip.
+template <int NOFF, int TAB, int THREADS, bool BYVAL, bool SPLIT = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void ndt_eval_lane_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq,
                                                                 const int nb, const int tab_bytes) {
   constexpr int NWAVES = THREADS / 64;
+  constexpr int PTS = SPLIT ? THREADS / 2 : THREADS;   // source points a workgroup covers per trip
   constexpr int NT = (NOFF + 3) / 4;                // neighbours per partial sum
   constexpr int GROUP = 4;                          // records fetched per gather round trip
   const NdtProblem& P = BYVAL ? pv : probs[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // a workgroup without points only stays if it is the one that carries the controller state forward
-  if (blockIdx.x > 0 && (long long)blockIdx.x * THREADS >= (long long)P.n) return;
+  if (blockIdx.x > 0 && (long long)blockIdx.x * PTS >= (long long)P.n) return;
+  const int role = SPLIT ? (wave & 1) : 0;      // SPLIT: which half of the per-point tree this wave forms
+  const int cw = SPLIT ? (wave >> 1) : wave;    // the chunk of the trip this wave works on
 
   __shared__ double s_bin[NDT_NBINS][32];
   __shared__ unsigned long long s_ibin[NDT_NBINS * 32];   // this workgroup's chunk totals, exact (ds_add_u64)
@@ -1356,8 +1366,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
 
   // ---- head: the same steps as the quad kernel's (bins of the previous launch, controller on wave 0, table DMA by the others)
   const int n = P.n;
-  const int stride = nb * THREADS;
-  int i = blockIdx.x * THREADS + tid;
+  const int stride = nb * PTS;
+  int i = blockIdx.x * PTS + cw * 64 + lane;
   float x = 0.f, y = 0.f, z = 0.f;
   unsigned int ang_entry = 0u, ang_entry_b = 0u;
   {
@@ -1463,7 +1473,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
   const GlbFloat* g_sz = (const GlbFloat*)P.sz;
   (void)g_rec; (void)g_cell_slot; (void)s_map; (void)map_bytes;
 
-  for (int base = blockIdx.x * THREADS + wave * 64; base < n; base += stride) {   // wave-uniform: one canonical chunk per trip
+  // one canonical chunk per wave (pair of waves) and trip.  SPLIT: the trip count is the WORKGROUP's (every wave meets the barrier
+  // inside), a wave whose chunk lies beyond the cloud works on absent points (zeros, no pairs: nothing reaches the bins)
+  for (int base = SPLIT ? blockIdx.x * PTS : blockIdx.x * PTS + cw * 64; base < n; base += stride) {
     const bool have = i < n;
     const float px = x, py = y, pz = z;
     const float tx = xform_ref(T[0], T[1], T[2], T[3], px, py, pz);
@@ -1531,6 +1543,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     float S[11];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
+      if (SPLIT && half != role) continue;   // wave-uniform: this wave forms ONE half
       float Pq[2][11];
 #pragma unroll
       for (int k = 0; k < 11; k++) { Pq[0][k] = 0.f; Pq[1][k] = 0.f; }
@@ -1561,13 +1574,30 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         }
       }
       // (lane 2 half) + (lane 2 half + 1) of the quad
-      if (half == 0) {
+      if (half == 0 || SPLIT) {
 #pragma unroll
         for (int k = 0; k < 11; k++) S[k] = Pq[0][k] + Pq[1][k];
       } else {
 #pragma unroll
         for (int k = 0; k < 11; k++) S[k] = S[k] + (Pq[0][k] + Pq[1][k]);
       }
+    }
+    if (SPLIT) {
+      // the halves meet: the odd wave parks (p2 + p3) in its own tile, the even wave adds it to its (p0 + p1) — the canonical order
+      if (role == 1) {
+#pragma unroll
+        for (int k = 0; k < 11; k++) s_tile[k * canon::TILE_PITCH + lane] = S[k];
+      }
+      __syncthreads();
+      if (role == 1) {
+        // nothing else to do for this chunk: the even wave carries it from here
+        if (base + stride < n) __syncthreads();   // the tile is read before the next trip writes it again
+        continue;
+      }
+      const float* other = s_tile + canon::TILE_FLOATS;   // the partner's tile (wave + 1)
+#pragma unroll
+      for (int k = 0; k < 11; k++) S[k] = S[k] + other[k * canon::TILE_PITCH + lane];
+      if (base + stride < n) __syncthreads();
     }
     // S = {score, #pairs, A0..2, E00, E01, E02, E11, E12, E22}
     // A point without a valid pair contributes zeros.  Its sums S are all zero already; its coordinates are replaced by zeros so
@@ -1740,7 +1770,7 @@ static int launch_quad(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream
   }
 }
 
-template <int NOFF, int TAB, int THREADS>
+template <int NOFF, int TAB, int THREADS, bool SPLIT = false>
 static int launch_lane_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq,
                                int tab_bytes) {
   static bool allowed[2][64] = {};
@@ -1748,7 +1778,7 @@ static int launch_lane_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_
     int dev = 0;
     LSR_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !allowed[byval ? 1 : 0][dev]) {
-      const void* fn = byval ? (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, true> : (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, false>;
+      const void* fn = byval ? (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, true, SPLIT> : (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, false, SPLIT>;
       // table image + staging tiles, bounded by what a workgroup can have on gfx950 (160 KiB minus the kernel's static LDS)
       const int want = std::min((int)NDT_LDS_TABLE_MAX + ndt_lane_tile_bytes(THREADS), 160 * 1024 - 6 * 1024);
       LSR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want));
@@ -1756,8 +1786,8 @@ static int launch_lane_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_
     }
   }
   const int nb = (int)grid.x;
-  if (byval) hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, true>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
-  else hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, false>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
+  if (byval) hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, true, SPLIT>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
+  else hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, false, SPLIT>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
   return LSR_OK;
 }
 
@@ -1765,6 +1795,13 @@ template <int NOFF>
 static int launch_lane(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq) {
   const int tab_bytes = (cfg.tab == NDT_TAB_LDS) ? cfg.lds_bytes : 0;
   const size_t dyn = (size_t)tab_bytes + (size_t)ndt_lane_tile_bytes(cfg.threads);
+  if (cfg.split && cfg.threads == 512) {   // two waves per chunk: the 512-thread form only (what single scans use)
+    switch (cfg.tab) {
+      case NDT_TAB_LDS: return launch_lane_variant<NOFF, NDT_TAB_LDS, 512, true>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+      case NDT_TAB_COMPACT: return launch_lane_variant<NOFF, NDT_TAB_COMPACT, 512, true>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+      default: return launch_lane_variant<NOFF, NDT_TAB_DENSE, 512, true>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+    }
+  }
   if (cfg.threads == 1024) {
     switch (cfg.tab) {
       case NDT_TAB_LDS: return launch_lane_variant<NOFF, NDT_TAB_LDS, 1024>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);

@@ -141,6 +141,8 @@ struct NdtLaunchCfg {
   int threads = NDT_LANE_THREADS;  // lane kernel: threads per workgroup (512 / 1024); quad kernel: POINTS per workgroup (64 / 128)
   int lds_bytes = 0;       // dynamic LDS (largest lds_bytes of the batch) when tab == NDT_TAB_LDS
   int sorted = 0;          // 1: the problems read the tile-ordered copy of the source (ndt_sort_source)
+  int split = 0;           // lane kernel, 512 threads: 1 = two waves per chunk (each forms one half of the per-point tree): single scans
+                           // that leave the chip half empty with one lane per point (cfg 5).  Same bits.
   int quad = 0;            // 1: four lanes per source point, 512-thread workgroups (single registrations: spreads a 30k-point scan
                            // over every CU; batches whose tables need NDT_TAB_TILE); 0: the lane kernel, one lane per point
                            // (candidate sets, large single scans).  Both return the same bits (canon:: in ndt.hip).

@@ -321,12 +321,13 @@ class Registration:
         return idx, d2
 
     def setTuning(self, workgroup: Optional[int] = None, table_mode: Optional[int] = None, grid_builder: Optional[int] = None,
-                  wait_mode: Optional[int] = None, quad: Optional[int] = None, sort: Optional[int] = None):
+                  wait_mode: Optional[int] = None, quad: Optional[int] = None, sort: Optional[int] = None, split: Optional[int] = None):
         """Tuning keys of the core (no effect on results: every derivative kernel returns the same bits): NDT workgroup (0 auto;
         quad kernel: 64 / 128 points, lane kernel: 512 / 1024 threads), kernel (quad: -1 auto, 0 lane kernel, 1 quad kernel),
         where the derivative pass reads the voxel table (-1 auto, 0 dense global, 1 compact global, 2 LDS, 3 tile), the
         grid builder (0 auto, 1 radix sort), how the calling thread waits (0 spin, 1 yield, 2 sleep), source ordering by
-        voxel tile (-1 auto, 0 never, 1 also for global-table gathers)."""
+        voxel tile (-1 auto, 0 never, 1 also for global-table gathers), two waves per chunk in the 512-thread lane kernel of a single
+        registration (split: -1 auto, 0, 1)."""
         if workgroup is not None:
             self._seti(capi.NDT_WORKGROUP, workgroup, "setTuning(workgroup)")
         if table_mode is not None:
@@ -339,6 +340,8 @@ class Registration:
             self._seti(capi.NDT_QUAD, quad, "setTuning(quad)")
         if sort is not None:
             self._seti(capi.NDT_SORT, sort, "setTuning(sort)")
+        if split is not None:
+            self._seti(capi.NDT_SPLIT, split, "setTuning(split)")
 
     def setProfiling(self, on: bool):
         self._seti(capi.PROFILE, 1 if on else 0, "setProfiling")

@@ -234,16 +234,23 @@ def test_gpu_matches_the_committed_golden_fixture():
 # ---- launch variants of the derivative pass and the two grid builders -----------------------------------------------
 # (quad: 1 = four lanes per point (workgroup = points per workgroup: 0 auto / 64 / 128), 0 = lane kernel, one lane per point
 #  (workgroup = threads: 512 / 1024); table mode: 0 dense global, 1 compact global, 2 LDS)
-VARIANTS = [(1, 0, 2), (1, 0, 0), (1, 0, 1), (1, 64, 2), (0, 1024, 0), (0, 1024, 1), (0, 1024, 2), (0, 512, 0), (0, 512, 2)]
+#  a fourth entry: split = 1 — two waves per chunk in the 512-thread lane kernel (round 6)
+VARIANTS = [(1, 0, 2), (1, 0, 0), (1, 0, 1), (1, 64, 2), (0, 1024, 0), (0, 1024, 1), (0, 1024, 2), (0, 512, 0), (0, 512, 2),
+            (0, 512, 0, 1), (0, 512, 1, 1), (0, 512, 2, 1)]
 
 
-@pytest.mark.parametrize("quad,workgroup,table_mode", VARIANTS)
-def test_every_launch_variant_matches_the_oracle(O, case, quad, workgroup, table_mode):
+def _tune(ndt, v):
+    quad, workgroup, table_mode = v[:3]
+    ndt.setTuning(workgroup=workgroup, table_mode=table_mode, quad=quad, split=(v[3] if len(v) > 3 else 0))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_every_launch_variant_matches_the_oracle(O, case, variant):
     """The same derivative pass and the same align through every kernel instantiation (kernel x workgroup size x where the
     leaf records are read from): oracle tolerances for one pass, north_star bar and equal iteration counts for align."""
     res = 5.0
     ndt = make_ndt(res)
-    ndt.setTuning(workgroup=workgroup, table_mode=table_mode, quad=quad)
+    _tune(ndt, variant)
     ndt.setInputTarget(synth.as_pointxyzi(case.target))
     ndt.setInputSource(synth.as_pointxyzi(case.source))
     ref = O.VoxelGridCovariance(case.target, res)
@@ -277,10 +284,9 @@ def test_launch_variants_agree_with_each_other(case, neighborhood):
     res = 5.0
     out, aligned = {}, {}
     for v in VARIANTS:
-        quad, workgroup, table_mode = v
         ndt = make_ndt(res)
         ndt.setNeighborhoodSearchMethod(getattr(L, neighborhood))
-        ndt.setTuning(workgroup=workgroup, table_mode=table_mode, quad=quad)
+        _tune(ndt, v)
         ndt.setInputTarget(synth.as_pointxyzi(case.target))
         ndt.setInputSource(synth.as_pointxyzi(case.source))
         res_v = []
