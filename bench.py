@@ -149,6 +149,29 @@ def make_comm(lib, dist, rank, world, dev_index):
     return box["comm"], f"lsr_comm_all_gather_records / lsr_align_batch_sharded / lsr_set_input_target_bcast: ncclAllGather + ncclBroadcast of the library's own communicator ({kind})"
 
 
+LDS_PEAK_GBS = 256 * 128 * 2.4   # 256 CUs x 128 B per clock x 2.4 GHz = 78 643 GB/s (MI355X_MICROARCH.md: LDS bandwidth per CU)
+SIMDS, CLOCK_MHZ = 1024.0, 2400.0
+LDS_BYTES_PER_PAIR = 50          # one (point, voxel) pair read from the LDS image: 2-byte cell -> slot entry + 48-byte leaf record
+
+
+def price_pass(us, pairs, valu_insts=None, traffic_bytes=None, table_in_lds=True):
+    """Every resource that can bind a derivative launch, each as a fraction of ITS peak (no SURVEY-8d bytes priced
+    against HBM where the records are gathered from LDS): VALU issue (wave-instructions x 4 cycles / SIMD-cycles of the launch), LDS
+    bandwidth (pairs x 50 B / 78.6 TB/s; global-table kernels: none), HBM (the counters' bytes / 8 TB/s).  `binding` = the largest of
+    them, or "latency" when none reaches 0.35 (the launch is a chain of dependent latencies: boundary, head read, controller,
+    gather -> exp -> weight)."""
+    r = {}
+    if valu_insts:
+        r["frac_valu"] = valu_insts * 4.0 / (SIMDS * us * CLOCK_MHZ)
+    r["frac_lds"] = (pairs * LDS_BYTES_PER_PAIR / (us * 1e-6) / 1e9 / LDS_PEAK_GBS) if table_in_lds else 0.0
+    if traffic_bytes:
+        r["frac_hbm_traffic"] = traffic_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+    cands = {"valu": r.get("frac_valu", 0.0), "lds": r["frac_lds"], "hbm": r.get("frac_hbm_traffic", 0.0)}
+    top = max(cands, key=cands.get)
+    r["binding"] = top if cands[top] >= 0.35 else "latency"
+    return r
+
+
 def pct(v, q):
     return float(np.percentile(np.asarray(v, np.float64), q))
 
@@ -484,7 +507,7 @@ def main():
         # the fed-chip figures next to the single-scan one: the derivative kernel on the workloads that fill the chip
         if isinstance(out.get("roofline"), dict):
             cr = (cfg4 or {}).get("chain_roofline") if isinstance(cfg4, dict) else None
-            if isinstance(cr, dict) and "frac" in cr:
+            if isinstance(cr, dict) and "achieved" in cr:
                 try:   # counter traffic of the lane kernel on a 16-member launch (tools/pmc_ndt.sh on tools/trace_probe.py)
                     pb = json.load(open(PMC_FILE)).get("batch")
                     if pb and pb.get("bytes_per_launch"):
@@ -499,31 +522,57 @@ def main():
                 # the VALU issue utilisation of its kernel — wave-instructions per member-pass x 4 issue cycles / (1024 SIMDs x time
                 # per member-pass at 2.4 GHz) — which is the roofline that actually binds this kernel
                 rl = out["roofline"]
-                rl["batch_frac"] = cr["frac"]; rl["batch_chain_ms"] = cr["chain_ms"]; rl["batch_member_passes"] = cr["member_passes"]
+                rl["batch_chain_ms"] = cr["chain_ms"]; rl["batch_member_passes"] = cr["member_passes"]
                 rl["batch_us_per_member_pass"] = cr["us_per_member_pass"]
+                rl["batch_algorithmic_8d_GBps"] = cr["achieved"]   # SURVEY 8d bytes per second: NOT an HBM utilisation (the records come from LDS)
                 if cr.get("traffic"):
                     rl["batch_traffic_bytes"] = cr["traffic"]
                 try:
                     pb = json.load(open(PMC_FILE)).get("batch") or {}
-                    if pb.get("SQ_INSTS_VALU") and pb.get("SQ_WAVES"):
-                        members = 16.0   # the counter launch holds 16 members (tools/pmc_ndt.sh)
+                    members = 16.0   # the counter launch holds 16 members (tools/pmc_ndt.sh)
+                    pairs_mp = cr["mean_valid_pairs_per_point"] * 30000.0   # valid pairs of one member-pass
+                    pr = price_pass(cr["us_per_member_pass"], pairs_mp, (pb["SQ_INSTS_VALU"] / members) if pb.get("SQ_INSTS_VALU") else None,
+                                    (pb["bytes_per_launch"] / members) if pb.get("bytes_per_launch") else None)
+                    if pb.get("SQ_INSTS_VALU"):
                         rl["batch_valu_insts_per_member_pass"] = pb["SQ_INSTS_VALU"] / members
-                        rl["batch_valu_utilisation"] = (pb["SQ_INSTS_VALU"] / members) * 4.0 / (1024.0 * cr["us_per_member_pass"] * 2400.0)
+                    for k_, v_ in pr.items():
+                        rl["batch_" + k_] = v_
+                        cr[k_] = v_
                 except Exception:
                     pass
+                cr.pop("frac", None); cr.pop("peak", None)   # (the 8d figure stays as `achieved`, labelled; no fraction of HBM is claimed for it)
+                cr["achieved_is"] = "SURVEY.md 8d algorithmic bytes per second of the set's launch chains; the kernel gathers its records from LDS: see frac_valu / frac_lds / frac_hbm_traffic"
             c5 = out.get("cfg5_dense")
             if isinstance(c5, dict) and "avg_pass_us" in c5:
-                out["roofline"]["cfg5"] = {"kernel": "ndt_eval_lane_kernel<7, dense global table, 512> (single 120k-pt scan)", "avg_launch_us": c5["avg_pass_us"],
-                                           "algorithmic_bytes_per_launch": c5.get("algorithmic_bytes_per_pass"), "frac": c5.get("algorithmic_frac_of_hbm_peak"),
-                                           "traffic": c5.get("traffic"), "frac_by_traffic": c5.get("frac_by_traffic")}
-                out["roofline"]["cfg5_frac"] = c5.get("algorithmic_frac_of_hbm_peak")
+                pr5 = {}
+                try:
+                    p5 = json.load(open(PMC_FILE)).get("cfg5") or {}
+                    pr5 = price_pass(c5["avg_pass_us"], c5.get("valid_pairs_per_pass", 0), p5.get("SQ_INSTS_VALU"), p5.get("bytes_per_launch"), table_in_lds=False)
+                except Exception:
+                    pass
+                out["roofline"]["cfg5"] = dict({"kernel": "ndt_eval_lane_kernel<7, dense global table, 512> (single 120k-pt scan)", "avg_launch_us": c5["avg_pass_us"],
+                                                "algorithmic_bytes_per_launch": c5.get("algorithmic_bytes_per_pass"),
+                                                "frac_algorithmic_8d": c5.get("algorithmic_frac_of_hbm_peak"), "traffic": c5.get("traffic")}, **pr5)
+                out["roofline"]["cfg5_frac"] = c5.get("algorithmic_frac_of_hbm_peak")   # global-table gathers: 8d bytes against HBM, as the contract prices them
                 out["roofline"]["cfg5_pass_us"] = c5["avg_pass_us"]
+                for k_, v_ in pr5.items():
+                    out["roofline"]["cfg5_" + k_] = v_
                 if c5.get("traffic"):
                     out["roofline"]["cfg5_traffic_bytes"] = c5.get("traffic")
             sb = out.get("ndt_shared_target_batch")
             if isinstance(sb, dict) and isinstance(sb.get("cfg2_fixed_30"), dict):
-                out["roofline"]["shared_target_batch_frac"] = sb["cfg2_fixed_30"].get("chain_frac_of_hbm_by_8d_bytes")
-                out["roofline"]["shared_target_us_per_member_pass"] = sb["cfg2_fixed_30"].get("us_per_member_pass")
+                st_ = sb["cfg2_fixed_30"]
+                out["roofline"]["shared_target_us_per_member_pass"] = st_.get("us_per_member_pass")
+                out["roofline"]["shared_target_algorithmic_8d_GBps"] = st_.get("chain_algorithmic_8d_GBps")
+                try:   # the same kernel as the candidate set's (lane, LDS table, 512): its counters per member-pass
+                    pb = json.load(open(PMC_FILE)).get("batch") or {}
+                    pr = price_pass(st_["us_per_member_pass"], st_.get("valid_pairs_per_member_pass", 0), (pb["SQ_INSTS_VALU"] / 16.0) if pb.get("SQ_INSTS_VALU") else None,
+                                    (pb["bytes_per_launch"] / 16.0) if pb.get("bytes_per_launch") else None)
+                    for k_, v_ in pr.items():
+                        out["roofline"]["shared_target_" + k_] = v_
+                        st_[k_] = v_
+                except Exception:
+                    pass
         # the 8-GPU projection of the candidate set as top-level scalars: inputs and result
         pj = (cfg4 or {}).get("projected_8gpu") if isinstance(cfg4, dict) else None
         if isinstance(pj, dict) and isinstance(pj.get("block"), dict):
@@ -591,8 +640,11 @@ def roofline_leg(ndt, step, n_src, grid):
             r["wave_cycles_waiting"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
         if pmc.get("SQ_LDS_BANK_CONFLICT") and pmc.get("SQ_ACTIVE_INST_LDS"):
             r["lds_conflict_frac_of_lds_active"] = pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_ACTIVE_INST_LDS"]   # bank-conflict cycles / LDS-active cycles
+        r.update(price_pass(avg_us, pairs, pmc.get("SQ_INSTS_VALU"), r["traffic"]))
+        r["bound"] = r["binding"] + (" (boundary + head read + controller + one dependent LDS gather)" if r["binding"] == "latency" else "")
     except Exception:
         pass
+    r["frac_is"] = "SURVEY.md 8d ALGORITHMIC bytes / launch time / 8 TB/s (the contract's figure); what binds the kernel: `binding`, frac_valu / frac_lds / frac_hbm_traffic"
     return r
 
 
@@ -713,7 +765,8 @@ def shared_target_leg(lib, make_ndt, owner, src_dev, g16, n_src_pts, torch, tgt_
                      "one_by_one_ms_per_registration": 1e3 * float(np.median(t1)), "speedup_vs_one_by_one": float(np.sum(t1)) / tb,
                      "same_bits_as_one_by_one": same, "member_passes": int(sum(passes)), "launches": int(prof["deriv_launches"]),
                      "chain_ms": ms_chain, "us_per_member_pass": 1e3 * ms_chain / max(1, sum(passes)),
-                     "chain_frac_of_hbm_by_8d_bytes": alg / (ms_chain * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                     "valid_pairs_per_member_pass": float(sum(e * p for e, p in zip(passes, pairs))) / max(1, sum(passes)),
+                     "chain_algorithmic_8d_GBps": alg / (ms_chain * 1e-3) / 1e9}   # SURVEY 8d bytes per second (gathers served from LDS: not an HBM utilisation)
         for r in regs:
             r.close()
     out["what"] = ("the stream's scans as ONE set against the shared 10-frame submap: lsr_set_input_source_batch + lsr_align_batch per set, "
@@ -1087,6 +1140,7 @@ def cfg5_leg(make_ndt, dense, torch, synth):
               "set_input_target_ms": 1e3 * float(np.median(tt)), "set_input_target_first_ms": 1e3 * t_first,
               "newton_iterations": r.last_result["iterations"], "derivative_passes": r.last_result["n_evaluations"],
               "avg_pass_us": avg_us, "algorithmic_bytes_per_pass": alg, "algorithmic_frac_of_hbm_peak": alg / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+              "valid_pairs_per_pass": int(p["deriv_pairs"]),
               "error_vs_truth": {"translation_m": e[0], "rotation_rad": e[1]},
               "what": "cfg 5: 120000-pt 64-line scan (vg 0.1) vs 20-frame submap, ndt_resolution 2.0, transformation_epsilon 0.01"})
     try:
@@ -1488,8 +1542,8 @@ def cfg4_chain_roofline(lib, regs, hs, nloc, G, srcs, fptr):
     achieved = alg / (ms * 1e-3) / 1e9
     return {"kernel": "ndt_eval_lane_kernel<7, LDS table, 512> (one lane per point, the set's two launch chains)",
             "members": nloc, "launches": prof["deriv_launches"], "member_passes": member_passes, "chain_ms": ms,
-            "us_per_member_pass": 1e3 * ms / member_passes, "algorithmic_bytes": alg, "bound": "valu (lds-gather)", "priced_against": "hbm",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "us_per_member_pass": 1e3 * ms / member_passes, "algorithmic_bytes": alg,
+            "achieved": achieved, "unit": "GB/s",
             "mean_valid_pairs_per_point": sum(p for _, p in per) / max(1, sum(n_pts)),
             "note": "hipEvents on the lead object's stream around the set's launch chains as production runs them (two chains on two streams: "
                     "before the state uploads -> both chains joined), best of 3; bytes per SURVEY.md 8d"}

@@ -84,7 +84,8 @@ def test_cfg2_properties(cfg12):
     # idempotence: starting from the answer, the answer does not move
     ndt.align(T)
     dt, ang = pose_delta(ndt.getFinalTransformation(), T)
-    assert dt < 2e-3 and ang < 2e-4
+    print("cfg 2 idempotence: %.2e m %.2e rad" % (dt, ang))
+    assert dt < 1e-3 and ang < 1e-4   # the north_star bar itself
     # rigid-motion recovery: move the source by a known transform, the estimate moves by its inverse
     D = synth.pose_matrix(0.15, -0.1, 0.02, 0.01).astype(np.float32)
     moved = (c.source - D[:3, 3]) @ D[:3, :3]          # D^-1 applied to the scan
