@@ -15,6 +15,7 @@
 #include <pclomp/ndt_omp.h>
 #include <pclomp/gicp_omp.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -203,7 +204,157 @@ int main(int argc, char** argv) {
       first = false;
       pos = J.find_key("truth_rowmajor", pos);
     }
-    std::fprintf(f, "\n]\n");
+    std::fprintf(f, "\n],\n");
+  }
+  {  // ---- the frontend loop over a drive: ScanMatcherComponent::receiveCloud + ::updateMap (scanmatcher_component.cpp:296-356, 436-481)
+     // with the map update applied before the next scan (tests/test_frontend_stream_gpu.py, hand-over lag 0)
+    const size_t at = J.find_key("frontend_stream", 0);
+    const double res = J.number("ndt_resolution", at), eps = J.number("eps", at);
+    const int mi = (int)J.number("max_iterations", at), window = (int)J.number("num_targeted_cloud", at);
+    const float vg_in = (float)J.number("vg_size_for_input", at), vg_map = (float)J.number("vg_size_for_map", at);
+    const double rmin = J.number("scan_min_range", at), rmax = J.number("scan_max_range", at), trans_upd = J.number("trans_for_mapupdate", at);
+    std::vector<Cloud::Ptr> submaps;            // filtered keyframes, pose-local
+    std::vector<Eigen::Matrix4f> submap_pose;
+    size_t pos = J.find_key("frames", at);
+    const size_t scans_at = J.find_key("scans", at);
+    for (;;) {
+      const size_t t = J.find_key("frame_cloud", pos + 1);
+      if (t == std::string::npos || t > scans_at) break;
+      pos = t;
+      submaps.push_back(load(in, J.str("frame_cloud", pos)));
+      submap_pose.push_back(to_matrix(J.array("pose_colmajor", pos)));
+    }
+    auto assemble = [&](Cloud& target) {   // newest first, each moved by its pose (:448-464)
+      target.clear();
+      const int n = (int)submaps.size();
+      for (int k = n - 1; k >= 0 && k >= n - window; k--) { Cloud moved; pcl::transformPointCloud(*submaps[k], moved, submap_pose[k]); target += moved; }
+    };
+    NdtProbe ndt;
+    configure(ndt, res, eps, mi);
+    Cloud::Ptr target(new Cloud);
+    assemble(*target);
+    ndt.setInputTarget(target);
+    Eigen::Matrix4f pose = to_matrix(J.array("guess0_colmajor", at));
+    float key_position[3] = {submap_pose.back().data()[12], submap_pose.back().data()[13], submap_pose.back().data()[14]};
+    std::vector<int> update_at;
+    std::fprintf(f, "\"frontend_stream\": {\n\"scans\": [\n");
+    pos = scans_at;
+    int scan_no = 0;
+    bool first = true;
+    for (;;) {
+      const size_t t = J.find_key("scan_cloud", pos + 1);
+      if (t == std::string::npos || t > J.find_key("loop_gate", 0)) break;
+      pos = t;
+      Cloud::Ptr raw = load(in, J.str("scan_cloud", pos)), ranged(new Cloud), filtered(new Cloud);
+      for (const Point& p : raw->points) {   // the subscription's range filter (:210-218): horizontal range, open interval, in double
+        const double r = std::sqrt(std::pow((double)p.x, 2.0) + std::pow((double)p.y, 2.0));
+        if (rmin < r && r < rmax) ranged->push_back(p);
+      }
+      pcl::VoxelGrid<Point> vg;
+      vg.setLeafSize(vg_in, vg_in, vg_in);
+      vg.setInputCloud(ranged);
+      vg.filter(*filtered);
+      ndt.setInputSource(filtered);
+      Cloud aligned;
+      ndt.align(aligned, pose);
+      pose = ndt.getFinalTransformation();
+      std::fprintf(f, "%s{", first ? "" : ",\n");
+      put(f, "final", pose.data(), 16);
+      std::fprintf(f, "\"iterations\": %d, \"points_kept\": %zu}", ndt.getFinalNumIteration(), filtered->size());
+      first = false;
+      const float dx = pose.data()[12] - key_position[0], dy = pose.data()[13] - key_position[1], dz = pose.data()[14] - key_position[2];
+      if (std::sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz) >= trans_upd) {   // :412-434 (Eigen::Vector3d norm), then updateMap
+        for (int k = 0; k < 3; k++) key_position[k] = pose.data()[12 + k];
+        update_at.push_back(scan_no);
+        Cloud::Ptr key(new Cloud);
+        pcl::VoxelGrid<Point> vgm;
+        vgm.setLeafSize(vg_map, vg_map, vg_map);
+        vgm.setInputCloud(ranged);
+        vgm.filter(*key);
+        submaps.push_back(key);
+        submap_pose.push_back(pose);
+        Cloud::Ptr next(new Cloud);
+        assemble(*next);
+        target = next;
+        ndt.setInputTarget(target);
+      }
+      scan_no++;
+    }
+    std::fprintf(f, "\n],\n");
+    std::vector<double> ua(update_at.begin(), update_at.end());
+    put(f, "update_at", ua.data(), ua.size(), true);
+    std::fprintf(f, "},\n");
+  }
+  {  // ---- the loop gate over a route: GraphBasedSlamComponent::searchLoop (graph_based_slam_component.cpp:164-252), NDT backend
+    const size_t at = J.find_key("loop_gate", 0);
+    const double thr = J.number("threshold_loop_closure_score", at), dist_lc = J.number("distance_loop_closure", at),
+                 range = J.number("range_of_searching_loop_closure", at);
+    const int num = (int)J.number("search_submap_num", at);
+    const float leaf = (float)J.number("voxel_leaf_size", at);
+    struct Sub { Cloud::Ptr cloud; Eigen::Matrix4f pose; double position[3]; double distance; };
+    std::vector<Sub> subs;
+    size_t pos = J.find_key("submaps", at);
+    for (;;) {
+      const size_t t = J.find_key("submap_cloud", pos + 1);
+      if (t == std::string::npos) break;
+      pos = t;
+      Sub S;
+      S.cloud = load(in, J.str("submap_cloud", pos));
+      const std::vector<double> p3 = J.array("position", pos), q = J.array("orientation_xyzw", pos);
+      for (int k = 0; k < 3; k++) S.position[k] = p3[k];
+      // tf2::fromMsg(geometry_msgs::Pose) = Translation * Quaterniond: Eigen's toRotationMatrix (no normalisation), cast to float (:177-181)
+      const double x = q[0], y = q[1], z = q[2], w = q[3];
+      const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+                   tyz = tz * y, tzz = tz * z;
+      const double M[16] = {1 - (tyy + tzz), txy + twz, txz - twy, 0, txy - twz, 1 - (txx + tzz), tyz + twx, 0, txz + twy, tyz - twx, 1 - (txx + tyy), 0,
+                            p3[0], p3[1], p3[2], 1};   // column-major
+      S.pose = Eigen::Matrix4f::Identity();
+      for (int k = 0; k < 16; k++) S.pose.data()[k] = (float)M[k];
+      S.distance = J.number("distance", pos);
+      subs.push_back(S);
+    }
+    const int n = (int)subs.size();
+    const Sub& latest = subs[n - 1];
+    Cloud::Ptr source(new Cloud);
+    pcl::transformPointCloud(*latest.cloud, *source, latest.pose);   // :176-181
+    int id_min = -1;
+    double min_dist = 1e300;
+    for (int i = 0; i < n; i++) {                                     // :188-205
+      double d = 0;
+      for (int k = 0; k < 3; k++) d += (latest.position[k] - subs[i].position[k]) * (latest.position[k] - subs[i].position[k]);
+      d = std::sqrt(d);
+      if (latest.distance - subs[i].distance > dist_lc && d < range && d < min_dist) { id_min = i; min_dist = d; }
+    }
+    std::fprintf(f, "\"loop_gate\": {\n");
+    if (id_min >= 0) {
+      Cloud::Ptr window(new Cloud), target(new Cloud);
+      for (int j = 0; j <= 2 * num; j++) {                            // :209-222 (the reference guards the lower end only)
+        const int idx = id_min + j - num;
+        if (idx < 0 || idx >= n) continue;
+        Cloud moved;
+        pcl::transformPointCloud(*subs[idx].cloud, moved, subs[idx].pose);
+        *window += moved;
+      }
+      pcl::VoxelGrid<Point> vg;
+      vg.setLeafSize(leaf, leaf, leaf);
+      vg.setInputCloud(window);
+      vg.filter(*target);                                             // :224-226
+      NdtProbe ndt;
+      configure(ndt, J.number("ndt_resolution", at), J.number("eps", at), (int)J.number("max_iterations", at));
+      ndt.setInputTarget(target);
+      ndt.setInputSource(source);
+      Cloud aligned;
+      ndt.align(aligned);                                             // :230 (identity guess)
+      const double fitness = ndt.getFitnessScore();                   // :231
+      const double pair[2] = {(double)id_min, (double)(n - 1)};
+      put(f, "pair_id", pair, 2);
+      put(f, "final", ndt.getFinalTransformation().data(), 16);
+      std::fprintf(f, "\"fitness\": %.17g, \"accepted\": %d, \"n_target_points\": %zu, \"iterations\": %d\n", fitness, (int)(fitness < thr), target->size(),
+                   ndt.getFinalNumIteration());
+    } else {
+      std::fprintf(f, "\"pair_id\": [-1, -1], \"final\": [1,0,0,0,0,1,0,0,0,0,1,0,0,0,0,1], \"fitness\": 0, \"accepted\": 0, \"n_target_points\": 0, \"iterations\": 0\n");
+    }
+    std::fprintf(f, "}\n");
   }
   std::fprintf(f, "}\n");
   std::fclose(f);

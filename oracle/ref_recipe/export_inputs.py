@@ -30,6 +30,7 @@ def write_pcd(path, xyz):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg4", type=int, default=64)
+    ap.add_argument("--stream-scans", dest="stream_scans", type=int, default=12, help="scans of the frontend drive (tests/test_frontend_stream_gpu.py: 12)")
     ap.add_argument("--out", default=os.path.join(ROOT, "oracle", "_ref", "inputs"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -57,9 +58,32 @@ def main():
                      "guess_colmajor": np.asarray(cc.guess, np.float32).T.reshape(-1).tolist(),
                      "truth_rowmajor": np.asarray(cc.truth, np.float64).reshape(-1).tolist()})
     cases["cfg4"] = {"resolution": 5.0, "eps": 0.01, "max_iterations": 100, "candidates": cfg4}
+    # ---- round 6: the two SEQUENCES the GPU tests hold against the oracle — the frontend loop over a drive (receiveCloud + updateMap,
+    # tests/test_frontend_stream_gpu.py) and the loop gate over a route (searchLoop, tests/test_loop_closure_gpu.py)
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(16, len(os.sched_getaffinity(0)))) as pool:
+        drive = synth.cfg_frontend_drive(a.stream_scans, pool=pool)
+    fs = {"frames": [], "scans": [], "guess0_colmajor": np.asarray(drive["guess0"], np.float64).T.reshape(-1).tolist(),
+          "ndt_resolution": 5.0, "eps": 0.01, "max_iterations": 35, "vg_size_for_input": 0.2, "vg_size_for_map": 0.1, "trans_for_mapupdate": 1.5,
+          "scan_min_range": 0.1, "scan_max_range": 100.0, "num_targeted_cloud": 10}
+    for k, (fr, P) in enumerate(zip(drive["frames"], drive["frame_poses"])):
+        write_pcd(os.path.join(a.out, "fs_frame_%02d.pcd" % k), fr)
+        fs["frames"].append({"frame_cloud": "fs_frame_%02d.pcd" % k, "pose_colmajor": np.asarray(P, np.float64).T.reshape(-1).tolist()})
+    for k, sc in enumerate(drive["scans"]):
+        write_pcd(os.path.join(a.out, "fs_scan_%02d.pcd" % k), sc)
+        fs["scans"].append({"scan_cloud": "fs_scan_%02d.pcd" % k})
+    cases["frontend_stream"] = fs
+    route = synth.make_loop_route()
+    lg = {"submaps": [], "threshold_loop_closure_score": 1.0, "distance_loop_closure": 20.0, "range_of_searching_loop_closure": 10.0,
+          "search_submap_num": 2, "voxel_leaf_size": 0.2, "ndt_resolution": 5.0, "eps": 0.01, "max_iterations": 100}
+    for k, sm in enumerate(route):
+        write_pcd(os.path.join(a.out, "lg_submap_%02d.pcd" % k), sm["cloud"])
+        lg["submaps"].append({"submap_cloud": "lg_submap_%02d.pcd" % k, "position": [float(v) for v in sm["position"]],
+                              "orientation_xyzw": [float(v) for v in sm["orientation"]], "distance": float(sm["distance"])})
+    cases["loop_gate"] = lg
     with open(os.path.join(a.out, "cases.json"), "w") as f:
         json.dump(cases, f)
-    print("wrote", a.out, "(%d cfg-4 candidates)" % len(cfg4))
+    print("wrote", a.out, "(%d cfg-4 candidates, %d drive scans, %d route submaps)" % (len(cfg4), len(fs["scans"]), len(lg["submaps"])))
 
 
 if __name__ == "__main__":

@@ -44,6 +44,19 @@ def main(path=None, out_dir=None):
                             converged=np.asarray([bool(x["converged"]) for x in c]), fitness=np.asarray([x["fitness"] for x in c], np.float64),
                             truth=np.stack([np.asarray(x["truth_rowmajor"], np.float64).reshape(4, 4) for x in c]))
         wrote.append("ref_cfg4_candidates_oracle.npz")
+    if R.get("frontend_stream"):
+        fsr = R["frontend_stream"]
+        np.savez_compressed(os.path.join(out_dir, "ref_frontend_stream.npz"),
+                            poses=np.stack([mat(x["final"]) for x in fsr["scans"]]), iterations=np.asarray([x["iterations"] for x in fsr["scans"]], np.int32),
+                            points_kept=np.asarray([x["points_kept"] for x in fsr["scans"]], np.int32),
+                            update_at=np.asarray(fsr["update_at"], np.int32))
+        wrote.append("ref_frontend_stream.npz")
+    if R.get("loop_gate"):
+        lgr = R["loop_gate"]
+        np.savez_compressed(os.path.join(out_dir, "ref_loop_gate.npz"), pair_id=np.asarray(lgr["pair_id"], np.int32), final=mat(lgr["final"]),
+                            fitness=float(lgr["fitness"]), accepted=bool(lgr["accepted"]), n_target_points=int(lgr["n_target_points"]),
+                            iterations=int(lgr["iterations"]))
+        wrote.append("ref_loop_gate.npz")
     print("wrote", wrote, "into", out_dir)
     return wrote
 

@@ -42,6 +42,9 @@ struct PointCloud {
   std::size_t size() const { return points.size(); }
   const PointT& operator[](std::size_t i) const { return points[i]; }
   PointT& operator[](std::size_t i) { return points[i]; }
+  void push_back(const PointT& p) { points.push_back(p); }
+  void clear() { points.clear(); }
+  PointCloud& operator+=(const PointCloud& o) { points.insert(points.end(), o.points.begin(), o.points.end()); return *this; }
 };
 
 using Indices = std::vector<int>;   // pcl::Indices (PCL 1.12: std::vector<index_t>, index_t = int)

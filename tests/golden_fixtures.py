@@ -30,3 +30,15 @@ def load_golden(name: str):
         print("[golden] %s: REFERENCE fixture %s" % (name, ref))
         return merged, "reference"
     return np.load(orc), "oracle"
+
+
+def load_reference(name: str):
+    """-> dict of arrays from tests/golden/ref_<name>.npz (a dump of the REFERENCE's own code, oracle/ref_recipe) or None when no such
+    dump has been made.  For the sequences whose oracle side is computed live by the tests (the frontend drive, the loop gate): the
+    tests hold the device to the oracle always and to the reference as well once the file exists."""
+    path = os.path.join(golden_dir(), "ref_" + name + ".npz")
+    if not os.path.exists(path):
+        return None
+    r = np.load(path)
+    print("[golden] %s: REFERENCE dump %s" % (name, path))
+    return {k: r[k] for k in r.files}

@@ -108,6 +108,14 @@ def test_frontend_stream_matches_the_oracle_on_every_scan(drive):
         dt, ang = pose_delta(a, t)
         assert dt <= 0.05 and ang <= 2e-3, (j, dt, ang)
     print("frontend stream: worst GPU-vs-oracle pose difference over %d scans: %.2e m %.2e rad" % (len(gpu.poses), worst[0], worst[1]))
+    # ... and against the REFERENCE's own run of the same drive, once oracle/ref_recipe has dumped it (make -C oracle ref)
+    from golden_fixtures import load_reference
+    ref = load_reference("frontend_stream")
+    if ref is not None and len(ref["poses"]) == len(gpu.poses):
+        assert gpu.update_at == ref["update_at"].tolist() and gpu.points_kept == ref["points_kept"].tolist()
+        for j, (a, b) in enumerate(zip(gpu.poses, ref["poses"])):
+            dt, ang = pose_delta(a, b)
+            assert dt <= 1e-3 and ang <= 1e-4, ("reference", j, dt, ang)
 
 
 def test_host_and_device_payloads_give_the_same_stream(drive):

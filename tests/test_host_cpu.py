@@ -436,6 +436,34 @@ def test_reference_dumper_is_well_formed():
     cm = open(os.path.join(rec, "CMakeLists.txt")).read()
     assert "dump_fixtures.cpp" in cm and "src/pclomp" in cm
     assert "ref:" in open(os.path.join(ROOT, "oracle", "Makefile")).read()
+    # round 6: the two SEQUENCES are part of the dump — the frontend drive (receiveCloud + updateMap) and the loop gate (searchLoop) —
+    # and the import step turns them into the files tests/golden_fixtures.py:load_reference() looks for
+    src = open(os.path.join(rec, "dump_fixtures.cpp")).read()
+    assert '"frontend_stream"' in src.replace("\\", "") and '"loop_gate"' in src.replace("\\", "")
+    import importlib.util
+    import json
+    import tempfile
+    spec = importlib.util.spec_from_file_location("import_results", os.path.join(rec, "import_results.py"))
+    imp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(imp)
+    eye = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 2.5, 0, 0, 1]   # column-major, x = 2.5
+    fake = {"frontend_stream": {"scans": [{"final": eye, "iterations": 6, "points_kept": 100}, {"final": eye, "iterations": 7, "points_kept": 90}], "update_at": [1]},
+            "loop_gate": {"pair_id": [1, 20], "final": eye, "fitness": 0.1, "accepted": 1, "n_target_points": 1234, "iterations": 5}}
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "results.json"), "w") as f:
+            json.dump(fake, f)
+        wrote = imp.main(os.path.join(d, "results.json"), d)
+        assert "ref_frontend_stream.npz" in wrote and "ref_loop_gate.npz" in wrote
+        os.environ["LSR_GOLDEN_DIR"] = d
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from golden_fixtures import load_reference
+            fs, lg = load_reference("frontend_stream"), load_reference("loop_gate")
+        finally:
+            del os.environ["LSR_GOLDEN_DIR"]
+        assert fs["poses"].shape == (2, 4, 4) and fs["poses"][0][0, 3] == 2.5 and fs["update_at"].tolist() == [1] and fs["points_kept"].tolist() == [100, 90]
+        assert lg["pair_id"].tolist() == [1, 20] and bool(lg["accepted"]) and int(lg["n_target_points"]) == 1234 and lg["final"][0, 3] == 2.5
+        assert load_reference("no_such_dump") is None
 
 
 def test_c_abi_argument_validation_needs_no_device():

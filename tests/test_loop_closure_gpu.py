@@ -68,6 +68,17 @@ def test_search_loop_matches_the_oracle_ndt(route):
     _check_edge(edges[0], ref[0])
     e = edges[0]
     assert e.accepted and e.pair_id[1] == len(route) - 1
+    # ... and against the REFERENCE's own searchLoop on this route, once oracle/ref_recipe has dumped it (make -C oracle ref)
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_fixtures import load_reference
+    rr = load_reference("loop_gate")
+    if rr is not None:
+        assert tuple(int(v) for v in rr["pair_id"]) == e.pair_id and int(rr["n_target_points"]) == e.n_target_points and bool(rr["accepted"]) == e.accepted
+        dt, dr = pose_delta(e.final_transformation, rr["final"])
+        assert dt <= TOL_T and dr <= TOL_R, ("reference", dt, dr)
+        assert e.fitness_score == pytest.approx(float(rr["fitness"]), rel=1e-3)
     # the edge undoes the drift: relative pose == ground-truth relative pose of the two submaps
     truth = np.linalg.inv(route[e.pair_id[0]]["truth"]) @ route[-1]["truth"]
     dt, dr = pose_delta(e.relative_pose, truth)
