@@ -281,6 +281,28 @@ __global__ __launch_bounds__(256) void gicp_cov_from_nbr_kernel(const float* __r
   cov_finish(S, k, gicp_eps, cov + (size_t)i * 9);
 }
 
+// The start of an align in ONE launch (round 6; a copy, this kernel and a fill until then: two launches and their gaps less on a chain of
+// short launches): the iteration block travels in the kernel arguments and is written to its device home by workgroup 0, the pair
+// counters / work-list head are zeroed, and output = guess * input as below.
+static_assert(sizeof(IterBlock) <= 3072, "IterBlock travels in the kernel arguments (4 KiB limit)");
+__global__ __launch_bounds__(256) void gicp_begin_align_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                                                               const IterBlock blk, IterBlock* __restrict__ d_blk, int* __restrict__ zero_words, int n_zero,
+                                                               float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz) {
+  if (blockIdx.x == 0) {
+    const unsigned int* src = reinterpret_cast<const unsigned int*>(&blk);
+    unsigned int* dst = reinterpret_cast<unsigned int*>(d_blk);
+    for (int k = threadIdx.x; k < (int)(sizeof(IterBlock) / 4); k += 256) dst[k] = src[k];
+    for (int k = threadIdx.x; k < n_zero; k += 256) zero_words[k] = 0;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* G16 = blk.out.G;
+  const float a = x[i], b = y[i], c = z[i];
+  ox[i] = xform_rn(G16[0], G16[4], G16[8], G16[12], a, b, c);
+  oy[i] = xform_rn(G16[1], G16[5], G16[9], G16[13], a, b, c);
+  oz[i] = xform_rn(G16[2], G16[6], G16[10], G16[14], a, b, c);
+}
+
 // output = guess * input (fp32, reference order of operations)
 __global__ __launch_bounds__(256) void gicp_apply_guess_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                const float* __restrict__ z, int n, const float* __restrict__ G16,
@@ -1414,9 +1436,6 @@ struct GicpChain {
     O.token = token;
     hb->st.max_inner = h->gicp.max_inner;
     gicp_begin_outer(*hb);
-    LSR_HIP(hipMemcpyAsync(d_blk, hb, sizeof(IterBlock), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(gicp_apply_guess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->source.x(), h->source.y(), h->source.z(),
-                       n, d_blk->out.G, ws.out.x(), ws.out.y(), ws.out.z());
     thr2 = (float)(h->gicp.max_corr_dist * h->gicp.max_corr_dist);
 
     // ---- launch chain.  A group = one correspondence pass + `steps` x (accumulate, update); every launch gates itself on
@@ -1436,15 +1455,20 @@ struct GicpChain {
     corr_fused = ball && corr_fused_on;
     d_work = nullptr;
     d_shards = nullptr;
+    int* zero_words = nullptr;
+    int n_zero = 0;
     if (corr_fused) {   // no work list; the pair counters start an align at zero
       if ((st = ws.count_shards.reserve((size_t)GICP_COUNT_SHARDS * GICP_SHARD_STRIDE))) return st;
       d_shards = ws.count_shards.p;
-      LSR_HIP(hipMemsetAsync(d_shards, 0, sizeof(int) * GICP_COUNT_SHARDS * GICP_SHARD_STRIDE, s));
+      zero_words = d_shards; n_zero = GICP_COUNT_SHARDS * GICP_SHARD_STRIDE;
     } else if (ball) {
       if ((st = ws.corr_work.reserve((size_t)n + 2))) return st;
       d_work = ws.corr_work.p;
-      LSR_HIP(hipMemsetAsync(d_work, 0, sizeof(int), s));
+      zero_words = d_work; n_zero = 1;
     }
+    // iteration block + zeroed counters + guess-moved source: one launch (gicp_begin_align_kernel)
+    hipLaunchKernelGGL(gicp_begin_align_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h->source.x(), h->source.y(), h->source.z(), n, *hb, d_blk,
+                       zero_words, n_zero, ws.out.x(), ws.out.y(), ws.out.z());
     // the first outer iteration typically needs 3-4 Gauss-Newton steps, later ones one or two; the fused chain needs one step
     // more per outer iteration (the step that finds the loop finished accumulates nothing)
     enqueue_group(fused ? 5 : 4);

@@ -406,6 +406,30 @@ __global__ __launch_bounds__(XS_THREADS) void xs_apply_kernel(const int* __restr
   }
 }
 
+// ... and for arrays of at most one block (the occupied-coarse-cell flags of a scan's neighbour grid: ~1000 entries) the three steps in ONE
+// launch: two launches and their gaps less on a chain of a dozen short launches (GICP setInputSource)
+__global__ __launch_bounds__(XS_THREADS) void xs_single_block_kernel(const int* __restrict__ in, int n, int* __restrict__ out) {
+  __shared__ int s_w[XS_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int first = tid * XS_ITEMS;
+  int v[XS_ITEMS];
+  int tot = 0;
+#pragma unroll
+  for (int j = 0; j < XS_ITEMS; j++) { v[j] = (first + j < n) ? in[first + j] : 0; tot += v[j]; }
+  int inc = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int x = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += x;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int run = inc - tot;
+  for (int w = 0; w < wave; w++) run += s_w[w];
+#pragma unroll
+  for (int j = 0; j < XS_ITEMS; j++) { if (first + j < n) out[first + j] = run; run += v[j]; }
+}
+
 struct LsdPlan { int passes, bits, steps, nblk, C; size_t table_bytes; };
 LsdPlan lsd_plan(size_t n, int end_bit) {
   LsdPlan P;
@@ -541,6 +565,11 @@ int exclusive_scan_i32_lsd(const int* in, int* out, size_t n, DevBuf<char>& temp
   if (n == 0) return LSR_OK;
   const size_t nblocks = (n + XS_CHUNK - 1) / XS_CHUNK;
   if (nblocks > (size_t)INT32_MAX / 2) { set_last_error("exclusive scan: too many elements"); return LSR_ERR_INVALID_ARGUMENT; }
+  if (nblocks == 1) {
+    hipLaunchKernelGGL(xs_single_block_kernel, dim3(1), dim3(XS_THREADS), 0, stream, in, (int)n, out);
+    LSR_HIP(hipGetLastError());
+    return LSR_OK;
+  }
   int st = temp.reserve(nblocks * sizeof(int) + 64);
   if (st) return st;
   int* sums = reinterpret_cast<int*>(temp.p);
