@@ -14,4 +14,9 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+mkdir -p $OUT/csv   # the GICP kernels' rows of every counter file, as rocprofv3 wrote them
+for g in fetch write sq tcc; do
+  f=$(find $OUT/$g -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && grep -E "Kernel_Name|gicp_|nn1_|nnb_|xs_" "$f" > $OUT/csv/${TAG}_pmc_gicp_$g.csv
+done
 cd $REPO && python tools/parse_pmc_gicp.py $OUT $TAG

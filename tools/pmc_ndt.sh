@@ -16,4 +16,10 @@ run write WRITE_SIZE
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
 run lds SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# the derivative kernels' rows of every counter file, as rocprofv3 wrote them: what the markdown table and the JSON are made of
+mkdir -p $OUT/csv
+for g in fetch write sq lds tcc; do
+  f=$(find $OUT/$g -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && grep -E "Kernel_Name|ndt_eval" "$f" > $OUT/csv/${TAG}_pmc_ndt_eval_$g.csv
+done
 cd $REPO && python tools/pmc_ndt_parse.py $OUT $TAG

@@ -3,7 +3,7 @@
 # Output: gpurun_out/profiles_<tag>/ (copy into profiles/ afterwards).  PMC passes are separate rocprofv3 runs with
 # --kernel-trace only (tools/pmc_ndt.sh).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 P=$REPO/gpurun_out/profiles_$TAG
 rm -rf $P; mkdir -p $P
@@ -12,12 +12,20 @@ export LSR_BENCH_CACHE_DIR=/tmp/lsr_bench_cache   # synthetic clouds ray-cast on
 # 1. PMC passes on the derivative kernel and on the GICP kernels -> the traffic files bench.py reads (profiles/*.json)
 bash tools/pmc_ndt.sh $TAG > $P/pmc.log 2>&1; tail -4 $P/pmc.log | head -3
 cp gpurun_out/pmc_ndt/${TAG}_pmc_ndt_eval.md gpurun_out/pmc_ndt/pmc_ndt_eval_latest.json $P/
+mkdir -p $P/${TAG}_pmc_csv; cp gpurun_out/pmc_ndt/csv/*.csv $P/${TAG}_pmc_csv/ 2>/dev/null
 cp gpurun_out/pmc_ndt/pmc_ndt_eval_latest.json profiles/pmc_ndt_eval_latest.json
-if [ "${LSR_PROFILE_GICP:-0}" = "1" ]; then   # the GICP kernels did not change in round 5: their counter passes are on request
+if [ "${LSR_PROFILE_GICP:-1}" = "1" ]; then   # (round 6: retaken on this round's build)
 bash tools/pmc_gicp.sh $TAG > $P/pmc_gicp.log 2>&1; tail -3 $P/pmc_gicp.log | cut -c1-300
 cp gpurun_out/pmc_gicp/${TAG}_pmc_gicp.md gpurun_out/pmc_gicp/pmc_gicp_latest.json $P/
+cp gpurun_out/pmc_gicp/csv/*.csv $P/${TAG}_pmc_csv/ 2>/dev/null
 cp gpurun_out/pmc_gicp/pmc_gicp_latest.json profiles/pmc_gicp_latest.json
 fi
+# 1b. the cfg-5 pass in its three forms (one lane per point, two waves per chunk, four lanes per point) and the two builder chains
+bash tools/pmc_cfg5.sh > $P/pmc_cfg5.log 2>&1
+{ echo "# cfg 5 (120 000-point scan, dense global table): the derivative pass in three forms — $TAG"; echo; echo "us per pass (hipEvents, tools/cfg5_mode_probe.py):"; echo '```'; grep "us per pass" gpurun_out/pmc_cfg5/timing.txt; echo '```'; echo; echo "Per-launch medians of the counters (separate rocprofv3 --kernel-trace --pmc passes; raw rows: ${TAG}_pmc_csv/cfg5_*.csv):"; echo; cat gpurun_out/pmc_cfg5/table.md; } > $P/${TAG}_pmc_cfg5.md
+for f in gpurun_out/pmc_cfg5/csv/*.csv; do cp $f $P/${TAG}_pmc_csv/cfg5_$(basename $f); done
+bash tools/pmc_builders.sh $TAG > $P/pmc_builders.log 2>&1
+cp gpurun_out/pmc_builders/${TAG}_pmc_builders.md $P/; cp gpurun_out/pmc_builders/csv/*.csv $P/${TAG}_pmc_csv/ 2>/dev/null
 # 2. default bench run (the driver's command), JSON line kept
 timeout 900 python bench.py > $P/${TAG}_bench_final.json 2> $P/bench.err; echo "bench rc=$?"
 # 3. kernel-trace summaries
