@@ -61,4 +61,7 @@ fi
 # 4. two ranks sharing this one device (gloo): exercises the self-spawn + sharded C-ABI path
 LSR_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 > $P/${TAG}_bench_2ranks_one_device.json 2> $P/bench2.err; echo "bench2 rc=$?"
 rm -f $P/*.stderr
+# the raw rocprofv3 trees are tens of MB each (gpurun merges at most 64 MiB back): what is kept of them is under $P
+rm -rf gpurun_out/pmc_ndt gpurun_out/pmc_gicp gpurun_out/pmc_cfg5 gpurun_out/pmc_builders
+du -sh $P gpurun_out
 ls -la $P
