@@ -1591,8 +1591,11 @@ def cfg4_projected_8gpu(lib, dev_index, regs, tgts, srcs, G, t_set, fptr):
         out[name] = {"share_ms": [round(1e3 * t, 4) for t in times], "max_share_ms": 1e3 * max(times), "mean_share_ms": 1e3 * sum(times) / len(times),
                      "set_ms_on_one_gpu": 1e3 * t_set, "projected_speedup_8_gpus": t_set / max(times)}
     lib.lsr_comm_destroy(comm)
+    out["plan_is_the_block_partition"] = bool(plans["block"] == plans["planned_longest_first"])
     out["note"] = ("shares run one after the other on ONE GPU; projected_speedup = 64-set time on one GPU / slowest share, before the 4 KiB "
-                   "all-gather (~0.03 ms).  north_star asks >= 6x at 8 GPUs")
+                   "all-gather (~0.03 ms).  north_star asks >= 6x at 8 GPUs.  The candidates of cfg 4 differ by a few hundred target points in "
+                   "661 k: costs within 2 % of each other are ties for lsr_shard_plan, whose plan is then the block partition (the two rows "
+                   "differ by measurement noise only)")
     return out
 
 

@@ -288,7 +288,8 @@ typedef struct lsr_shard_record {   /* 64 bytes */
 void lsr_shard_range(int n_items, int world, int rank, int* first, int* count);
 /* Cost-aware plan for batches whose members differ in size (the ring gate's candidates: targets from a few thousand to
  * 661 k points): longest-processing-time-first — items by cost descending (ties: lower index), each to the least-loaded
- * rank (ties: lower rank).  cost may be NULL (all equal: round-robin).  owner[i] = rank of item i; order = the batch
+ * rank (ties: lower rank).  cost may be NULL; without costs, or with costs the model cannot tell apart (spread within 2 % of the
+ * largest), the plan is the block partition of lsr_shard_range.  owner[i] = rank of item i; order = the batch
  * regrouped rank by rank, each rank's items longest first; rank r owns order[rank_first[r] .. rank_first[r+1]).
  * Device-free and deterministic: every rank computes the same plan from the same costs. */
 int lsr_shard_plan(int n_items, const double* cost, int world, int32_t* owner /* n_items */, int32_t* order /* n_items */,

@@ -119,27 +119,43 @@ void lsr_shard_range(int n_items, int world, int rank, int* first, int* count) {
 }
 
 // Longest-processing-time-first: items by cost descending (ties: lower index first), each to the rank with the least load so
-// far (ties: lower rank).  Greedy LPT is within 4/3 - 1/(3 world) of the best makespan; with equal costs it is round-robin.
+// far (ties: lower rank).  Greedy LPT is within 4/3 - 1/(3 world) of the best makespan.  Costs within 2 % of each other (or none) give
+// the block partition.
 int lsr_shard_plan(int n_items, const double* cost, int world, int32_t* owner, int32_t* order, int32_t* rank_first) {
   if (n_items < 0 || world < 1 || (n_items > 0 && (!owner || !order)) || !rank_first) { lsr::set_last_error("bad shard-plan arguments"); return LSR_ERR_INVALID_ARGUMENT; }
   std::vector<int> by_cost((size_t)n_items);
   for (int i = 0; i < n_items; i++) by_cost[i] = i;
   if (cost) {
-    for (int i = 0; i < n_items; i++)
+    double lo = 0.0, hi = 0.0;
+    for (int i = 0; i < n_items; i++) {
       if (!(cost[i] >= 0.0) || std::isinf(cost[i])) { lsr::set_last_error("shard-plan costs must be finite and non-negative"); return LSR_ERR_INVALID_ARGUMENT; }
-    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+      lo = (i == 0) ? cost[i] : std::min(lo, cost[i]);
+      hi = (i == 0) ? cost[i] : std::max(hi, cost[i]);
+    }
+    // Costs the model cannot tell apart (spread within 2 % of the largest: cfg 4's candidates differ by a few hundred target points in
+    // 661 k) are TIES: reshuffling the set by differences below the noise of the cost model buys nothing — the pass counts of the members,
+    // which the sizes do not predict, decide the shares — so the plan is then the block partition (round 6; until then equal costs gave
+    // round-robin, whose shares are as arbitrary and not contiguous)
+    if (hi - lo <= 0.02 * hi) cost = nullptr;
+    else std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  }
+  if (!cost) {   // no costs / tied costs: the block partition of lsr_shard_range
+    rank_first[0] = 0;
+    for (int r = 0; r < world; r++) {
+      int f = 0, c = 0;
+      lsr_shard_range(n_items, world, r, &f, &c);
+      for (int k = f; k < f + c; k++) { owner[k] = r; order[k] = k; }
+      rank_first[r + 1] = f + c;
+    }
+    return LSR_OK;
   }
   std::vector<double> load((size_t)world, 0.0);
   std::vector<int> count((size_t)world, 0);
   for (int k = 0; k < n_items; k++) {
     int best = 0;
-    if (cost) {
-      for (int r = 1; r < world; r++) if (load[r] < load[best]) best = r;
-    } else {
-      best = k % world;
-    }
+    for (int r = 1; r < world; r++) if (load[r] < load[best]) best = r;
     owner[by_cost[k]] = best;
-    load[best] += cost ? cost[by_cost[k]] : 1.0;
+    load[best] += cost[by_cost[k]];
     count[best]++;
   }
   rank_first[0] = 0;

@@ -59,12 +59,15 @@ def block_plan(n_items: int, world: int) -> ShardPlan:
 
 def shard_plan(costs, world: int) -> ShardPlan:
     """Longest-processing-time-first: items by cost descending (ties: lower index first), each to the rank with the least
-    load so far (ties: lower rank).  Within 4/3 - 1/(3 world) of the best makespan; equal costs give round-robin.  The ring
+    load so far (ties: lower rank).  Within 4/3 - 1/(3 world) of the best makespan; costs within 2 % of each other give the block
+    partition (differences below the noise of the cost model should not reshuffle a set).  The ring
     gate's candidate sets are the case it is for: targets from a few thousand to 661 k points in one set."""
     c = np.asarray(costs, np.float64)
     if c.ndim != 1 or not np.all(np.isfinite(c)) or np.any(c < 0):
         raise ValueError("costs must be a 1-D array of finite non-negative numbers")
     n = len(c)
+    if n == 0 or float(c.max() - c.min()) <= 0.02 * float(c.max()):
+        return block_plan(n, world)   # costs the model cannot tell apart are ties: the block partition (lsr_shard_plan does the same)
     by_cost = np.argsort(-c, kind="stable")
     load = np.zeros(world)
     owner = np.zeros(n, np.int32)

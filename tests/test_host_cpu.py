@@ -290,8 +290,12 @@ def test_shard_plan_is_longest_first_and_the_c_plan_is_the_python_plan():
                     span, lower = P.loads(costs).max(), max(costs.sum() / world, costs.max())
                     assert span <= block_plan(n, world).loads(costs).max() + 1e-9
                     assert span <= (4.0 / 3.0 - 1.0 / (3.0 * world)) * lower + costs.max() * (world > 1) + 1e-9
-    P = shard_plan(np.ones(64), 8)                       # equal costs: round-robin, 8 each (cfg 4 over 8 GPUs)
-    assert [len(P.items(r)) for r in range(8)] == [8] * 8 and P.items(1)[:3] == [1, 9, 17]
+    P = shard_plan(np.ones(64), 8)                       # costs the model cannot tell apart: the block partition, 8 each (cfg 4 over 8 GPUs)
+    assert [len(P.items(r)) for r in range(8)] == [8] * 8 and P.items(1)[:3] == [8, 9, 10]
+    near = 661000.0 + 300.0 * np.sin(np.arange(64.0))    # ... and so are costs within 2 % of each other (cfg 4's own candidates)
+    Pn, Qn = shard_plan(near, 8), c_shard_plan(near, 8)
+    assert Pn.items(3) == list(range(24, 32)) and np.array_equal(Pn.order, Qn.order) and np.array_equal(Pn.rank_first, Qn.rank_first)
+    assert np.array_equal(c_shard_plan(64, 8).order, np.arange(64))   # no costs at all: the same
     costs = _ring_gate_costs(64)                         # the case it is for: block partition vs plan on ring-gate sizes
     assert shard_plan(costs, 8).loads(costs).max() < 0.8 * block_plan(64, 8).loads(costs).max()
     with pytest.raises(ValueError):
