@@ -64,14 +64,15 @@ int defer_members_behind(lsr_handle lead, lsr_handle* members, int count) {
 // Make everything `h` still has in flight on its own stream precede what is enqueued on `lead` next (group launches of a
 // candidate set run on the first member's stream).  An idle stream — the usual case — costs one query and no event.
 int order_lead_after(hipStream_t lead, lsr_handle h) {
-  if (h->stream == lead) return LSR_OK;
   if (h->dep) {
     // everything this member has had enqueued since its last own use went to dep_stream (a group call ordered that stream behind the
-    // member's own one before it started): on the same lead stream there is nothing to order, on another one the event is the order
-    if (h->dep_stream == lead) return LSR_OK;
-    LSR_HIP(hipStreamWaitEvent(lead, h->dep->ev, 0));
+    // member's own one before it started): on the same lead stream there is nothing to order, on another one the event is the order —
+    // also when the member is the lead of THIS call (its own stream is `lead`: the dependency is then settled for good)
+    if (h->dep_stream != lead) LSR_HIP(hipStreamWaitEvent(lead, h->dep->ev, 0));
+    if (h->stream == lead) { h->dep.reset(); h->dep_stream = nullptr; }
     return LSR_OK;
   }
+  if (h->stream == lead) return LSR_OK;
   if (hipStreamQuery(h->stream) == hipSuccess) return LSR_OK;
   LSR_HIP(hipEventRecord(h->ev1, h->stream));
   LSR_HIP(hipStreamWaitEvent(lead, h->ev1, 0));

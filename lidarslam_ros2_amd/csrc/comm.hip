@@ -199,6 +199,7 @@ int lsr_comm_create(const void* id128, int rank, int world, int device_id, lsr_c
     const int rc = r->comm_init_rank(&c->comm, world, id, rank);
     if (rc) { (void)hipStreamDestroy(c->stream); delete c; return rccl_fail("ncclCommInitRank", rc); }
     if (c->d_send.reserve(COMM_PREALLOC) || c->d_recv.reserve(COMM_PREALLOC * (size_t)world) || c->d_header.reserve(8 + (size_t)world) ||
+        hipMemset(c->d_header.p, 0, sizeof(unsigned long long) * (8 + (size_t)world)) != hipSuccess ||   // a header upload that fails announces zero points
         hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess || arm_send(c, COMM_PREALLOC)) {
       (void)r->comm_destroy(c->comm); (void)hipStreamDestroy(c->stream); if (c->ev) (void)hipEventDestroy(c->ev); delete c;
       return LSR_ERR_HIP;
@@ -375,8 +376,12 @@ int lsr_set_input_target_bcast(lsr_comm c, lsr_handle h, const void* pts, size_t
       }
     }
     if (!local_status) { header[0] = (unsigned long long)n; header[1] = (unsigned long long)stride_bytes; }
-    // (a root that failed announces zero points)
-    (void)hipMemcpyAsync(c->d_header.p, header, sizeof(header), hipMemcpyHostToDevice, c->stream);
+    // (a root that failed announces zero points; so does one whose header upload fails: the send words then keep what the last call —
+    // or the zero fill at creation — left there only if that was zero, so they are cleared first)
+    if (hipMemcpyAsync(c->d_header.p, header, sizeof(header), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      fail(LSR_ERR_HIP, "broadcast target: the header could not be uploaded");
+      (void)hipMemsetAsync(c->d_header.p, 0, sizeof(header), c->stream);
+    }
   }
   // 1. header (send and receive buffers are kept apart: out-of-place collectives throughout)
   int rc = r->broadcast(c->d_header.p, c->d_header.p + 2, sizeof(header), /*ncclUint8*/ 1, root, c->comm, c->stream);

@@ -186,3 +186,36 @@ def test_objects_sharing_one_target_from_three_threads():
         for i, got in enumerate(results[k]):
             assert _same(got, alone[k]), ("object", k, "round", i)
     del owner_keep
+
+
+def test_a_member_of_one_set_leads_the_next_set():
+    """The candidate sets rotate: the object that led a set is a member of the next, a member leads it — what one set left in flight
+    on its lead's stream for a member (lsr_set_input_source_batch defers the members' own streams behind it) has to be honoured
+    when that member's stream becomes the lead stream of the following call."""
+    from lidarslam_ros2_amd import NormalDistributionsTransform
+    from lidarslam_ros2_amd.registration import align_fitness_batch, set_input_source_batch, set_input_target_batch
+
+    cases = [synth.small_case(n_source=2000, n_keyframes=3, seed=s) for s in (41, 42, 43, 44)]
+    regs = []
+    for _ in cases:
+        r = NormalDistributionsTransform(device=0)
+        r.setResolution(5.0); r.setTransformationEpsilon(0.01); r.setMaximumIterations(100)
+        regs.append(r)
+    set_input_target_batch(regs, [synth.as_pointxyzi(c.target) for c in cases])
+    sources = [synth.as_pointxyzi(c.source) for c in cases]
+    alone = []
+    for r, c in zip(regs, cases):
+        r.setInputSource(c.source); r.align(c.guess)
+        alone.append((np.array(r.getFinalTransformation()), r.getFinalNumIteration(), r.getFitnessScore()))
+    order = list(range(len(regs)))
+    for rnd in range(12):
+        # every object gets ANOTHER object's source first (from a set led by order[0]) …
+        wrong = order[1:] + order[:1]
+        set_input_source_batch([regs[i] for i in order], [sources[j] for j in wrong])
+        # … and its own one right after, from a set led by what was a member a moment ago
+        order = order[1:] + order[:1]
+        set_input_source_batch([regs[i] for i in order], [sources[i] for i in order])
+        finals, res, fit = align_fitness_batch([regs[i] for i in order], [cases[i].guess for i in order])
+        for k, i in enumerate(order):
+            assert np.array_equal(np.asarray(finals[k]), alone[i][0]), (rnd, i)
+            assert int(res[k]["iterations"]) == alone[i][1] and float(fit[k]) == pytest.approx(alone[i][2], rel=1e-12), (rnd, i)

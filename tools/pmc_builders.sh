@@ -22,7 +22,7 @@ python - "$OUT" "$TAG" <<'PY'
 import collections, csv, glob, os, re, sys
 out, tag = sys.argv[1], sys.argv[2]
 lines = ["# HBM traffic of the builder chains (counters) — " + tag, "",
-         "`2 x FETCH_SIZE + WRITE_SIZE` per kernel launch (medians), separate rocprofv3 `--kernel-trace --pmc` passes (tools/pmc_builders.sh); raw rows: `%s_pmc_csv/%s_pmc_builders_*.csv`." % (tag, tag), ""]
+         "`2 x FETCH_SIZE + WRITE_SIZE` per kernel launch (medians), separate rocprofv3 `--kernel-trace --pmc` passes (tools/pmc_builders.sh); raw rows: `%s_pmc_csv/%s_pmc_builders_*.csv.gz` (compacted by tools/compact_pmc_csv.py)." % (tag, tag), ""]
 for probe, what in (("preprocess", "N1: lsr_set_input_source_frontend on the raw 147 443-point scan (range filter + VoxelGrid(0.2) + setInputSource)"),
                     ("target", "setInputTarget on the 661 519-point 10-frame submap: counting-sort builder (vg_*) and radix builder (grid_builder = 1: leaf_key / rs_* / leaf_*)")):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -22,7 +22,7 @@ cp gpurun_out/pmc_gicp/pmc_gicp_latest.json profiles/pmc_gicp_latest.json
 fi
 # 1b. the cfg-5 pass in its three forms (one lane per point, two waves per chunk, four lanes per point) and the two builder chains
 bash tools/pmc_cfg5.sh > $P/pmc_cfg5.log 2>&1
-{ echo "# cfg 5 (120 000-point scan, dense global table): the derivative pass in three forms — $TAG"; echo; echo "us per pass (hipEvents, tools/cfg5_mode_probe.py):"; echo '```'; grep "us per pass" gpurun_out/pmc_cfg5/timing.txt; echo '```'; echo; echo "Per-launch medians of the counters (separate rocprofv3 --kernel-trace --pmc passes; raw rows: ${TAG}_pmc_csv/cfg5_*.csv):"; echo; cat gpurun_out/pmc_cfg5/table.md; } > $P/${TAG}_pmc_cfg5.md
+{ echo "# cfg 5 (120 000-point scan, dense global table): the derivative pass in three forms — $TAG"; echo; echo "us per pass (hipEvents, tools/cfg5_mode_probe.py):"; echo '```'; grep "us per pass" gpurun_out/pmc_cfg5/timing.txt; echo '```'; echo; echo "Per-launch medians of the counters (separate rocprofv3 --kernel-trace --pmc passes; raw rows: ${TAG}_pmc_csv/cfg5_*.csv.gz, compacted by tools/compact_pmc_csv.py):"; echo; cat gpurun_out/pmc_cfg5/table.md; } > $P/${TAG}_pmc_cfg5.md
 for f in gpurun_out/pmc_cfg5/csv/*.csv; do cp $f $P/${TAG}_pmc_csv/cfg5_$(basename $f); done
 bash tools/pmc_builders.sh $TAG > $P/pmc_builders.log 2>&1
 cp gpurun_out/pmc_builders/${TAG}_pmc_builders.md $P/; cp gpurun_out/pmc_builders/csv/*.csv $P/${TAG}_pmc_csv/ 2>/dev/null
