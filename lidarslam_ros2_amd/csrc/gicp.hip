@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256) void gicp_corr_seeded_kernel(NNGridView G, con
     general = !(isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]));
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     int seeded_reach = -1, seed_lo[3] = {0, 0, 0}, seed_hi[3] = {0, 0, 0};   // self-seeded: the cells the seed was the best of
+    int fq[3] = {0, 0, 0};
     if (!general && seed >= 0) {
       bd = dist2_rn(q[0], q[1], q[2], tx[seed], ty[seed], tz[seed]);
       bi = seed;
@@ -566,7 +567,6 @@ __global__ __launch_bounds__(256) void gicp_corr_seeded_kernel(NNGridView G, con
       // no seed (first outer iteration; a point that had no neighbour within the gate): the best point of the query's own
       // fine cell — of the 3 x 3 x 3 cells around it if that one is empty — is a real point, hence a bound (nn.hip: nn1_ball_body)
       const float ff[3] = {floorf(q[0] * G.inv_cell), floorf(q[1] * G.inv_cell), floorf(q[2] * G.inv_cell)};
-      int fq[3] = {0, 0, 0};
       if (!(fabsf(ff[0]) < 1.0e9f && fabsf(ff[1]) < 1.0e9f && fabsf(ff[2]) < 1.0e9f)) general = true;
       if (!general) {
         for (int a = 0; a < 3; a++) {
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void gicp_corr_seeded_kernel(NNGridView G, con
       // a self-seeded point whose ball stays inside the cells its seed came from has read them already
       bool covered = seeded_reach >= 0;
       for (int a = 0; a < 3; a++) covered = covered && lo[a] >= seed_lo[a] && hi[a] <= seed_hi[a];
-      if (!covered) scan_cells_group16(G, q, lo, hi, gl, bd, bi);
+      if (!covered) scan_cells_group16(G, q, lo, hi, gl, bd, bi, seeded_reach == 0 ? fq : nullptr);   // (its own cell has been offered)
     }
   }
   // the points the seeded search cannot serve, one after the other, all 64 lanes on each (exactly gicp_corr_search_kernel's body)

@@ -517,7 +517,7 @@ __device__ __forceinline__ void nn1_ball_body(const NNGridView& G, const float* 
   const int reach = own_cell_done ? 0 : 1;
   bool covered = true;
   for (int a = 0; a < 3; a++) covered = covered && lo[a] >= fq[a] - reach && hi[a] <= fq[a] + reach;
-  if (!covered) scan_cells_group16(G, q, lo, hi, gl, bd, bi);
+  if (!covered) scan_cells_group16(G, q, lo, hi, gl, bd, bi, own_cell_done ? fq : nullptr);   // (the own cell has been offered)
   if (gl == 0) { idx[i] = bi; d2[i] = bd; }
 }
 __global__ __launch_bounds__(256) void nn1_list_group_kernel(const FitGroup g) {

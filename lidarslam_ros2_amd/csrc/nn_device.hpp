@@ -395,14 +395,17 @@ __device__ __forceinline__ void scan_cell_group16(const NNGridView& G, const flo
 
 // Every point of the fine cells [lo, hi] (<= 8 per axis, clamped to the grid by the caller) offered to the group's best: one lane
 // per (row, coarse segment) — an x-range of <= 8 cells touches at most two coarse cells, and inside one it is contiguous in
-// memory —, the group's candidates laid end to end and read sixteen at a time; then row16_best.  Called by all sixteen lanes.
-__device__ __forceinline__ void scan_cells_group16(const NNGridView& G, const float* q, const int* lo, const int* hi, const int gl, float& bd, int& bi) {
+// memory —, the occupied slots read one after the other by the sixteen lanes; then row16_best.  Called by all sixteen lanes.
+// `skip` (optional): a fine cell the caller has offered already (the query's own cell, scan_cell_group16) — its points are left out.
+__device__ __forceinline__ void scan_cells_group16(const NNGridView& G, const float* q, const int* lo, const int* hi, const int gl, float& bd, int& bi,
+                                                   const int* skip = nullptr) {
   const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;   // >= 1 unless the box misses the grid (then no slot is valid)
   const int n_slots = (ny > 0 && nz > 0 && hi[0] >= lo[0]) ? ny * nz * 2 : 0;
   const unsigned int ny_magic = 65536u / (unsigned int)max(ny, 1) + 1u;
   for (int s0 = 0; s0 < n_slots; s0 += 16) {
     const int slot = s0 + gl;
     int beg = 0, len = 0;
+    int beg2 = 0, len2 = 0;   // the part of the slot's row behind a skipped cell
     if (slot < n_slots) {
       const int cseg = slot & 1, row = slot >> 1;
       const int dz = (int)(((unsigned int)row * ny_magic) >> 16);   // row / ny (row < 128, ny <= 8)
@@ -415,46 +418,47 @@ __device__ __forceinline__ void scan_cells_group16(const NNGridView& G, const fl
           const int* fs = G.fine_start + (size_t)blk * FINE_STRIDE + (((y & 7) << 3) | ((z & 7) << 6));
           beg = fs[xa];
           len = fs[xb + 1] - beg;
+          if (skip && y == skip[1] && z == skip[2] && cx == (skip[0] >> 3)) {
+            const int sx = skip[0] & 7;
+            if (sx >= xa && sx <= xb) {
+              len = fs[sx] - beg;
+              beg2 = fs[sx + 1];
+              len2 = fs[xb + 1] - beg2;
+            }
+          }
         }
       }
     }
-    // inclusive scan over the row (zero fill below lane d), its total from lane 15
-    int incl = len;
-    incl += row16_i<DPP_ROW_SHR + 1, true>(incl);
-    incl += row16_i<DPP_ROW_SHR + 2, true>(incl);
-    incl += row16_i<DPP_ROW_SHR + 4, true>(incl);
-    incl += row16_i<DPP_ROW_SHR + 8, true>(incl);
-    const int excl = incl - len;
-    const int total = row16_i<DPP_ROW_NEWBCAST + 15, false>(incl);
-    // thirty-two candidates per trip, two per lane: both loads are in flight before either is compared (a query's candidates are a
-    // few dozen points; the trips are a chain of L2 / HBM round trips — the minimum over a total order does not care in which order
-    // it meets them)
-    for (int t0 = 0; t0 < total; t0 += 32) {
-      const int f0 = t0 + gl, f1 = t0 + 16 + gl;
-      int sl0 = 0, sl1 = 0;   // the slot that holds flat position f: the largest lane whose exclusive offset is <= f
-#pragma unroll
-      for (int step = 8; step >= 1; step >>= 1) {
-        const int c0 = sl0 + step, c1 = sl1 + step;
-        const int o0 = __shfl(excl, c0, 16), o1 = __shfl(excl, c1, 16);
-        if (o0 <= f0) sl0 = c0;
-        if (o1 <= f1) sl1 = c1;
+    // the occupied slots one after the other (a ball of a few centimetres touches one to four rows: two or three slots hold points),
+    // each read by the sixteen lanes two points per lane and trip, both loads in flight: a trip starts with its loads.  (Rounds 3-5
+    // laid the group's candidates end to end and found the slot of every flat position by a four-step search over the row's
+    // exclusive offsets: eight dependent LDS-crossbar shuffles before a trip's loads could be issued; 182 -> 156 us for the searches
+    // of a share of 8.)  The minimum over a total order does not care in which order it meets the candidates.
+    const unsigned long long wave_mask = __ballot((len | len2) > 0);
+    unsigned int todo = (unsigned int)(wave_mask >> (__lane_id() & 48)) & 0xFFFFu;   // this group's sixteen bits
+    auto offer = [&](const int sb, const int sn) {
+      for (int f = gl; f < sn; f += 32) {
+        const bool in1 = f + 16 < sn;
+        const float4 p0 = G.p[sb + f];
+        float4 p1 = p0;
+        if (in1) p1 = G.p[sb + f + 16];
+        {
+          const float d = dist2_rn(q[0], q[1], q[2], p0.x, p0.y, p0.z);
+          const int oi = __float_as_int(p0.w);
+          if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+        }
+        if (in1) {
+          const float d = dist2_rn(q[0], q[1], q[2], p1.x, p1.y, p1.z);
+          const int oi = __float_as_int(p1.w);
+          if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+        }
       }
-      const int sb0 = __shfl(beg, sl0, 16), so0 = __shfl(excl, sl0, 16);
-      const int sb1 = __shfl(beg, sl1, 16), so1 = __shfl(excl, sl1, 16);
-      const bool in0 = f0 < total, in1 = f1 < total;
-      float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-      if (in0) p0 = G.p[sb0 + (f0 - so0)];
-      if (in1) p1 = G.p[sb1 + (f1 - so1)];
-      if (in0) {
-        const float d = dist2_rn(q[0], q[1], q[2], p0.x, p0.y, p0.z);
-        const int oi = __float_as_int(p0.w);
-        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
-      }
-      if (in1) {
-        const float d = dist2_rn(q[0], q[1], q[2], p1.x, p1.y, p1.z);
-        const int oi = __float_as_int(p1.w);
-        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
-      }
+    };
+    while (todo) {
+      const int k = __builtin_ctz(todo);
+      todo &= todo - 1;
+      offer(__shfl(beg, k, 16), __shfl(len, k, 16));
+      if (skip) offer(__shfl(beg2, k, 16), __shfl(len2, k, 16));
     }
   }
   row16_best(bd, bi);

@@ -56,6 +56,24 @@ if MODE == "chain":
     print("chain x%d first %d: align_batch best %.3f median %.3f ms | passes %s (max %d sum %d) | launches x %.2f us" %
           (N, FIRST, 1e3 * min(ts[1:]), 1e3 * float(np.median(ts[1:])), ev, max(ev), sum(ev), 1e6 * min(ts[1:]) / (max(ev) + 1)), flush=True)
     sys.exit(0)
+if MODE == "fitness":   # the fitness stage alone, REPS times (for a kernel trace of its launches)
+    stage_all()
+    _capi.check(lib.lsr_align_batch(hs, N, G.ctypes.data_as(fptr), finals.ctypes.data_as(fptr), res), "a")
+    ts = []
+    for it in range(REPS + 2):
+        t0 = time.perf_counter(); _capi.check(lib.lsr_get_fitness_score_batch(hs, N, BIG, fit), "f"); ts.append(time.perf_counter() - t0)
+    print("fitness x%d first %d: best %.3f median %.3f ms" % (N, FIRST, 1e3 * min(ts[2:]), 1e3 * float(np.median(ts[2:]))), flush=True)
+    sys.exit(0)
+if MODE == "fitness_each":   # the fitness stage of every member on its own (which member makes a share's stage long)
+    stage_all()
+    _capi.check(lib.lsr_align_batch(hs, N, G.ctypes.data_as(fptr), finals.ctypes.data_as(fptr), res), "a")
+    for b in range(N):
+        one = (C.c_void_p * 1)(hs[b]); f1 = (C.c_double * 1)()
+        ts = []
+        for it in range(REPS + 2):
+            t0 = time.perf_counter(); _capi.check(lib.lsr_get_fitness_score_batch(one, 1, BIG, f1), "f"); ts.append(time.perf_counter() - t0)
+        print("member %d: fitness alone best %.3f median %.3f ms | score %.4f" % (FIRST + b, 1e3 * min(ts[2:]), 1e3 * float(np.median(ts[2:])), f1[0]), flush=True)
+    sys.exit(0)
 if MODE == "share":
     ts = [whole() for _ in range(REPS + 2)][2:]
     print("share x%d first %d: whole path best %.3f median %.3f ms" % (N, FIRST, 1e3 * min(ts), 1e3 * float(np.median(ts))), flush=True)
