@@ -243,6 +243,10 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   else tab = all_dense ? NDT_TAB_DENSE : NDT_TAB_COMPACT;   // measured: the pass is not gather bound, the tile mode's
                                                             // extra barriers cost more than its LDS gathers save — on request only
   cfg.tab = tab;
+  if (std::getenv("LSR_DEBUG_TABLE")) {
+    static int shown = 0;
+    if (shown++ < 4) fprintf(stderr, "[lidarslam_reg] table mode %d for %d member(s): LDS image up to %d bytes (cap %d, static %d)\n", tab, B, lds_max, table_cap, static_lds);
+  }
   cfg.quad = (want_quad_single || tab == NDT_TAB_TILE) ? 1 : 0;
   cfg.lds_bytes = (tab == NDT_TAB_LDS) ? lds_max : (tab == NDT_TAB_TILE ? NDT_TILE_BYTES : 0);
   if (cfg.quad) cfg.threads = (lead->ndt_threads == 64 || lead->ndt_threads == 128) ? lead->ndt_threads : NDT_QUAD_POINTS;  // POINTS per workgroup
