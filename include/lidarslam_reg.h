@@ -39,7 +39,7 @@ typedef enum lsr_status {
   LSR_ERR_HIP = -3,             /* a HIP call failed; see lsr_last_error() */
   LSR_ERR_NO_TARGET = -4,       /* align/getFitnessScore before setInputTarget */
   LSR_ERR_NO_SOURCE = -5,       /* align/getFitnessScore before setInputSource */
-  LSR_ERR_NOT_IMPLEMENTED = -6, /* e.g. NDT neighbourhood KDTREE */
+  LSR_ERR_NOT_IMPLEMENTED = -6, /* (no entry returns it at present; until round 6 the NDT neighbourhood KDTREE did) */
   LSR_ERR_INDEX_OVERFLOW = -7,  /* voxel index space exceeds int32 (PCL: "Leaf size is too small") */
   LSR_ERR_TOO_FEW_POINTS = -8   /* GICP: cloud smaller than k_correspondences */
 } lsr_status;
@@ -47,7 +47,10 @@ typedef enum lsr_status {
 /* registration_method: scanmatcher_component.cpp:103-124, graph_based_slam_component.cpp:63-86 */
 typedef enum lsr_method { LSR_METHOD_NDT = 0, LSR_METHOD_GICP = 1 } lsr_method;
 
-/* pclomp::NeighborSearchMethod, selected at scanmatcher_component.cpp:110 */
+/* pclomp::NeighborSearchMethod, selected at scanmatcher_component.cpp:110 (the reference only ever selects DIRECT7).
+ * KDTREE (round 6): ndt_omp's radiusSearch(x', resolution) over the kd-tree of the leaves' float centroids, restated as the 27 cells
+ * around the point's cell filtered by the kd-tree's own test (FLANN L2_Simple<float> strictly below (float)(resolution^2)) — a
+ * centroid lies inside its own cell, so no leaf outside those cells can pass.  The centroids are built on first use. */
 typedef enum lsr_neighborhood { LSR_KDTREE = 0, LSR_DIRECT26 = 1, LSR_DIRECT7 = 2, LSR_DIRECT1 = 3 } lsr_neighborhood;
 
 typedef enum lsr_key {
@@ -379,6 +382,10 @@ int lsr_search_loop(lsr_handle h, const lsr_submap* submaps, int num_submaps, si
 int lsr_ndt_grid_info(lsr_handle h, int32_t* info8);
 /* Dump all leaves sorted by linear index: idx[L], npts[L] (-1 = invalidated), mean[L*3], icov[L*9] (row-major). */
 int lsr_ndt_grid_dump(lsr_handle h, int32_t* idx, int32_t* npts, double* mean, double* icov);
+/* The FLOAT centroids of the leaves (pclomp::VoxelGridCovariance::Leaf::centroid: the float running sum of a leaf's points in cloud
+ * order over (float) count) — the points of the voxel-centroid kd-tree that the KDTREE neighbourhood searches —, in the order of
+ * lsr_ndt_grid_dump: centroid[L*3]; NaN for leaves that are not in the kd-tree (fewer than 6 points, invalid covariance). */
+int lsr_ndt_grid_centroids(lsr_handle h, float* centroid);
 /* One derivative pass at pose p = (tx,ty,tz,rx,ry,rz); T16 (nullable, col-major) overrides the point
  * transform like the first pass of align().  grad: 6, hess: 36 (row-major). */
 int lsr_ndt_derivatives(lsr_handle h, const double* p6, const float* T16, int compute_hessian, double* score,

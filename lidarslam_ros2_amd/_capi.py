@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "lsr_set_input_target_frames", "lsr_set_input_source", "lsr_set_input_source_device", "lsr_set_input_source_filtered", "lsr_set_input_source_frontend", "lsr_voxel_grid_filter",
     "lsr_share_target", "lsr_wait_stream", "lsr_align", "lsr_align_batch",
     "lsr_get_final_transformation", "lsr_has_converged", "lsr_get_fitness_score", "lsr_search_loop", "lsr_ndt_grid_info",
-    "lsr_ndt_grid_dump", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
+    "lsr_ndt_grid_dump", "lsr_ndt_grid_centroids", "lsr_ndt_derivatives", "lsr_gicp_covariances", "lsr_nearest_neighbors", "lsr_get_profile",
     "lsr_debug_angle_tables", "lsr_set_input_source_pc2", "lsr_get_source_pc2", "lsr_voxel_grid_filter_pc2", "lsr_shard_range", "lsr_comm_unique_id", "lsr_comm_create", "lsr_comm_destroy", "lsr_align_batch_sharded",
     "lsr_shard_plan", "lsr_align_batch_planned", "lsr_align_fitness_batch",
     "lsr_set_input_target_batch", "lsr_set_input_source_batch", "lsr_get_fitness_score_batch", "lsr_set_input_target_bcast", "lsr_get_source_pc2_device",
@@ -129,6 +129,7 @@ def load() -> C.CDLL:
                                   C.POINTER(LoopEdge), C.c_int, ip]
     L.lsr_ndt_grid_info.argtypes = [vp, ip]
     L.lsr_ndt_grid_dump.argtypes = [vp, ip, ip, dp, dp]
+    L.lsr_ndt_grid_centroids.argtypes = [vp, fp]
     L.lsr_ndt_derivatives.argtypes = [vp, dp, fp, C.c_int, dp, dp, dp]
     L.lsr_gicp_covariances.argtypes = [vp, C.c_int, dp]
     L.lsr_nearest_neighbors.argtypes = [vp, fp, ip, fp]

@@ -196,6 +196,10 @@ void fill_problem(NdtProblem& P, lsr_handle h, NdtState* d_state, long long* d_b
   P.st = d_state;
   P.bins = d_bins;
   P.mailbox = nullptr;
+  // KDTREE: the 27-cell kernels with the kd-tree's radius test (ensure_ndt_grid built the centroids); resolution_ is a float member
+  const bool kd = h->ndt.neighborhood == LSR_KDTREE && h->target->has_centroids;
+  P.centroid = kd ? g.centroid.p : nullptr;
+  P.radius2 = kd ? (float)((double)(float)h->ndt.resolution * (double)(float)h->ndt.resolution) : 0.f;
 }
 
 // Where the derivative pass reads the leaf records, and with which kernel.  grids: the batch's targets.
@@ -233,7 +237,8 @@ void choose_table_mode(lsr_handle lead, lsr_handle* hs, int B, NdtLaunchCfg& cfg
   const int static_lds = want_quad_single ? NDT_QUAD_STATIC_LDS : NDT_LANE_STATIC_LDS + ndt_lane_tile_bytes(lane_threads);
   const int table_cap = std::min(want_quad_single ? NDT_LDS_TABLE_MAX_QUAD : NDT_LDS_TABLE_MAX, lds_cap - static_lds);
   const bool lds_ok = all_lds && lds_max <= table_cap;
-  const bool tile_ok = all_dense && lead->ndt_quad != 0 && lead->ndt_sort != 0 && NDT_TILE_BYTES + NDT_QUAD_STATIC_LDS <= lds_cap;
+  const bool tile_ok = all_dense && lead->ndt_quad != 0 && lead->ndt_sort != 0 && NDT_TILE_BYTES + NDT_QUAD_STATIC_LDS <= lds_cap &&
+                       lead->ndt.neighborhood != LSR_KDTREE;   // (the tile mode numbers cells per tile: no centroid lookup there)
   int tab;
   if (override_mode == NDT_TAB_COMPACT) tab = NDT_TAB_COMPACT;
   else if (override_mode == NDT_TAB_DENSE && all_dense) tab = NDT_TAB_DENSE;
@@ -282,7 +287,7 @@ std::shared_ptr<TargetData> fresh_target(lsr_handle h) {
   else t = std::make_shared<TargetData>();
   h->spare_target = t;  // survives a failed setInputTarget (which resets h->target)
   t->n = 0;
-  t->has_grid = t->has_hash = t->has_cov = false;
+  t->has_grid = t->has_hash = t->has_cov = t->has_centroids = false;
   t->grid_leaf = 0.f;
   return t;
 }
@@ -295,17 +300,25 @@ int ensure_ndt_grid(lsr_handle h) {
   TargetData& t = *h->target;
   std::lock_guard<std::mutex> lock(t.build_mutex);
   float leaf = (float)h->ndt.resolution;
-  if (t.has_grid && t.grid_leaf == leaf) return LSR_OK;
+  // the KDTREE neighbourhood reads the leaves' float centroids: built on first use, for the grid in place
+  auto centroids = [&]() -> int {
+    if (h->ndt.neighborhood != LSR_KDTREE || t.has_centroids || t.grid.ncells == 0) return LSR_OK;
+    const int cst = ndt_build_centroids(t.cloud, t.grid, h->scratch, h->stream);
+    if (!cst) t.has_centroids = true;
+    return cst;
+  };
+  if (t.has_grid && t.grid_leaf == leaf) return centroids();
   if (t.has_grid && target_is_shared(h)) {
     // rebuilding in place would pull the grid from under the other handles (their d1/d2 and leaf size belong to the old one)
     set_last_error("the shared target's voxel grid was built at another resolution: sharers must use one ndt_resolution");
     return LSR_ERR_INVALID_ARGUMENT;
   }
+  t.has_centroids = false;
   int st = ndt_build_grid(t.cloud, leaf, t.grid, h->scratch, h->stream);
   if (st) return st;
   t.has_grid = true;
   t.grid_leaf = leaf;
-  return LSR_OK;
+  return centroids();
 }
 
 // An NDT target whose voxel grid was built by the counting-sort builder keeps its points in voxel order: the neighbour grid is
@@ -573,7 +586,6 @@ int align_ndt_batch(lsr_handle* hs, int B, const float* guesses, float* finals, 
     lsr_handle h = hs[b];
     if (!h->target || h->target->n == 0) { set_last_error("align before setInputTarget"); return LSR_ERR_NO_TARGET; }
     if (!h->has_source) { set_last_error("align before setInputSource"); return LSR_ERR_NO_SOURCE; }
-    if (h->ndt.neighborhood == LSR_KDTREE) { set_last_error("NDT neighbourhood KDTREE is not implemented (reference uses DIRECT7)"); return LSR_ERR_NOT_IMPLEMENTED; }
     if (h->ndt.neighborhood != lead->ndt.neighborhood) { set_last_error("batched handles must share the neighbourhood method"); return LSR_ERR_INVALID_ARGUMENT; }
     int st = ensure_ndt_grid(h);
     if (st) return st;
@@ -973,7 +985,6 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
       h->ndt.max_iterations = v; h->gicp.max_iterations = v; return LSR_OK;
     case LSR_NEIGHBORHOOD:
       if (v < LSR_KDTREE || v > LSR_DIRECT1) { set_last_error("unknown neighbourhood"); return LSR_ERR_INVALID_ARGUMENT; }
-      if (v == LSR_KDTREE) { set_last_error("NDT neighbourhood KDTREE is not implemented (reference uses DIRECT7)"); return LSR_ERR_NOT_IMPLEMENTED; }
       h->ndt.neighborhood = v; return LSR_OK;
     case LSR_NUM_THREADS: h->num_threads = v; return LSR_OK;          // CPU-only hint: accepted, ignored
     case LSR_K_CORRESPONDENCES:
@@ -1006,7 +1017,7 @@ int lsr_set_i32(lsr_handle h, int key, int v) {
     case LSR_GRID_BUILDER:
       if (v < 0 || v > 1) { set_last_error("grid builder must be 0 (auto) or 1 (radix-sort builder)"); return LSR_ERR_INVALID_ARGUMENT; }
       h->scratch.force_sort_path = (v == 1);
-      if (h->target) h->target->has_grid = false;
+      if (h->target) h->target->has_grid = h->target->has_centroids = false;
       return LSR_OK;
     case LSR_WAIT_MODE:
       if (v < 0 || v > 2) { set_last_error("wait mode must be 0 (spin), 1 (yield) or 2 (sleep)"); return LSR_ERR_INVALID_ARGUMENT; }
@@ -1192,6 +1203,7 @@ int lsr_set_input_target_batch(lsr_handle* handles, int count, const void* const
     if (h->method == LSR_METHOD_NDT) {
       if ((st = ndt_build_grid_end(t.grid, h->scratch, lead_stream))) return fail(st);
       t.has_grid = true;
+      t.has_centroids = false;
       t.grid_leaf = (float)h->ndt.resolution;
     } else if (hipStreamSynchronize(h->stream) != hipSuccess) {
       set_last_error("stream error in the target batch");
@@ -1894,6 +1906,39 @@ int lsr_ndt_grid_dump(lsr_handle h, int32_t* idx, int32_t* npts, double* mean, d
     npts[c] = cnt[r];
     for (int k = 0; k < 3; k++) mean[c * 3 + k] = m[(size_t)r * 3 + k];
     for (int k = 0; k < 9; k++) icov[c * 9 + k] = ic[(size_t)r * 9 + k];
+    c++;
+  }
+  return LSR_OK;
+}
+
+int lsr_ndt_grid_centroids(lsr_handle h, float* centroid) {
+  LSR_CHECK_HANDLE(h);
+  if (!centroid) return LSR_ERR_INVALID_ARGUMENT;
+  if (!h->target) return LSR_ERR_NO_TARGET;
+  int st = ensure_ndt_grid(h);
+  if (st) return st;
+  TargetData& t = *h->target;
+  {
+    std::lock_guard<std::mutex> lock(t.build_mutex);
+    if (!t.has_centroids && t.grid.ncells > 0) {
+      if ((st = ndt_build_centroids(t.cloud, t.grid, h->scratch, h->stream))) return st;
+      t.has_centroids = true;
+    }
+  }
+  const VoxelGridDev& g = t.grid;
+  const int L = g.n_leaves;
+  if (L == 0) return LSR_OK;
+  const size_t n_slots = g.dense ? g.ncells : (size_t)L;
+  std::vector<int> keys(L), slot(g.ncells);
+  std::vector<float> cen(n_slots * 4);
+  LSR_HIP(hipMemcpy(keys.data(), g.leaf_key.p, sizeof(int) * L, hipMemcpyDeviceToHost));
+  LSR_HIP(hipMemcpy(slot.data(), g.cell_slot.p, sizeof(int) * g.ncells, hipMemcpyDeviceToHost));
+  LSR_HIP(hipMemcpy(cen.data(), g.centroid.p, sizeof(float) * 4 * n_slots, hipMemcpyDeviceToHost));
+  int c = 0;
+  for (int r = 0; r < L; r++) {
+    if (keys[r] < 0) continue;
+    const int s = slot[(size_t)keys[r]];
+    for (int k = 0; k < 3; k++) centroid[c * 3 + k] = (s >= 0) ? cen[(size_t)s * 4 + k] : std::numeric_limits<float>::quiet_NaN();
     c++;
   }
   return LSR_OK;

@@ -145,6 +145,10 @@ struct VoxelGridDev {
   // fp64 copies for inspection/parity (mean 3, icov 9 row-major) + key + count per leaf
   DevBuf<double> mean64, icov64;
   DevBuf<int> leaf_key, leaf_n;
+  // KDTREE neighbourhood only (built on first use, ndt_build_centroids): Leaf::centroid of every usable leaf — the FLOAT running sum
+  // of its points in cloud order over (float) count, what the reference's voxel-centroid kd-tree holds — indexed like rec[] (by
+  // cell_slot[cell]); .w unused
+  DevBuf<float4> centroid;
   // what the counting-sort builder leaves behind (dense key spaces): the target's points in cell order (x | y | z planes of
   // `sorted_pitch` floats), their original indices, the start of every cell (ncells + 2 entries: [ncells] = first non-finite
   // point, [ncells + 1] = n) and the rank of every cell among the occupied ones.  getFitnessScore's neighbour grid is a
@@ -241,6 +245,7 @@ struct TargetData {
   DeviceCloud cloud;
   size_t n = 0;
   bool has_grid = false;
+  bool has_centroids = false;   // grid.centroid belongs to the grid in place
   VoxelGridDev grid;
   float grid_leaf = 0.f;
   bool has_hash = false;

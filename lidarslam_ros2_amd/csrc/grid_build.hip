@@ -487,6 +487,75 @@ static int ndt_build_grid_general(const DeviceCloud& cloud, float leaf, VoxelGri
   return LSR_OK;
 }
 
+// ---- KDTREE neighbourhood: the leaves' float centroids --------------------------------------------------------------------------
+// pclomp::VoxelGridCovariance keeps, next to the fp64 mean_, a FLOAT Leaf::centroid ("leaf.centroid += pt" point by point in cloud
+// order, then "/= static_cast<float>(nr_points)"); the centroid cloud it hands to its kd-tree — the one radiusSearch() queries for the
+// KDTREE neighbourhood — is made of these.  A float running sum is a function of the order of the points, so it is rebuilt here in
+// that order: stable LSD sort of the point indices by leaf key (equal keys keep ascending index = cloud order), run table, one thread
+// per leaf adding its points one after the other.  Independent of which builder made the grid; runs once per target, on first use.
+namespace {
+__global__ __launch_bounds__(256) void leaf_centroid_seq_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                                const int* __restrict__ order, const unsigned int* __restrict__ run_key,
+                                                                const int* __restrict__ run_off, const int* __restrict__ n_runs_dev,
+                                                                unsigned int sentinel, const int* __restrict__ cell_slot,
+                                                                float4* __restrict__ centroid) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *n_runs_dev) return;
+  const unsigned int key = run_key[r];
+  if (key == sentinel) return;          // the run of the non-finite points
+  const int slot = cell_slot[key];
+  if (slot < 0) return;                 // fewer than min_points_per_voxel points / invalid covariance: not in the kd-tree
+  const int beg = run_off[r], end = run_off[r + 1];
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int j = beg; j < end; j++) {
+    const int i = order[j];
+    sx = __fadd_rn(sx, x[i]); sy = __fadd_rn(sy, y[i]); sz = __fadd_rn(sz, z[i]);
+  }
+  const float n = (float)(end - beg);
+  centroid[slot] = make_float4(__fdiv_rn(sx, n), __fdiv_rn(sy, n), __fdiv_rn(sz, n), 0.f);
+}
+}  // namespace
+
+int ndt_build_centroids(const DeviceCloud& cloud, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
+  const int n = (int)cloud.n;
+  if (n == 0 || grid.ncells == 0) return LSR_OK;
+  const size_t n_slots = grid.dense ? grid.ncells : (size_t)std::max(grid.n_leaves, 1);
+  int st = grid.centroid.reserve(n_slots);
+  if (st) return st;
+  const unsigned int sentinel = (unsigned int)grid.ncells;
+  const size_t nb = sorted_runs_blocks((size_t)n);
+  // scratch: pad[16] | key_in[n] | key_out[n] | val_in[n] | val_out[n] | run_key[n+1] | run_off[n+1] | nruns[16] | block_heads[nb] | block_base[nb]
+  if ((st = sc.words.reserve(16 + 6 * (size_t)n + 2 + 16 + 2 * nb))) return st;
+  unsigned int* key_in = sc.words.p + 16;
+  unsigned int* key_out = key_in + n;
+  int* val_in = (int*)(key_out + n);
+  int* val_out = val_in + n;
+  unsigned int* run_key = (unsigned int*)(val_out + n);
+  int* run_off = (int*)(run_key + n + 1);
+  int* d_nruns = run_off + n + 1;
+  int* block_heads = d_nruns + 16;
+  int* block_base = block_heads + nb;
+  hipLaunchKernelGGL(leaf_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(), n, 1.0f / grid.leaf,
+                     grid.min_b[0], grid.min_b[1], grid.min_b[2], grid.div_b[0], grid.div_b[0] * grid.div_b[1], sentinel, key_in, (int*)nullptr,
+                     (uint4*)nullptr, (size_t)0, (int*)nullptr, (size_t)0, (int*)nullptr);
+  bool in_b = false;
+  if ((st = sort_pairs_u32_lsd(key_in, key_out, nullptr, val_in, val_out, (size_t)n, bits_for(sentinel), sc.temp, stream, &in_b))) return st;
+  const unsigned int* ks = in_b ? key_out : key_in;
+  const int* order = in_b ? val_out : val_in;
+  unsigned int rtoken = 0;
+  if ((st = sorted_runs_begin(ks, (size_t)n, block_heads, block_base, sc, stream, &rtoken, nullptr, d_nruns))) return st;
+  if ((st = sorted_runs_table(ks, (size_t)n, block_base, run_key, run_off, stream))) return st;
+  const size_t run_bound = std::min((size_t)n, grid.ncells + 1);
+  hipLaunchKernelGGL(leaf_centroid_seq_kernel, dim3((unsigned)((run_bound + 255) / 256)), dim3(256), 0, stream, cloud.x(), cloud.y(), cloud.z(),
+                     order, run_key, run_off, d_nruns, sentinel, grid.cell_slot.p, grid.centroid.p);
+  LSR_HIP(hipGetLastError());
+  int n_runs = 0;
+  if ((st = sorted_runs_count(sc, stream, rtoken, &n_runs))) return st;   // the run count's mailbox word is consumed
+  // complete on return: a target may be shared by objects on other streams
+  if (hipStreamSynchronize(stream) != hipSuccess) { set_last_error("stream error while the leaf centroids were built"); return LSR_ERR_HIP; }
+  return LSR_OK;
+}
+
 // Everything up to the last enqueue.  Dense key spaces leave the build pending (sc.grid_pending): ndt_build_grid_end() collects it.
 int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream) {
   int path = 0;

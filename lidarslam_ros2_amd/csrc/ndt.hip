@@ -1148,6 +1148,14 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
         if (TAB == NDT_TAB_TILE && use_tile) cellv[t] = in ? ((a - lo0) + (b - lo1) * tdx + (c - lo2) * tdxy) : 0;
         else cellv[t] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
       }
+      if (NOFF == 27 && P.centroid) {   // KDTREE: of the 27 cells, the leaves whose centroid the kd-tree's radius search would return
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const int sl = valid[t] ? P.cell_slot[cellv[t]] : -1;
+          const float4 cen = P.centroid[sl >= 0 ? sl : 0];
+          valid[t] = (sl >= 0) & centroid_in_radius(tx, ty, tz, cen.x, cen.y, cen.z, P.radius2);
+        }
+      }
       float4 r0[NT], r1[NT], r2[NT];
       if (TAB == NDT_TAB_LDS) {
         int slot[NT];
@@ -1510,6 +1518,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
       nb_ok[o] = in;
       nb_rec[o] = cell;
     }
+    if (NOFF == 27 && P.centroid) {   // KDTREE: of the 27 cells, the leaves whose centroid the kd-tree's radius search would return
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) {
+        const int ks = nb_ok[o] ? P.cell_slot[nb_rec[o]] : -1;
+        const float4 cen = P.centroid[ks >= 0 ? ks : 0];
+        nb_ok[o] = (ks >= 0) & centroid_in_radius(tx, ty, tz, cen.x, cen.y, cen.z, P.radius2);
+      }
+    }
     if (TAB == NDT_TAB_LDS) {
       int sl[NOFF];
 #pragma unroll
@@ -1837,12 +1853,14 @@ int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, cons
     if (cfg.quad) {
       switch (cfg.neighborhood) {
         case LSR_DIRECT1: st = launch_quad<1>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+        case LSR_KDTREE:   // the 27 cells, filtered by the radius test on the leaves' centroids (NdtProblem::centroid)
         case LSR_DIRECT26: st = launch_quad<27>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
         default: st = launch_quad<7>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
       }
     } else {
       switch (cfg.neighborhood) {
         case LSR_DIRECT1: st = launch_lane<1>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
+        case LSR_KDTREE:
         case LSR_DIRECT26: st = launch_lane<27>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
         default: st = launch_lane<7>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
       }

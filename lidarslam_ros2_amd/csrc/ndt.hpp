@@ -110,6 +110,8 @@ struct NdtProblem {
   long long* bins;          // [NDT_NBANKS][NDT_NSHARDS][NDT_NBINS][32] int64 accumulators (zeroed before launch 0)
   NdtState* st;             // [2] double buffered by launch parity
   NdtMailbox* mailbox;      // device view of the host mailbox (single registrations fed by polling) or nullptr
+  const float4* centroid;   // KDTREE neighbourhood: float centroid of the leaf in slot cell_slot[cell] (nullptr for the DIRECT methods)
+  float radius2;            // KDTREE: (float)(resolution * resolution), the kd-tree's squared search radius
 };
 
 struct NdtParamsHost {
@@ -131,6 +133,9 @@ int ndt_build_grid(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, Bui
 // the result.  A batch of targets runs every _begin before the first _end, so the builds overlap on the device.
 int ndt_build_grid_begin(const DeviceCloud& cloud, float leaf, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
 int ndt_build_grid_end(VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
+// KDTREE neighbourhood: grid.centroid of a complete grid (stable sort of the cloud by leaf + one thread per leaf adding its points in
+// cloud order, in float, as VoxelGridCovariance does for Leaf::centroid).  Returns with the array complete.
+int ndt_build_centroids(const DeviceCloud& cloud, VoxelGridDev& grid, BuildScratch& sc, hipStream_t stream);
 
 // Geometry of a launch chain (fixed for the whole align()).
 struct NdtLaunchCfg {

@@ -83,6 +83,19 @@ __device__ __forceinline__ float exp_pair(const float x) {
 // reference's q to the last bit except for double roundings (a mean rounded to fp32 alone biases every point of a voxel by the
 // same ~2e-6 m).  A record of an unusable leaf (no points, n < 6, invalid covariance) is all NaN: q, e and w0 become NaN and
 // the range test below drops the pair — no count or flag is read in the hot loop.
+// KDTREE neighbourhood (ndt_omp: target_cells_.radiusSearch(x_trans_pt, resolution_, ...) on the kd-tree over the leaves' float
+// centroids): FLANN's L2_Simple<float> between the transformed point and a centroid — dx*dx, + dy*dy, + dz*dz, no contraction —
+// strictly below the squared radius (RadiusResultSet::addPoint).
+__device__ __forceinline__ bool centroid_in_radius(const float tx, const float ty, const float tz, const float cx, const float cy,
+                                                   const float cz, const float radius2) {
+#pragma clang fp contract(off)
+  const float dx = tx - cx, dy = ty - cy, dz = tz - cz;
+  float d = dx * dx;
+  d = d + dy * dy;
+  d = d + dz * dz;
+  return d < radius2;
+}
+
 __device__ __forceinline__ void pair_terms(const bool leaf_ok, const bool hess, const float tx, const float ty, const float tz,
                                            const float4 r0, const float4 r1, const float4 r2, const float d2, const double d1d,
                                            float& score, float& npairs, float& A0, float& A1, float& A2, float& E00, float& E01,

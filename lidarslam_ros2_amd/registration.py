@@ -403,6 +403,13 @@ class NormalDistributionsTransform(Registration):
                                                icov.ctypes.data_as(C.POINTER(C.c_double))), "gridDump")
         return dict(idx=idx, n=npts, mean=mean, icov=icov)
 
+    def gridCentroids(self) -> np.ndarray:
+        """(n_leaves, 3) fp32, in gridDump's order: the leaves' FLOAT centroids (the points of the voxel-centroid kd-tree that the
+        KDTREE neighbourhood searches); NaN for leaves outside the kd-tree (fewer than 6 points)."""
+        c = np.zeros((self.gridInfo()["n_leaves"], 3), np.float32)
+        capi.check(self._lib.lsr_ndt_grid_centroids(self._h, c.ctypes.data_as(C.POINTER(C.c_float))), "gridCentroids")
+        return c
+
     def derivatives(self, p, T=None, compute_hessian: bool = True):
         p = np.ascontiguousarray(p, np.float64)
         t = _mat_to_col16(T) if T is not None else None

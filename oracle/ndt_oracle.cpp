@@ -33,6 +33,8 @@ namespace {
 struct Leaf {
   int n = 0;            // nr_points (-1 = invalidated)
   double sum[3] = {0, 0, 0};     // running sum of points (mean_ before normalisation)
+  float csum[3] = {0.f, 0.f, 0.f};   // Leaf::centroid: the FLOAT running sum of the points, in cloud order ("leaf.centroid += pt")
+  float centroid[3] = {0.f, 0.f, 0.f};   // ... normalised by (float)nr_points: the point the voxel-centroid kd-tree holds (KDTREE search)
   double sq[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // running sum of p p^T
   double mean[3];
   double cov[9];
@@ -96,6 +98,7 @@ Grid* grid_build(const float* pts, size_t stride_f, size_t n, float leaf) {
     double q[3] = {(double)p[0], (double)p[1], (double)p[2]};
     for (int a = 0; a < 3; a++) {
       L.sum[a] += q[a];
+      L.csum[a] += p[a];   // float accumulation (Eigen::VectorXf centroid)
       for (int b = 0; b < 3; b++) L.sq[a * 3 + b] += q[a] * q[b];
     }
     L.n++;
@@ -106,6 +109,7 @@ Grid* grid_build(const float* pts, size_t stride_f, size_t n, float leaf) {
     Leaf& L = kv.second;
     double nn = (double)L.n;
     for (int a = 0; a < 3; a++) L.mean[a] = L.sum[a] / nn;
+    for (int a = 0; a < 3; a++) L.centroid[a] = L.csum[a] / (float)L.n;   // "leaf.centroid /= static_cast<float>(leaf.nr_points)"
     if (L.n < g->min_points) continue;
     for (int a = 0; a < 3; a++)
       for (int b = 0; b < 3; b++)
@@ -145,13 +149,19 @@ Grid* grid_build(const float* pts, size_t stride_f, size_t n, float leaf) {
 }
 
 // Neighbourhood offsets.  search: 7 = DIRECT7, 1 = DIRECT1, 26 = DIRECT26
-// (DIRECT26 in ndt_omp visits the full 3x3x3 block = 27 offsets including the centre).
+// (DIRECT26 in ndt_omp visits the full 3x3x3 block = 27 offsets including the centre), 0 = KDTREE.
+// KDTREE (ndt_omp: target_cells_.radiusSearch(x_trans_pt, resolution_, ...) = a radius search of the kd-tree over the centroids of the
+// leaves with >= min_points_per_voxel points): every leaf whose centroid lies within `resolution` of the point.  A centroid lies inside
+// its own cell, so such a leaf is one of the 3 x 3 x 3 cells around the point's cell: the search is restated as those 27 cells
+// filtered by the kd-tree's own test — FLANN L2_Simple<float> (dx*dx, + dy*dy, + dz*dz in float) strictly below (float)(r*r), as
+// RadiusResultSet::addPoint compares.  (The kd-tree returns its hits sorted by distance; the order only decides in which order a
+// point's voxel contributions are added.)
 int neighbour_offsets(int search, int off[27][3]) {
   if (search == 1) {
     off[0][0] = off[0][1] = off[0][2] = 0;
     return 1;
   }
-  if (search == 26) {
+  if (search == 26 || search == 0) {
     int c = 0;
     for (int dx = -1; dx <= 1; dx++)
       for (int dy = -1; dy <= 1; dy++)
@@ -167,7 +177,7 @@ int neighbour_offsets(int search, int off[27][3]) {
   return 7;
 }
 
-inline int neighbours(const Grid& g, const float* xt, const int off[27][3], int noff, const Leaf** out) {
+inline int neighbours(const Grid& g, const float* xt, const int off[27][3], int noff, const Leaf** out, float radius2 = -1.f) {
   int ijk[3];
   for (int k = 0; k < 3; k++) ijk[k] = (int)std::floor(xt[k] / g.leaf);  // float / float, then floor
   int cnt = 0;
@@ -181,7 +191,17 @@ inline int neighbours(const Grid& g, const float* xt, const int off[27][3], int 
     int idx = (ijk[0] + off[o][0] - g.min_b[0]) * g.mul[0] + (ijk[1] + off[o][1] - g.min_b[1]) * g.mul[1] +
               (ijk[2] + off[o][2] - g.min_b[2]) * g.mul[2];
     auto it = g.leaves.find(idx);
-    if (it != g.leaves.end() && it->second.n >= g.min_points) out[cnt++] = &it->second;
+    if (it == g.leaves.end() || it->second.n < g.min_points) continue;
+    if (radius2 >= 0.f) {   // KDTREE: the kd-tree's radius test on the leaf's float centroid
+      const Leaf& L = it->second;
+      float d = 0.f;
+      for (int k = 0; k < 3; k++) {
+        const float diff = xt[k] - L.centroid[k];
+        d += diff * diff;
+      }
+      if (!(d < radius2)) continue;
+    }
+    out[cnt++] = &it->second;
   }
   return cnt;
 }
@@ -330,6 +350,7 @@ struct Ndt {
   AngleDeriv ang;
   int off[27][3];
   int noff;
+  float radius2 = -1.f;   // KDTREE: (float)(resolution * resolution) as pcl::KdTreeFLANN::radiusSearch hands it to FLANN; < 0 otherwise
   std::vector<float> trans;  // transformed cloud xyz
   std::vector<double> sc, gr, he;  // per-point results (ndt_omp keeps scores[]/score_gradients[]/hessians[])
   NdtResult* res;
@@ -371,7 +392,7 @@ double compute_derivatives(Ndt& S, const double* p, bool compute_hessian, double
     const float* xs = P(S.src, S.stride_f, idx);
     const float* xt = &S.trans[3 * idx];
     const Leaf* nb[27];
-    int cnt = neighbours(*S.g, xt, S.off, S.noff, nb);
+    int cnt = neighbours(*S.g, xt, S.off, S.noff, nb, S.radius2);
     double score_pt = 0, g_pt[6] = {0, 0, 0, 0, 0, 0}, h_pt[36];
     for (int a = 0; a < 36; a++) h_pt[a] = 0;
     // computePointDerivatives (float): x is the ORIGINAL point
@@ -460,7 +481,7 @@ void compute_hessian_only(Ndt& S, double* hess) {
     const float* xs = P(S.src, S.stride_f, idx);
     const float* xt = &S.trans[3 * idx];
     const Leaf* nb[27];
-    int cnt = neighbours(*S.g, xt, S.off, S.noff, nb);
+    int cnt = neighbours(*S.g, xt, S.off, S.noff, nb, S.radius2);
     if (!cnt) continue;
     double x[3] = {xs[0], xs[1], xs[2]};
     double ja[8], hh[15];
@@ -676,6 +697,23 @@ int orc_grid_dump(void* gp, int* idx, int* npts, double* mean, double* cov, doub
   return c;
 }
 
+// The float centroids (Leaf::centroid, what the voxel-centroid kd-tree of the KDTREE search holds) of all leaves, sorted by linear
+// index like orc_grid_dump: centroid[3 c .. 3 c + 2].
+int orc_grid_centroids(void* gp, float* centroid) {
+  Grid* g = (Grid*)gp;
+  std::vector<int> keys;
+  keys.reserve(g->leaves.size());
+  for (auto& kv : g->leaves) keys.push_back(kv.first);
+  std::sort(keys.begin(), keys.end());
+  int c = 0;
+  for (int k : keys) {
+    const Leaf& L = g->leaves[k];
+    for (int a = 0; a < 3; a++) centroid[c * 3 + a] = L.centroid[a];
+    c++;
+  }
+  return c;
+}
+
 void orc_gauss_constants(double res, double outlier, double* d1, double* d2, double* d3) {
   gauss_constants(res, outlier, d1, d2, d3);
 }
@@ -702,6 +740,7 @@ double orc_ndt_derivatives(void* gp, const float* src, size_t stride_floats, siz
   double d3;
   gauss_constants(resolution, outlier_ratio, &S.d1, &S.d2, &d3);
   S.noff = neighbour_offsets(search, S.off);
+  if (search == 0) S.radius2 = (float)((double)(float)resolution * (double)(float)resolution);   // resolution_ is a float member
   float M[16];
   if (T16) std::memcpy(M, T16, sizeof(M)); else pose_to_matrix_f(p, M);
   transform_cloud(S, M);
@@ -721,6 +760,7 @@ static int ndt_align_impl(void* gp, const float* src, size_t stride_floats, size
   double d3;
   gauss_constants(prm->resolution, prm->outlier_ratio, &S.d1, &S.d2, &d3);
   S.noff = neighbour_offsets(prm->search, S.off);
+  if (prm->search == 0) S.radius2 = (float)((double)(float)prm->resolution * (double)(float)prm->resolution);
   float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   float* F = R->final_transformation;
   std::memcpy(F, I16, sizeof(I16));

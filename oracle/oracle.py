@@ -58,6 +58,8 @@ def lib():
         L.orc_grid_info.argtypes = [vp, ip]
         L.orc_grid_dump.restype = C.c_int
         L.orc_grid_dump.argtypes = [vp, ip, ip, dp, dp, dp]
+        L.orc_grid_centroids.restype = C.c_int
+        L.orc_grid_centroids.argtypes = [vp, fp]
         L.orc_gauss_constants.argtypes = [C.c_double, C.c_double, dp, dp, dp]
         L.orc_pose_to_matrix.argtypes = [dp, fp]
         L.orc_matrix_to_pose.argtypes = [fp, dp]
@@ -168,6 +170,13 @@ class VoxelGridCovariance:
         mean, cov, icov = np.zeros((n, 3)), np.zeros((n, 3, 3)), np.zeros((n, 3, 3))
         lib().orc_grid_dump(self.h, _i32p(idx), _i32p(npts), _f64p(mean), _f64p(cov), _f64p(icov))
         return dict(idx=idx, n=npts, mean=mean, cov=cov, icov=icov)
+
+    def centroids(self):
+        """(n_leaves, 3) fp32: Leaf::centroid of every leaf (float running sum in cloud order / float(n)), sorted by linear index —
+        the points of the voxel-centroid kd-tree that the KDTREE neighbourhood search (search=0) queries."""
+        c = np.zeros((self.n_leaves, 3), np.float32)
+        lib().orc_grid_centroids(self.h, c.ctypes.data_as(C.POINTER(C.c_float)))
+        return c
 
     def __del__(self):
         try:

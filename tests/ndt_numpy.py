@@ -26,14 +26,20 @@ def jang_rows(p):
 
 
 class NumpyNdt:
-    def __init__(self, dump, min_b, max_b, leaf, d1, d2, search=7):
+    def __init__(self, dump, min_b, max_b, leaf, d1, d2, search=7, centroids=None):
         self.leaf, self.d1, self.d2 = float(leaf), d1, d2
         self.min_b, self.max_b = np.asarray(min_b, np.int64), np.asarray(max_b, np.int64)
         div = self.max_b - self.min_b + 1
         self.mul = np.array([1, div[0], div[0] * div[1]], np.int64)
         ok = dump["n"] >= 6
         self.table = {int(k): (m, c) for k, m, c in zip(dump["idx"][ok], dump["mean"][ok], dump["icov"][ok])}
-        if search == 1:      # DIRECT1: the cell of the transformed point only
+        self.kd = None
+        if search == 0:      # KDTREE: a radius search over ALL leaf centroids (brute force: no cell structure is assumed here)
+            assert centroids is not None
+            self.kd = (np.asarray(centroids, np.float32)[ok], [self.table[int(k)] for k in dump["idx"][ok]],
+                       np.float32(np.float64(np.float32(leaf)) * np.float64(np.float32(leaf))))
+            self.off = np.zeros((0, 3), np.int64)
+        elif search == 1:    # DIRECT1: the cell of the transformed point only
             self.off = np.zeros((1, 3), np.int64)
         elif search == 26:   # DIRECT26: the full 3x3x3 block, centre included (27 cells)
             self.off = np.array([[a, b, c] for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)], np.int64)
@@ -53,13 +59,20 @@ class NumpyNdt:
             x = src[n].astype(np.float64)
             ja = Jr @ x
             J = np.array([[1, 0, 0, 0, ja[2], ja[5]], [0, 1, 0, ja[0], ja[3], ja[6]], [0, 0, 1, ja[1], ja[4], ja[7]]])
+            leaves = []
+            if self.kd is not None:
+                # pcl::KdTreeFLANN::radiusSearch on the float point: L2_Simple<float>, strictly inside (float)(r * r)
+                diff = np.float32(xt[n]).astype(np.float32) - self.kd[0]
+                d = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+                leaves = [self.kd[1][k] for k in np.nonzero(d < self.kd[2])[0]]
             for o in self.off:
                 c = ijk[n] + o
                 if np.any(c < self.min_b) or np.any(c > self.max_b):
                     continue
                 leaf = self.table.get(int(((c - self.min_b) * self.mul).sum()))
-                if leaf is None:
-                    continue
+                if leaf is not None:
+                    leaves.append(leaf)
+            for leaf in leaves:
                 q = xt[n] - leaf[0]
                 Cq = leaf[1] @ q
                 e = np.exp(-self.d2 * (q @ Cq) / 2)

@@ -88,7 +88,7 @@ def test_nonfinite_points_are_ignored(O, case):
     assert b.getTransformationProbability() == pytest.approx(a.getTransformationProbability() * len(case.source) / len(src), rel=1e-6)
 
 
-@pytest.mark.parametrize("method,search", [("DIRECT1", 1), ("DIRECT7", 7), ("DIRECT26", 26)])
+@pytest.mark.parametrize("method,search", [("DIRECT1", 1), ("DIRECT7", 7), ("DIRECT26", 26), ("KDTREE", 0)])
 def test_neighbourhood_variants_match_oracle(O, case, method, search):
     import lidarslam_ros2_amd as L
 
@@ -108,14 +108,51 @@ def test_neighbourhood_variants_match_oracle(O, case, method, search):
     assert dt <= 1e-3 and ang <= 1e-4
 
 
-def test_kdtree_neighbourhood_is_refused():
-    import lidarslam_ros2_amd as L
-    from lidarslam_ros2_amd import _capi
+@pytest.mark.parametrize("res,force_radix", [(4.0, False), (2.0, False), (4.0, True)])
+def test_kdtree_centroids_are_the_float_running_sums(O, case, res, force_radix):
+    """The voxel-centroid kd-tree of the KDTREE neighbourhood holds Leaf::centroid — a FLOAT running sum of the leaf's points in cloud
+    order over (float) count —, not the fp64 mean: bit for bit the oracle's, whichever builder made the grid."""
+    r = make_ndt(res)
+    if force_radix:
+        r.setTuning(grid_builder=1)
+    r.setInputTarget(case.target)
+    grid = O.VoxelGridCovariance(case.target, res)
+    d, dump = r.gridDump(), grid.dump()
+    assert np.array_equal(d["idx"], dump["idx"])
+    cen, ref = r.gridCentroids(), grid.centroids()
+    in_tree = dump["n"] >= 6
+    assert in_tree.sum() > 20
+    assert np.array_equal(cen[in_tree], ref[in_tree])
+    assert np.isnan(cen[~in_tree]).all()
+    assert np.abs(ref[in_tree] - dump["mean"][in_tree]).max() > 0            # ... and they are not the rounded fp64 means
 
-    r = make_ndt()
-    with pytest.raises(_capi.RegistrationError) as ei:
-        r.setNeighborhoodSearchMethod(L.KDTREE)
-    assert ei.value.status == -6                                   # LSR_ERR_NOT_IMPLEMENTED
+
+def test_kdtree_neighbourhood_sets_and_batches(O, case):
+    """KDTREE after the target was set (centroids built on first use), inside a candidate set (lane kernel) and alone (quad kernel):
+    the same registration bit for bit, and the oracle's."""
+    import lidarslam_ros2_amd as L
+    from lidarslam_ros2_amd.registration import align_batch
+
+    regs = []
+    for _ in range(3):
+        r = make_ndt(4.0)
+        r.setInputTarget(case.target)
+        r.setInputSource(case.source)
+        r.setNeighborhoodSearchMethod(L.KDTREE)                              # after setInputTarget: built lazily
+        regs.append(r)
+    regs[0].align(case.guess)
+    alone = (regs[0].getFinalTransformation(), regs[0].getFinalNumIteration())
+    finals, results = align_batch(regs, [case.guess] * 3)
+    for k in range(3):
+        assert np.array_equal(np.asarray(finals[k]), alone[0]) and int(results[k]["iterations"]) == alone[1]
+    grid = O.VoxelGridCovariance(case.target, 4.0)
+    ref = O.ndt_align(grid, case.source, case.guess, resolution=4.0, search=0)
+    dt, ang = pose_delta(alone[0], ref["final"])
+    assert dt <= 1e-3 and ang <= 1e-4 and alone[1] == ref["iterations"]
+    # the DIRECT26 answer is another one: the radius test drops neighbours
+    regs[1].setNeighborhoodSearchMethod(L.DIRECT26)
+    p = O.matrix_to_pose(case.guess)
+    assert regs[1].derivatives(p)[0] != regs[0].derivatives(p)[0]
 
 
 def test_hessian_d1_sign_option_matches_oracle(O, case):

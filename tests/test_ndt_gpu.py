@@ -273,7 +273,7 @@ def test_every_launch_variant_matches_the_oracle(O, case, variant):
         assert ndt.getFinalNumIteration() == r["iterations"]
 
 
-@pytest.mark.parametrize("neighborhood", ["DIRECT7", "DIRECT1", "DIRECT26"])
+@pytest.mark.parametrize("neighborhood", ["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"])
 def test_launch_variants_agree_with_each_other(case, neighborhood):
     """One input, one answer: every kernel (four lanes per point / one), every workgroup size, every table form returns the
     same score, gradient and Hessian — and the same registration — bit for bit: a point's terms are formed in one fp32

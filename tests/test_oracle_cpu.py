@@ -153,6 +153,34 @@ def test_direct1_and_direct26_match_fp64_numpy(small, search):
     assert np.abs(g - g64).max() <= 1e-4 * np.abs(g64).max()
 
 
+def test_kdtree_neighbourhood_is_a_radius_search_over_the_leaf_centroids(small):
+    """pclomp's KDTREE neighbourhood = radiusSearch(x', resolution) on the kd-tree of the leaves' float centroids.  The oracle restates
+    it as the 27 cells around the point's cell + the radius test; the numpy model searches ALL centroids by brute force: the same
+    voxel sets (score and gradient agree as for the DIRECT methods), strictly between DIRECT7's and DIRECT26's."""
+    case, res, grid, _ = small
+    d1, d2, _ = O.gauss_constants(res)
+    cen = grid.centroids()
+    dump = grid.dump()
+    ok = dump["n"] >= 6
+    # Leaf::centroid is a float running sum over float(n): close to the fp64 mean, not equal to its rounding
+    assert np.abs(cen[ok] - dump["mean"][ok]).max() < 1e-3 and (cen[ok] != dump["mean"][ok].astype(np.float32)).any()
+    ref = NumpyNdt(dump, grid.min_b, grid.max_b, res, d1, d2, search=0, centroids=cen)
+    for dp in (np.array([-0.06, 0.09, 0.02, -0.003, 0.005, 0.008]), np.array([0.3, -0.2, 0.05, 0.01, -0.015, 0.02])):
+        p = O.matrix_to_pose(case.guess) + dp
+        s, g, _ = O.ndt_derivatives(grid, case.source, p, resolution=res, search=0)
+        s64, g64 = ref.score_grad(case.source, p)
+        assert abs(s - s64) <= 2e-5 * abs(s64)
+        assert np.abs(g - g64).max() <= 1e-4 * np.abs(g64).max()
+        s7 = O.ndt_derivatives(grid, case.source, p, resolution=res, search=7)[0]
+        s27 = O.ndt_derivatives(grid, case.source, p, resolution=res, search=26)[0]
+        assert s7 != s and s < s27
+    # a registration with it converges to the same place as with DIRECT7 (the reference's choice) on this easy case
+    a = O.ndt_align(grid, case.source, case.guess, resolution=res, search=0)
+    b = O.ndt_align(grid, case.source, case.guess, resolution=res, search=7)
+    dt, ang = pose_delta(a["final"], b["final"])
+    assert a["converged"] and dt < 0.05 and ang < 0.01
+
+
 def test_direct7_boundary_cases(small):
     case, res, grid, ref = small
     far = (case.source + np.float32(1e4)).astype(np.float32)     # outside the bbox: zero neighbours
