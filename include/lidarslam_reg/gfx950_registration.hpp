@@ -72,7 +72,7 @@ class Gfx950Registration : public pcl::Registration<PointSource, PointTarget> {
   }
   // NDT-only setters the nodes call (scanmatcher_component.cpp:107-111, graph_based_slam_component.cpp:66-71)
   void setResolution(float r) { report(lsr_set_f64(h_, LSR_RESOLUTION, r)); }
-  void setNeighborhoodSearchMethod(int m) { report(lsr_set_i32(h_, LSR_NEIGHBORHOOD, m)); }   // LSR_DIRECT7 == pclomp::DIRECT7
+  void setNeighborhoodSearchMethod(int m) { report(lsr_set_i32(h_, LSR_NEIGHBORHOOD, m)); }   // LSR_DIRECT7 == pclomp::DIRECT7 (all four pclomp methods are served, KDTREE included)
   void setNumThreads(int n) { report(lsr_set_i32(h_, LSR_NUM_THREADS, n)); }                  // accepted, ignored
 
   // getFitnessScore is NOT virtual in PCL: call it through this type (one device launch chain, the score comes back through a

@@ -136,7 +136,23 @@ int main(int argc, char** argv) {
     configure(ndt, res, 1e-6, 30);
     ndt.align(aligned, guess);
     put(f, "final_tight", ndt.getFinalTransformation().data(), 16);
-    std::fprintf(f, "\"iters_tight\": %d\n},\n", ndt.getFinalNumIteration());
+    std::fprintf(f, "\"iters_tight\": %d,\n", ndt.getFinalNumIteration());
+    // the fourth pclomp neighbourhood: radiusSearch(x', resolution_) on the kd-tree over the leaves' float centroids
+    configure(ndt, res, 0.01, 35);
+    ndt.setNeighborhoodSearchMethod(pclomp::KDTREE);
+    ndt.align(aligned, guess);
+    put(f, "final_kdtree", ndt.getFinalTransformation().data(), 16);
+    std::fprintf(f, "\"iters_kdtree\": %d,\n", ndt.getFinalNumIteration());
+    const double score_kd = ndt.derivatives(p, g, H);
+    std::fprintf(f, "\"score_kdtree\": %.17g,\n", score_kd);
+    put(f, "grad_kdtree", g.data(), 6);
+    for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Hrow[r * 6 + c] = H(r, c);
+    put(f, "hess_kdtree", Hrow, 36);
+    std::vector<double> cen;   // Leaf::centroid (Eigen::VectorXf) of every leaf, ascending leaf index; the leaves below min_points_per_voxel are not in the kd-tree
+    for (const auto& kv : ndt.cells().getLeaves())
+      for (int k = 0; k < 3; k++) cen.push_back(kv.second.nr_points >= 6 ? (double)kv.second.centroid[k] : 1e300);   // (1e300: not in the tree; JSON has no NaN)
+    put(f, "leaf_centroid", cen.data(), cen.size());
+    std::fprintf(f, "\"kdtree\": 1\n},\n");
   }
   {  // ---- gicp_small (tests/golden/make_golden_gicp.py): target re-filtered like the GICP frontend (scanmatcher_component.cpp:309-315)
     const size_t at = J.find_key("gicp_small", 0);

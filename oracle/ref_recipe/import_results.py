@@ -21,7 +21,14 @@ def main(path=None, out_dir=None):
     wrote = []
     if "ndt_small" in R:
         n = R["ndt_small"]
-        np.savez_compressed(os.path.join(out_dir, "ref_ndt_small_golden.npz"),
+        kd = {}
+        if "score_kdtree" in n:   # round 6: the KDTREE neighbourhood (dumps made by an older recipe do not hold it: the oracle's arrays stay)
+            kd = dict(score_kdtree=float(n["score_kdtree"]), grad_kdtree=np.asarray(n["grad_kdtree"], np.float64),
+                      hess_kdtree=np.asarray(n["hess_kdtree"], np.float64).reshape(6, 6), final_kdtree=mat(n["final_kdtree"]).astype(np.float32),
+                      iters_kdtree=int(n["iters_kdtree"]),
+                      leaf_centroid=np.where(np.asarray(n["leaf_centroid"], np.float64) > 1e299, np.nan,
+                                             np.asarray(n["leaf_centroid"], np.float64)).astype(np.float32).reshape(-1, 3))
+        np.savez_compressed(os.path.join(out_dir, "ref_ndt_small_golden.npz"), **kd,
                             score=float(n["score"]), grad=np.asarray(n["grad"], np.float64), hess=np.asarray(n["hess"], np.float64).reshape(6, 6),
                             final_eps001=mat(n["final_eps001"]).astype(np.float32), iters_eps001=int(n["iters_eps001"]),
                             final_tight=mat(n["final_tight"]).astype(np.float32), iters_tight=int(n["iters_tight"]),

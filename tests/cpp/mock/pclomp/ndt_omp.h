@@ -7,7 +7,8 @@ namespace pclomp {
 enum NeighborSearchMethod { KDTREE, DIRECT26, DIRECT7, DIRECT1 };
 template <typename PointT> class VoxelGridCovariance : public pcl::VoxelGrid<PointT> {
  public:
-  struct Leaf { int nr_points = 0; Eigen::Matrix3d cov_, icov_; };
+  struct FloatVec { float v[4] = {0, 0, 0, 0}; float operator[](int k) const { return v[k]; } };   // Eigen::VectorXf centroid
+  struct Leaf { int nr_points = 0; Eigen::Matrix3d cov_, icov_; FloatVec centroid; };
   const std::map<std::size_t, Leaf>& getLeaves() const { return leaves_; }
  protected:
   std::map<std::size_t, Leaf> leaves_;

@@ -229,6 +229,21 @@ def test_gpu_matches_the_committed_golden_fixture():
             assert ndt.getFinalNumIteration() == int(gold["iters_" + key])
         else:
             assert abs(ndt.getFinalNumIteration() - int(gold["iters_" + key])) <= 2
+    # the KDTREE neighbourhood: the kd-tree's centroids bit for bit, a derivative pass, the reference's schedule
+    import lidarslam_ros2_amd as L
+    ndt.setNeighborhoodSearchMethod(L.KDTREE)
+    cen = ndt.gridCentroids()
+    in_tree = ~np.isnan(gold["leaf_centroid"][:, 0])
+    assert np.array_equal(np.isnan(cen[:, 0]), ~in_tree) and np.array_equal(cen[in_tree], gold["leaf_centroid"][in_tree])
+    s, g, H = ndt.derivatives(gold["p"], compute_hessian=True)
+    assert abs(s - float(gold["score_kdtree"])) <= 1e-5 * abs(float(gold["score_kdtree"]))
+    assert np.abs(g - gold["grad_kdtree"]).max() <= 2e-5 * np.abs(gold["grad_kdtree"]).max()
+    assert np.abs(H - gold["hess_kdtree"]).max() <= 2e-5 * np.abs(gold["hess_kdtree"]).max()
+    ndt.setTransformationEpsilon(0.01)
+    ndt.setMaximumIterations(35)
+    ndt.align(gold["guess"])
+    dt, ang = pose_delta(ndt.getFinalTransformation(), gold["final_kdtree"])
+    assert dt <= POSE_T_TOL and ang <= POSE_R_TOL and ndt.getFinalNumIteration() == int(gold["iters_kdtree"])
 
 
 # ---- launch variants of the derivative pass and the two grid builders -----------------------------------------------

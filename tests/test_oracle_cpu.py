@@ -264,6 +264,15 @@ def test_oracle_reproduces_golden():
     assert np.allclose(g, gold["grad"], rtol=1e-10, atol=1e-9) and np.allclose(H, gold["hess"], rtol=1e-10, atol=1e-7)
     r = O.ndt_align(grid, case.source, case.guess, resolution=float(gold["res"]), trans_eps=0.01, num_threads=1)
     assert np.allclose(r["final"], gold["final_eps001"], atol=1e-6) and r["iterations"] == int(gold["iters_eps001"])
+    # KDTREE neighbourhood (search = 0): the centroids of the kd-tree bit for bit, one derivative pass, one registration
+    cen = grid.centroids()
+    in_tree = ~np.isnan(gold["leaf_centroid"][:, 0])
+    assert np.array_equal(in_tree, gold["leaf_n"] >= 6) and np.array_equal(cen[in_tree], gold["leaf_centroid"][in_tree])
+    s, g, H = O.ndt_derivatives(grid, case.source, gold["p"], resolution=float(gold["res"]), search=0, num_threads=1)
+    assert s == pytest.approx(float(gold["score_kdtree"]), rel=1e-12)
+    assert np.allclose(g, gold["grad_kdtree"], rtol=1e-10, atol=1e-9) and np.allclose(H, gold["hess_kdtree"], rtol=1e-10, atol=1e-7)
+    r = O.ndt_align(grid, case.source, case.guess, resolution=float(gold["res"]), trans_eps=0.01, search=0, num_threads=1)
+    assert np.allclose(r["final"], gold["final_kdtree"], atol=1e-6) and r["iterations"] == int(gold["iters_kdtree"])
 
 
 def test_fixture_loader_prefers_a_reference_dump(tmp_path, monkeypatch):
