@@ -905,7 +905,7 @@ __device__ __forceinline__ unsigned int div_small(unsigned int n, unsigned int d
 //                workgroup read the global table directly for that pass, as NDT_TAB_DENSE does for all.
 //  NDT_TAB_DENSE / NDT_TAB_COMPACT  records gathered from global memory.
 // BYVAL: the problem travels in the kernel arguments (single registrations); otherwise probs[blockIdx.y] (batches).
-template <int NOFF, int TAB, int PTS, bool BYVAL>
+template <int NOFF, int TAB, int PTS, bool BYVAL, bool KD = false>
 __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq) {
   constexpr int THREADS = 4 * PTS;
   // floats per row of the per-point buffers, chosen against the 32-lane groups of ds_*_b32: phase A writes rows
@@ -1148,7 +1148,8 @@ __global__ __launch_bounds__(4 * PTS) void ndt_eval_quad_kernel(const NdtProblem
         if (TAB == NDT_TAB_TILE && use_tile) cellv[t] = in ? ((a - lo0) + (b - lo1) * tdx + (c - lo2) * tdxy) : 0;
         else cellv[t] = in ? ((a - P.min_b[0]) + (b - P.min_b[1]) * P.mul1 + (c - P.min_b[2]) * P.mul2) : 0;
       }
-      if (NOFF == 27 && P.centroid) {   // KDTREE: of the 27 cells, the leaves whose centroid the kd-tree's radius search would return
+      if (KD) {   // KDTREE (a template form of its own: the DIRECT26 kernels keep their registers): of the 27 cells, the leaves whose centroid
+                  // the kd-tree's radius search would return
 #pragma unroll
         for (int t = 0; t < NT; t++) {
           const int sl = valid[t] ? P.cell_slot[cellv[t]] : -1;
@@ -1345,7 +1346,7 @@ typedef __attribute__((address_space(1))) const int GlbInt;
 //      staging tile, one workgroup barrier, the even wave adds the halves, forms the point's terms and reduces the chunk as before.
 //      Same bits (the association is the canonical one), half the serial chain per wave, twice the waves: a workgroup covers
 //      THREADS / 2 points per trip.
-template <int NOFF, int TAB, int THREADS, bool BYVAL, bool SPLIT = false>
+template <int NOFF, int TAB, int THREADS, bool BYVAL, bool SPLIT = false, bool KD = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void ndt_eval_lane_kernel(const NdtProblem pv, const NdtProblem* __restrict__ probs, const int seq,
                                                                 const int nb, const int tab_bytes) {
   constexpr int NWAVES = THREADS / 64;
@@ -1518,7 +1519,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
       nb_ok[o] = in;
       nb_rec[o] = cell;
     }
-    if (NOFF == 27 && P.centroid) {   // KDTREE: of the 27 cells, the leaves whose centroid the kd-tree's radius search would return
+    if (KD) {   // KDTREE (a template form of its own): of the 27 cells, the leaves whose centroid the kd-tree's radius search would return
 #pragma unroll
       for (int o = 0; o < NOFF; o++) {
         const int ks = nb_ok[o] ? P.cell_slot[nb_rec[o]] : -1;
@@ -1750,43 +1751,47 @@ int ndt_init_batch(const NdtProblem* src_probs, const NdtState* src_states, NdtP
   return LSR_OK;
 }
 
-template <int NOFF, int TAB, int PTS>
+template <int NOFF, int TAB, int PTS, bool KD = false>
 static int launch_quad_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq) {
   static bool allowed[2][64] = {};
   if (dyn_lds > 32 * 1024) {
     int dev = 0;
     LSR_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !allowed[byval ? 1 : 0][dev]) {
-      const void* fn = byval ? (const void*)ndt_eval_quad_kernel<NOFF, TAB, PTS, true> : (const void*)ndt_eval_quad_kernel<NOFF, TAB, PTS, false>;
+      const void* fn = byval ? (const void*)ndt_eval_quad_kernel<NOFF, TAB, PTS, true, KD> : (const void*)ndt_eval_quad_kernel<NOFF, TAB, PTS, false, KD>;
       LSR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NDT_LDS_TABLE_MAX_QUAD));
       allowed[byval ? 1 : 0][dev] = true;
     }
   }
-  if (byval) hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB, PTS, true>), grid, dim3(4 * PTS), dyn_lds, stream, pv, d_probs, seq);
-  else hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB, PTS, false>), grid, dim3(4 * PTS), dyn_lds, stream, pv, d_probs, seq);
+  if (byval) hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB, PTS, true, KD>), grid, dim3(4 * PTS), dyn_lds, stream, pv, d_probs, seq);
+  else hipLaunchKernelGGL((ndt_eval_quad_kernel<NOFF, TAB, PTS, false, KD>), grid, dim3(4 * PTS), dyn_lds, stream, pv, d_probs, seq);
   return LSR_OK;
 }
 
-template <int NOFF>
+template <int NOFF, bool KD = false>
 static int launch_quad(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq) {
   const size_t dyn = (cfg.tab == NDT_TAB_LDS || cfg.tab == NDT_TAB_TILE) ? (size_t)cfg.lds_bytes : 0;
   if (cfg.threads == 64) {  // points per workgroup
     switch (cfg.tab) {
-      case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 64>(byval, grid, dyn, stream, pv, d_probs, seq);
-      case NDT_TAB_TILE: return launch_quad_variant<NOFF, NDT_TAB_TILE, 64>(byval, grid, dyn, stream, pv, d_probs, seq);
-      case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 64>(byval, grid, dyn, stream, pv, d_probs, seq);
-      default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 64>(byval, grid, dyn, stream, pv, d_probs, seq);
+      case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 64, KD>(byval, grid, dyn, stream, pv, d_probs, seq);
+      case NDT_TAB_TILE:   // (never chosen for KDTREE — choose_table_mode —: that form is not instantiated)
+        if constexpr (!KD) return launch_quad_variant<NOFF, NDT_TAB_TILE, 64, KD>(byval, grid, dyn, stream, pv, d_probs, seq);
+        else { set_last_error("the tile mode has no KDTREE form"); return LSR_ERR_INVALID_ARGUMENT; }
+      case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 64, KD>(byval, grid, dyn, stream, pv, d_probs, seq);
+      default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 64, KD>(byval, grid, dyn, stream, pv, d_probs, seq);
     }
   }
   switch (cfg.tab) {
-    case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
-    case NDT_TAB_TILE: return launch_quad_variant<NOFF, NDT_TAB_TILE, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
-    case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
-    default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 128>(byval, grid, dyn, stream, pv, d_probs, seq);
+    case NDT_TAB_LDS: return launch_quad_variant<NOFF, NDT_TAB_LDS, 128, KD>(byval, grid, dyn, stream, pv, d_probs, seq);
+    case NDT_TAB_TILE:   // (never chosen for KDTREE — choose_table_mode —: that form is not instantiated)
+      if constexpr (!KD) return launch_quad_variant<NOFF, NDT_TAB_TILE, 128, KD>(byval, grid, dyn, stream, pv, d_probs, seq);
+      else { set_last_error("the tile mode has no KDTREE form"); return LSR_ERR_INVALID_ARGUMENT; }
+    case NDT_TAB_COMPACT: return launch_quad_variant<NOFF, NDT_TAB_COMPACT, 128, KD>(byval, grid, dyn, stream, pv, d_probs, seq);
+    default: return launch_quad_variant<NOFF, NDT_TAB_DENSE, 128, KD>(byval, grid, dyn, stream, pv, d_probs, seq);
   }
 }
 
-template <int NOFF, int TAB, int THREADS, bool SPLIT = false>
+template <int NOFF, int TAB, int THREADS, bool SPLIT = false, bool KD = false>
 static int launch_lane_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq,
                                int tab_bytes) {
   static bool allowed[2][64] = {};
@@ -1794,7 +1799,7 @@ static int launch_lane_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_
     int dev = 0;
     LSR_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !allowed[byval ? 1 : 0][dev]) {
-      const void* fn = byval ? (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, true, SPLIT> : (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, false, SPLIT>;
+      const void* fn = byval ? (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, true, SPLIT, KD> : (const void*)ndt_eval_lane_kernel<NOFF, TAB, THREADS, false, SPLIT, KD>;
       // table image + staging tiles, bounded by what a workgroup can have on gfx950 (160 KiB minus the kernel's static LDS)
       const int want = std::min((int)NDT_LDS_TABLE_MAX + ndt_lane_tile_bytes(THREADS), 160 * 1024 - 6 * 1024);
       LSR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want));
@@ -1802,16 +1807,16 @@ static int launch_lane_variant(bool byval, dim3 grid, size_t dyn_lds, hipStream_
     }
   }
   const int nb = (int)grid.x;
-  if (byval) hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, true, SPLIT>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
-  else hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, false, SPLIT>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
+  if (byval) hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, true, SPLIT, KD>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
+  else hipLaunchKernelGGL((ndt_eval_lane_kernel<NOFF, TAB, THREADS, false, SPLIT, KD>), grid, dim3(THREADS), dyn_lds, stream, pv, d_probs, seq, nb, tab_bytes);
   return LSR_OK;
 }
 
-template <int NOFF>
+template <int NOFF, bool KD = false>
 static int launch_lane(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream_t stream, const NdtProblem& pv, const NdtProblem* d_probs, int seq) {
   const int tab_bytes = (cfg.tab == NDT_TAB_LDS) ? cfg.lds_bytes : 0;
   const size_t dyn = (size_t)tab_bytes + (size_t)ndt_lane_tile_bytes(cfg.threads);
-  if (cfg.split && cfg.threads == 512) {   // two waves per chunk: the 512-thread form only (what single scans use)
+  if (cfg.split && cfg.threads == 512 && !KD) {   // two waves per chunk: the 512-thread form only (what single scans use; the KDTREE form has no such variant)
     switch (cfg.tab) {
       case NDT_TAB_LDS: return launch_lane_variant<NOFF, NDT_TAB_LDS, 512, true>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
       case NDT_TAB_COMPACT: return launch_lane_variant<NOFF, NDT_TAB_COMPACT, 512, true>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
@@ -1820,15 +1825,15 @@ static int launch_lane(const NdtLaunchCfg& cfg, bool byval, dim3 grid, hipStream
   }
   if (cfg.threads == 1024) {
     switch (cfg.tab) {
-      case NDT_TAB_LDS: return launch_lane_variant<NOFF, NDT_TAB_LDS, 1024>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
-      case NDT_TAB_COMPACT: return launch_lane_variant<NOFF, NDT_TAB_COMPACT, 1024>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
-      default: return launch_lane_variant<NOFF, NDT_TAB_DENSE, 1024>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+      case NDT_TAB_LDS: return launch_lane_variant<NOFF, NDT_TAB_LDS, 1024, false, KD>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+      case NDT_TAB_COMPACT: return launch_lane_variant<NOFF, NDT_TAB_COMPACT, 1024, false, KD>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+      default: return launch_lane_variant<NOFF, NDT_TAB_DENSE, 1024, false, KD>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
     }
   }
   switch (cfg.tab) {
-    case NDT_TAB_LDS: return launch_lane_variant<NOFF, NDT_TAB_LDS, 512>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
-    case NDT_TAB_COMPACT: return launch_lane_variant<NOFF, NDT_TAB_COMPACT, 512>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
-    default: return launch_lane_variant<NOFF, NDT_TAB_DENSE, 512>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+    case NDT_TAB_LDS: return launch_lane_variant<NOFF, NDT_TAB_LDS, 512, false, KD>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+    case NDT_TAB_COMPACT: return launch_lane_variant<NOFF, NDT_TAB_COMPACT, 512, false, KD>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
+    default: return launch_lane_variant<NOFF, NDT_TAB_DENSE, 512, false, KD>(byval, grid, dyn, stream, pv, d_probs, seq, tab_bytes);
   }
 }
 
@@ -1853,14 +1858,14 @@ int ndt_launch_evals(const NdtProblem* d_probs, const NdtProblem* h_single, cons
     if (cfg.quad) {
       switch (cfg.neighborhood) {
         case LSR_DIRECT1: st = launch_quad<1>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
-        case LSR_KDTREE:   // the 27 cells, filtered by the radius test on the leaves' centroids (NdtProblem::centroid)
+        case LSR_KDTREE: st = launch_quad<27, true>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;   // the 27 cells + the kd-tree's radius test (NdtProblem::centroid)
         case LSR_DIRECT26: st = launch_quad<27>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
         default: st = launch_quad<7>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
       }
     } else {
       switch (cfg.neighborhood) {
         case LSR_DIRECT1: st = launch_lane<1>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
-        case LSR_KDTREE:
+        case LSR_KDTREE: st = launch_lane<27, true>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
         case LSR_DIRECT26: st = launch_lane<27>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
         default: st = launch_lane<7>(cfg, byval, grid, stream, pv, d_probs, seq0 + i); break;
       }
