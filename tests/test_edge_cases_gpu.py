@@ -226,6 +226,16 @@ def test_compact_leaf_table_path_for_huge_extents(O, case):
         dt, ang = pose_delta(r.getFinalTransformation(), ref["final"])
         assert dt <= 1e-3 and ang <= 1e-4, (shift, dt, ang)
         assert r.hasConverged() == ref["converged"]
+    # the KDTREE neighbourhood on the compact table (centroids indexed by leaf slot, not by cell)
+    import lidarslam_ros2_amd as L
+    r.setNeighborhoodSearchMethod(L.KDTREE)
+    dump = ref_grid.dump()
+    in_tree = dump["n"] >= 6
+    assert np.array_equal(r.gridCentroids()[in_tree], ref_grid.centroids()[in_tree])
+    p = O.matrix_to_pose(case.guess)
+    s, g, H = r.derivatives(p)
+    rs, rg, rH = O.ndt_derivatives(ref_grid, case.source, p, resolution=res, search=0)
+    assert abs(s - rs) <= 1e-5 * abs(rs) and np.abs(g - rg).max() <= 2e-4 * np.abs(rg).max()
 
 
 def test_points_exactly_on_voxel_faces(O, case):
