@@ -273,6 +273,11 @@ __global__ __launch_bounds__(256) void vg_scatter_kernel(const float* __restrict
 // 0.28 ms against 0.25 ms for the targets of an 8-candidate share.  The large cells are not what this kernel waits for.)  Dense record layout
 // (record of cell c at rec[4c]); empty cells are written as zero records.
 constexpr int VG_LEAF_THREADS = 256;
+// SUMS_ONLY (round 6, candidate sets): the wave leaves its nine sums in icov64[9 cell ..] and the finalisation to vg_leaf_finish_body — one
+// THREAD per cell in a launch of its own.  A wave whose lanes 1..63 have left still takes a full wave's issue slots for every one of the
+// ~1000 serial fp64 instructions of leaf_finalize_dev; with eight targets' cells in one launch (a dozen such waves per SIMD) that tail
+// was most of the kernel.  Same function on the same sums: the same records.
+template <bool SUMS_ONLY = false>
 __device__ __forceinline__ void vg_leaf_kernel_body(const float* __restrict__ sx, const float* __restrict__ sy,
                                                                   const float* __restrict__ sz, const unsigned int* __restrict__ start,
                                                                   int ncells, int min_points, double eig_mult, float4* __restrict__ rec,
@@ -286,6 +291,7 @@ __device__ __forceinline__ void vg_leaf_kernel_body(const float* __restrict__ sx
   const unsigned int off = start[cell];
   const int cnt = (int)(start[cell + 1] - off);
   if (cnt == 0) {
+    if (SUMS_ONLY) return;   // (the finishing launch writes the empty cell's record)
     if (lane == 0) {
       const double zero[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       leaf_record_dev(zero, zero, 0, false, rec + (size_t)cell * 4);   // NaN pieces: an empty cell answers no lookup
@@ -317,6 +323,11 @@ __device__ __forceinline__ void vg_leaf_kernel_body(const float* __restrict__ sx
 #pragma unroll
   for (int k = 0; k < 9; k++) s[k] = wave_sum64(s[k]);
   if (lane != 0) return;
+  if (SUMS_ONLY) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) icov64[(size_t)cell * 9 + k] = s[k];
+    return;
+  }
   double mean[3], icov[9];
   bool valid;
   const int n = leaf_finalize_dev(s, cnt, min_points, eig_mult, mean, icov, &valid);
@@ -336,6 +347,30 @@ __global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_kernel(const float* _
   vg_leaf_kernel_body(sx, sy, sz, start, ncells, min_points, eig_mult, rec, mean64, icov64, leaf_key, leaf_n, cell_slot, (int)blockIdx.x);
 }
 
+// the second half of the SUMS_ONLY form: one thread per cell
+__device__ __forceinline__ void vg_leaf_finish_body(const unsigned int* __restrict__ start, int ncells, int min_points, double eig_mult,
+                                                    float4* __restrict__ rec, double* __restrict__ mean64, double* __restrict__ icov64,
+                                                    int* __restrict__ leaf_key, int* __restrict__ leaf_n, int* __restrict__ cell_slot, const int cell) {
+  if (cell >= ncells) return;
+  const int cnt = (int)(start[cell + 1] - start[cell]);
+  if (cnt == 0) {
+    const double zero[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    leaf_record_dev(zero, zero, 0, false, rec + (size_t)cell * 4);   // NaN pieces: an empty cell answers no lookup
+    leaf_key[cell] = -1; leaf_n[cell] = 0; cell_slot[cell] = -1;
+    return;
+  }
+  double s[9], mean[3], icov[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) s[k] = icov64[(size_t)cell * 9 + k];
+  bool valid;
+  const int n = leaf_finalize_dev(s, cnt, min_points, eig_mult, mean, icov, &valid);
+  leaf_key[cell] = cell;
+  leaf_n[cell] = n;
+  for (int k = 0; k < 3; k++) mean64[(size_t)cell * 3 + k] = mean[k];
+  for (int k = 0; k < 9; k++) icov64[(size_t)cell * 9 + k] = icov[k];
+  leaf_record_dev(mean, icov, n, valid, rec + (size_t)cell * 4);
+  cell_slot[cell] = valid ? cell : -1;
+}
 
 // ---- the same builders over a GROUP of targets: blockIdx.y selects the member, whose parameters travel in the kernel arguments ----
 struct VgMember {
@@ -439,6 +474,15 @@ __global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_group_kernel(const Vg
   const VgMember& M = g.m[blockIdx.y];
   if ((int)blockIdx.x * (VG_LEAF_THREADS / 64) >= M.ncells) return;
   vg_leaf_kernel_body(M.sx, M.sy, M.sz, M.start, M.ncells, 6, 0.01, M.rec, M.mean64, M.icov64, M.leaf_key, M.leaf_n, M.cell_slot, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(VG_LEAF_THREADS) void vg_leaf_sums_group_kernel(const VgGroup g) {
+  const VgMember& M = g.m[blockIdx.y];
+  if ((int)blockIdx.x * (VG_LEAF_THREADS / 64) >= M.ncells) return;
+  vg_leaf_kernel_body<true>(M.sx, M.sy, M.sz, M.start, M.ncells, 6, 0.01, M.rec, M.mean64, M.icov64, M.leaf_key, M.leaf_n, M.cell_slot, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void vg_leaf_finish_group_kernel(const VgGroup g) {
+  const VgMember& M = g.m[blockIdx.y];
+  vg_leaf_finish_body(M.start, M.ncells, 6, 0.01, M.rec, M.mean64, M.icov64, M.leaf_key, M.leaf_n, M.cell_slot, (int)(blockIdx.x * 256 + threadIdx.x));
 }
 
 // ---- source ordering for the tile-staged derivative pass (NDT_TAB_TILE) -------------------------------------------------
@@ -665,7 +709,14 @@ int ndt_build_grids_dense_group(TargetBuildJob* const* jobs, int count, hipStrea
     hipLaunchKernelGGL(vg_scan_group_kernel, dim3((maxC + 31) / 32, ng), dim3(256), 0, stream, grp);
     hipLaunchKernelGGL(vg_cellscan_group_kernel, dim3(ng), dim3(1024), 0, stream, grp);
     hipLaunchKernelGGL(vg_scatter_group_kernel, dim3(max_nblk, ng), dim3(256), (size_t)maxC * 8, stream, grp);
-    hipLaunchKernelGGL(vg_leaf_group_kernel, dim3((max_cells + VG_LEAF_THREADS / 64 - 1) / (VG_LEAF_THREADS / 64), ng), dim3(VG_LEAF_THREADS), 0, stream, grp);
+    // from two targets on: the sums by one wave per cell, the finalisation by one thread per cell in a launch of its own (LSR_VG_LEAF_SPLIT=0 / 1 forces)
+    static const int split_env = [] { const char* e = getenv("LSR_VG_LEAF_SPLIT"); return e ? atoi(e) : -1; }();
+    if (split_env == 1 || (split_env < 0 && ng >= 2)) {
+      hipLaunchKernelGGL(vg_leaf_sums_group_kernel, dim3((max_cells + VG_LEAF_THREADS / 64 - 1) / (VG_LEAF_THREADS / 64), ng), dim3(VG_LEAF_THREADS), 0, stream, grp);
+      hipLaunchKernelGGL(vg_leaf_finish_group_kernel, dim3((max_cells + 255) / 256, ng), dim3(256), 0, stream, grp);
+    } else {
+      hipLaunchKernelGGL(vg_leaf_group_kernel, dim3((max_cells + VG_LEAF_THREADS / 64 - 1) / (VG_LEAF_THREADS / 64), ng), dim3(VG_LEAF_THREADS), 0, stream, grp);
+    }
   }
   LSR_HIP(hipGetLastError());
   return LSR_OK;
